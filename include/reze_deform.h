@@ -1,0 +1,150 @@
+/*
+ * reze_deform.h — C ABI of libreze_deform.so: the MI355X-native replacement for the reference's
+ * per-frame PMX morph + skin GPU path.
+ *
+ * The reference (AmyangXYZ/reze-engine, TypeScript + WGSL) has no FFI; its de-facto boundary is
+ * the set of WebGPU calls class Engine makes for this path. Every entry point below names the
+ * reference call site it replaces (paths relative to the reference repo root). The N-API addon
+ * (reze-engine_amd/csrc/napi_addon.c) and the Python ctypes binding (reze-engine_amd/capi.py) are
+ * thin shims over exactly these symbols — see INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a negative rz_status;
+ *     rz_last_error() returns a thread-local human-readable message for the last failure.
+ *   - "host" pointers are caller-owned and are copied (or fully consumed) before the call returns.
+ *   - one rz_ctx drives ONE GPU (one process — or one context — per GPU); calls on a context are
+ *     serialised by the caller (Node's main thread). Work is enqueued on the context's own HIP
+ *     stream and is asynchronous unless stated; rz_sync() drains it.
+ *   - matrices are column-major float[16] exactly as engine/src/math.ts stores them.
+ *   - a context owns a contiguous vertex shard [v_begin, v_begin + V) of a mesh of v_total
+ *     vertices (v_begin = 0, v_total = V on a single GPU).
+ */
+#ifndef REZE_DEFORM_H
+#define REZE_DEFORM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RZ_ABI_VERSION 1
+
+typedef struct rz_ctx rz_ctx;
+
+typedef enum rz_status {
+    RZ_OK = 0,
+    RZ_ERR_INVALID = -1,      /* bad argument / call order                       */
+    RZ_ERR_HIP = -2,          /* a HIP runtime call failed (message has details) */
+    RZ_ERR_NO_DEVICE = -3,    /* no usable gfx950 device                         */
+    RZ_ERR_RCCL = -4,         /* an RCCL call failed                             */
+    RZ_ERR_OOM = -5,
+    RZ_ERR_UNSUPPORTED = -6
+} rz_status;
+
+/* Timing of the most recent rz_time_frames() / per-frame statistics (getStats() additions). */
+typedef struct rz_timing {
+    double frame_ms;          /* average wall ms per frame over the timed run (HIP events)     */
+    double deform_kernel_ms;  /* average ms of the fused morph+skin kernel alone               */
+    double prep_kernel_ms;    /* average ms of the palette / active-morph prep kernel          */
+    uint64_t verts_per_frame; /* instances x vertices of this shard                            */
+    uint64_t algorithmic_bytes_per_frame; /* SURVEY §8d formula for this shard                 */
+    uint32_t frames;
+    uint32_t reserved;
+} rz_timing;
+
+const char *rz_last_error(void);
+int rz_abi_version(void);
+
+/* Number of visible HIP devices. */
+int rz_device_count(int *count);
+
+/* Engine.init()  engine/src/engine.ts:157-185 (requestAdapter/requestDevice): bind to one GPU,
+ * create the stream, events and staging memory. */
+int rz_create(int device, rz_ctx **out);
+/* Engine.dispose()  engine/src/engine.ts:1692-1701. */
+int rz_destroy(rz_ctx *ctx);
+
+/* Pure helper: contiguous shard of rank `rank` of `nranks` over v_total vertices.
+ * Shards are equal-sized (a multiple of 256 vertices) except the last; *count may be 0. */
+int rz_shard_range(uint32_t v_total, int nranks, int rank, uint32_t *begin, uint32_t *count);
+
+/* setupModelBuffers()  engine/src/engine.ts:1734-1765: vertex buffer in the reference's
+ * interleaved layout (8 floats/vertex: pos3 nrm3 uv2, engine.ts:340-347), joints Uint16x4
+ * (:348-352), weights Unorm8x4 (:353-356). De-interleaved to planar SoA on upload.
+ * The arrays describe ONLY this context's shard (V vertices). */
+int rz_upload_mesh(rz_ctx *ctx, uint32_t V, const float *interleaved8, const uint16_t *joints4,
+                   const uint8_t *weights4);
+/* Same, from separate packed position / normal arrays ([V][3] each). */
+int rz_upload_mesh_soa(rz_ctx *ctx, uint32_t V, const float *pos3, const float *nrm3,
+                       const uint16_t *joints4, const uint8_t *weights4);
+
+/* inverseBindMatrixBuffer + boneCountBuffer  engine/src/engine.ts:1767-1804. */
+int rz_upload_skeleton(rz_ctx *ctx, uint32_t B, const float *inverse_bind16);
+
+/* Vertex-morph targets — NEW capability, no reference counterpart (the reference skips the PMX
+ * morph section, engine/src/pmx-loader.ts:450-553). Dense: deltas[M][V][3] for this shard.
+ * Sparse: PMX on-disk form (pmx-loader.ts:483-488) — morph m owns entries
+ * [morph_off[m], morph_off[m+1]) of (vert_idx relative to this shard, delta xyz).
+ * Passing M = 0 removes morphs. */
+int rz_upload_morphs_dense(rz_ctx *ctx, uint32_t M, const float *deltas);
+int rz_upload_morphs_sparse(rz_ctx *ctx, uint32_t M, const uint32_t *morph_off,
+                            const uint32_t *vert_idx, const float *delta3);
+
+/* Instancing — NEW (the reference draws one model): I poses of the same static mesh. */
+int rz_set_instances(rz_ctx *ctx, uint32_t I);
+
+/* updateModelPose()  engine/src/engine.ts:2383-2389: queue.writeBuffer(worldMatrixBuffer).
+ * world = I x B x 16 floats; morph_weights = I x M floats or NULL (all zero). Asynchronous H2D
+ * through pinned staging; the data is consumed by the next rz_deform(). */
+int rz_set_pose(rz_ctx *ctx, const float *world, const float *morph_weights);
+
+/* computeSkinMatrices() dispatch  engine/src/engine.ts:2393-2402 (WGSL :906-930) followed by the
+ * per-vertex body of vs()  engine/src/engine.ts:253-272 (copies :440-443/:700-703), executed
+ * once per frame instead of once per draw pass. Enqueues the frame; asynchronous. */
+int rz_deform(rz_ctx *ctx);
+/* Enqueue `frames` consecutive frames of the resident pose without returning to the host
+ * in between (steady-state replay; same kernels as rz_deform). Asynchronous. */
+int rz_deform_n(rz_ctx *ctx, uint32_t frames);
+
+int rz_sync(rz_ctx *ctx);
+
+/* Blocking readback of deformed positions / normals of instance `instance`, vertices
+ * [v0, v0+n) of this shard, packed [n][3]. Either pointer may be NULL. (getDeformed()) */
+int rz_read(rz_ctx *ctx, uint32_t instance, uint32_t v0, uint32_t n, float *pos3, float *nrm3);
+/* Blocking readback of the skin-matrix palette of one instance as B x 12 floats (rows 0..2 of
+ * world*inverseBind, row-major 3x4) — the skinMatrixBuffer of engine.ts:1770-1774. */
+int rz_read_palette(rz_ctx *ctx, uint32_t instance, float *rows3x4);
+
+/* Benchmark helper: enqueue `frames` back-to-back frames of the resident pose between two HIP
+ * events on the context's stream, then (mode 1) time the deform kernel alone and (mode 2) the
+ * prep kernel alone the same way. Blocking. */
+int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
+
+/* Tuning knobs (bench sweeps / tests). Keys: "morph_split" (1,2,4,8,16; 0 = auto),
+ * "unroll" (1,2,4,8), "grid_cap" (total workgroups, 0 = auto), "geo_lds" (0/1: rest geometry
+ * transposed through LDS vs 4-byte loads), "nontemporal" (0/1). rz_get_tuning also answers
+ * "effective_split" / "effective_grid". Unknown keys return RZ_ERR_INVALID. */
+int rz_set_tuning(rz_ctx *ctx, const char *key, int value);
+int rz_get_tuning(rz_ctx *ctx, const char *key, int *value);
+
+/* Device pointers of the output buffers ([I][Vpad][3] floats each) and the padded vertex count,
+ * so a host framework can wrap them without a copy. */
+int rz_output_ptrs(rz_ctx *ctx, void **pos, void **nrm, uint32_t *v_padded);
+
+/* ---- multi-GPU: vertex shards + optional all-gather of deformed positions ----
+ * One context per GPU / process. rz_comm_unique_id() is called by rank 0 and the 128 bytes are
+ * broadcast by the host (IPC, torch.distributed, files ...); every rank then calls
+ * rz_comm_init() with the same id. rz_allgather() runs ncclAllGather over xGMI on the
+ * context's stream: every rank ends up with the full [v_total_padded][3] position (and, when
+ * with_normals != 0, normal) arrays of instance 0. */
+int rz_comm_unique_id(char id[128]);
+int rz_comm_init(rz_ctx *ctx, int nranks, int rank, const char id[128], uint32_t v_total);
+int rz_allgather(rz_ctx *ctx, int with_normals);
+int rz_read_gathered(rz_ctx *ctx, uint32_t v0, uint32_t n, float *pos3, float *nrm3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REZE_DEFORM_H */

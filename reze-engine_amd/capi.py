@@ -1,0 +1,264 @@
+"""ctypes binding of libreze_deform.so (include/reze_deform.h) for bench.py and the GPU tests.
+
+This is plumbing only: every method is a 1:1 call of a C-ABI entry point, so the parity tests
+exercise exactly what the N-API addon binds. There is deliberately no CPU fallback — if the HIP
+library is missing or no MI355X is visible, construction raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libreze_deform.so")
+
+# every symbol include/reze_deform.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_destroy", "rz_shard_range",
+    "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
+    "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
+    "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_output_ptrs",
+    "rz_comm_unique_id", "rz_comm_init", "rz_allgather", "rz_read_gathered",
+]
+
+
+class RzTiming(ctypes.Structure):
+    _fields_ = [("frame_ms", ctypes.c_double), ("deform_kernel_ms", ctypes.c_double),
+                ("prep_kernel_ms", ctypes.c_double), ("verts_per_frame", ctypes.c_uint64),
+                ("algorithmic_bytes_per_frame", ctypes.c_uint64), ("frames", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
+
+
+class RzError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("reze_deform error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree HIP library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    vp = ctypes.c_void_p
+    fp = ctypes.POINTER(ctypes.c_float)
+    u32 = ctypes.c_uint32
+    L.rz_last_error.restype = ctypes.c_char_p
+    L.rz_last_error.argtypes = []
+    L.rz_abi_version.argtypes = []
+    L.rz_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
+    L.rz_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.rz_destroy.argtypes = [vp]
+    L.rz_shard_range.argtypes = [u32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.rz_upload_mesh.argtypes = [vp, u32, fp, ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint8)]
+    L.rz_upload_mesh_soa.argtypes = [vp, u32, fp, fp, ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint8)]
+    L.rz_upload_skeleton.argtypes = [vp, u32, fp]
+    L.rz_upload_morphs_dense.argtypes = [vp, u32, fp]
+    L.rz_upload_morphs_sparse.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), fp]
+    L.rz_set_instances.argtypes = [vp, u32]
+    L.rz_set_pose.argtypes = [vp, fp, fp]
+    L.rz_deform.argtypes = [vp]
+    L.rz_deform_n.argtypes = [vp, u32]
+    L.rz_sync.argtypes = [vp]
+    L.rz_read.argtypes = [vp, u32, u32, u32, fp, fp]
+    L.rz_read_palette.argtypes = [vp, u32, fp]
+    L.rz_time_frames.argtypes = [vp, u32, ctypes.POINTER(RzTiming)]
+    L.rz_set_tuning.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
+    L.rz_get_tuning.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    L.rz_output_ptrs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u32)]
+    L.rz_comm_unique_id.argtypes = [ctypes.c_char_p]
+    L.rz_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, u32]
+    L.rz_allgather.argtypes = [vp, ctypes.c_int]
+    L.rz_read_gathered.argtypes = [vp, u32, u32, fp, fp]
+    for name in SYMBOLS:
+        if name != "rz_last_error":
+            getattr(L, name).restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def _chk(code):
+    if code != 0:
+        raise RzError(code, load().rz_last_error().decode("utf-8", "replace"))
+
+
+def _fptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = load().rz_device_count(ctypes.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def shard_range(v_total, nranks, rank):
+    """Pure host helper (works without a GPU): (begin, count) of `rank`'s vertex shard."""
+    b = ctypes.c_uint32(0)
+    n = ctypes.c_uint32(0)
+    _chk(load().rz_shard_range(int(v_total), int(nranks), int(rank), ctypes.byref(b), ctypes.byref(n)))
+    return b.value, n.value
+
+
+def comm_unique_id():
+    buf = ctypes.create_string_buffer(128)
+    _chk(load().rz_comm_unique_id(buf))
+    return buf.raw
+
+
+class DeformContext:
+    """One GPU's deformation context (rz_ctx)."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        h = ctypes.c_void_p()
+        _chk(self._L.rz_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.V = 0
+        self.B = 0
+        self.M = 0
+        self.I = 1
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rz_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- static uploads ----
+    def upload_mesh_interleaved(self, vertices8, joints4, weights4):
+        v = _f32(vertices8).reshape(-1, 8)
+        j = np.ascontiguousarray(joints4, dtype=np.uint16).reshape(-1, 4)
+        w = np.ascontiguousarray(weights4, dtype=np.uint8).reshape(-1, 4)
+        assert len(v) == len(j) == len(w)
+        _chk(self._L.rz_upload_mesh(self._h, len(v), _fptr(v), j.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
+                                    w.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
+        self.V = len(v)
+        self.M = 0
+
+    def upload_mesh(self, pos, nrm, joints4, weights4):
+        p = _f32(pos).reshape(-1, 3)
+        n = _f32(nrm).reshape(-1, 3)
+        j = np.ascontiguousarray(joints4, dtype=np.uint16).reshape(-1, 4)
+        w = np.ascontiguousarray(weights4, dtype=np.uint8).reshape(-1, 4)
+        assert len(p) == len(n) == len(j) == len(w)
+        _chk(self._L.rz_upload_mesh_soa(self._h, len(p), _fptr(p), _fptr(n),
+                                        j.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
+                                        w.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
+        self.V = len(p)
+        self.M = 0
+
+    def upload_skeleton(self, inverse_bind):
+        ib = _f32(inverse_bind).reshape(-1, 16)
+        _chk(self._L.rz_upload_skeleton(self._h, len(ib), _fptr(ib)))
+        self.B = len(ib)
+
+    def upload_morphs_dense(self, deltas):
+        if deltas is None or len(deltas) == 0:
+            _chk(self._L.rz_upload_morphs_dense(self._h, 0, None))
+            self.M = 0
+            return
+        d = _f32(deltas)
+        assert d.ndim == 3 and d.shape[1] == self.V and d.shape[2] == 3, d.shape
+        _chk(self._L.rz_upload_morphs_dense(self._h, d.shape[0], _fptr(d)))
+        self.M = d.shape[0]
+
+    def upload_morphs_sparse(self, morph_off, vert_idx, delta3):
+        mo = np.ascontiguousarray(morph_off, dtype=np.uint32)
+        vi = np.ascontiguousarray(vert_idx, dtype=np.uint32)
+        d = _f32(delta3).reshape(-1, 3)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        _chk(self._L.rz_upload_morphs_sparse(self._h, len(mo) - 1, mo.ctypes.data_as(u32p),
+                                             vi.ctypes.data_as(u32p), _fptr(d)))
+        self.M = len(mo) - 1
+
+    def set_instances(self, n):
+        _chk(self._L.rz_set_instances(self._h, int(n)))
+        self.I = int(n)
+
+    # ---- per frame ----
+    def set_pose(self, world, morph_weights=None):
+        w = _f32(world).reshape(-1)
+        assert w.size == self.I * self.B * 16, (w.size, self.I, self.B)
+        if morph_weights is not None and self.M > 0:
+            mw = _f32(morph_weights).reshape(-1)
+            assert mw.size == self.I * self.M
+            _chk(self._L.rz_set_pose(self._h, _fptr(w), _fptr(mw)))
+        else:
+            _chk(self._L.rz_set_pose(self._h, _fptr(w), None))
+
+    def deform(self):
+        _chk(self._L.rz_deform(self._h))
+
+    def deform_n(self, frames):
+        _chk(self._L.rz_deform_n(self._h, int(frames)))
+
+    def sync(self):
+        _chk(self._L.rz_sync(self._h))
+
+    def read(self, instance=0, v0=0, n=None):
+        n = self.V - v0 if n is None else n
+        pos = np.empty((n, 3), dtype=np.float32)
+        nrm = np.empty((n, 3), dtype=np.float32)
+        _chk(self._L.rz_read(self._h, int(instance), int(v0), int(n), _fptr(pos), _fptr(nrm)))
+        return pos, nrm
+
+    def read_palette(self, instance=0):
+        out = np.empty((self.B, 12), dtype=np.float32)
+        _chk(self._L.rz_read_palette(self._h, int(instance), _fptr(out)))
+        return out
+
+    def time_frames(self, frames):
+        t = RzTiming()
+        _chk(self._L.rz_time_frames(self._h, int(frames), ctypes.byref(t)))
+        return {k: getattr(t, k) for k, _ in RzTiming._fields_ if k != "reserved"}
+
+    def set_tuning(self, **kw):
+        for k, v in kw.items():
+            _chk(self._L.rz_set_tuning(self._h, k.encode(), int(v)))
+
+    def get_tuning(self, key):
+        v = ctypes.c_int(0)
+        _chk(self._L.rz_get_tuning(self._h, key.encode(), ctypes.byref(v)))
+        return v.value
+
+    def output_ptrs(self):
+        p = ctypes.c_void_p()
+        n = ctypes.c_void_p()
+        vp = ctypes.c_uint32(0)
+        _chk(self._L.rz_output_ptrs(self._h, ctypes.byref(p), ctypes.byref(n), ctypes.byref(vp)))
+        return p.value, n.value, vp.value
+
+    # ---- multi-GPU ----
+    def comm_init(self, nranks, rank, unique_id, v_total):
+        assert len(unique_id) == 128
+        _chk(self._L.rz_comm_init(self._h, int(nranks), int(rank), unique_id, int(v_total)))
+        self.v_total = int(v_total)
+
+    def allgather(self, with_normals=False):
+        _chk(self._L.rz_allgather(self._h, 1 if with_normals else 0))
+
+    def read_gathered(self, v0=0, n=None):
+        n = self.v_total - v0 if n is None else n
+        pos = np.empty((n, 3), dtype=np.float32)
+        nrm = np.empty((n, 3), dtype=np.float32)
+        _chk(self._L.rz_read_gathered(self._h, int(v0), int(n), _fptr(pos), _fptr(nrm)))
+        return pos, nrm

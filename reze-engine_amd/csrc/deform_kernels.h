@@ -1,0 +1,53 @@
+// deform_kernels.h — parameter blocks and launchers shared by deform_kernels.hip and reze_deform.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// rz_prep_kernel: palette = rows 0..2 of world * inverseBind (engine/src/engine.ts:926-928) and the
+// ordered list of morphs with a non-zero weight.
+struct RzPrepParams {
+    const float *world;      // [I][B][16] column-major
+    const float *inv_bind;   // [B][16]
+    float4 *palette;         // [I][B][3]  row-major 3x4
+    const float *morph_w;    // [I][M]
+    uint32_t *act_idx;       // [I][Mpad]
+    float *act_w;            // [I][Mpad]
+    int *act_count;          // [I]
+    int B;
+    int M;
+    int Mpad;
+};
+
+// rz_deform_kernel: fused morph + 4-bone LBS (engine/src/engine.ts:253-272).
+struct RzDeformParams {
+    const float *geom;          // 6 planes of Vp floats: x y z nx ny nz
+    const uint32_t *joints01;   // [Vp] j0 | j1 << 16
+    const uint32_t *joints23;   // [Vp] j2 | j3 << 16
+    const uint32_t *weights;    // [Vp] 4 x unorm8
+    const float4 *palette;      // [I][B][3]
+    const float *dense;         // [M][3][Vp] planes (MODE 1)
+    const uint32_t *act_idx;    // [I][Mpad]
+    const float *act_w;         // [I][Mpad]
+    const int *act_count;       // [I]
+    const float *morph_w;       // [I][M]   (MODE 2)
+    const uint32_t *sp_ptr;     // [Vp+1]   (MODE 2) per-vertex CSR row pointers
+    const float4 *sp_entries;   // [E]      (dx,dy,dz,bits(morph))
+    float *out_pos;             // [I][Vp][3]
+    float *out_nrm;             // [I][Vp][3]
+    uint32_t Vp;                // padded vertex count (multiple of 1024)
+    uint32_t n_tiles;           // Vp/4 / quads-per-tile
+    int B;
+    int M;
+    int Mpad;
+};
+
+hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t st);
+hipError_t rz_launch_deform(const RzDeformParams &p, int mode, int S, int U, bool nt, bool geo, uint32_t grid_x,
+                            uint32_t instances, hipStream_t st);
+size_t rz_deform_lds_bytes(const RzDeformParams &p, int S, bool geo);
+uint32_t rz_quads_per_tile(int S);
+hipError_t rz_launch_deinterleave(const float *src, int stride, int offset, uint32_t n, float *px, float *py,
+                                  float *pz, hipStream_t st);
+hipError_t rz_launch_pack_skinning(const uint16_t *joints4, const uint8_t *weights4, uint32_t n, uint32_t *j01,
+                                   uint32_t *j23, uint32_t *wq, hipStream_t st);

@@ -1,0 +1,464 @@
+// deform_kernels.hip — hand-written CDNA4 (gfx950) kernels for the per-frame PMX morph + skin path.
+//
+// Replaces, in the reference (paths relative to the reference repo root):
+//   rz_prep_kernel    the WGSL compute shader  engine/src/engine.ts:906-930
+//                     (skinMatrices[b] = worldMatrices[b] * inverseBindMatrices[b]) — plus the
+//                     active-morph compaction, which has no reference counterpart.
+//   rz_deform_kernel  the skinning body of the WGSL vertex shader vs()  engine/src/engine.ts:253-272
+//                     (and its copies :440-443, :700-703), run once per frame instead of once per
+//                     draw pass, fused with vertex-morph accumulation (new capability; the reference
+//                     skips PMX morphs, engine/src/pmx-loader.ts:450-553).
+//
+// Design (memory-bound gather-transform, no MFMA):
+//   * static mesh is planar SoA in HBM: x[],y[],z[],nx[],ny[],nz[] float planes, joints as two
+//     u32 planes (j0|j1<<16, j2|j3<<16), weights as one u32 plane, dense morph targets as
+//     D[m][3][Vp] planes. A lane owns a QUAD of 4 consecutive vertices, so every stream is read
+//     with one 16-byte load per lane = 1 KiB contiguous per wave-instruction.
+//   * the per-instance bone palette (3x4 affine rows, 48 B/bone) and the active-morph list are
+//     staged once per workgroup into LDS; bones are gathered from LDS with ds_read_b128.
+//   * MORPH SPLIT S: S lanes of a wave cooperate on one quad; lane-slice s accumulates the active
+//     morphs a = s, s+S, ... and the partial sums are combined with a __shfl_xor butterfly. S > 1
+//     multiplies the number of waves in flight when the per-GPU shard is small (8-GPU strong
+//     scaling); S = 1 is the pure streaming form for large shards.
+//   * outputs are packed float3 arrays (the vertex-buffer layout a renderer binds).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "deform_kernels.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float4 ld_stream(const float4 *p, bool nt)
+{
+    // morph planes are read exactly once per frame: optionally bypass-hint the load
+    if (nt) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: palette rows + ordered compaction of the non-zero morph weights. One workgroup per instance.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) rz_prep_kernel(RzPrepParams p)
+{
+    const int inst = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float *world = p.world + (size_t)inst * p.B * 16;
+    float4 *pal = p.palette + (size_t)inst * p.B * 3;
+
+    for (int b = tid; b < p.B; b += kBlock) {
+        const float4 *Wm = reinterpret_cast<const float4 *>(world + (size_t)b * 16);
+        const float4 *Im = reinterpret_cast<const float4 *>(p.inv_bind + (size_t)b * 16);
+        // column-major: a_k = column k of W (x,y,z = rows 0..2)
+        float4 a0 = Wm[0], a1 = Wm[1], a2 = Wm[2], a3 = Wm[3];
+        float r0[4], r1[4], r2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 bc = Im[c];
+            // out[c*4+r] = ((a0[r]*b0 + a1[r]*b1) + a2[r]*b2) + a3[r]*b3   (engine.ts:928)
+            r0[c] = fmaf(a3.x, bc.w, fmaf(a2.x, bc.z, fmaf(a1.x, bc.y, a0.x * bc.x)));
+            r1[c] = fmaf(a3.y, bc.w, fmaf(a2.y, bc.z, fmaf(a1.y, bc.y, a0.y * bc.x)));
+            r2[c] = fmaf(a3.z, bc.w, fmaf(a2.z, bc.z, fmaf(a1.z, bc.y, a0.z * bc.x)));
+        }
+        pal[b * 3 + 0] = make_float4(r0[0], r0[1], r0[2], r0[3]);
+        pal[b * 3 + 1] = make_float4(r1[0], r1[1], r1[2], r1[3]);
+        pal[b * 3 + 2] = make_float4(r2[0], r2[1], r2[2], r2[3]);
+    }
+
+    if (p.M > 0) {
+        __shared__ int wave_cnt[kBlock / 64];
+        const float *mw = p.morph_w + (size_t)inst * p.M;
+        uint32_t *aidx = p.act_idx + (size_t)inst * p.Mpad;
+        float *aw = p.act_w + (size_t)inst * p.Mpad;
+        const int lane = tid & 63, wave = tid >> 6;
+        int base = 0;
+        for (int m0 = 0; m0 < p.M; m0 += kBlock) {
+            int m = m0 + tid;
+            float w = (m < p.M) ? mw[m] : 0.0f;
+            bool on = (w != 0.0f);
+            unsigned long long bal = __ballot(on);
+            int rank = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_cnt[wave] = __popcll(bal);
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < kBlock / 64; ++k) {
+                int c = wave_cnt[k];
+                before += (k < wave) ? c : 0;
+                total += c;
+            }
+            if (on) {
+                aidx[base + before + rank] = (uint32_t)m;
+                aw[base + before + rank] = w;
+            }
+            base += total;
+            __syncthreads();
+        }
+        // pad the tail so unrolled readers may over-read harmlessly (weight 0, morph 0)
+        for (int k = base + tid; k < p.Mpad; k += kBlock) { aidx[k] = 0; aw[k] = 0.0f; }
+        if (tid == 0) p.act_count[inst] = base;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers for the skin phase
+// ------------------------------------------------------------------------------------------------
+struct Skinned { float px, py, pz, nx, ny, nz; };
+
+// vs() lines engine.ts:255-272 for one vertex. `pal` = LDS palette (3 float4 rows per bone),
+// `lut` = LDS table i/255 (exact unorm8 conversion, engine.ts:354-355).
+__device__ __forceinline__ Skinned skin_vertex(const float4 *pal, const float *lut, float x, float y,
+                                               float z, float nx, float ny, float nz, uint32_t j01,
+                                               uint32_t j23, uint32_t wq, uint32_t bmax)
+{
+    float w0 = lut[wq & 255u], w1 = lut[(wq >> 8) & 255u], w2 = lut[(wq >> 16) & 255u],
+          w3 = lut[wq >> 24];
+    float sum = ((w0 + w1) + w2) + w3;
+    bool ok = sum > 0.0001f;
+    float inv = ok ? 1.0f / sum : 1.0f;
+    w0 = ok ? w0 * inv : 1.0f;
+    w1 = ok ? w1 * inv : 0.0f;
+    w2 = ok ? w2 * inv : 0.0f;
+    w3 = ok ? w3 * inv : 0.0f;
+    // joints are < B by construction (pmx-loader.ts:861-880); clamp so bad input cannot read past the palette
+    const uint32_t j[4] = { min(j01 & 0xffffu, bmax), min(j01 >> 16, bmax), min(j23 & 0xffffu, bmax),
+                            min(j23 >> 16, bmax) };
+    const float w[4] = { w0, w1, w2, w3 };
+    float sx = 0.f, sy = 0.f, sz = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 r0 = pal[j[i] * 3 + 0], r1 = pal[j[i] * 3 + 1], r2 = pal[j[i] * 3 + 2];
+        float ax = fmaf(r0.z, z, fmaf(r0.y, y, r0.x * x)) + r0.w;
+        float ay = fmaf(r1.z, z, fmaf(r1.y, y, r1.x * x)) + r1.w;
+        float az = fmaf(r2.z, z, fmaf(r2.y, y, r2.x * x)) + r2.w;
+        sx = fmaf(ax, w[i], sx);
+        sy = fmaf(ay, w[i], sy);
+        sz = fmaf(az, w[i], sz);
+        float bx = fmaf(r0.z, nz, fmaf(r0.y, ny, r0.x * nx));
+        float by = fmaf(r1.z, nz, fmaf(r1.y, ny, r1.x * nx));
+        float bz = fmaf(r2.z, nz, fmaf(r2.y, ny, r2.x * nx));
+        tx = fmaf(bx, w[i], tx);
+        ty = fmaf(by, w[i], ty);
+        tz = fmaf(bz, w[i], tz);
+    }
+    float l2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+    bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
+    float rl = good ? (1.0f / sqrtf(l2)) : 0.0f;
+    Skinned o;
+    o.px = sx; o.py = sy; o.pz = sz;
+    o.nx = good ? tx * rl : nx;
+    o.ny = good ? ty * rl : ny;
+    o.nz = good ? tz * rl : nz;
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused morph + skin.
+//   S     morph-split: lanes per quad (1,2,4,8,16)
+//   U     morphs in flight per lane-slice iteration (3*U 16-byte loads issued back to back)
+//   MODE  0 = no morphs, 1 = dense planes, 2 = per-vertex sparse CSR (S must be 1)
+//   NT    nontemporal loads on the morph stream
+//   GEO   1 = rest geometry is read with 16-byte loads by the quad owner and transposed through
+//             the wave's LDS scratch; 0 = only the morphed position goes through LDS and the
+//             vertex-per-lane phase reads normal/joints/weights with 4-byte loads
+// grid = (tiles capped, instances); block = 256.
+// dynamic LDS = palette | 256-entry unorm LUT | active-morph list | per-wave transpose scratch.
+//
+// Two phases per tile, both fully coalesced:
+//   phase 1 (lane = quad of 4 vertices, slice s of S): stream the active morph planes with
+//           16-byte loads, FMA into 12 partial sums, __shfl_xor butterfly across the S slices,
+//           add to the rest position, park the quad in the wave's LDS scratch (ds_write_b128).
+//   phase 2 (lane = one vertex): read its attributes back (conflict-free ds_read_b32), gather the
+//           four bones' 3x4 rows from the LDS palette, LBS, normalize, store 12 B + 12 B per lane
+//           (a wave writes 768 contiguous bytes per store instruction).
+// ------------------------------------------------------------------------------------------------
+template <int S, int U, int MODE, bool NT, bool GEO>
+__global__ void __launch_bounds__(kBlock) rz_deform_kernel(RzDeformParams p)
+{
+    constexpr int QPW = 64 / S;              // quads per wave
+    constexpr int VW = 4 * QPW;              // vertices per wave per tile
+    constexpr int QPB = (kBlock / 64) * QPW; // quads per workgroup tile
+    constexpr int NPL = GEO ? 9 : 3;         // scratch planes per wave
+    constexpr int ROUNDS = (VW + 63) / 64;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *pal = reinterpret_cast<float4 *>(smem);                       // B*3 float4
+    float *lut = reinterpret_cast<float *>(smem + (size_t)p.B * 48);      // 256 floats
+    uint32_t *s_idx = reinterpret_cast<uint32_t *>(lut + 256);            // Mpad
+    float *s_w = reinterpret_cast<float *>(s_idx + p.Mpad);               // Mpad (MODE 2: all M weights)
+    float *scratch_all = s_w + p.Mpad;                                    // 4 waves x NPL x VW (16-B aligned: Mpad % 4 == 0)
+
+    const int tid = threadIdx.x;
+    const int inst = blockIdx.y;
+
+    {   // ---- stage per-instance state in LDS ----
+        const float4 *gpal = p.palette + (size_t)inst * p.B * 3;
+        for (int i = tid; i < p.B * 3; i += kBlock) pal[i] = gpal[i];
+        lut[tid] = (float)tid / 255.0f;
+        if (MODE == 1) {
+            const uint32_t *gi = p.act_idx + (size_t)inst * p.Mpad;
+            const float *gw = p.act_w + (size_t)inst * p.Mpad;
+            for (int i = tid; i < p.Mpad; i += kBlock) { s_idx[i] = gi[i]; s_w[i] = gw[i]; }
+        } else if (MODE == 2) {
+            const float *gw = p.morph_w + (size_t)inst * p.M;
+            for (int i = tid; i < p.M; i += kBlock) s_w[i] = gw[i];
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int s = lane / QPW;                // morph slice of this lane
+    const int qi = lane % QPW;
+    const int count = (MODE == 1) ? p.act_count[inst] : 0;
+    const size_t Vp = p.Vp;
+    const size_t plane4 = Vp / 4;            // float4 per plane
+    float *scr = scratch_all + (size_t)wave * NPL * VW;
+    const uint32_t bmax = (uint32_t)(p.B - 1);
+    float *opos = p.out_pos + (size_t)inst * Vp * 3;
+    float *onrm = p.out_nrm + (size_t)inst * Vp * 3;
+
+    for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        const size_t qw = (size_t)tile * QPB + (size_t)wave * QPW;   // first quad of this wave
+        const size_t q = qw + qi;                                    // this lane's quad
+        float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), ay = ax, az = ax;
+
+        // rest geometry of the quad (slice 0 only); issued first so it overlaps the morph stream
+        float4 gx, gy, gz, gnx, gny, gnz;
+        uint4 gj01, gj23, gw;
+        if (s == 0) {
+            const float4 *G = reinterpret_cast<const float4 *>(p.geom) + q;
+            gx = G[0]; gy = G[plane4]; gz = G[2 * plane4];
+            if (GEO) {
+                gnx = G[3 * plane4]; gny = G[4 * plane4]; gnz = G[5 * plane4];
+                gj01 = reinterpret_cast<const uint4 *>(p.joints01)[q];
+                gj23 = reinterpret_cast<const uint4 *>(p.joints23)[q];
+                gw = reinterpret_cast<const uint4 *>(p.weights)[q];
+            }
+        }
+
+        if (MODE == 1) {
+            const float4 *D = reinterpret_cast<const float4 *>(p.dense) + q;
+            int a = s;
+            // full groups of U morphs: 3*U independent 16-byte loads in flight per lane
+            for (; a + (U - 1) * S < count; a += U * S) {
+                float4 dx[U], dy[U], dz[U];
+                float w[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t m = s_idx[a + u * S];
+                    w[u] = s_w[a + u * S];
+                    const float4 *d = D + (size_t)m * 3 * plane4;
+                    dx[u] = ld_stream(d, NT);
+                    dy[u] = ld_stream(d + plane4, NT);
+                    dz[u] = ld_stream(d + 2 * plane4, NT);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    ax.x = fmaf(w[u], dx[u].x, ax.x); ax.y = fmaf(w[u], dx[u].y, ax.y);
+                    ax.z = fmaf(w[u], dx[u].z, ax.z); ax.w = fmaf(w[u], dx[u].w, ax.w);
+                    ay.x = fmaf(w[u], dy[u].x, ay.x); ay.y = fmaf(w[u], dy[u].y, ay.y);
+                    ay.z = fmaf(w[u], dy[u].z, ay.z); ay.w = fmaf(w[u], dy[u].w, ay.w);
+                    az.x = fmaf(w[u], dz[u].x, az.x); az.y = fmaf(w[u], dz[u].y, az.y);
+                    az.z = fmaf(w[u], dz[u].z, az.z); az.w = fmaf(w[u], dz[u].w, az.w);
+                }
+            }
+            for (; a < count; a += S) {     // remainder, one morph at a time
+                const uint32_t m = s_idx[a];
+                const float w = s_w[a];
+                const float4 *d = D + (size_t)m * 3 * plane4;
+                float4 dx = ld_stream(d, NT), dy = ld_stream(d + plane4, NT), dz = ld_stream(d + 2 * plane4, NT);
+                ax.x = fmaf(w, dx.x, ax.x); ax.y = fmaf(w, dx.y, ax.y); ax.z = fmaf(w, dx.z, ax.z); ax.w = fmaf(w, dx.w, ax.w);
+                ay.x = fmaf(w, dy.x, ay.x); ay.y = fmaf(w, dy.y, ay.y); ay.z = fmaf(w, dy.z, ay.z); ay.w = fmaf(w, dy.w, ay.w);
+                az.x = fmaf(w, dz.x, az.x); az.y = fmaf(w, dz.y, az.y); az.z = fmaf(w, dz.z, az.z); az.w = fmaf(w, dz.w, az.w);
+            }
+            if (S > 1) {
+                // combine the S partial sums of each quad: butterfly over the slice bits of the lane id
+#pragma unroll
+                for (int off = QPW; off < 64; off <<= 1) {
+                    ax.x += __shfl_xor(ax.x, off); ax.y += __shfl_xor(ax.y, off);
+                    ax.z += __shfl_xor(ax.z, off); ax.w += __shfl_xor(ax.w, off);
+                    ay.x += __shfl_xor(ay.x, off); ay.y += __shfl_xor(ay.y, off);
+                    ay.z += __shfl_xor(ay.z, off); ay.w += __shfl_xor(ay.w, off);
+                    az.x += __shfl_xor(az.x, off); az.y += __shfl_xor(az.y, off);
+                    az.z += __shfl_xor(az.z, off); az.w += __shfl_xor(az.w, off);
+                }
+            }
+        } else if (MODE == 2) {
+            // per-vertex CSR: entry = (dx,dy,dz, bits(morph)); entries of a vertex sorted by morph
+            const uint32_t *ptr = p.sp_ptr + q * 4;
+            const uint4 lo = *reinterpret_cast<const uint4 *>(ptr);
+            const uint32_t b[5] = { lo.x, lo.y, lo.z, lo.w, ptr[4] };
+            float sx[4] = {0, 0, 0, 0}, sy[4] = {0, 0, 0, 0}, sz[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                for (uint32_t e = b[k]; e < b[k + 1]; ++e) {
+                    const float4 ent = p.sp_entries[e];
+                    const float w = s_w[__float_as_uint(ent.w)];
+                    sx[k] = fmaf(w, ent.x, sx[k]); sy[k] = fmaf(w, ent.y, sy[k]); sz[k] = fmaf(w, ent.z, sz[k]);
+                }
+            }
+            ax = make_float4(sx[0], sx[1], sx[2], sx[3]);
+            ay = make_float4(sy[0], sy[1], sy[2], sy[3]);
+            az = make_float4(sz[0], sz[1], sz[2], sz[3]);
+        }
+
+        // ---- park the quad in the wave's scratch: plane-major [NPL][VW] dwords ----
+        if (s == 0) {
+            float4 *sc4 = reinterpret_cast<float4 *>(scr) + qi;
+            sc4[0 * QPW] = make_float4(gx.x + ax.x, gx.y + ax.y, gx.z + ax.z, gx.w + ax.w);
+            sc4[1 * QPW] = make_float4(gy.x + ay.x, gy.y + ay.y, gy.z + ay.z, gy.w + ay.w);
+            sc4[2 * QPW] = make_float4(gz.x + az.x, gz.y + az.y, gz.z + az.z, gz.w + az.w);
+            if (GEO) {
+                sc4[3 * QPW] = gnx; sc4[4 * QPW] = gny; sc4[5 * QPW] = gnz;
+                uint4 *su4 = reinterpret_cast<uint4 *>(scr) + qi;
+                su4[6 * QPW] = gj01; su4[7 * QPW] = gj23; su4[8 * QPW] = gw;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- phase 2: one vertex per lane ----
+        const size_t vw0 = qw * 4;     // first vertex of this wave's tile
+#pragma unroll 1
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int vl = r * 64 + lane;
+            if (vl < VW) {
+                const size_t v = vw0 + vl;
+                const float x = scr[0 * VW + vl], y = scr[1 * VW + vl], z = scr[2 * VW + vl];
+                float nx, ny, nz;
+                uint32_t j01, j23, wq;
+                if (GEO) {
+                    nx = scr[3 * VW + vl]; ny = scr[4 * VW + vl]; nz = scr[5 * VW + vl];
+                    const uint32_t *su = reinterpret_cast<const uint32_t *>(scr);
+                    j01 = su[6 * VW + vl]; j23 = su[7 * VW + vl]; wq = su[8 * VW + vl];
+                } else {
+                    nx = p.geom[3 * Vp + v]; ny = p.geom[4 * Vp + v]; nz = p.geom[5 * Vp + v];
+                    j01 = p.joints01[v]; j23 = p.joints23[v]; wq = p.weights[v];
+                }
+                Skinned o = skin_vertex(pal, lut, x, y, z, nx, ny, nz, j01, j23, wq, bmax);
+                float *dp = opos + v * 3;
+                float *dn = onrm + v * 3;
+                dp[0] = o.px; dp[1] = o.py; dp[2] = o.pz;
+                dn[0] = o.nx; dn[1] = o.ny; dn[2] = o.nz;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// upload-time re-layout kernels (one-off, not on the per-frame path)
+// ------------------------------------------------------------------------------------------------
+// packed [n][stride] floats -> planes; `stride` = 3 (packed xyz) or 8 (reference interleaved vertex)
+__global__ void rz_deinterleave_kernel(const float *src, int stride, int offset, uint32_t n, float *px,
+                                       float *py, float *pz)
+{
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const float *s = src + (size_t)v * stride + offset;
+    px[v] = s[0]; py[v] = s[1]; pz[v] = s[2];
+}
+
+__global__ void rz_pack_skinning_kernel(const uint16_t *joints4, const uint8_t *weights4, uint32_t n,
+                                        uint32_t *j01, uint32_t *j23, uint32_t *wq)
+{
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint2 j = reinterpret_cast<const uint2 *>(joints4)[v];
+    j01[v] = j.x; j23[v] = j.y;
+    wq[v] = reinterpret_cast<const uint32_t *>(weights4)[v];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers (C++ linkage, used by reze_deform.cpp)
+// ------------------------------------------------------------------------------------------------
+hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t st)
+{
+    hipLaunchKernelGGL(rz_prep_kernel, dim3(instances), dim3(kBlock), 0, st, p);
+    return hipGetLastError();
+}
+
+size_t rz_deform_lds_bytes(const RzDeformParams &p, int S, bool geo)
+{
+    const size_t vw = 256 / S;   // vertices per wave per tile
+    return (size_t)p.B * 48 + 256 * 4 + (size_t)p.Mpad * 8 + (size_t)(kBlock / 64) * (geo ? 9 : 3) * vw * 4;
+}
+
+uint32_t rz_quads_per_tile(int S) { return (kBlock / 64) * (64 / S); }
+
+template <int S, int U, int MODE, bool NT, bool GEO>
+static hipError_t launch_one(const RzDeformParams &p, dim3 grid, size_t lds, hipStream_t st)
+{
+    auto k = rz_deform_kernel<S, U, MODE, NT, GEO>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p);
+    return hipGetLastError();
+}
+
+template <int S, int U, int MODE>
+static hipError_t launch_flags(const RzDeformParams &p, bool nt, bool geo, dim3 grid, size_t lds, hipStream_t st)
+{
+    if (MODE != 1) nt = false;   // the nontemporal hint only exists on the dense morph stream
+    if (nt) return geo ? launch_one<S, U, MODE, true, true>(p, grid, lds, st)
+                       : launch_one<S, U, MODE, true, false>(p, grid, lds, st);
+    return geo ? launch_one<S, U, MODE, false, true>(p, grid, lds, st)
+               : launch_one<S, U, MODE, false, false>(p, grid, lds, st);
+}
+
+template <int S>
+static hipError_t launch_dense(const RzDeformParams &p, int U, bool nt, bool geo, dim3 grid, size_t lds,
+                               hipStream_t st)
+{
+    switch (U) {
+    case 1: return launch_flags<S, 1, 1>(p, nt, geo, grid, lds, st);
+    case 2: return launch_flags<S, 2, 1>(p, nt, geo, grid, lds, st);
+    case 8: return launch_flags<S, 8, 1>(p, nt, geo, grid, lds, st);
+    default: return launch_flags<S, 4, 1>(p, nt, geo, grid, lds, st);
+    }
+}
+
+hipError_t rz_launch_deform(const RzDeformParams &p, int mode, int S, int U, bool nt, bool geo, uint32_t grid_x,
+                            uint32_t instances, hipStream_t st)
+{
+    if (mode != 1) S = 1;        // morph split only applies to the dense stream
+    const size_t lds = rz_deform_lds_bytes(p, S, geo);
+    dim3 grid(grid_x, instances);
+    if (mode == 0) return launch_flags<1, 1, 0>(p, false, geo, grid, lds, st);
+    if (mode == 2) return launch_flags<1, 1, 2>(p, false, geo, grid, lds, st);
+    switch (S) {
+    case 2: return launch_dense<2>(p, U, nt, geo, grid, lds, st);
+    case 4: return launch_dense<4>(p, U, nt, geo, grid, lds, st);
+    case 8: return launch_dense<8>(p, U, nt, geo, grid, lds, st);
+    case 16: return launch_dense<16>(p, U, nt, geo, grid, lds, st);
+    default: return launch_dense<1>(p, U, nt, geo, grid, lds, st);
+    }
+}
+
+hipError_t rz_launch_deinterleave(const float *src, int stride, int offset, uint32_t n, float *px, float *py,
+                                  float *pz, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rz_deinterleave_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, stride, offset, n,
+                       px, py, pz);
+    return hipGetLastError();
+}
+
+hipError_t rz_launch_pack_skinning(const uint16_t *joints4, const uint8_t *weights4, uint32_t n, uint32_t *j01,
+                                   uint32_t *j23, uint32_t *wq, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rz_pack_skinning_kernel, dim3((n + 255) / 256), dim3(256), 0, st, joints4, weights4, n,
+                       j01, j23, wq);
+    return hipGetLastError();
+}

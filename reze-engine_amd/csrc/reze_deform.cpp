@@ -1,0 +1,780 @@
+// reze_deform.cpp — implementation of the C ABI in include/reze_deform.h.
+//
+// One rz_ctx = one MI355X: a HIP stream, the static mesh shard re-laid-out as planar SoA, the
+// skeleton, optional morph targets, per-frame pose staging, output buffers, and (optionally) an
+// RCCL communicator for the all-gather of deformed positions. Every entry point cites, in the
+// header, the reference call site it replaces; this file is only plumbing around
+// deform_kernels.hip. There is NO CPU fallback: without a working HIP device every call fails.
+#include "../../include/reze_deform.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "deform_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(e_ == hipErrorOutOfMemory ? RZ_ERR_OOM : RZ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                 \
+    } while (0)
+
+uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+constexpr uint32_t kVertPad = 1024;   // planes are padded to a whole S=1 tile (256 quads)
+constexpr int kStageSlots = 4;
+
+// ---- lazily bound RCCL (librccl.so.1 is only needed by the multi-GPU entry points) ----
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_bind()
+{
+    if (g_rccl.h) return RZ_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(RZ_ERR_UNSUPPORTED, "RCCL not available: %s", dlerror());
+    Rccl r;
+    r.h = h;
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+        return fail(RZ_ERR_UNSUPPORTED, "RCCL symbols missing");
+    g_rccl = r;
+    return RZ_OK;
+}
+
+#define NCCL_TRY(expr)                                                                              \
+    do {                                                                                            \
+        ncclResult_t r_ = (expr);                                                                   \
+        if (r_ != ncclSuccess)                                                                      \
+            return fail(RZ_ERR_RCCL, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));            \
+    } while (0)
+
+}  // namespace
+
+struct rz_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // static mesh shard
+    uint32_t V = 0, Vp = 0;
+    float *geom = nullptr;              // 6 x Vp
+    uint32_t *j01 = nullptr, *j23 = nullptr, *wq = nullptr;
+
+    // skeleton
+    uint32_t B = 0;
+    float *inv_bind = nullptr;          // B x 16
+
+    // morphs
+    int morph_mode = 0;                 // 0 none, 1 dense, 2 sparse
+    uint32_t M = 0, Mpad = 4;
+    float *dense = nullptr;             // M x 3 x Vp
+    uint32_t *sp_ptr = nullptr;         // Vp + 1
+    float4 *sp_entries = nullptr;
+    uint64_t sp_count = 0;
+
+    // per-frame state
+    uint32_t I = 1;
+    float *world = nullptr;             // I x B x 16
+    float4 *palette = nullptr;          // I x B x 3
+    float *morph_w = nullptr;           // I x M
+    uint32_t *act_idx = nullptr;        // I x Mpad
+    float *act_w = nullptr;             // I x Mpad
+    int *act_count = nullptr;           // I
+    bool pose_set = false;
+    size_t pose_alloc_I = 0, pose_alloc_B = 0, pose_alloc_M = 0;
+
+    // outputs
+    float *out_pos = nullptr, *out_nrm = nullptr;
+    size_t out_alloc_floats = 0;
+
+    // pinned staging ring for rz_set_pose
+    void *stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes = 0;
+    hipEvent_t stage_ev[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool stage_used[kStageSlots] = {false, false, false, false};
+    int stage_next = 0;
+
+    // tuning
+    int t_split = 0, t_unroll = 4, t_grid_cap = 0, t_nt = 0, t_geo = 1;
+
+    // multi-GPU
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    uint32_t v_total = 0, chunk = 0;
+    float *g_pos = nullptr, *g_nrm = nullptr;   // nranks x chunk x 3
+};
+
+namespace {
+
+int use(rz_ctx *c)
+{
+    if (!c) return fail(RZ_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return RZ_OK;
+}
+
+template <class T> void dfree(T *&p)
+{
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+int ensure_outputs(rz_ctx *c)
+{
+    // one instance: room for a whole all-gather chunk; instances are strided by Vp
+    const size_t need = (c->I == 1) ? std::max<size_t>(c->Vp, c->chunk) * 3 : (size_t)c->I * c->Vp * 3;
+    if (need == 0) return RZ_OK;
+    if (need > c->out_alloc_floats) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        dfree(c->out_pos);
+        dfree(c->out_nrm);
+        HIP_TRY(hipMalloc(&c->out_pos, need * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->out_nrm, need * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(c->out_pos, 0, need * sizeof(float), c->stream));
+        HIP_TRY(hipMemsetAsync(c->out_nrm, 0, need * sizeof(float), c->stream));
+        c->out_alloc_floats = need;
+    }
+    return RZ_OK;
+}
+
+int ensure_pose_buffers(rz_ctx *c)
+{
+    if (c->B == 0) return RZ_OK;
+    const uint32_t Mq = std::max<uint32_t>(c->M, 1);
+    if (c->I <= c->pose_alloc_I && c->B <= c->pose_alloc_B && Mq <= c->pose_alloc_M && c->world) return RZ_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dfree(c->world); dfree(c->palette); dfree(c->morph_w); dfree(c->act_idx); dfree(c->act_w); dfree(c->act_count);
+    const size_t I = c->I, B = c->B;
+    const size_t Mpad = round_up(Mq, 4);
+    HIP_TRY(hipMalloc(&c->world, I * B * 16 * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->palette, I * B * 3 * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->morph_w, I * Mq * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->act_idx, I * Mpad * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->act_w, I * Mpad * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->act_count, I * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(c->morph_w, 0, I * Mq * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->act_idx, 0, I * Mpad * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->act_w, 0, I * Mpad * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->act_count, 0, I * sizeof(int), c->stream));
+    c->pose_alloc_I = I; c->pose_alloc_B = B; c->pose_alloc_M = Mq;
+    c->pose_set = false;
+    return RZ_OK;
+}
+
+void free_morphs(rz_ctx *c)
+{
+    dfree(c->dense); dfree(c->sp_ptr); dfree(c->sp_entries);
+    c->morph_mode = 0; c->M = 0; c->Mpad = 4; c->sp_count = 0;
+    c->pose_set = false;                  // morph weights belong to the old target set
+}
+
+int auto_split(const rz_ctx *c)
+{
+    if (c->morph_mode != 1) return 1;
+    // enough waves to cover every CU ~8 deep; S lanes share a quad, so waves = quads * S / 64
+    const uint64_t quads = (uint64_t)c->Vp / 4 * c->I;
+    const uint64_t want = (uint64_t)c->n_cu * 8;
+    int S = 1;
+    while (S < 16 && quads * S / 64 < want) S <<= 1;
+    while (S > 1 && (uint32_t)S > c->M) S >>= 1;
+    return S;
+}
+
+struct Plan { int mode, S, U; bool nt, geo; uint32_t grid_x, n_tiles; };
+
+Plan make_plan(const rz_ctx *c)
+{
+    Plan pl;
+    pl.mode = c->morph_mode;
+    pl.S = (pl.mode == 1) ? (c->t_split > 0 ? c->t_split : auto_split(c)) : 1;
+    pl.U = c->t_unroll;
+    pl.nt = c->t_nt != 0;
+    pl.geo = c->t_geo != 0;
+    pl.n_tiles = (c->Vp / 4) / rz_quads_per_tile(pl.S);
+    uint32_t cap = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : 8u * (uint32_t)c->n_cu;   // total workgroups
+    uint32_t gx = std::max<uint32_t>(1, cap / std::max<uint32_t>(1, c->I));
+    pl.grid_x = std::min(pl.n_tiles, gx);
+    return pl;
+}
+
+RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
+{
+    RzDeformParams p;
+    memset(&p, 0, sizeof p);
+    p.geom = c->geom; p.joints01 = c->j01; p.joints23 = c->j23; p.weights = c->wq;
+    p.palette = c->palette; p.dense = c->dense;
+    p.act_idx = c->act_idx; p.act_w = c->act_w; p.act_count = c->act_count; p.morph_w = c->morph_w;
+    p.sp_ptr = c->sp_ptr; p.sp_entries = c->sp_entries;
+    p.out_pos = c->out_pos; p.out_nrm = c->out_nrm;
+    p.Vp = c->Vp; p.n_tiles = pl.n_tiles; p.B = (int)c->B; p.M = (int)c->M; p.Mpad = (int)c->Mpad;
+    return p;
+}
+
+RzPrepParams prep_params(const rz_ctx *c)
+{
+    RzPrepParams p;
+    memset(&p, 0, sizeof p);
+    p.world = c->world; p.inv_bind = c->inv_bind; p.palette = c->palette; p.morph_w = c->morph_w;
+    p.act_idx = c->act_idx; p.act_w = c->act_w; p.act_count = c->act_count;
+    p.B = (int)c->B; p.M = (int)c->M; p.Mpad = (int)c->Mpad;
+    return p;
+}
+
+int check_ready(rz_ctx *c)
+{
+    if (c->V == 0 || !c->geom) return fail(RZ_ERR_INVALID, "no mesh uploaded (rz_upload_mesh)");
+    if (c->B == 0 || !c->inv_bind) return fail(RZ_ERR_INVALID, "no skeleton uploaded (rz_upload_skeleton)");
+    if (!c->pose_set) return fail(RZ_ERR_INVALID, "no pose set (rz_set_pose)");
+    return RZ_OK;
+}
+
+int launch_prep(rz_ctx *c)
+{
+    HIP_TRY(rz_launch_prep(prep_params(c), c->I, c->stream));
+    return RZ_OK;
+}
+
+int launch_deform(rz_ctx *c, const Plan &pl)
+{
+    RzDeformParams p = deform_params(c, pl);
+    size_t lds = rz_deform_lds_bytes(p, pl.S, pl.geo);
+    if (lds > 160 * 1024) return fail(RZ_ERR_UNSUPPORTED, "skeleton too large for the LDS palette (%zu B)", lds);
+    HIP_TRY(rz_launch_deform(p, pl.mode, pl.S, pl.U, pl.nt, pl.geo, pl.grid_x, c->I, c->stream));
+    return RZ_OK;
+}
+
+uint64_t algorithmic_bytes(const rz_ctx *c)
+{
+    // 36 B read + 24 B written per vertex, 12*M B of dense morph targets per vertex,
+    // world + inverse-bind matrices, morph weights. The static mesh is counted once for instances.
+    const uint64_t V = c->V, I = c->I, B = c->B, M = c->M;
+    uint64_t bytes = V * 36 + I * (V * 24 + B * 64) + B * 64;
+    if (c->morph_mode == 1) bytes += I * (V * 12 * M + M * 4);
+    if (c->morph_mode == 2) bytes += V * 4 + I * (c->sp_count * 16 + M * 4);
+    return bytes;
+}
+
+int upload_skinning(rz_ctx *c, uint32_t V, const uint16_t *joints4, const uint8_t *weights4)
+{
+    uint16_t *dj = nullptr;
+    uint8_t *dw = nullptr;
+    HIP_TRY(hipMalloc(&dj, (size_t)V * 8));
+    HIP_TRY(hipMalloc(&dw, (size_t)V * 4));
+    HIP_TRY(hipMemcpy(dj, joints4, (size_t)V * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dw, weights4, (size_t)V * 4, hipMemcpyHostToDevice));
+    HIP_TRY(rz_launch_pack_skinning(dj, dw, V, c->j01, c->j23, c->wq, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(dj);
+    (void)hipFree(dw);
+    return RZ_OK;
+}
+
+int alloc_mesh(rz_ctx *c, uint32_t V)
+{
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq);
+    free_morphs(c);                       // morph targets are per-vertex: a new mesh invalidates them
+    c->V = V;
+    c->Vp = round_up(V, kVertPad);
+    const size_t Vp = c->Vp;
+    HIP_TRY(hipMalloc(&c->geom, 6 * Vp * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->j01, Vp * 4));
+    HIP_TRY(hipMalloc(&c->j23, Vp * 4));
+    HIP_TRY(hipMalloc(&c->wq, Vp * 4));
+    // padding vertices: zero position/normal, joint 0, weights 0 (takes the (1,0,0,0) branch)
+    HIP_TRY(hipMemsetAsync(c->geom, 0, 6 * Vp * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->j01, 0, Vp * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->j23, 0, Vp * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->wq, 0, Vp * 4, c->stream));
+    return RZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rz_last_error(void) { return g_err.c_str(); }
+int rz_abi_version(void) { return RZ_ABI_VERSION; }
+
+int rz_device_count(int *count)
+{
+    if (!count) return fail(RZ_ERR_INVALID, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(RZ_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return RZ_OK;
+}
+
+int rz_create(int device, rz_ctx **out)
+{
+    if (!out) return fail(RZ_ERR_INVALID, "null out");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(RZ_ERR_NO_DEVICE, "no HIP device: %s", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(RZ_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RZ_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", device,
+                    prop.gcnArchName);
+    rz_ctx *c = new rz_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipEventCreate(&c->ev0);
+    if (se == hipSuccess) se = hipEventCreate(&c->ev1);
+    for (int i = 0; i < kStageSlots && se == hipSuccess; ++i)
+        se = hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming);
+    if (se != hipSuccess) {
+        rz_destroy(c);
+        return fail(RZ_ERR_HIP, "context setup failed: %s", hipGetErrorString(se));
+    }
+    *out = c;
+    return RZ_OK;
+}
+
+int rz_destroy(rz_ctx *c)
+{
+    if (!c) return RZ_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->inv_bind);
+    free_morphs(c);
+    dfree(c->world); dfree(c->palette); dfree(c->morph_w); dfree(c->act_idx); dfree(c->act_w); dfree(c->act_count);
+    dfree(c->out_pos); dfree(c->out_nrm); dfree(c->g_pos); dfree(c->g_nrm);
+    for (int i = 0; i < kStageSlots; ++i) {
+        if (c->stage[i]) (void)hipHostFree(c->stage[i]);
+        if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
+    }
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RZ_OK;
+}
+
+int rz_shard_range(uint32_t v_total, int nranks, int rank, uint32_t *begin, uint32_t *count)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks || !begin || !count)
+        return fail(RZ_ERR_INVALID, "bad shard query (nranks=%d rank=%d)", nranks, rank);
+    const uint64_t per = ((uint64_t)v_total + nranks - 1) / nranks;
+    const uint64_t chunk = (per + kVertPad - 1) / kVertPad * kVertPad;
+    uint64_t b = std::min<uint64_t>(v_total, chunk * (uint64_t)rank);
+    uint64_t n = std::min<uint64_t>(chunk, v_total - b);
+    *begin = (uint32_t)b;
+    *count = (uint32_t)n;
+    return RZ_OK;
+}
+
+int rz_upload_mesh(rz_ctx *c, uint32_t V, const float *interleaved8, const uint16_t *joints4, const uint8_t *weights4)
+{
+    if (int r = use(c)) return r;
+    if (V == 0 || !interleaved8 || !joints4 || !weights4) return fail(RZ_ERR_INVALID, "rz_upload_mesh: empty mesh or null array");
+    if (int r = alloc_mesh(c, V)) return r;
+    float *tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)V * 8 * sizeof(float)));
+    HIP_TRY(hipMemcpy(tmp, interleaved8, (size_t)V * 8 * sizeof(float), hipMemcpyHostToDevice));
+    const size_t Vp = c->Vp;
+    HIP_TRY(rz_launch_deinterleave(tmp, 8, 0, V, c->geom, c->geom + Vp, c->geom + 2 * Vp, c->stream));
+    HIP_TRY(rz_launch_deinterleave(tmp, 8, 3, V, c->geom + 3 * Vp, c->geom + 4 * Vp, c->geom + 5 * Vp, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(tmp);
+    if (int r = upload_skinning(c, V, joints4, weights4)) return r;
+    return ensure_outputs(c);
+}
+
+int rz_upload_mesh_soa(rz_ctx *c, uint32_t V, const float *pos3, const float *nrm3, const uint16_t *joints4,
+                       const uint8_t *weights4)
+{
+    if (int r = use(c)) return r;
+    if (V == 0 || !pos3 || !nrm3 || !joints4 || !weights4) return fail(RZ_ERR_INVALID, "rz_upload_mesh_soa: empty mesh or null array");
+    if (int r = alloc_mesh(c, V)) return r;
+    float *tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)V * 3 * sizeof(float)));
+    const size_t Vp = c->Vp;
+    HIP_TRY(hipMemcpy(tmp, pos3, (size_t)V * 3 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(rz_launch_deinterleave(tmp, 3, 0, V, c->geom, c->geom + Vp, c->geom + 2 * Vp, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(tmp, nrm3, (size_t)V * 3 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(rz_launch_deinterleave(tmp, 3, 0, V, c->geom + 3 * Vp, c->geom + 4 * Vp, c->geom + 5 * Vp, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(tmp);
+    if (int r = upload_skinning(c, V, joints4, weights4)) return r;
+    return ensure_outputs(c);
+}
+
+int rz_upload_skeleton(rz_ctx *c, uint32_t B, const float *inverse_bind16)
+{
+    if (int r = use(c)) return r;
+    if (B == 0 || !inverse_bind16) return fail(RZ_ERR_INVALID, "rz_upload_skeleton: model has no bones");
+    if ((size_t)B * 48 + 8192 > 160 * 1024) return fail(RZ_ERR_UNSUPPORTED, "more than %d bones do not fit the LDS palette", (160 * 1024 - 8192) / 48);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dfree(c->inv_bind);
+    HIP_TRY(hipMalloc(&c->inv_bind, (size_t)B * 16 * sizeof(float)));
+    HIP_TRY(hipMemcpy(c->inv_bind, inverse_bind16, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice));
+    c->B = B;
+    c->pose_set = false;
+    return ensure_pose_buffers(c);
+}
+
+int rz_upload_morphs_dense(rz_ctx *c, uint32_t M, const float *deltas)
+{
+    if (int r = use(c)) return r;
+    if (c->V == 0) return fail(RZ_ERR_INVALID, "upload the mesh before its morph targets");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_morphs(c);
+    if (M == 0) return ensure_pose_buffers(c);
+    if (!deltas) return fail(RZ_ERR_INVALID, "null morph deltas");
+    const size_t Vp = c->Vp, V = c->V;
+    HIP_TRY(hipMalloc(&c->dense, (size_t)M * 3 * Vp * sizeof(float)));
+    if (Vp != V) HIP_TRY(hipMemsetAsync(c->dense, 0, (size_t)M * 3 * Vp * sizeof(float), c->stream));
+    // stream the host array through a bounded device staging buffer, re-laying each morph into planes
+    const uint32_t batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(M, (64u << 20) / (V * 12)));
+    float *tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)batch * V * 3 * sizeof(float)));
+    for (uint32_t m0 = 0; m0 < M; m0 += batch) {
+        const uint32_t nb = std::min(batch, M - m0);
+        HIP_TRY(hipMemcpy(tmp, deltas + (size_t)m0 * V * 3, (size_t)nb * V * 3 * sizeof(float), hipMemcpyHostToDevice));
+        for (uint32_t k = 0; k < nb; ++k) {
+            float *pl = c->dense + (size_t)(m0 + k) * 3 * Vp;
+            HIP_TRY(rz_launch_deinterleave(tmp + (size_t)k * V * 3, 3, 0, (uint32_t)V, pl, pl + Vp, pl + 2 * Vp, c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    (void)hipFree(tmp);
+    c->morph_mode = 1;
+    c->M = M;
+    c->Mpad = round_up(M, 4);
+    return ensure_pose_buffers(c);
+}
+
+int rz_upload_morphs_sparse(rz_ctx *c, uint32_t M, const uint32_t *morph_off, const uint32_t *vert_idx, const float *delta3)
+{
+    if (int r = use(c)) return r;
+    if (c->V == 0) return fail(RZ_ERR_INVALID, "upload the mesh before its morph targets");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_morphs(c);
+    if (M == 0) return ensure_pose_buffers(c);
+    if (!morph_off) return fail(RZ_ERR_INVALID, "null morph offsets");
+    const uint32_t E = morph_off[M];
+    if (E > 0 && (!vert_idx || !delta3)) return fail(RZ_ERR_INVALID, "null morph entries");
+    for (uint32_t m = 0; m < M; ++m)
+        if (morph_off[m] > morph_off[m + 1]) return fail(RZ_ERR_INVALID, "morph offsets must be non-decreasing");
+    // transpose morph-major (PMX file order) into a per-vertex CSR; a vertex's entries keep
+    // ascending morph order (then file order), which is the oracle's accumulation order
+    const size_t Vp = c->Vp;
+    std::vector<uint32_t> ptr(Vp + 1, 0);
+    for (uint32_t e = 0; e < E; ++e)
+        if (vert_idx[e] < c->V) ptr[vert_idx[e] + 1]++;
+    for (size_t v = 0; v < Vp; ++v) ptr[v + 1] += ptr[v];
+    const uint32_t kept = ptr[Vp];
+    std::vector<float4> ent(std::max<uint32_t>(kept, 1));
+    std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
+    for (uint32_t m = 0; m < M; ++m)
+        for (uint32_t e = morph_off[m]; e < morph_off[m + 1]; ++e) {
+            const uint32_t v = vert_idx[e];
+            if (v >= c->V) continue;
+            float4 x;
+            x.x = delta3[(size_t)e * 3]; x.y = delta3[(size_t)e * 3 + 1]; x.z = delta3[(size_t)e * 3 + 2];
+            memcpy(&x.w, &m, 4);
+            ent[cur[v]++] = x;
+        }
+    HIP_TRY(hipMalloc(&c->sp_ptr, (Vp + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->sp_entries, ent.size() * sizeof(float4)));
+    HIP_TRY(hipMemcpy(c->sp_ptr, ptr.data(), (Vp + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->sp_entries, ent.data(), ent.size() * sizeof(float4), hipMemcpyHostToDevice));
+    c->sp_count = kept;
+    c->morph_mode = 2;
+    c->M = M;
+    c->Mpad = round_up(M, 4);
+    return ensure_pose_buffers(c);
+}
+
+int rz_set_instances(rz_ctx *c, uint32_t I)
+{
+    if (int r = use(c)) return r;
+    if (I == 0 || I > 65535) return fail(RZ_ERR_INVALID, "instance count must be 1..65535");
+    if (I > 1 && c->comm) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive");
+    c->I = I;
+    if (int r = ensure_pose_buffers(c)) return r;
+    return ensure_outputs(c);
+}
+
+int rz_set_pose(rz_ctx *c, const float *world, const float *morph_weights)
+{
+    if (int r = use(c)) return r;
+    if (c->B == 0) return fail(RZ_ERR_INVALID, "no skeleton uploaded");
+    if (!world) return fail(RZ_ERR_INVALID, "null world matrices");
+    if (int r = ensure_pose_buffers(c)) return r;
+    const size_t wb = (size_t)c->I * c->B * 16 * sizeof(float);
+    const size_t mb = (size_t)c->I * c->M * sizeof(float);
+    const size_t need = wb + mb;
+    if (need > c->stage_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < kStageSlots; ++i) {
+            if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; }
+            HIP_TRY(hipHostMalloc(&c->stage[i], need, hipHostMallocDefault));
+            c->stage_used[i] = false;
+        }
+        c->stage_bytes = need;
+    }
+    const int slot = c->stage_next;
+    c->stage_next = (slot + 1) % kStageSlots;
+    if (c->stage_used[slot]) HIP_TRY(hipEventSynchronize(c->stage_ev[slot]));
+    char *s = static_cast<char *>(c->stage[slot]);
+    memcpy(s, world, wb);
+    HIP_TRY(hipMemcpyAsync(c->world, s, wb, hipMemcpyHostToDevice, c->stream));
+    if (c->M > 0) {
+        if (morph_weights) {
+            memcpy(s + wb, morph_weights, mb);
+            HIP_TRY(hipMemcpyAsync(c->morph_w, s + wb, mb, hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIP_TRY(hipMemsetAsync(c->morph_w, 0, mb, c->stream));
+        }
+    }
+    HIP_TRY(hipEventRecord(c->stage_ev[slot], c->stream));
+    c->stage_used[slot] = true;
+    c->pose_set = true;
+    return RZ_OK;
+}
+
+int rz_deform(rz_ctx *c)
+{
+    if (int r = use(c)) return r;
+    if (int r = check_ready(c)) return r;
+    if (int r = ensure_outputs(c)) return r;
+    if (int r = launch_prep(c)) return r;
+    return launch_deform(c, make_plan(c));
+}
+
+int rz_deform_n(rz_ctx *c, uint32_t frames)
+{
+    if (int r = use(c)) return r;
+    if (int r = check_ready(c)) return r;
+    if (int r = ensure_outputs(c)) return r;
+    const Plan pl = make_plan(c);
+    for (uint32_t f = 0; f < frames; ++f) {
+        if (int r = launch_prep(c)) return r;
+        if (int r = launch_deform(c, pl)) return r;
+    }
+    return RZ_OK;
+}
+
+int rz_sync(rz_ctx *c)
+{
+    if (int r = use(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RZ_OK;
+}
+
+int rz_read(rz_ctx *c, uint32_t instance, uint32_t v0, uint32_t n, float *pos3, float *nrm3)
+{
+    if (int r = use(c)) return r;
+    if (instance >= c->I) return fail(RZ_ERR_INVALID, "instance %u out of range", instance);
+    if ((uint64_t)v0 + n > c->V) return fail(RZ_ERR_INVALID, "vertex range [%u,%u) exceeds %u", v0, v0 + n, c->V);
+    if (!c->out_pos) return fail(RZ_ERR_INVALID, "nothing deformed yet");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t off = ((size_t)instance * c->Vp + v0) * 3;
+    if (pos3 && n) HIP_TRY(hipMemcpy(pos3, c->out_pos + off, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (nrm3 && n) HIP_TRY(hipMemcpy(nrm3, c->out_nrm + off, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return RZ_OK;
+}
+
+int rz_read_palette(rz_ctx *c, uint32_t instance, float *rows3x4)
+{
+    if (int r = use(c)) return r;
+    if (instance >= c->I || !rows3x4 || !c->palette) return fail(RZ_ERR_INVALID, "bad palette read");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(rows3x4, c->palette + (size_t)instance * c->B * 3, (size_t)c->B * 12 * sizeof(float), hipMemcpyDeviceToHost));
+    return RZ_OK;
+}
+
+int rz_time_frames(rz_ctx *c, uint32_t frames, rz_timing *out)
+{
+    if (int r = use(c)) return r;
+    if (!out || frames == 0) return fail(RZ_ERR_INVALID, "rz_time_frames: bad arguments");
+    if (int r = check_ready(c)) return r;
+    if (int r = ensure_outputs(c)) return r;
+    const Plan pl = make_plan(c);
+    memset(out, 0, sizeof *out);
+    float ms = 0.f;
+    // whole frames: prep + fused kernel, back to back on the context's stream
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (uint32_t f = 0; f < frames; ++f) {
+        if (int r = launch_prep(c)) return r;
+        if (int r = launch_deform(c, pl)) return r;
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    out->frame_ms = ms / frames;
+    // the fused morph+skin kernel alone
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (uint32_t f = 0; f < frames; ++f)
+        if (int r = launch_deform(c, pl)) return r;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    out->deform_kernel_ms = ms / frames;
+    // the prep kernel alone
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (uint32_t f = 0; f < frames; ++f)
+        if (int r = launch_prep(c)) return r;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    out->prep_kernel_ms = ms / frames;
+    out->verts_per_frame = (uint64_t)c->V * c->I;
+    out->algorithmic_bytes_per_frame = algorithmic_bytes(c);
+    out->frames = frames;
+    return RZ_OK;
+}
+
+int rz_set_tuning(rz_ctx *c, const char *key, int value)
+{
+    if (!c || !key) return fail(RZ_ERR_INVALID, "null argument");
+    if (!strcmp(key, "morph_split")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
+            return fail(RZ_ERR_INVALID, "morph_split must be 0,1,2,4,8,16");
+        c->t_split = value;
+    } else if (!strcmp(key, "unroll")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(RZ_ERR_INVALID, "unroll must be 1,2,4,8");
+        c->t_unroll = value;
+    } else if (!strcmp(key, "grid_cap")) {
+        if (value < 0) return fail(RZ_ERR_INVALID, "grid_cap must be >= 0");
+        c->t_grid_cap = value;
+    } else if (!strcmp(key, "nontemporal")) {
+        c->t_nt = value ? 1 : 0;
+    } else if (!strcmp(key, "geo_lds")) {
+        c->t_geo = value ? 1 : 0;
+    } else {
+        return fail(RZ_ERR_INVALID, "unknown tuning key '%s'", key);
+    }
+    return RZ_OK;
+}
+
+int rz_get_tuning(rz_ctx *c, const char *key, int *value)
+{
+    if (!c || !key || !value) return fail(RZ_ERR_INVALID, "null argument");
+    if (!strcmp(key, "morph_split")) *value = c->t_split;
+    else if (!strcmp(key, "unroll")) *value = c->t_unroll;
+    else if (!strcmp(key, "grid_cap")) *value = c->t_grid_cap;
+    else if (!strcmp(key, "nontemporal")) *value = c->t_nt;
+    else if (!strcmp(key, "geo_lds")) *value = c->t_geo;
+    else if (!strcmp(key, "effective_split")) *value = make_plan(c).S;
+    else if (!strcmp(key, "effective_grid")) *value = (int)make_plan(c).grid_x;
+    else return fail(RZ_ERR_INVALID, "unknown tuning key '%s'", key);
+    return RZ_OK;
+}
+
+int rz_output_ptrs(rz_ctx *c, void **pos, void **nrm, uint32_t *v_padded)
+{
+    if (int r = use(c)) return r;
+    if (int r = ensure_outputs(c)) return r;
+    if (pos) *pos = c->out_pos;
+    if (nrm) *nrm = c->out_nrm;
+    if (v_padded) *v_padded = c->Vp;
+    return RZ_OK;
+}
+
+int rz_comm_unique_id(char id[128])
+{
+    if (!id) return fail(RZ_ERR_INVALID, "null id");
+    if (int r = rccl_bind()) return r;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    NCCL_TRY(g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, 128);
+    return RZ_OK;
+}
+
+int rz_comm_init(rz_ctx *c, int nranks, int rank, const char id[128], uint32_t v_total)
+{
+    if (int r = use(c)) return r;
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id) return fail(RZ_ERR_INVALID, "bad communicator arguments");
+    if (c->I != 1) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive");
+    if (c->V == 0) return fail(RZ_ERR_INVALID, "upload this rank's mesh shard before rz_comm_init");
+    uint32_t b = 0, n = 0;
+    if (int r = rz_shard_range(v_total, nranks, rank, &b, &n)) return r;
+    if (n != c->V) return fail(RZ_ERR_INVALID, "rank %d holds %u vertices but rz_shard_range assigns %u", rank, c->V, n);
+    if (int r = rccl_bind()) return r;
+    if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    NCCL_TRY(g_rccl.CommInitRank(&c->comm, nranks, u, rank));
+    c->nranks = nranks; c->rank = rank; c->v_total = v_total;
+    uint32_t b0 = 0, n0 = 0;
+    rz_shard_range(v_total, nranks, 0, &b0, &n0);
+    c->chunk = round_up(n0, kVertPad);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dfree(c->g_pos); dfree(c->g_nrm);
+    const size_t g = (size_t)nranks * c->chunk * 3 * sizeof(float);
+    HIP_TRY(hipMalloc(&c->g_pos, g));
+    HIP_TRY(hipMalloc(&c->g_nrm, g));
+    return ensure_outputs(c);
+}
+
+int rz_allgather(rz_ctx *c, int with_normals)
+{
+    if (int r = use(c)) return r;
+    if (!c->comm) return fail(RZ_ERR_INVALID, "rz_comm_init has not been called");
+    const size_t count = (size_t)c->chunk * 3;
+    NCCL_TRY(g_rccl.AllGather(c->out_pos, c->g_pos, count, ncclFloat, c->comm, c->stream));
+    if (with_normals) NCCL_TRY(g_rccl.AllGather(c->out_nrm, c->g_nrm, count, ncclFloat, c->comm, c->stream));
+    return RZ_OK;
+}
+
+int rz_read_gathered(rz_ctx *c, uint32_t v0, uint32_t n, float *pos3, float *nrm3)
+{
+    if (int r = use(c)) return r;
+    if (!c->g_pos) return fail(RZ_ERR_INVALID, "no gathered buffer");
+    if ((uint64_t)v0 + n > c->v_total) return fail(RZ_ERR_INVALID, "range exceeds the full mesh");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (pos3 && n) HIP_TRY(hipMemcpy(pos3, c->g_pos + (size_t)v0 * 3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (nrm3 && n) HIP_TRY(hipMemcpy(nrm3, c->g_nrm + (size_t)v0 * 3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return RZ_OK;
+}
+
+}  // extern "C"

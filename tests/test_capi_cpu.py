@@ -1,0 +1,62 @@
+"""CPU-side checks of the C ABI: the library builds/loads, exports every symbol the header
+declares, the pure host helpers behave, and the product path fails loudly without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "reze_deform.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rz_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol(rz):
+    L = rz.capi.load()
+    names = header_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "libreze_deform.so does not export %s" % n
+    assert sorted(rz.capi.SYMBOLS) == names
+    assert L.rz_abi_version() == 1
+
+
+def test_shard_ranges_tile_the_mesh(rz):
+    for v_total in (1, 1023, 1024, 30000, 1000000, 1000001):
+        for n in (1, 2, 4, 8):
+            spans = [rz.shard_range(v_total, n, r) for r in range(n)]
+            assert spans[0][0] == 0
+            assert sum(c for _, c in spans) == v_total
+            for (b0, c0), (b1, _c1) in zip(spans, spans[1:]):
+                assert b1 == b0 + c0 or (c0 == 0 and b1 == v_total) or b1 == v_total
+            full = [c for _, c in spans if c and c != spans[0][1]]
+            assert len(full) <= 1                      # only the last non-empty shard may be short
+            assert spans[0][1] % 1024 == 0 or n == 1 or spans[0][1] == v_total
+    with pytest.raises(rz.RzError):
+        rz.shard_range(10, 0, 0)
+
+
+def test_no_gpu_means_loud_failure_not_fallback(rz):
+    if rz.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(rz.RzError) as e:
+        rz.DeformContext(0)
+    assert e.value.code == -3
+    assert "device" in str(e.value).lower()
+
+
+def test_product_never_imports_the_oracle():
+    """③: nothing under reze-engine_amd/ may reference oracle/."""
+    pkg = os.path.join(ROOT, "reze-engine_amd")
+    bad = []
+    for d, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".js", ".c", ".cpp", ".h", ".hip", ".ts")):
+                src = open(os.path.join(d, f), errors="replace").read()
+                if re.search(r"\boracle[/.]|from oracle|import oracle|rzo_|librz_oracle", src):
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad

@@ -1,0 +1,238 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs (BASELINE.json configs C2-C5), plus size-independent properties at full size."""
+import numpy as np
+import pytest
+
+from helpers import assert_parity
+from reze_engine_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(rz):
+    c = rz.DeformContext(0)
+    yield c
+    c.close()
+
+
+def run_gpu(ctx, mesh, world=None, deltas=None, mw=None, sparse=None, **tuning):
+    ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    ctx.upload_skeleton(mesh["inv_bind"])
+    if deltas is not None:
+        ctx.upload_morphs_dense(deltas)
+    elif sparse is not None:
+        ctx.upload_morphs_sparse(*sparse)
+    ctx.set_instances(1)
+    ctx.set_tuning(morph_split=0, unroll=4, nontemporal=0, geo_lds=1, grid_cap=0)
+    ctx.set_tuning(**tuning)
+    ctx.set_pose(mesh["world"] if world is None else world, mw)
+    ctx.deform()
+    return ctx.read()
+
+
+def test_c2_lbs_30k_200_bones(ctx, oracle):
+    """config 2: 30k verts / 200 bones / 0 morphs, fp32, vs the vs() restatement."""
+    mesh = synth.make_mesh(30000, 200)
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"])
+    for geo in (1, 0):
+        pg, ng = run_gpu(ctx, mesh, geo_lds=geo)
+        assert_parity(pg, ng, pr, nr, "C2 geo_lds=%d" % geo)
+    # palette kernel vs engine.ts:926-928 restatement (rows 0..2)
+    S = oracle.palette(mesh["world"], mesh["inv_bind"]).reshape(-1, 4, 4)      # [b, col, row]
+    rows = np.transpose(S, (0, 2, 1))[:, :3, :].reshape(-1, 12)
+    np.testing.assert_allclose(ctx.read_palette(), rows, rtol=1e-6, atol=1e-6)
+
+
+def test_interleaved_upload_matches_soa_upload(ctx):
+    """rz_upload_mesh takes the reference's 8-float interleaved vertex buffer (model.ts:196-200)."""
+    mesh = synth.make_mesh(5000, 64, seed=11)
+    pg, ng = run_gpu(ctx, mesh)
+    inter = np.zeros((5000, 8), dtype=np.float32)
+    inter[:, 0:3] = mesh["pos"]
+    inter[:, 3:6] = mesh["nrm"]
+    inter[:, 6:8] = 0.25
+    ctx.upload_mesh_interleaved(inter, mesh["joints"], mesh["weights"])
+    ctx.set_pose(mesh["world"])
+    ctx.deform()
+    p2, n2 = ctx.read()
+    assert np.array_equal(pg, p2) and np.array_equal(ng, n2)
+
+
+def test_identity_pose_known_answer(ctx):
+    mesh = synth.make_mesh(10000, 100, seed=4)
+    q = np.zeros((100, 4), dtype=np.float32)
+    q[:, 3] = 1
+    world = synth.fk_world(mesh["parents"], mesh["bind"], q)
+    pg, ng = run_gpu(ctx, mesh, world=world)
+    np.testing.assert_allclose(pg, mesh["pos"], rtol=1e-6, atol=2e-5)
+    np.testing.assert_allclose(ng, mesh["nrm"], atol=1e-6)
+
+
+@pytest.mark.parametrize("split", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("unroll", [1, 4, 8])
+def test_c3_fused_morph_skin_all_kernel_variants(ctx, oracle, split, unroll):
+    """config 3: 30k verts / 200 bones / 64 active morph targets, every morph-split x unroll variant."""
+    mesh = synth.make_mesh(30000, 200)
+    deltas, mw = synth.make_morphs_dense(30000, 64)
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"],
+                           mesh["inv_bind"], deltas, mw, threads=8)
+    pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, morph_split=split, unroll=unroll)
+    assert_parity(pg, ng, pr, nr, "C3 S=%d U=%d" % (split, unroll))
+    assert ctx.get_tuning("effective_split") == split
+
+
+@pytest.mark.parametrize("nt,geo", [(1, 1), (0, 0), (1, 0)])
+def test_c3_load_path_variants(ctx, oracle, nt, geo):
+    mesh = synth.make_mesh(30000, 200)
+    deltas, mw = synth.make_morphs_dense(30000, 64)
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"],
+                           mesh["inv_bind"], deltas, mw, threads=8)
+    pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, nontemporal=nt, geo_lds=geo)
+    assert_parity(pg, ng, pr, nr, "C3 nt=%d geo=%d" % (nt, geo))
+
+
+@pytest.mark.parametrize("V,B,M", [(1, 1, 1), (3, 2, 7), (1023, 17, 3), (1025, 300, 9), (4097, 471, 33)])
+def test_ragged_sizes_and_partial_weights(ctx, oracle, V, B, M):
+    """edge cases: single vertex, non-multiple-of-tile sizes, odd morph counts, zero weights mixed in."""
+    mesh = synth.make_mesh(V, B, seed=V)
+    deltas, mw = synth.make_morphs_dense(V, M, seed=M)
+    mw[::3] = 0.0                                    # inactive morphs are skipped, not multiplied
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"],
+                           mesh["inv_bind"], deltas, mw)
+    for split in (0, 1, 4):
+        pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, morph_split=split)
+        assert_parity(pg, ng, pr, nr, "ragged V=%d M=%d S=%d" % (V, M, split))
+
+
+def test_all_morph_weights_zero_equals_plain_skin(ctx, oracle):
+    mesh = synth.make_mesh(9000, 50, seed=8)
+    deltas, mw = synth.make_morphs_dense(9000, 16)
+    pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=np.zeros_like(mw))
+    p0, n0 = run_gpu(ctx, mesh, deltas=deltas, mw=None)          # NULL weights == all zero
+    ctx.upload_morphs_dense(None)
+    ctx.set_pose(mesh["world"])
+    ctx.deform()
+    p1, n1 = ctx.read()
+    assert np.array_equal(pg, p1) and np.array_equal(ng, n1)
+    assert np.array_equal(p0, p1) and np.array_equal(n0, n1)
+
+
+def test_degenerate_weights_and_normals(ctx, oracle):
+    """zero weight sum takes the (1,0,0,0) branch (engine.ts:257); a zero normal stays the rest normal."""
+    mesh = synth.make_mesh(2048, 30, seed=12)
+    mesh["weights"][::5] = 0
+    mesh["nrm"][::7] = 0
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"])
+    pg, ng = run_gpu(ctx, mesh)
+    assert_parity(pg, ng, pr, nr, "degenerate")
+    assert np.array_equal(ng[::35], np.zeros_like(ng[::35]))
+
+
+def test_sparse_morphs_match_oracle_and_dense_path(ctx, oracle):
+    V, B, M = 28842, 349, 60                         # the demo model's shape
+    mesh = synth.make_mesh(V, B, seed=21)
+    off, idx, d3, mw = synth.make_morphs_sparse(V, M, density=0.02)
+    mw[5] = 0
+    pm = oracle.morph_sparse(V, off, idx, d3, mw, mesh["pos"])
+    S = oracle.palette(mesh["world"], mesh["inv_bind"])
+    pr, nr = oracle.skin(pm, mesh["nrm"], mesh["joints"], mesh["weights"], S)
+    pg, ng = run_gpu(ctx, mesh, sparse=(off, idx, d3), mw=mw)
+    assert_parity(pg, ng, pr, nr, "sparse")
+    pd, nd = run_gpu(ctx, mesh, deltas=synth.sparse_to_dense(V, off, idx, d3), mw=mw, morph_split=1)
+    assert_parity(pd, nd, pr, nr, "dense expansion")
+
+
+def test_c4_instances_each_match_their_own_pose(ctx, oracle):
+    """config 4 (reduced instance count for the oracle): per-instance palette, shared static mesh."""
+    V, B, I = 30000, 200, 6
+    mesh = synth.make_mesh(V, B)
+    worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=100 + i) for i in range(I)])
+    ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    ctx.upload_skeleton(mesh["inv_bind"])
+    ctx.set_instances(I)
+    ctx.set_pose(worlds)
+    ctx.deform()
+    for i in range(I):
+        pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[i], mesh["inv_bind"])
+        pg, ng = ctx.read(instance=i)
+        assert_parity(pg, ng, pr, nr, "instance %d" % i)
+    ctx.set_instances(1)
+
+
+def test_instanced_morph_weights_are_per_instance(ctx, oracle):
+    V, B, M, I = 5000, 40, 8, 3
+    mesh = synth.make_mesh(V, B, seed=31)
+    deltas, _ = synth.make_morphs_dense(V, M, seed=32)
+    rng = np.random.default_rng(33)
+    mws = rng.random((I, M), dtype=np.float32)
+    mws[1] = 0
+    worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=200 + i) for i in range(I)])
+    ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    ctx.upload_skeleton(mesh["inv_bind"])
+    ctx.upload_morphs_dense(deltas)
+    ctx.set_instances(I)
+    ctx.set_pose(worlds, mws)
+    ctx.deform()
+    for i in range(I):
+        pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[i],
+                               mesh["inv_bind"], deltas, mws[i])
+        pg, ng = ctx.read(instance=i)
+        assert_parity(pg, ng, pr, nr, "instance %d" % i)
+    ctx.set_instances(1)
+
+
+def test_c5_full_size_parity_and_properties(ctx, oracle, rz):
+    """config 5 at full size on one GPU: 1M verts / 256 bones / 64 dense morphs.
+    (a) direct parity with the threaded C oracle; (b) vertex shards computed independently are
+    bit-identical to the single-context result (the multi-GPU partition);
+    (c) identity-pose + zero-weight property: output == rest mesh."""
+    V, B, M = 1000000, 256, 64
+    mesh = synth.make_mesh(V, B)
+    deltas, mw = synth.make_morphs_dense(V, M)
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"],
+                           mesh["inv_bind"], deltas, mw, threads=16)
+    pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, morph_split=1)
+    ep, en = assert_parity(pg, ng, pr, nr, "C5 full")
+    print("C5 full-size parity: max rel pos err %.3e, max nrm err %.3e" % (ep, en))
+    # (b) shard 3 of 8 with the same kernel variant
+    b, n = rz.shard_range(V, 8, 3)
+    shard = {k: mesh[k][b:b + n] for k in ("pos", "nrm", "joints", "weights")}
+    shard.update(inv_bind=mesh["inv_bind"], world=mesh["world"])
+    ps, ns = run_gpu(ctx, shard, deltas=np.ascontiguousarray(deltas[:, b:b + n]), mw=mw, morph_split=1)
+    assert np.array_equal(ps, pg[b:b + n]) and np.array_equal(ns, ng[b:b + n])
+    # (c) identity pose, zero morph weights
+    q = np.zeros((B, 4), dtype=np.float32)
+    q[:, 3] = 1
+    world = synth.fk_world(mesh["parents"], mesh["bind"], q)
+    pi, ni = run_gpu(ctx, mesh, world=world, deltas=deltas, mw=np.zeros(M, dtype=np.float32))
+    np.testing.assert_allclose(pi, mesh["pos"], rtol=1e-6, atol=2e-5)
+
+
+def test_allgather_single_rank_roundtrip(ctx, rz, oracle):
+    """RCCL all-gather entry points with a world of 1: gathered buffer == local result."""
+    mesh = synth.make_mesh(5000, 20, seed=41)
+    pg, ng = run_gpu(ctx, mesh)
+    uid = rz.capi.comm_unique_id()
+    ctx.comm_init(1, 0, uid, 5000)
+    ctx.allgather(with_normals=True)
+    p2, n2 = ctx.read_gathered()
+    assert np.array_equal(p2, pg) and np.array_equal(n2, ng)
+
+
+def test_error_paths(ctx, rz):
+    c = rz.DeformContext(0)
+    with pytest.raises(rz.RzError):
+        c.deform()                                    # nothing uploaded
+    mesh = synth.make_mesh(100, 4, seed=1)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    with pytest.raises(rz.RzError):
+        c.deform()                                    # no skeleton
+    c.upload_skeleton(mesh["inv_bind"])
+    with pytest.raises(rz.RzError):
+        c.deform()                                    # no pose
+    with pytest.raises(rz.RzError):
+        c.set_tuning(morph_split=3)
+    with pytest.raises(rz.RzError):
+        c._L.rz_read and c.read(v0=90, n=20)          # out of range
+    c.close()

@@ -1,0 +1,149 @@
+"""CPU tests of the oracle itself: known-answer tests that pin the restatement of
+engine/src/engine.ts:253-272 / :926-928, and the bit-exact C <-> NumPy cross-check."""
+import numpy as np
+import pytest
+
+from reze_engine_amd import synth
+
+
+def rot_z(angle, t=(0, 0, 0)):
+    c, s = np.cos(angle), np.sin(angle)
+    m = np.zeros(16, dtype=np.float32)
+    m[0], m[1], m[4], m[5], m[10], m[15] = c, s, -s, c, 1, 1
+    m[12:15] = t
+    return m
+
+
+def ident():
+    m = np.zeros(16, dtype=np.float32)
+    m[0] = m[5] = m[10] = m[15] = 1
+    return m
+
+
+def test_palette_matches_column_major_product(oracle):
+    rng = np.random.default_rng(1)
+    W = rng.normal(size=(7, 16)).astype(np.float32)
+    IB = rng.normal(size=(7, 16)).astype(np.float32)
+    S = oracle.palette(W, IB)
+    for b in range(7):
+        ref = (W[b].reshape(4, 4).T.astype(np.float64) @ IB[b].reshape(4, 4).T.astype(np.float64)).T.reshape(16)
+        np.testing.assert_allclose(S[b], ref, rtol=2e-6, atol=2e-6)
+    # bit-exact against the NumPy twin
+    assert np.array_equal(S, oracle.np_twin.palette(W, IB))
+
+
+def test_identity_pose_returns_rest_mesh(oracle):
+    """inverse bind is translation-only (pmx-loader.ts:818-822), so identity rotations give
+    skin = T(b) * T(-b) = I and the deformed mesh equals the rest mesh."""
+    mesh = synth.make_mesh(4096, 64, seed=3)
+    quats = np.zeros((64, 4), dtype=np.float32)
+    quats[:, 3] = 1
+    world = synth.fk_world(mesh["parents"], mesh["bind"], quats)
+    S = oracle.palette(world, mesh["inv_bind"])
+    eye = np.tile(ident(), (64, 1))
+    np.testing.assert_allclose(S, eye, atol=2e-6)
+    pos, nrm = oracle.skin(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], eye)
+    # weights are u8/255 renormalised by their f32 sum: exact up to a couple of ulp
+    np.testing.assert_allclose(pos, mesh["pos"], rtol=4e-7, atol=1e-6)
+    np.testing.assert_allclose(nrm, mesh["nrm"], rtol=0, atol=3e-7)
+
+
+def test_single_bone_rigid_rotation(oracle):
+    """BDEF1 vertices under one bone rotating about a pivot: P' = R (p - c) + c exactly (to f32)."""
+    rng = np.random.default_rng(5)
+    V = 257
+    pos = rng.uniform(-5, 5, size=(V, 3)).astype(np.float32)
+    nrm = rng.normal(size=(V, 3))
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    joints = np.zeros((V, 4), dtype=np.uint16)
+    weights = np.zeros((V, 4), dtype=np.uint8)
+    weights[:, 0] = 255
+    pivot = np.array([1.5, 2.0, -0.5])
+    ang = 0.7
+    world = rot_z(ang, pivot)[None]                    # W = T(c) R
+    ib = ident()[None].copy()
+    ib[0, 12:15] = -pivot                              # IB = T(-c)
+    S = oracle.palette(world, ib)
+    p, n = oracle.skin(pos, nrm, joints, weights, S)
+    R = rot_z(ang).reshape(4, 4).T[:3, :3].astype(np.float64)
+    ref_p = (pos.astype(np.float64) - pivot) @ R.T + pivot
+    ref_n = nrm.astype(np.float64) @ R.T
+    np.testing.assert_allclose(p, ref_p, atol=5e-6)
+    np.testing.assert_allclose(n, ref_n, atol=5e-7)
+    np.testing.assert_allclose(np.linalg.norm(n, axis=1), 1.0, atol=3e-7)
+
+
+def test_two_bone_blend_hand_computed(oracle):
+    """weights (64,191): w = u8/255 then / f32 sum; position is the weighted mean of the two bone transforms."""
+    pos = np.array([[1.0, 2.0, 3.0]], dtype=np.float32)
+    nrm = np.array([[0.0, 1.0, 0.0]], dtype=np.float32)
+    joints = np.array([[1, 0, 0, 0]], dtype=np.uint16)
+    weights = np.array([[64, 191, 0, 0]], dtype=np.uint8)
+    S = np.stack([ident(), ident()])
+    S[0, 12:15] = [10, 0, 0]       # bone 0 translates +10 x
+    S[1, 12:15] = [0, -4, 0]       # bone 1 translates -4 y
+    p, n = oracle.skin(pos, nrm, joints, weights, S)
+    w0, w1 = np.float32(64) / np.float32(255), np.float32(191) / np.float32(255)
+    s = np.float32(w0 + w1)
+    w0, w1 = w0 * (np.float32(1) / s), w1 * (np.float32(1) / s)
+    ref = np.float64(w0) * np.array([1, -2, 3.0]) + np.float64(w1) * np.array([11, 2, 3.0])
+    np.testing.assert_allclose(p[0], ref, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(n[0], [0, 1, 0], atol=1e-7)
+
+
+def test_zero_weight_sum_and_zero_normal_are_defined(oracle):
+    pos = np.array([[1.0, 2.0, 3.0], [1.0, 2.0, 3.0]], dtype=np.float32)
+    nrm = np.array([[0.0, 0.0, 0.0], [0.0, 0.6, 0.8]], dtype=np.float32)
+    joints = np.array([[1, 0, 0, 0], [1, 0, 0, 0]], dtype=np.uint16)
+    weights = np.zeros((2, 4), dtype=np.uint8)         # sum 0 -> select((1,0,0,0)) branch, engine.ts:257
+    S = np.stack([ident(), ident()])
+    S[1, 12:15] = [5, 5, 5]
+    p, n = oracle.skin(pos, nrm, joints, weights, S)
+    np.testing.assert_array_equal(p, [[6, 7, 8], [6, 7, 8]])
+    np.testing.assert_array_equal(n[0], [0, 0, 0])     # zero-length normal: rest normal returned (build-defined)
+    np.testing.assert_allclose(n[1], [0, 0.6, 0.8], atol=1e-7)
+    assert np.isfinite(p).all() and np.isfinite(n).all()
+
+
+@pytest.mark.parametrize("V,B,M", [(1, 1, 0), (1000, 40, 0), (3001, 200, 5), (4096, 256, 64)])
+def test_c_and_numpy_twins_agree_bit_for_bit(oracle, V, B, M):
+    mesh = synth.make_mesh(V, B, seed=V + B)
+    deltas = mw = None
+    if M:
+        deltas, mw = synth.make_morphs_dense(V, M, seed=M)
+        mw[1] = 0.0                                     # a skipped morph
+    pc, nc = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"],
+                           mesh["inv_bind"], deltas, mw, threads=3)
+    pn, nn = oracle.np_twin.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"],
+                                   mesh["inv_bind"], deltas, mw)
+    assert np.array_equal(pc, pn)
+    assert np.array_equal(nc, nn)
+    # threaded whole-frame driver == the single calls
+    S = oracle.palette(mesh["world"], mesh["inv_bind"])
+    p0 = mesh["pos"] if not M else oracle.morph_dense(deltas, mw, mesh["pos"])
+    p1, n1 = oracle.skin(p0, mesh["nrm"], mesh["joints"], mesh["weights"], S)
+    assert np.array_equal(pc, p1) and np.array_equal(nc, n1)
+
+
+def test_sparse_morph_equals_dense_expansion(oracle):
+    V, M = 5000, 24
+    off, idx, d3, w = synth.make_morphs_sparse(V, M, density=0.03, seed=9)
+    w[3] = 0
+    pos = synth.make_mesh(V, 8, seed=2)["pos"]
+    dense = synth.sparse_to_dense(V, off, idx, d3)
+    a = oracle.morph_sparse(V, off, idx, d3, w, pos)
+    b = oracle.morph_dense(dense, w, pos)
+    # dense adds w*0 for untouched vertices (exact) so the two forms agree bit for bit
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, oracle.np_twin.morph_sparse(V, off, idx, d3, w, pos))
+
+
+def test_synthetic_mesh_respects_loader_invariants():
+    """pmx-loader.ts:855-951 guarantees weights sum to exactly 255 and joints < boneCount."""
+    mesh = synth.make_mesh(30000, 200)
+    assert (mesh["weights"].astype(np.int64).sum(axis=1) == 255).all()
+    assert mesh["joints"].max() < 200
+    assert (mesh["parents"][1:] < np.arange(1, 200)).all()
+    np.testing.assert_allclose(np.linalg.norm(mesh["nrm"], axis=1), 1.0, atol=1e-6)
+    # world matrices are affine (bottom row 0,0,0,1)
+    np.testing.assert_array_equal(mesh["world"][:, [3, 7, 11, 15]], np.tile([0, 0, 0, 1], (200, 1)))

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Kernel-variant sweep on one MI355X (run through gpurun). Times the fused morph+skin kernel
+alone with HIP events (rz_time_frames) for every tuning combination on the BASELINE configs and
+prints achieved algorithmic GB/s. Output: a table on stdout + gpurun_out/sweep.json."""
+import itertools
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import reze_engine_amd as rz  # noqa: E402
+from reze_engine_amd import synth  # noqa: E402
+
+
+def setup(ctx, V, B, M, I=1):
+    mesh = synth.make_mesh(V, B)
+    ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    ctx.upload_skeleton(mesh["inv_bind"])
+    mw = None
+    if M:
+        deltas, mw = synth.make_morphs_dense(V, M)
+        ctx.upload_morphs_dense(deltas)
+        del deltas
+    else:
+        ctx.upload_morphs_dense(None)
+    ctx.set_instances(I)
+    worlds = mesh["world"]
+    if I > 1:
+        worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=1000 + i) for i in range(I)])
+        if mw is not None:
+            mw = np.tile(mw, (I, 1))
+    ctx.set_pose(worlds, mw)
+
+
+def run(ctx, name, frames, grid):
+    rows = []
+    keys = list(grid.keys())
+    for combo in itertools.product(*[grid[k] for k in keys]):
+        kw = dict(zip(keys, combo))
+        try:
+            ctx.set_tuning(**kw)
+            ctx.time_frames(5)
+            best = None
+            for _ in range(3):
+                t = ctx.time_frames(frames)
+                if best is None or t["deform_kernel_ms"] < best["deform_kernel_ms"]:
+                    best = t
+            gbps = best["algorithmic_bytes_per_frame"] / (best["deform_kernel_ms"] * 1e-3) / 1e9
+            row = dict(config=name, **kw, kernel_ms=best["deform_kernel_ms"], frame_ms=best["frame_ms"],
+                       prep_ms=best["prep_kernel_ms"], gbps=gbps, frac=gbps / 8000.0,
+                       gverts=best["verts_per_frame"] / (best["deform_kernel_ms"] * 1e-3) / 1e9,
+                       S=ctx.get_tuning("effective_split"), grid=ctx.get_tuning("effective_grid"))
+        except Exception as e:   # keep sweeping
+            row = dict(config=name, **kw, error=str(e))
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+    return rows
+
+
+def main():
+    which = sys.argv[1:] or ["c5", "c5shard", "c4", "c3", "c2"]
+    ctx = rz.DeformContext(0)
+    out = []
+    t0 = time.time()
+    if "c5" in which:
+        setup(ctx, 1000000, 256, 64)
+        out += run(ctx, "C5 1M/256/64", 30, dict(morph_split=[1, 2, 4], unroll=[2, 4, 8], nontemporal=[0, 1],
+                                                 geo_lds=[1, 0], grid_cap=[0]))
+        out += run(ctx, "C5 grid", 30, dict(morph_split=[1], unroll=[4], nontemporal=[0], geo_lds=[1],
+                                            grid_cap=[256, 512, 768, 1024]))
+    if "c5shard" in which:
+        b, n = rz.shard_range(1000000, 8, 0)
+        setup(ctx, n, 256, 64)
+        out += run(ctx, "C5 shard 1/8 (%d)" % n, 100, dict(morph_split=[1, 2, 4, 8, 16], unroll=[2, 4, 8],
+                                                           nontemporal=[0, 1], geo_lds=[1], grid_cap=[0]))
+    if "c4" in which:
+        setup(ctx, 30000, 200, 0, I=256)
+        out += run(ctx, "C4 256x30k", 50, dict(geo_lds=[1, 0], grid_cap=[0, 512, 1024, 4096, 8192]))
+    if "c3" in which:
+        setup(ctx, 30000, 200, 64)
+        out += run(ctx, "C3 30k/200/64", 200, dict(morph_split=[1, 4, 8, 16], unroll=[2, 4, 8], nontemporal=[0],
+                                                   geo_lds=[1], grid_cap=[0]))
+    if "c2" in which:
+        setup(ctx, 30000, 200, 0)
+        out += run(ctx, "C2 30k/200/0", 200, dict(geo_lds=[1, 0], grid_cap=[0]))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "sweep.json"), "w"), indent=1)
+    print("sweep done in %.1f s" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
