@@ -79,7 +79,7 @@ def cpu_baseline(args, mesh, deltas, mw):
                     d.tofile(os.path.join(td, "deltas.f32"))
                     mw.astype(np.float32).tofile(os.path.join(td, "mw.f32"))
                 out = subprocess.check_output(
-                    [node, "--experimental-worker", js, td, str(n), str(len(mesh["world"])),
+                    [node, js, td, str(n), str(len(mesh["world"])),
                      str(0 if d is None else d.shape[0]), str(cores), "15"],
                     stderr=subprocess.STDOUT, timeout=180).decode()
             r = json.loads(out.strip().splitlines()[-1])
