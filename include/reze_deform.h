@@ -122,10 +122,13 @@ int rz_read_palette(rz_ctx *ctx, uint32_t instance, float *rows3x4);
  * prep kernel alone the same way. Blocking. */
 int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
 
-/* Tuning knobs (bench sweeps / tests). Keys: "morph_split" (1,2,4,8,16; 0 = auto),
- * "unroll" (1,2,4,8), "grid_cap" (total workgroups, 0 = auto), "geo_lds" (0/1: rest geometry
- * transposed through LDS vs 4-byte loads), "nontemporal" (0/1). rz_get_tuning also answers
- * "effective_split" / "effective_grid". Unknown keys return RZ_ERR_INVALID. */
+/* Tuning knobs (bench sweeps / tests); 0 / -1 = automatic. Keys: "morph_split" (0,1,2,4,8 lanes
+ * per vertex quad), "unroll" (0,4,8 morphs in flight per lane), "grid_cap" (total workgroups),
+ * "geo_lds" (0/1: rest geometry transposed through LDS vs 4-byte loads), "nontemporal" (0/1,
+ * morph-stream loads), "nt_store" (0/1, output stores), "fast" (-1 auto, 0 always run the
+ * separate prep kernel, 1 one-launch frame when possible). rz_get_tuning also answers
+ * "effective_split" / "effective_unroll" / "effective_grid" / "effective_fast".
+ * Unknown keys return RZ_ERR_INVALID. */
 int rz_set_tuning(rz_ctx *ctx, const char *key, int value);
 int rz_get_tuning(rz_ctx *ctx, const char *key, int *value);
 

@@ -25,7 +25,9 @@ struct RzDeformParams {
     const uint32_t *joints01;   // [Vp] j0 | j1 << 16
     const uint32_t *joints23;   // [Vp] j2 | j3 << 16
     const uint32_t *weights;    // [Vp] 4 x unorm8
-    const float4 *palette;      // [I][B][3]
+    float4 *palette;            // [I][B][3]  (read by !FAST, written once per frame by FAST)
+    const float *world;         // [I][B][16] (FAST)
+    const float *inv_bind;      // [B][16]    (FAST)
     const float *dense;         // [M][3][Vp] planes (MODE 1)
     const uint32_t *act_idx;    // [I][Mpad]
     const float *act_w;         // [I][Mpad]
@@ -42,10 +44,31 @@ struct RzDeformParams {
     int Mpad;
 };
 
+// Active-morph list of a single-instance frame, passed BY VALUE in the kernel arguments (FAST path):
+// compacted on the host by rz_set_pose, so the frame needs no prep kernel and no dependent load
+// before the morph stream starts.
+constexpr int kKargMorphs = 128;
+struct RzMorphList {
+    int count;
+    uint16_t idx[kKargMorphs];
+    float w[kKargMorphs];
+};
+
+// Compile-time variant selection of rz_deform_kernel (see deform_kernels.hip).
+struct RzVariant {
+    int mode;    // 0 none, 1 dense, 2 sparse
+    int S;       // morph split 1,2,4,8 (mode 1 only)
+    int U;       // 4 or 8
+    bool nt;     // nontemporal morph loads
+    bool nts;    // nontemporal output stores
+    bool geo;    // rest geometry through LDS
+    bool fast;   // fused palette + kernarg morph list (single instance)
+};
+
 hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t st);
-hipError_t rz_launch_deform(const RzDeformParams &p, int mode, int S, int U, bool nt, bool geo, uint32_t grid_x,
+hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, const RzVariant &v, uint32_t grid_x,
                             uint32_t instances, hipStream_t st);
-size_t rz_deform_lds_bytes(const RzDeformParams &p, int S, bool geo);
+size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v);
 uint32_t rz_quads_per_tile(int S);
 hipError_t rz_launch_deinterleave(const float *src, int stride, int offset, uint32_t n, float *px, float *py,
                                   float *pz, hipStream_t st);

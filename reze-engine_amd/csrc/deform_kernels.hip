@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "deform_kernels.h"
 
 namespace {
@@ -159,15 +161,22 @@ __device__ __forceinline__ Skinned skin_vertex(const float4 *pal, const float *l
 
 // ------------------------------------------------------------------------------------------------
 // fused morph + skin.
-//   S     morph-split: lanes per quad (1,2,4,8,16)
+//   S     morph-split: lanes per quad (1,2,4,8)
 //   U     morphs in flight per lane-slice iteration (3*U 16-byte loads issued back to back)
 //   MODE  0 = no morphs, 1 = dense planes, 2 = per-vertex sparse CSR (S must be 1)
-//   NT    nontemporal loads on the morph stream
+//   NT    nontemporal loads on the morph stream (read once per frame: do not keep it in cache)
+//   NTS   nontemporal stores of the outputs
 //   GEO   1 = rest geometry is read with 16-byte loads by the quad owner and transposed through
 //             the wave's LDS scratch; 0 = only the morphed position goes through LDS and the
 //             vertex-per-lane phase reads normal/joints/weights with 4-byte loads
+//   FAST  single-instance frame in ONE launch: the palette (world * inverseBind, engine.ts:926-928)
+//         is computed by every workgroup while it stages it into LDS — the raw matrices arrive by
+//         asynchronous global->LDS DMA that overlaps the first tile's morph stream — and the
+//         active-morph list comes in the kernel arguments (compacted on the host by rz_set_pose).
+//         !FAST reads the palette / list produced by rz_prep_kernel (instanced frames).
 // grid = (tiles capped, instances); block = 256.
-// dynamic LDS = palette | 256-entry unorm LUT | active-morph list | per-wave transpose scratch.
+// dynamic LDS = palette | 256-entry unorm LUT | active-morph list (!FAST) | per-wave transpose
+//               scratch (aliased by the raw world/inverse-bind matrices during the prologue).
 //
 // Two phases per tile, both fully coalesced:
 //   phase 1 (lane = quad of 4 vertices, slice s of S): stream the active morph planes with
@@ -177,29 +186,58 @@ __device__ __forceinline__ Skinned skin_vertex(const float4 *pal, const float *l
 //           four bones' 3x4 rows from the LDS palette, LBS, normalize, store 12 B + 12 B per lane
 //           (a wave writes 768 contiguous bytes per store instruction).
 // ------------------------------------------------------------------------------------------------
-template <int S, int U, int MODE, bool NT, bool GEO>
-__global__ void __launch_bounds__(kBlock) rz_deform_kernel(RzDeformParams p)
+template <bool NTS> __device__ __forceinline__ void st3(float *d, float a, float b, float c)
+{
+    if (NTS) {
+        __builtin_nontemporal_store(a, d); __builtin_nontemporal_store(b, d + 1); __builtin_nontemporal_store(c, d + 2);
+    } else {
+        d[0] = a; d[1] = b; d[2] = c;
+    }
+}
+
+template <int S, int U, int MODE, bool NT, bool NTS, bool GEO, bool FAST>
+__global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams p, const RzMorphList ml)
 {
     constexpr int QPW = 64 / S;              // quads per wave
     constexpr int VW = 4 * QPW;              // vertices per wave per tile
     constexpr int QPB = (kBlock / 64) * QPW; // quads per workgroup tile
     constexpr int NPL = GEO ? 9 : 3;         // scratch planes per wave
     constexpr int ROUNDS = (VW + 63) / 64;
+    constexpr bool LDS_LIST = !FAST && MODE != 0;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *pal = reinterpret_cast<float4 *>(smem);                       // B*3 float4
     float *lut = reinterpret_cast<float *>(smem + (size_t)p.B * 48);      // 256 floats
-    uint32_t *s_idx = reinterpret_cast<uint32_t *>(lut + 256);            // Mpad
-    float *s_w = reinterpret_cast<float *>(s_idx + p.Mpad);               // Mpad (MODE 2: all M weights)
-    float *scratch_all = s_w + p.Mpad;                                    // 4 waves x NPL x VW (16-B aligned: Mpad % 4 == 0)
+    uint32_t *s_idx = reinterpret_cast<uint32_t *>(lut + 256);            // Mpad   (LDS_LIST)
+    float *s_w = reinterpret_cast<float *>(s_idx + (LDS_LIST ? p.Mpad : 0));
+    float *scratch_all = s_w + (LDS_LIST ? p.Mpad : 0);                   // 16-B aligned: Mpad % 4 == 0
 
     const int tid = threadIdx.x;
     const int inst = blockIdx.y;
+    const int lane = tid & 63, wave = tid >> 6;
 
-    {   // ---- stage per-instance state in LDS ----
+    lut[tid] = (float)tid / 255.0f;
+    if (FAST) {
+        // raw world (B*4 float4) then inverse bind (B*4 float4) -> scratch, by LDS-DMA: no VGPRs,
+        // in flight while the first tile's morph planes stream in
+        const float4 *gw = reinterpret_cast<const float4 *>(p.world);
+        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind);
+        const int n4 = p.B * 4;
+        for (int c = wave * 64; c < 2 * n4; c += kBlock) {
+            const int e = c + lane;
+            if (e < 2 * n4) {
+                const float4 *src = (e < n4) ? gw + e : gi + (e - n4);
+                typedef const __attribute__((address_space(1))) void *gptr_t;
+                typedef __attribute__((address_space(3))) void *lptr_t;
+                // LDS destination = wave-uniform base (+ lane * 16 added by the hardware)
+                __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)src,
+                                                 (lptr_t)(uint32_t)(uintptr_t)(reinterpret_cast<float4 *>(scratch_all) + c),
+                                                 16, 0, 0);
+            }
+        }
+    } else {
         const float4 *gpal = p.palette + (size_t)inst * p.B * 3;
         for (int i = tid; i < p.B * 3; i += kBlock) pal[i] = gpal[i];
-        lut[tid] = (float)tid / 255.0f;
         if (MODE == 1) {
             const uint32_t *gi = p.act_idx + (size_t)inst * p.Mpad;
             const float *gw = p.act_w + (size_t)inst * p.Mpad;
@@ -208,19 +246,19 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(RzDeformParams p)
             const float *gw = p.morph_w + (size_t)inst * p.M;
             for (int i = tid; i < p.M; i += kBlock) s_w[i] = gw[i];
         }
+        __syncthreads();
     }
-    __syncthreads();
 
-    const int lane = tid & 63, wave = tid >> 6;
     const int s = lane / QPW;                // morph slice of this lane
     const int qi = lane % QPW;
-    const int count = (MODE == 1) ? p.act_count[inst] : 0;
+    const int count = (MODE == 1) ? (FAST ? ml.count : p.act_count[inst]) : 0;
     const size_t Vp = p.Vp;
     const size_t plane4 = Vp / 4;            // float4 per plane
     float *scr = scratch_all + (size_t)wave * NPL * VW;
     const uint32_t bmax = (uint32_t)(p.B - 1);
     float *opos = p.out_pos + (size_t)inst * Vp * 3;
     float *onrm = p.out_nrm + (size_t)inst * Vp * 3;
+    bool need_palette = FAST;
 
     for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         const size_t qw = (size_t)tile * QPB + (size_t)wave * QPW;   // first quad of this wave
@@ -250,8 +288,8 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(RzDeformParams p)
                 float w[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const uint32_t m = s_idx[a + u * S];
-                    w[u] = s_w[a + u * S];
+                    const uint32_t m = FAST ? (uint32_t)ml.idx[a + u * S] : s_idx[a + u * S];
+                    w[u] = FAST ? ml.w[a + u * S] : s_w[a + u * S];
                     const float4 *d = D + (size_t)m * 3 * plane4;
                     dx[u] = ld_stream(d, NT);
                     dy[u] = ld_stream(d + plane4, NT);
@@ -268,8 +306,8 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(RzDeformParams p)
                 }
             }
             for (; a < count; a += S) {     // remainder, one morph at a time
-                const uint32_t m = s_idx[a];
-                const float w = s_w[a];
+                const uint32_t m = FAST ? (uint32_t)ml.idx[a] : s_idx[a];
+                const float w = FAST ? ml.w[a] : s_w[a];
                 const float4 *d = D + (size_t)m * 3 * plane4;
                 float4 dx = ld_stream(d, NT), dy = ld_stream(d + plane4, NT), dz = ld_stream(d + 2 * plane4, NT);
                 ax.x = fmaf(w, dx.x, ax.x); ax.y = fmaf(w, dx.y, ax.y); ax.z = fmaf(w, dx.z, ax.z); ax.w = fmaf(w, dx.w, ax.w);
@@ -290,6 +328,7 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(RzDeformParams p)
             }
         } else if (MODE == 2) {
             // per-vertex CSR: entry = (dx,dy,dz, bits(morph)); entries of a vertex sorted by morph
+            const float *mwv = FAST ? p.morph_w : s_w;    // FAST: weights straight from global (L2-resident, tiny)
             const uint32_t *ptr = p.sp_ptr + q * 4;
             const uint4 lo = *reinterpret_cast<const uint4 *>(ptr);
             const uint32_t b[5] = { lo.x, lo.y, lo.z, lo.w, ptr[4] };
@@ -298,13 +337,47 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(RzDeformParams p)
             for (int k = 0; k < 4; ++k) {
                 for (uint32_t e = b[k]; e < b[k + 1]; ++e) {
                     const float4 ent = p.sp_entries[e];
-                    const float w = s_w[__float_as_uint(ent.w)];
+                    const float w = mwv[__float_as_uint(ent.w)];
                     sx[k] = fmaf(w, ent.x, sx[k]); sy[k] = fmaf(w, ent.y, sy[k]); sz[k] = fmaf(w, ent.z, sz[k]);
                 }
             }
             ax = make_float4(sx[0], sx[1], sx[2], sx[3]);
             ay = make_float4(sy[0], sy[1], sy[2], sy[3]);
             az = make_float4(sz[0], sz[1], sz[2], sz[3]);
+        }
+
+        if (FAST && need_palette) {
+            // the raw matrices have landed (every wave drains its own DMA, the barrier publishes them):
+            // palette rows 0..2 of world * inverseBind, out[c*4+r] = ((a0[r]*b0 + a1[r]*b1) + a2[r]*b2) + a3[r]*b3
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const float4 *raw = reinterpret_cast<const float4 *>(scratch_all);
+            const int n4 = p.B * 4;
+            float4 rows[ (1) ][3];
+            for (int b0 = 0; b0 < p.B; b0 += kBlock) {
+                const int b = b0 + tid;
+                if (b < p.B) {
+                    const float4 a0 = raw[b * 4 + 0], a1 = raw[b * 4 + 1], a2 = raw[b * 4 + 2], a3 = raw[b * 4 + 3];
+                    float r0[4], r1[4], r2[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float4 bc = raw[n4 + b * 4 + c];
+                        r0[c] = fmaf(a3.x, bc.w, fmaf(a2.x, bc.z, fmaf(a1.x, bc.y, a0.x * bc.x)));
+                        r1[c] = fmaf(a3.y, bc.w, fmaf(a2.y, bc.z, fmaf(a1.y, bc.y, a0.y * bc.x)));
+                        r2[c] = fmaf(a3.z, bc.w, fmaf(a2.z, bc.z, fmaf(a1.z, bc.y, a0.z * bc.x)));
+                    }
+                    pal[b * 3 + 0] = make_float4(r0[0], r0[1], r0[2], r0[3]);
+                    pal[b * 3 + 1] = make_float4(r1[0], r1[1], r1[2], r1[3]);
+                    pal[b * 3 + 2] = make_float4(r2[0], r2[1], r2[2], r2[3]);
+                    if (blockIdx.x == 0 && p.palette) {      // keep the skinMatrixBuffer observable (rz_read_palette)
+                        float4 *gp = p.palette + (size_t)b * 3;
+                        gp[0] = pal[b * 3 + 0]; gp[1] = pal[b * 3 + 1]; gp[2] = pal[b * 3 + 2];
+                    }
+                }
+            }
+            (void)rows;
+            __syncthreads();      // palette visible; the raw region may now be reused as transpose scratch
+            need_palette = false;
         }
 
         // ---- park the quad in the wave's scratch: plane-major [NPL][VW] dwords ----
@@ -341,10 +414,8 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(RzDeformParams p)
                     j01 = p.joints01[v]; j23 = p.joints23[v]; wq = p.weights[v];
                 }
                 Skinned o = skin_vertex(pal, lut, x, y, z, nx, ny, nz, j01, j23, wq, bmax);
-                float *dp = opos + v * 3;
-                float *dn = onrm + v * 3;
-                dp[0] = o.px; dp[1] = o.py; dp[2] = o.pz;
-                dn[0] = o.nx; dn[1] = o.ny; dn[2] = o.nz;
+                st3<NTS>(opos + v * 3, o.px, o.py, o.pz);
+                st3<NTS>(onrm + v * 3, o.nx, o.ny, o.nz);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -385,63 +456,72 @@ hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t
     return hipGetLastError();
 }
 
-size_t rz_deform_lds_bytes(const RzDeformParams &p, int S, bool geo)
+size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v)
 {
-    const size_t vw = 256 / S;   // vertices per wave per tile
-    return (size_t)p.B * 48 + 256 * 4 + (size_t)p.Mpad * 8 + (size_t)(kBlock / 64) * (geo ? 9 : 3) * vw * 4;
+    const size_t vw = 256 / v.S;   // vertices per wave per tile
+    size_t scratch = (size_t)(kBlock / 64) * (v.geo ? 9 : 3) * vw * 4;
+    if (v.fast) scratch = std::max(scratch, (size_t)p.B * 128);          // raw world + inverse bind alias it
+    const size_t list = (!v.fast && v.mode != 0) ? (size_t)p.Mpad * 8 : 0;
+    return (size_t)p.B * 48 + 256 * 4 + list + scratch;
 }
 
 uint32_t rz_quads_per_tile(int S) { return (kBlock / 64) * (64 / S); }
 
-template <int S, int U, int MODE, bool NT, bool GEO>
-static hipError_t launch_one(const RzDeformParams &p, dim3 grid, size_t lds, hipStream_t st)
+template <int S, int U, int MODE, bool NT, bool NTS, bool GEO, bool FAST>
+static hipError_t launch_one(const RzDeformParams &p, const RzMorphList &ml, dim3 grid, size_t lds, hipStream_t st)
 {
-    auto k = rz_deform_kernel<S, U, MODE, NT, GEO>;
+    auto k = rz_deform_kernel<S, U, MODE, NT, NTS, GEO, FAST>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p);
+    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p, ml);
     return hipGetLastError();
 }
 
-template <int S, int U, int MODE>
-static hipError_t launch_flags(const RzDeformParams &p, bool nt, bool geo, dim3 grid, size_t lds, hipStream_t st)
+template <int S, int U, int MODE, bool NT, bool NTS>
+static hipError_t launch_gf(const RzDeformParams &p, const RzMorphList &ml, const RzVariant &v, dim3 grid, size_t lds,
+                            hipStream_t st)
 {
-    if (MODE != 1) nt = false;   // the nontemporal hint only exists on the dense morph stream
-    if (nt) return geo ? launch_one<S, U, MODE, true, true>(p, grid, lds, st)
-                       : launch_one<S, U, MODE, true, false>(p, grid, lds, st);
-    return geo ? launch_one<S, U, MODE, false, true>(p, grid, lds, st)
-               : launch_one<S, U, MODE, false, false>(p, grid, lds, st);
+    if (v.geo) return v.fast ? launch_one<S, U, MODE, NT, NTS, true, true>(p, ml, grid, lds, st)
+                             : launch_one<S, U, MODE, NT, NTS, true, false>(p, ml, grid, lds, st);
+    return v.fast ? launch_one<S, U, MODE, NT, NTS, false, true>(p, ml, grid, lds, st)
+                  : launch_one<S, U, MODE, NT, NTS, false, false>(p, ml, grid, lds, st);
+}
+
+template <int S, int U, int MODE>
+static hipError_t launch_nt(const RzDeformParams &p, const RzMorphList &ml, const RzVariant &v, dim3 grid, size_t lds,
+                            hipStream_t st)
+{
+    if constexpr (MODE == 1) {           // the nontemporal load hint only exists on the dense morph stream
+        if (v.nt) return v.nts ? launch_gf<S, U, MODE, true, true>(p, ml, v, grid, lds, st)
+                               : launch_gf<S, U, MODE, true, false>(p, ml, v, grid, lds, st);
+    }
+    return v.nts ? launch_gf<S, U, MODE, false, true>(p, ml, v, grid, lds, st)
+                 : launch_gf<S, U, MODE, false, false>(p, ml, v, grid, lds, st);
 }
 
 template <int S>
-static hipError_t launch_dense(const RzDeformParams &p, int U, bool nt, bool geo, dim3 grid, size_t lds,
+static hipError_t launch_dense(const RzDeformParams &p, const RzMorphList &ml, const RzVariant &v, dim3 grid, size_t lds,
                                hipStream_t st)
 {
-    switch (U) {
-    case 1: return launch_flags<S, 1, 1>(p, nt, geo, grid, lds, st);
-    case 2: return launch_flags<S, 2, 1>(p, nt, geo, grid, lds, st);
-    case 8: return launch_flags<S, 8, 1>(p, nt, geo, grid, lds, st);
-    default: return launch_flags<S, 4, 1>(p, nt, geo, grid, lds, st);
-    }
+    if (v.U >= 8) return launch_nt<S, 8, 1>(p, ml, v, grid, lds, st);
+    return launch_nt<S, 4, 1>(p, ml, v, grid, lds, st);
 }
 
-hipError_t rz_launch_deform(const RzDeformParams &p, int mode, int S, int U, bool nt, bool geo, uint32_t grid_x,
+hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, const RzVariant &v, uint32_t grid_x,
                             uint32_t instances, hipStream_t st)
 {
-    if (mode != 1) S = 1;        // morph split only applies to the dense stream
-    const size_t lds = rz_deform_lds_bytes(p, S, geo);
+    const size_t lds = rz_deform_lds_bytes(p, v);
     dim3 grid(grid_x, instances);
-    if (mode == 0) return launch_flags<1, 1, 0>(p, false, geo, grid, lds, st);
-    if (mode == 2) return launch_flags<1, 1, 2>(p, false, geo, grid, lds, st);
-    switch (S) {
-    case 2: return launch_dense<2>(p, U, nt, geo, grid, lds, st);
-    case 4: return launch_dense<4>(p, U, nt, geo, grid, lds, st);
-    case 8: return launch_dense<8>(p, U, nt, geo, grid, lds, st);
-    case 16: return launch_dense<16>(p, U, nt, geo, grid, lds, st);
-    default: return launch_dense<1>(p, U, nt, geo, grid, lds, st);
+    if (v.mode == 0) return launch_nt<1, 1, 0>(p, ml, v, grid, lds, st);
+    if (v.mode == 2) return launch_nt<1, 1, 2>(p, ml, v, grid, lds, st);
+    switch (v.S) {
+    case 2: return launch_dense<2>(p, ml, v, grid, lds, st);
+    case 4: return launch_dense<4>(p, ml, v, grid, lds, st);
+    case 8: return launch_dense<8>(p, ml, v, grid, lds, st);
+    default: return launch_dense<1>(p, ml, v, grid, lds, st);
     }
 }
 

@@ -132,8 +132,12 @@ struct rz_ctx {
     bool stage_used[kStageSlots] = {false, false, false, false};
     int stage_next = 0;
 
-    // tuning
-    int t_split = 0, t_unroll = 4, t_grid_cap = 0, t_nt = 0, t_geo = 1;
+    // host-compacted active-morph list of the current pose (single-instance FAST path);
+    // count < 0 means "more than kKargMorphs active: use the prep kernel"
+    RzMorphList ml;
+
+    // tuning (0 / -1 = automatic)
+    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = 1, t_geo = 1, t_fast = -1;
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -208,26 +212,33 @@ void free_morphs(rz_ctx *c)
 int auto_split(const rz_ctx *c)
 {
     if (c->morph_mode != 1) return 1;
-    // enough waves to cover every CU ~8 deep; S lanes share a quad, so waves = quads * S / 64
+    // S lanes share a quad, so waves = quads * S / 64. Measured on MI355X (profiles/r1_a_sweep*):
+    // 1 M verts -> S=1..2, 126 k -> S=4, 30 k -> S=8; i.e. aim for ~1500 waves, never beyond 8.
     const uint64_t quads = (uint64_t)c->Vp / 4 * c->I;
-    const uint64_t want = (uint64_t)c->n_cu * 8;
+    const uint64_t want = 1500;
     int S = 1;
-    while (S < 16 && quads * S / 64 < want) S <<= 1;
+    while (S < 8 && quads * S / 64 < want) S <<= 1;
     while (S > 1 && (uint32_t)S > c->M) S >>= 1;
     return S;
 }
 
-struct Plan { int mode, S, U; bool nt, geo; uint32_t grid_x, n_tiles; };
+struct Plan { RzVariant v; uint32_t grid_x, n_tiles; bool prep; };
 
 Plan make_plan(const rz_ctx *c)
 {
     Plan pl;
-    pl.mode = c->morph_mode;
-    pl.S = (pl.mode == 1) ? (c->t_split > 0 ? c->t_split : auto_split(c)) : 1;
-    pl.U = c->t_unroll;
-    pl.nt = c->t_nt != 0;
-    pl.geo = c->t_geo != 0;
-    pl.n_tiles = (c->Vp / 4) / rz_quads_per_tile(pl.S);
+    RzVariant &v = pl.v;
+    v.mode = c->morph_mode;
+    v.S = (v.mode == 1) ? (c->t_split > 0 ? c->t_split : auto_split(c)) : 1;
+    v.U = c->t_unroll > 0 ? c->t_unroll : (v.S <= 2 ? 8 : 4);
+    v.nt = c->t_nt != 0;
+    v.nts = c->t_nts != 0;
+    v.geo = c->t_geo != 0;
+    // one-launch frame: single instance, and (dense) the active list fits the kernel arguments
+    const bool can_fast = c->I == 1 && (v.mode != 1 || c->ml.count >= 0);
+    v.fast = can_fast && c->t_fast != 0;
+    pl.prep = !v.fast;
+    pl.n_tiles = (c->Vp / 4) / rz_quads_per_tile(v.S);
     uint32_t cap = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : 8u * (uint32_t)c->n_cu;   // total workgroups
     uint32_t gx = std::max<uint32_t>(1, cap / std::max<uint32_t>(1, c->I));
     pl.grid_x = std::min(pl.n_tiles, gx);
@@ -239,7 +250,7 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     RzDeformParams p;
     memset(&p, 0, sizeof p);
     p.geom = c->geom; p.joints01 = c->j01; p.joints23 = c->j23; p.weights = c->wq;
-    p.palette = c->palette; p.dense = c->dense;
+    p.palette = c->palette; p.world = c->world; p.inv_bind = c->inv_bind; p.dense = c->dense;
     p.act_idx = c->act_idx; p.act_w = c->act_w; p.act_count = c->act_count; p.morph_w = c->morph_w;
     p.sp_ptr = c->sp_ptr; p.sp_entries = c->sp_entries;
     p.out_pos = c->out_pos; p.out_nrm = c->out_nrm;
@@ -274,9 +285,9 @@ int launch_prep(rz_ctx *c)
 int launch_deform(rz_ctx *c, const Plan &pl)
 {
     RzDeformParams p = deform_params(c, pl);
-    size_t lds = rz_deform_lds_bytes(p, pl.S, pl.geo);
+    size_t lds = rz_deform_lds_bytes(p, pl.v);
     if (lds > 160 * 1024) return fail(RZ_ERR_UNSUPPORTED, "skeleton too large for the LDS palette (%zu B)", lds);
-    HIP_TRY(rz_launch_deform(p, pl.mode, pl.S, pl.U, pl.nt, pl.geo, pl.grid_x, c->I, c->stream));
+    HIP_TRY(rz_launch_deform(p, c->ml, pl.v, pl.grid_x, c->I, c->stream));
     return RZ_OK;
 }
 
@@ -359,6 +370,7 @@ int rz_create(int device, rz_ctx **out)
         return fail(RZ_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", device,
                     prop.gcnArchName);
     rz_ctx *c = new rz_ctx();
+    memset(&c->ml, 0, sizeof c->ml);
     c->device = device;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -576,6 +588,18 @@ int rz_set_pose(rz_ctx *c, const float *world, const float *morph_weights)
     }
     HIP_TRY(hipEventRecord(c->stage_ev[slot], c->stream));
     c->stage_used[slot] = true;
+    // ordered compaction of the non-zero weights for the one-launch path (instance 0)
+    c->ml.count = 0;
+    if (c->M > 0 && morph_weights && c->I == 1) {
+        int n = 0;
+        for (uint32_t m = 0; m < c->M; ++m) {
+            const float w = morph_weights[m];
+            if (w == 0.0f) continue;
+            if (n < kKargMorphs && m < 65536u) { c->ml.idx[n] = (uint16_t)m; c->ml.w[n] = w; }
+            ++n;
+        }
+        c->ml.count = (n <= kKargMorphs && c->M <= 65536u) ? n : -1;
+    }
     c->pose_set = true;
     return RZ_OK;
 }
@@ -585,8 +609,10 @@ int rz_deform(rz_ctx *c)
     if (int r = use(c)) return r;
     if (int r = check_ready(c)) return r;
     if (int r = ensure_outputs(c)) return r;
-    if (int r = launch_prep(c)) return r;
-    return launch_deform(c, make_plan(c));
+    const Plan pl = make_plan(c);
+    if (pl.prep)
+        if (int r = launch_prep(c)) return r;
+    return launch_deform(c, pl);
 }
 
 int rz_deform_n(rz_ctx *c, uint32_t frames)
@@ -596,7 +622,8 @@ int rz_deform_n(rz_ctx *c, uint32_t frames)
     if (int r = ensure_outputs(c)) return r;
     const Plan pl = make_plan(c);
     for (uint32_t f = 0; f < frames; ++f) {
-        if (int r = launch_prep(c)) return r;
+        if (pl.prep)
+            if (int r = launch_prep(c)) return r;
         if (int r = launch_deform(c, pl)) return r;
     }
     return RZ_OK;
@@ -640,10 +667,14 @@ int rz_time_frames(rz_ctx *c, uint32_t frames, rz_timing *out)
     const Plan pl = make_plan(c);
     memset(out, 0, sizeof *out);
     float ms = 0.f;
-    // whole frames: prep + fused kernel, back to back on the context's stream
+    // whole frames (prep kernel when the plan needs one + fused kernel), back to back on the context's stream
+    if (pl.prep)
+        if (int r = launch_prep(c)) return r;     // !FAST: the deform-only loop below needs a palette
+    HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     for (uint32_t f = 0; f < frames; ++f) {
-        if (int r = launch_prep(c)) return r;
+        if (pl.prep)
+            if (int r = launch_prep(c)) return r;
         if (int r = launch_deform(c, pl)) return r;
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -658,14 +689,16 @@ int rz_time_frames(rz_ctx *c, uint32_t frames, rz_timing *out)
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     out->deform_kernel_ms = ms / frames;
-    // the prep kernel alone
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    for (uint32_t f = 0; f < frames; ++f)
-        if (int r = launch_prep(c)) return r;
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipEventSynchronize(c->ev1));
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    out->prep_kernel_ms = ms / frames;
+    // the prep kernel alone (only part of the frame when the plan is not the one-launch FAST form)
+    if (pl.prep) {
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        for (uint32_t f = 0; f < frames; ++f)
+            if (int r = launch_prep(c)) return r;
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev1));
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        out->prep_kernel_ms = ms / frames;
+    }
     out->verts_per_frame = (uint64_t)c->V * c->I;
     out->algorithmic_bytes_per_frame = algorithmic_bytes(c);
     out->frames = frames;
@@ -676,11 +709,11 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
 {
     if (!c || !key) return fail(RZ_ERR_INVALID, "null argument");
     if (!strcmp(key, "morph_split")) {
-        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
-            return fail(RZ_ERR_INVALID, "morph_split must be 0,1,2,4,8,16");
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+            return fail(RZ_ERR_INVALID, "morph_split must be 0 (auto),1,2,4,8");
         c->t_split = value;
     } else if (!strcmp(key, "unroll")) {
-        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(RZ_ERR_INVALID, "unroll must be 1,2,4,8");
+        if (value != 0 && value != 4 && value != 8) return fail(RZ_ERR_INVALID, "unroll must be 0 (auto), 4 or 8");
         c->t_unroll = value;
     } else if (!strcmp(key, "grid_cap")) {
         if (value < 0) return fail(RZ_ERR_INVALID, "grid_cap must be >= 0");
@@ -689,6 +722,10 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
         c->t_nt = value ? 1 : 0;
     } else if (!strcmp(key, "geo_lds")) {
         c->t_geo = value ? 1 : 0;
+    } else if (!strcmp(key, "nt_store")) {
+        c->t_nts = value ? 1 : 0;
+    } else if (!strcmp(key, "fast")) {
+        c->t_fast = value;        // -1 auto, 0 never (always prep kernel), 1 when possible
     } else {
         return fail(RZ_ERR_INVALID, "unknown tuning key '%s'", key);
     }
@@ -703,7 +740,11 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "grid_cap")) *value = c->t_grid_cap;
     else if (!strcmp(key, "nontemporal")) *value = c->t_nt;
     else if (!strcmp(key, "geo_lds")) *value = c->t_geo;
-    else if (!strcmp(key, "effective_split")) *value = make_plan(c).S;
+    else if (!strcmp(key, "nt_store")) *value = c->t_nts;
+    else if (!strcmp(key, "fast")) *value = c->t_fast;
+    else if (!strcmp(key, "effective_split")) *value = make_plan(c).v.S;
+    else if (!strcmp(key, "effective_unroll")) *value = make_plan(c).v.U;
+    else if (!strcmp(key, "effective_fast")) *value = make_plan(c).v.fast ? 1 : 0;
     else if (!strcmp(key, "effective_grid")) *value = (int)make_plan(c).grid_x;
     else return fail(RZ_ERR_INVALID, "unknown tuning key '%s'", key);
     return RZ_OK;

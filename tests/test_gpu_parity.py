@@ -24,7 +24,7 @@ def run_gpu(ctx, mesh, world=None, deltas=None, mw=None, sparse=None, **tuning):
     elif sparse is not None:
         ctx.upload_morphs_sparse(*sparse)
     ctx.set_instances(1)
-    ctx.set_tuning(morph_split=0, unroll=4, nontemporal=0, geo_lds=1, grid_cap=0)
+    ctx.set_tuning(morph_split=0, unroll=0, nontemporal=1, nt_store=1, geo_lds=1, grid_cap=0, fast=-1)
     ctx.set_tuning(**tuning)
     ctx.set_pose(mesh["world"] if world is None else world, mw)
     ctx.deform()
@@ -36,12 +36,13 @@ def test_c2_lbs_30k_200_bones(ctx, oracle):
     mesh = synth.make_mesh(30000, 200)
     pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"])
     for geo in (1, 0):
-        pg, ng = run_gpu(ctx, mesh, geo_lds=geo)
-        assert_parity(pg, ng, pr, nr, "C2 geo_lds=%d" % geo)
-    # palette kernel vs engine.ts:926-928 restatement (rows 0..2)
-    S = oracle.palette(mesh["world"], mesh["inv_bind"]).reshape(-1, 4, 4)      # [b, col, row]
-    rows = np.transpose(S, (0, 2, 1))[:, :3, :].reshape(-1, 12)
-    np.testing.assert_allclose(ctx.read_palette(), rows, rtol=1e-6, atol=1e-6)
+        for fast in (1, 0):
+            pg, ng = run_gpu(ctx, mesh, geo_lds=geo, fast=fast)
+            assert_parity(pg, ng, pr, nr, "C2 geo_lds=%d fast=%d" % (geo, fast))
+            # palette (engine.ts:926-928 restatement, rows 0..2) is observable in both forms
+            S = oracle.palette(mesh["world"], mesh["inv_bind"]).reshape(-1, 4, 4)      # [b, col, row]
+            rows = np.transpose(S, (0, 2, 1))[:, :3, :].reshape(-1, 12)
+            np.testing.assert_allclose(ctx.read_palette(), rows, rtol=1e-6, atol=1e-6)
 
 
 def test_interleaved_upload_matches_soa_upload(ctx):
@@ -69,27 +70,31 @@ def test_identity_pose_known_answer(ctx):
     np.testing.assert_allclose(ng, mesh["nrm"], atol=1e-6)
 
 
-@pytest.mark.parametrize("split", [1, 2, 4, 8, 16])
-@pytest.mark.parametrize("unroll", [1, 4, 8])
-def test_c3_fused_morph_skin_all_kernel_variants(ctx, oracle, split, unroll):
-    """config 3: 30k verts / 200 bones / 64 active morph targets, every morph-split x unroll variant."""
+@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("split", [1, 2, 4, 8])
+@pytest.mark.parametrize("unroll", [4, 8])
+def test_c3_fused_morph_skin_all_kernel_variants(ctx, oracle, split, unroll, fast):
+    """config 3: 30k verts / 200 bones / 64 active morph targets, every morph-split x unroll variant,
+    both as the one-launch frame (fast=1: palette fused, kernarg morph list) and with the prep kernel."""
     mesh = synth.make_mesh(30000, 200)
     deltas, mw = synth.make_morphs_dense(30000, 64)
     pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"],
                            mesh["inv_bind"], deltas, mw, threads=8)
-    pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, morph_split=split, unroll=unroll)
-    assert_parity(pg, ng, pr, nr, "C3 S=%d U=%d" % (split, unroll))
+    pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, morph_split=split, unroll=unroll, fast=fast)
+    assert_parity(pg, ng, pr, nr, "C3 S=%d U=%d fast=%d" % (split, unroll, fast))
     assert ctx.get_tuning("effective_split") == split
+    assert ctx.get_tuning("effective_fast") == fast
 
 
-@pytest.mark.parametrize("nt,geo", [(1, 1), (0, 0), (1, 0)])
-def test_c3_load_path_variants(ctx, oracle, nt, geo):
+@pytest.mark.parametrize("nt,nts,geo", [(0, 0, 1), (0, 1, 0), (1, 0, 0), (0, 0, 0)])
+def test_c3_load_path_variants(ctx, oracle, nt, nts, geo):
     mesh = synth.make_mesh(30000, 200)
     deltas, mw = synth.make_morphs_dense(30000, 64)
     pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"],
                            mesh["inv_bind"], deltas, mw, threads=8)
-    pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, nontemporal=nt, geo_lds=geo)
-    assert_parity(pg, ng, pr, nr, "C3 nt=%d geo=%d" % (nt, geo))
+    for fast in (1, 0):
+        pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, nontemporal=nt, nt_store=nts, geo_lds=geo, fast=fast)
+        assert_parity(pg, ng, pr, nr, "C3 nt=%d nts=%d geo=%d fast=%d" % (nt, nts, geo, fast))
 
 
 @pytest.mark.parametrize("V,B,M", [(1, 1, 1), (3, 2, 7), (1023, 17, 3), (1025, 300, 9), (4097, 471, 33)])
@@ -101,8 +106,37 @@ def test_ragged_sizes_and_partial_weights(ctx, oracle, V, B, M):
     pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"],
                            mesh["inv_bind"], deltas, mw)
     for split in (0, 1, 4):
-        pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, morph_split=split)
-        assert_parity(pg, ng, pr, nr, "ragged V=%d M=%d S=%d" % (V, M, split))
+        for fast in (1, 0):
+            pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, morph_split=split, fast=fast)
+            assert_parity(pg, ng, pr, nr, "ragged V=%d M=%d S=%d fast=%d" % (V, M, split, fast))
+
+
+def test_more_active_morphs_than_kernel_arguments_hold(ctx, oracle):
+    """> 128 active morphs cannot ride in the kernel arguments: the frame silently uses the prep kernel."""
+    V, B, M = 6000, 33, 200
+    mesh = synth.make_mesh(V, B, seed=51)
+    deltas, mw = synth.make_morphs_dense(V, M, seed=52)
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"],
+                           mesh["inv_bind"], deltas, mw, threads=4)
+    pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw)
+    assert ctx.get_tuning("effective_fast") == 0
+    assert_parity(pg, ng, pr, nr, "M=200 active")
+    mw[100:] = 0                                      # 100 active: back on the one-launch path
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"],
+                           mesh["inv_bind"], deltas, mw, threads=4)
+    pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw)
+    assert ctx.get_tuning("effective_fast") == 1
+    assert_parity(pg, ng, pr, nr, "M=200, 100 active")
+
+
+def test_large_skeleton_palette(ctx, oracle):
+    """B > 256 exercises the multi-pass palette staging (demo models have 349 / 471 bones; stress 1500)."""
+    for B in (471, 1500):
+        mesh = synth.make_mesh(20000, B, seed=B)
+        pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"])
+        for fast in (1, 0):
+            pg, ng = run_gpu(ctx, mesh, fast=fast)
+            assert_parity(pg, ng, pr, nr, "B=%d fast=%d" % (B, fast))
 
 
 def test_all_morph_weights_zero_equals_plain_skin(ctx, oracle):
@@ -137,8 +171,9 @@ def test_sparse_morphs_match_oracle_and_dense_path(ctx, oracle):
     pm = oracle.morph_sparse(V, off, idx, d3, mw, mesh["pos"])
     S = oracle.palette(mesh["world"], mesh["inv_bind"])
     pr, nr = oracle.skin(pm, mesh["nrm"], mesh["joints"], mesh["weights"], S)
-    pg, ng = run_gpu(ctx, mesh, sparse=(off, idx, d3), mw=mw)
-    assert_parity(pg, ng, pr, nr, "sparse")
+    for fast in (1, 0):
+        pg, ng = run_gpu(ctx, mesh, sparse=(off, idx, d3), mw=mw, fast=fast)
+        assert_parity(pg, ng, pr, nr, "sparse fast=%d" % fast)
     pd, nd = run_gpu(ctx, mesh, deltas=synth.sparse_to_dense(V, off, idx, d3), mw=mw, morph_split=1)
     assert_parity(pd, nd, pr, nr, "dense expansion")
 
@@ -232,7 +267,7 @@ def test_error_paths(ctx, rz):
     with pytest.raises(rz.RzError):
         c.deform()                                    # no pose
     with pytest.raises(rz.RzError):
-        c.set_tuning(morph_split=3)
+        c.set_tuning(morph_split=16)
     with pytest.raises(rz.RzError):
         c._L.rz_read and c.read(v0=90, n=20)          # out of range
     c.close()

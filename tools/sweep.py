@@ -36,6 +36,16 @@ def setup(ctx, V, B, M, I=1):
     ctx.set_pose(worlds, mw)
 
 
+def setup_sparse(ctx, V, B, M):
+    mesh = synth.make_mesh(V, B)
+    ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    ctx.upload_skeleton(mesh["inv_bind"])
+    off, idx, d3, mw = synth.make_morphs_sparse(V, M)
+    ctx.upload_morphs_sparse(off, idx, d3)
+    ctx.set_instances(1)
+    ctx.set_pose(mesh["world"], mw)
+
+
 def run(ctx, name, frames, grid):
     rows = []
     keys = list(grid.keys())
@@ -53,7 +63,8 @@ def run(ctx, name, frames, grid):
             row = dict(config=name, **kw, kernel_ms=best["deform_kernel_ms"], frame_ms=best["frame_ms"],
                        prep_ms=best["prep_kernel_ms"], gbps=gbps, frac=gbps / 8000.0,
                        gverts=best["verts_per_frame"] / (best["deform_kernel_ms"] * 1e-3) / 1e9,
-                       S=ctx.get_tuning("effective_split"), grid=ctx.get_tuning("effective_grid"))
+                       S=ctx.get_tuning("effective_split"), U=ctx.get_tuning("effective_unroll"),
+                       F=ctx.get_tuning("effective_fast"), grid=ctx.get_tuning("effective_grid"))
         except Exception as e:   # keep sweeping
             row = dict(config=name, **kw, error=str(e))
         rows.append(row)
@@ -62,31 +73,41 @@ def run(ctx, name, frames, grid):
 
 
 def main():
-    which = sys.argv[1:] or ["c5", "c5shard", "c4", "c3", "c2"]
+    which = sys.argv[1:] or ["c5", "c5shard", "c4", "c3", "c2", "real"]
     ctx = rz.DeformContext(0)
     out = []
     t0 = time.time()
+    base = dict(morph_split=[0], unroll=[0], nontemporal=[1], nt_store=[1], geo_lds=[1], grid_cap=[0], fast=[-1])
+
+    def g(**kw):
+        d = dict(base)
+        d.update(kw)
+        return d
     if "c5" in which:
         setup(ctx, 1000000, 256, 64)
-        out += run(ctx, "C5 1M/256/64", 30, dict(morph_split=[1, 2, 4], unroll=[2, 4, 8], nontemporal=[0, 1],
-                                                 geo_lds=[1, 0], grid_cap=[0]))
-        out += run(ctx, "C5 grid", 30, dict(morph_split=[1], unroll=[4], nontemporal=[0], geo_lds=[1],
-                                            grid_cap=[256, 512, 768, 1024]))
+        out += run(ctx, "C5 1M/256/64", 30, g(morph_split=[1, 2, 4], unroll=[4, 8], nt_store=[0, 1], geo_lds=[1, 0], fast=[1, 0]))
+        out += run(ctx, "C5 1M nt-load A/B", 30, g(morph_split=[1, 2], unroll=[8], nontemporal=[0, 1]))
+        out += run(ctx, "C5 1M grid", 30, g(morph_split=[1], grid_cap=[256, 512, 768, 1024]))
     if "c5shard" in which:
         b, n = rz.shard_range(1000000, 8, 0)
         setup(ctx, n, 256, 64)
-        out += run(ctx, "C5 shard 1/8 (%d)" % n, 100, dict(morph_split=[1, 2, 4, 8, 16], unroll=[2, 4, 8],
-                                                           nontemporal=[0, 1], geo_lds=[1], grid_cap=[0]))
+        out += run(ctx, "C5 shard 1/8 (%d)" % n, 200, g(morph_split=[1, 2, 4, 8], unroll=[4, 8], geo_lds=[1, 0], fast=[1, 0]))
+        for nr in (2, 4):
+            b, n = rz.shard_range(1000000, nr, 0)
+            setup(ctx, n, 256, 64)
+            out += run(ctx, "C5 shard 1/%d (%d)" % (nr, n), 100, g(morph_split=[1, 2, 4], unroll=[4, 8]))
     if "c4" in which:
         setup(ctx, 30000, 200, 0, I=256)
-        out += run(ctx, "C4 256x30k", 50, dict(geo_lds=[1, 0], grid_cap=[0, 512, 1024, 4096, 8192]))
+        out += run(ctx, "C4 256x30k", 50, g(nt_store=[0, 1], geo_lds=[1, 0], grid_cap=[0, 1024, 4096, 8192]))
     if "c3" in which:
         setup(ctx, 30000, 200, 64)
-        out += run(ctx, "C3 30k/200/64", 200, dict(morph_split=[1, 4, 8, 16], unroll=[2, 4, 8], nontemporal=[0],
-                                                   geo_lds=[1], grid_cap=[0]))
+        out += run(ctx, "C3 30k/200/64", 300, g(morph_split=[1, 2, 4, 8], unroll=[4, 8], fast=[1, 0]))
     if "c2" in which:
         setup(ctx, 30000, 200, 0)
-        out += run(ctx, "C2 30k/200/0", 200, dict(geo_lds=[1, 0], grid_cap=[0]))
+        out += run(ctx, "C2 30k/200/0", 300, g(geo_lds=[1, 0], fast=[1, 0], nt_store=[0, 1]))
+    if "real" in which:
+        setup_sparse(ctx, 28842, 349, 60)
+        out += run(ctx, "demo-shaped 28842/349/60 sparse", 300, g(geo_lds=[1, 0], fast=[1, 0]))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "sweep.json"), "w"), indent=1)
     print("sweep done in %.1f s" % (time.time() - t0))
