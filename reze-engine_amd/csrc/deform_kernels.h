@@ -38,7 +38,9 @@ struct RzDeformParams {
     float *out_pos;             // [I][Vp][3]
     float *out_nrm;             // [I][Vp][3]
     uint32_t Vp;                // padded vertex count (multiple of 1024)
-    uint32_t n_tiles;           // Vp/4 / quads-per-tile
+    uint32_t n_quads;           // Vp / 4
+    uint32_t quads_per_wave;    // contiguous run owned by each wave of the grid (multiple of 8)
+    int dma;                    // FAST: stage raw matrices by LDS-DMA (else plain loads after the first morph phase)
     int B;
     int M;
     int Mpad;

@@ -28,6 +28,8 @@
 
 #include "deform_kernels.h"
 
+#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"   // 32-bit LDS pointers built from integers
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -112,47 +114,42 @@ __global__ void __launch_bounds__(kBlock) rz_prep_kernel(RzPrepParams p)
 // ------------------------------------------------------------------------------------------------
 struct Skinned { float px, py, pz, nx, ny, nz; };
 
-// vs() lines engine.ts:255-272 for one vertex. `pal` = LDS palette (3 float4 rows per bone),
-// `lut` = LDS table i/255 (exact unorm8 conversion, engine.ts:354-355).
-__device__ __forceinline__ Skinned skin_vertex(const float4 *pal, const float *lut, float x, float y,
-                                               float z, float nx, float ny, float nz, uint32_t j01,
-                                               uint32_t j23, uint32_t wq, uint32_t bmax)
+// vs() lines engine.ts:255-272 for one vertex. `pal` = LDS palette (3 float4 rows per bone).
+//   weights: w_i = (u8_i/255) / sum_k(u8_k/255)  (engine.ts:255-257)  ==  u8_i / isum  up to rounding;
+//            isum == 0 takes the select((1,0,0,0)) branch (a sum of unorm8 values is either 0 or >= 1/255 > 1e-4).
+//   blend:   because the map is linear, M = sum_i w_i * S[j_i] is formed once (12 FMA per bone) and applied
+//            to the position and the normal, instead of transforming both by every bone (24 FMA per bone).
+//            Rounding differs from the oracle's evaluation order by a few ulp (tolerance 1e-4).
+__device__ __forceinline__ Skinned skin_vertex(const float4 *pal, float x, float y, float z, float nx, float ny,
+                                               float nz, uint32_t j01, uint32_t j23, uint32_t wq, uint32_t bmax)
 {
-    float w0 = lut[wq & 255u], w1 = lut[(wq >> 8) & 255u], w2 = lut[(wq >> 16) & 255u],
-          w3 = lut[wq >> 24];
-    float sum = ((w0 + w1) + w2) + w3;
-    bool ok = sum > 0.0001f;
-    float inv = ok ? 1.0f / sum : 1.0f;
-    w0 = ok ? w0 * inv : 1.0f;
-    w1 = ok ? w1 * inv : 0.0f;
-    w2 = ok ? w2 * inv : 0.0f;
-    w3 = ok ? w3 * inv : 0.0f;
+    const uint32_t b0 = wq & 255u, b1 = (wq >> 8) & 255u, b2 = (wq >> 16) & 255u, b3 = wq >> 24;
+    const uint32_t isum = b0 + b1 + b2 + b3;
+    const bool ok = isum != 0u;
+    const float inv = __builtin_amdgcn_rcpf((float)(ok ? isum : 1u));
+    const float w[4] = { ok ? (float)b0 * inv : 1.0f, (float)b1 * inv, (float)b2 * inv, (float)b3 * inv };
     // joints are < B by construction (pmx-loader.ts:861-880); clamp so bad input cannot read past the palette
     const uint32_t j[4] = { min(j01 & 0xffffu, bmax), min(j01 >> 16, bmax), min(j23 & 0xffffu, bmax),
                             min(j23 >> 16, bmax) };
-    const float w[4] = { w0, w1, w2, w3 };
-    float sx = 0.f, sy = 0.f, sz = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
+    float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0, m2 = m0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float4 r0 = pal[j[i] * 3 + 0], r1 = pal[j[i] * 3 + 1], r2 = pal[j[i] * 3 + 2];
-        float ax = fmaf(r0.z, z, fmaf(r0.y, y, r0.x * x)) + r0.w;
-        float ay = fmaf(r1.z, z, fmaf(r1.y, y, r1.x * x)) + r1.w;
-        float az = fmaf(r2.z, z, fmaf(r2.y, y, r2.x * x)) + r2.w;
-        sx = fmaf(ax, w[i], sx);
-        sy = fmaf(ay, w[i], sy);
-        sz = fmaf(az, w[i], sz);
-        float bx = fmaf(r0.z, nz, fmaf(r0.y, ny, r0.x * nx));
-        float by = fmaf(r1.z, nz, fmaf(r1.y, ny, r1.x * nx));
-        float bz = fmaf(r2.z, nz, fmaf(r2.y, ny, r2.x * nx));
-        tx = fmaf(bx, w[i], tx);
-        ty = fmaf(by, w[i], ty);
-        tz = fmaf(bz, w[i], tz);
+        m0.x = fmaf(w[i], r0.x, m0.x); m0.y = fmaf(w[i], r0.y, m0.y); m0.z = fmaf(w[i], r0.z, m0.z); m0.w = fmaf(w[i], r0.w, m0.w);
+        m1.x = fmaf(w[i], r1.x, m1.x); m1.y = fmaf(w[i], r1.y, m1.y); m1.z = fmaf(w[i], r1.z, m1.z); m1.w = fmaf(w[i], r1.w, m1.w);
+        m2.x = fmaf(w[i], r2.x, m2.x); m2.y = fmaf(w[i], r2.y, m2.y); m2.z = fmaf(w[i], r2.z, m2.z); m2.w = fmaf(w[i], r2.w, m2.w);
     }
-    float l2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
-    bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
-    float rl = good ? (1.0f / sqrtf(l2)) : 0.0f;
     Skinned o;
-    o.px = sx; o.py = sy; o.pz = sz;
+    o.px = fmaf(m0.z, z, fmaf(m0.y, y, fmaf(m0.x, x, m0.w)));
+    o.py = fmaf(m1.z, z, fmaf(m1.y, y, fmaf(m1.x, x, m1.w)));
+    o.pz = fmaf(m2.z, z, fmaf(m2.y, y, fmaf(m2.x, x, m2.w)));
+    const float tx = fmaf(m0.z, nz, fmaf(m0.y, ny, m0.x * nx));
+    const float ty = fmaf(m1.z, nz, fmaf(m1.y, ny, m1.x * nx));
+    const float tz = fmaf(m2.z, nz, fmaf(m2.y, ny, m2.x * nx));
+    const float l2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+    // normalize() of a zero / non-finite vector is undefined in WGSL: the rest normal is returned (build-defined)
+    const bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
+    const float rl = __builtin_amdgcn_rsqf(good ? l2 : 1.0f);
     o.nx = good ? tx * rl : nx;
     o.ny = good ? ty * rl : ny;
     o.nz = good ? tz * rl : nz;
@@ -175,7 +172,7 @@ __device__ __forceinline__ Skinned skin_vertex(const float4 *pal, const float *l
 //         active-morph list comes in the kernel arguments (compacted on the host by rz_set_pose).
 //         !FAST reads the palette / list produced by rz_prep_kernel (instanced frames).
 // grid = (tiles capped, instances); block = 256.
-// dynamic LDS = palette | 256-entry unorm LUT | active-morph list (!FAST) | per-wave transpose
+// dynamic LDS = palette | active-morph list (!FAST) | per-wave transpose
 //               scratch (aliased by the raw world/inverse-bind matrices during the prologue).
 //
 // Two phases per tile, both fully coalesced:
@@ -200,15 +197,13 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
 {
     constexpr int QPW = 64 / S;              // quads per wave
     constexpr int VW = 4 * QPW;              // vertices per wave per tile
-    constexpr int QPB = (kBlock / 64) * QPW; // quads per workgroup tile
     constexpr int NPL = GEO ? 9 : 3;         // scratch planes per wave
     constexpr int ROUNDS = (VW + 63) / 64;
     constexpr bool LDS_LIST = !FAST && MODE != 0;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *pal = reinterpret_cast<float4 *>(smem);                       // B*3 float4
-    float *lut = reinterpret_cast<float *>(smem + (size_t)p.B * 48);      // 256 floats
-    uint32_t *s_idx = reinterpret_cast<uint32_t *>(lut + 256);            // Mpad   (LDS_LIST)
+    uint32_t *s_idx = reinterpret_cast<uint32_t *>(smem + (size_t)p.B * 48);   // Mpad   (LDS_LIST)
     float *s_w = reinterpret_cast<float *>(s_idx + (LDS_LIST ? p.Mpad : 0));
     float *scratch_all = s_w + (LDS_LIST ? p.Mpad : 0);                   // 16-B aligned: Mpad % 4 == 0
 
@@ -216,8 +211,7 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
     const int inst = blockIdx.y;
     const int lane = tid & 63, wave = tid >> 6;
 
-    lut[tid] = (float)tid / 255.0f;
-    if (FAST) {
+    if (FAST && p.dma) {
         // raw world (B*4 float4) then inverse bind (B*4 float4) -> scratch, by LDS-DMA: no VGPRs,
         // in flight while the first tile's morph planes stream in
         const float4 *gw = reinterpret_cast<const float4 *>(p.world);
@@ -235,7 +229,7 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
                                                  16, 0, 0);
             }
         }
-    } else {
+    } else if (!FAST) {
         const float4 *gpal = p.palette + (size_t)inst * p.B * 3;
         for (int i = tid; i < p.B * 3; i += kBlock) pal[i] = gpal[i];
         if (MODE == 1) {
@@ -260,15 +254,54 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
     float *onrm = p.out_nrm + (size_t)inst * Vp * 3;
     bool need_palette = FAST;
 
-    for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-        const size_t qw = (size_t)tile * QPB + (size_t)wave * QPW;   // first quad of this wave
+    // the raw matrices have landed (every wave drains its own DMA, the barrier publishes them): palette rows
+    // 0..2 of world * inverseBind, out[c*4+r] = ((a0[r]*b0 + a1[r]*b1) + a2[r]*b2) + a3[r]*b3  (engine.ts:928)
+    auto stage_palette = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int n4 = p.B * 4;
+        const float4 *rw = p.dma ? reinterpret_cast<const float4 *>(scratch_all) : reinterpret_cast<const float4 *>(p.world);
+        const float4 *ri = p.dma ? rw + n4 : reinterpret_cast<const float4 *>(p.inv_bind);
+        for (int b0 = 0; b0 < p.B; b0 += kBlock) {
+            const int b = b0 + tid;
+            if (b < p.B) {
+                const float4 a0 = rw[b * 4 + 0], a1 = rw[b * 4 + 1], a2 = rw[b * 4 + 2], a3 = rw[b * 4 + 3];
+                float r0[4], r1[4], r2[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 bc = ri[b * 4 + c];
+                    r0[c] = fmaf(a3.x, bc.w, fmaf(a2.x, bc.z, fmaf(a1.x, bc.y, a0.x * bc.x)));
+                    r1[c] = fmaf(a3.y, bc.w, fmaf(a2.y, bc.z, fmaf(a1.y, bc.y, a0.y * bc.x)));
+                    r2[c] = fmaf(a3.z, bc.w, fmaf(a2.z, bc.z, fmaf(a1.z, bc.y, a0.z * bc.x)));
+                }
+                const float4 q0 = make_float4(r0[0], r0[1], r0[2], r0[3]), q1 = make_float4(r1[0], r1[1], r1[2], r1[3]),
+                             q2 = make_float4(r2[0], r2[1], r2[2], r2[3]);
+                pal[b * 3 + 0] = q0; pal[b * 3 + 1] = q1; pal[b * 3 + 2] = q2;
+                if (blockIdx.x == 0 && p.palette) {      // keep the skinMatrixBuffer observable (rz_read_palette)
+                    float4 *gp = p.palette + (size_t)b * 3;
+                    gp[0] = q0; gp[1] = q1; gp[2] = q2;
+                }
+            }
+        }
+        __syncthreads();      // palette visible; the raw region may now be reused as transpose scratch
+        need_palette = false;
+    };
+
+    // persistent, evenly balanced partition: every wave of the grid owns one contiguous run of quads
+    // (a multiple of 8 quads = 128 B per plane) and walks it QPW quads at a time; the last step is masked.
+    const uint32_t wave_global = blockIdx.x * (kBlock / 64) + wave;
+    const size_t q_begin = (size_t)wave_global * p.quads_per_wave;
+    const size_t q_end = min((size_t)p.n_quads, q_begin + p.quads_per_wave);
+
+    for (size_t qw = q_begin; qw < q_end; qw += QPW) {
         const size_t q = qw + qi;                                    // this lane's quad
+        const bool live = q < q_end;
         float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), ay = ax, az = ax;
 
         // rest geometry of the quad (slice 0 only); issued first so it overlaps the morph stream
         float4 gx, gy, gz, gnx, gny, gnz;
         uint4 gj01, gj23, gw;
-        if (s == 0) {
+        if (s == 0 && live) {
             const float4 *G = reinterpret_cast<const float4 *>(p.geom) + q;
             gx = G[0]; gy = G[plane4]; gz = G[2 * plane4];
             if (GEO) {
@@ -279,7 +312,7 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
             }
         }
 
-        if (MODE == 1) {
+        if (MODE == 1 && live) {
             const float4 *D = reinterpret_cast<const float4 *>(p.dense) + q;
             int a = s;
             // full groups of U morphs: 3*U independent 16-byte loads in flight per lane
@@ -314,19 +347,7 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
                 ay.x = fmaf(w, dy.x, ay.x); ay.y = fmaf(w, dy.y, ay.y); ay.z = fmaf(w, dy.z, ay.z); ay.w = fmaf(w, dy.w, ay.w);
                 az.x = fmaf(w, dz.x, az.x); az.y = fmaf(w, dz.y, az.y); az.z = fmaf(w, dz.z, az.z); az.w = fmaf(w, dz.w, az.w);
             }
-            if (S > 1) {
-                // combine the S partial sums of each quad: butterfly over the slice bits of the lane id
-#pragma unroll
-                for (int off = QPW; off < 64; off <<= 1) {
-                    ax.x += __shfl_xor(ax.x, off); ax.y += __shfl_xor(ax.y, off);
-                    ax.z += __shfl_xor(ax.z, off); ax.w += __shfl_xor(ax.w, off);
-                    ay.x += __shfl_xor(ay.x, off); ay.y += __shfl_xor(ay.y, off);
-                    ay.z += __shfl_xor(ay.z, off); ay.w += __shfl_xor(ay.w, off);
-                    az.x += __shfl_xor(az.x, off); az.y += __shfl_xor(az.y, off);
-                    az.z += __shfl_xor(az.z, off); az.w += __shfl_xor(az.w, off);
-                }
-            }
-        } else if (MODE == 2) {
+        } else if (MODE == 2 && live) {
             // per-vertex CSR: entry = (dx,dy,dz, bits(morph)); entries of a vertex sorted by morph
             const float *mwv = FAST ? p.morph_w : s_w;    // FAST: weights straight from global (L2-resident, tiny)
             const uint32_t *ptr = p.sp_ptr + q * 4;
@@ -345,43 +366,24 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
             ay = make_float4(sy[0], sy[1], sy[2], sy[3]);
             az = make_float4(sz[0], sz[1], sz[2], sz[3]);
         }
-
-        if (FAST && need_palette) {
-            // the raw matrices have landed (every wave drains its own DMA, the barrier publishes them):
-            // palette rows 0..2 of world * inverseBind, out[c*4+r] = ((a0[r]*b0 + a1[r]*b1) + a2[r]*b2) + a3[r]*b3
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const float4 *raw = reinterpret_cast<const float4 *>(scratch_all);
-            const int n4 = p.B * 4;
-            float4 rows[ (1) ][3];
-            for (int b0 = 0; b0 < p.B; b0 += kBlock) {
-                const int b = b0 + tid;
-                if (b < p.B) {
-                    const float4 a0 = raw[b * 4 + 0], a1 = raw[b * 4 + 1], a2 = raw[b * 4 + 2], a3 = raw[b * 4 + 3];
-                    float r0[4], r1[4], r2[4];
+        if (MODE == 1 && S > 1) {
+            // combine the S partial sums of each quad: __shfl_xor butterfly over the slice bits of the
+            // lane id (every lane takes part; lanes past the end of the run carry zeros)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float4 bc = raw[n4 + b * 4 + c];
-                        r0[c] = fmaf(a3.x, bc.w, fmaf(a2.x, bc.z, fmaf(a1.x, bc.y, a0.x * bc.x)));
-                        r1[c] = fmaf(a3.y, bc.w, fmaf(a2.y, bc.z, fmaf(a1.y, bc.y, a0.y * bc.x)));
-                        r2[c] = fmaf(a3.z, bc.w, fmaf(a2.z, bc.z, fmaf(a1.z, bc.y, a0.z * bc.x)));
-                    }
-                    pal[b * 3 + 0] = make_float4(r0[0], r0[1], r0[2], r0[3]);
-                    pal[b * 3 + 1] = make_float4(r1[0], r1[1], r1[2], r1[3]);
-                    pal[b * 3 + 2] = make_float4(r2[0], r2[1], r2[2], r2[3]);
-                    if (blockIdx.x == 0 && p.palette) {      // keep the skinMatrixBuffer observable (rz_read_palette)
-                        float4 *gp = p.palette + (size_t)b * 3;
-                        gp[0] = pal[b * 3 + 0]; gp[1] = pal[b * 3 + 1]; gp[2] = pal[b * 3 + 2];
-                    }
-                }
+            for (int off = QPW; off < 64; off <<= 1) {
+                ax.x += __shfl_xor(ax.x, off); ax.y += __shfl_xor(ax.y, off);
+                ax.z += __shfl_xor(ax.z, off); ax.w += __shfl_xor(ax.w, off);
+                ay.x += __shfl_xor(ay.x, off); ay.y += __shfl_xor(ay.y, off);
+                ay.z += __shfl_xor(ay.z, off); ay.w += __shfl_xor(ay.w, off);
+                az.x += __shfl_xor(az.x, off); az.y += __shfl_xor(az.y, off);
+                az.z += __shfl_xor(az.z, off); az.w += __shfl_xor(az.w, off);
             }
-            (void)rows;
-            __syncthreads();      // palette visible; the raw region may now be reused as transpose scratch
-            need_palette = false;
         }
 
+        if (FAST && need_palette) stage_palette();
+
         // ---- park the quad in the wave's scratch: plane-major [NPL][VW] dwords ----
-        if (s == 0) {
+        if (s == 0 && live) {
             float4 *sc4 = reinterpret_cast<float4 *>(scr) + qi;
             sc4[0 * QPW] = make_float4(gx.x + ax.x, gx.y + ax.y, gx.z + ax.z, gx.w + ax.w);
             sc4[1 * QPW] = make_float4(gy.x + ay.x, gy.y + ay.y, gy.z + ay.z, gy.w + ay.w);
@@ -396,11 +398,12 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
         __builtin_amdgcn_wave_barrier();
 
         // ---- phase 2: one vertex per lane ----
-        const size_t vw0 = qw * 4;     // first vertex of this wave's tile
+        const size_t vw0 = qw * 4;     // first vertex of this wave's step
+        const int v_live = (int)min((size_t)VW, (q_end - qw) * 4);
 #pragma unroll 1
         for (int r = 0; r < ROUNDS; ++r) {
             const int vl = r * 64 + lane;
-            if (vl < VW) {
+            if (vl < v_live) {
                 const size_t v = vw0 + vl;
                 const float x = scr[0 * VW + vl], y = scr[1 * VW + vl], z = scr[2 * VW + vl];
                 float nx, ny, nz;
@@ -413,13 +416,14 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
                     nx = p.geom[3 * Vp + v]; ny = p.geom[4 * Vp + v]; nz = p.geom[5 * Vp + v];
                     j01 = p.joints01[v]; j23 = p.joints23[v]; wq = p.weights[v];
                 }
-                Skinned o = skin_vertex(pal, lut, x, y, z, nx, ny, nz, j01, j23, wq, bmax);
+                Skinned o = skin_vertex(pal, x, y, z, nx, ny, nz, j01, j23, wq, bmax);
                 st3<NTS>(opos + v * 3, o.px, o.py, o.pz);
                 st3<NTS>(onrm + v * 3, o.nx, o.ny, o.nz);
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (FAST && need_palette) stage_palette();   // a wave with an empty run still owes the workgroup its barriers
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -460,9 +464,9 @@ size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v)
 {
     const size_t vw = 256 / v.S;   // vertices per wave per tile
     size_t scratch = (size_t)(kBlock / 64) * (v.geo ? 9 : 3) * vw * 4;
-    if (v.fast) scratch = std::max(scratch, (size_t)p.B * 128);          // raw world + inverse bind alias it
+    if (v.fast && p.dma) scratch = std::max(scratch, (size_t)p.B * 128);  // raw world + inverse bind alias it
     const size_t list = (!v.fast && v.mode != 0) ? (size_t)p.Mpad * 8 : 0;
-    return (size_t)p.B * 48 + 256 * 4 + list + scratch;
+    return (size_t)p.B * 48 + list + scratch;
 }
 
 uint32_t rz_quads_per_tile(int S) { return (kBlock / 64) * (64 / S); }

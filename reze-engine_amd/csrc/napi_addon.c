@@ -1,0 +1,438 @@
+/*
+ * napi_addon.c — raw N-API (node_api.h, N-API <= 8, plain C) shim over the C ABI of
+ * include/reze_deform.h. Builds reze_deform.node next to libreze_deform.so.
+ *
+ * It is the Node-side binding of the reference's de-facto GPU boundary: where class Engine calls
+ * device.createBuffer / queue.writeBuffer / dispatchWorkgroups (reference engine/src/engine.ts:
+ * 1734-1817, 2383-2401), host/engine.js calls these functions instead. Typed arrays are passed
+ * zero-copy (napi_get_typedarray_info); every failure becomes a JS exception carrying
+ * rz_last_error(). No threads are created here; calls are serialised by Node's main thread.
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/reze_deform.h"
+
+#define MAX_ARGS 8
+
+static napi_value throw_msg(napi_env env, const char *msg)
+{
+    napi_throw_error(env, "REZE_DEFORM", msg);
+    return NULL;
+}
+
+static napi_value throw_rz(napi_env env, int code)
+{
+    char buf[640];
+    snprintf(buf, sizeof buf, "reze_deform error %d: %s", code, rz_last_error());
+    napi_throw_error(env, "REZE_DEFORM", buf);
+    return NULL;
+}
+
+#define ARGS(n_min)                                                                       \
+    size_t argc = MAX_ARGS;                                                               \
+    napi_value argv[MAX_ARGS];                                                            \
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < (n_min)) \
+        return throw_msg(env, "wrong number of arguments")
+
+static int get_ctx(napi_env env, napi_value v, rz_ctx **out)
+{
+    void *p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) return 0;
+    *out = *(rz_ctx **)p;
+    return *out != NULL;
+}
+
+#define CTX(i)                                              \
+    rz_ctx *ctx = NULL;                                     \
+    if (!get_ctx(env, argv[i], &ctx)) return throw_msg(env, "invalid or destroyed deform context")
+
+/* typed array of an exact element type (or null/undefined when `optional`); returns element count */
+static int get_ta(napi_env env, napi_value v, napi_typedarray_type want, int optional, void **data, size_t *len)
+{
+    napi_valuetype t;
+    *data = NULL;
+    *len = 0;
+    if (napi_typeof(env, v, &t) != napi_ok) return 0;
+    if (t == napi_null || t == napi_undefined) return optional;
+    bool is_ta = false;
+    if (napi_is_typedarray(env, v, &is_ta) != napi_ok || !is_ta) return 0;
+    napi_typedarray_type tt;
+    napi_value ab;
+    size_t off;
+    if (napi_get_typedarray_info(env, v, &tt, len, data, &ab, &off) != napi_ok) return 0;
+    return tt == want;
+}
+
+static int get_u32(napi_env env, napi_value v, uint32_t *out) { return napi_get_value_uint32(env, v, out) == napi_ok; }
+static int get_i32(napi_env env, napi_value v, int32_t *out) { return napi_get_value_int32(env, v, out) == napi_ok; }
+
+static napi_value undef(napi_env env)
+{
+    napi_value u;
+    napi_get_undefined(env, &u);
+    return u;
+}
+
+static void finalize_ctx(napi_env env, void *data, void *hint)
+{
+    (void)env; (void)hint;
+    rz_ctx **slot = (rz_ctx **)data;
+    if (slot) {
+        if (*slot) rz_destroy(*slot);
+        free(slot);
+    }
+}
+
+#include <stdlib.h>
+
+static napi_value fn_abi_version(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    napi_value v;
+    napi_create_int32(env, rz_abi_version(), &v);
+    return v;
+}
+
+static napi_value fn_device_count(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    int n = 0;
+    rz_device_count(&n);
+    napi_value v;
+    napi_create_int32(env, n, &v);
+    return v;
+}
+
+static napi_value fn_create(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    int32_t dev = 0;
+    if (!get_i32(env, argv[0], &dev)) return throw_msg(env, "create(device: number)");
+    rz_ctx *c = NULL;
+    int rc = rz_create(dev, &c);
+    if (rc) return throw_rz(env, rc);
+    rz_ctx **slot = (rz_ctx **)malloc(sizeof *slot);
+    *slot = c;
+    napi_value ext;
+    if (napi_create_external(env, slot, finalize_ctx, NULL, &ext) != napi_ok) {
+        rz_destroy(c);
+        free(slot);
+        return throw_msg(env, "napi_create_external failed");
+    }
+    return ext;
+}
+
+static napi_value fn_destroy(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    void *p = NULL;
+    if (napi_get_value_external(env, argv[0], &p) != napi_ok || !p) return throw_msg(env, "invalid context");
+    rz_ctx **slot = (rz_ctx **)p;
+    if (*slot) { rz_destroy(*slot); *slot = NULL; }
+    return undef(env);
+}
+
+static napi_value fn_shard_range(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    uint32_t vt, b = 0, n = 0;
+    int32_t nr, r;
+    if (!get_u32(env, argv[0], &vt) || !get_i32(env, argv[1], &nr) || !get_i32(env, argv[2], &r))
+        return throw_msg(env, "shardRange(vTotal, nranks, rank)");
+    int rc = rz_shard_range(vt, nr, r, &b, &n);
+    if (rc) return throw_rz(env, rc);
+    napi_value arr, vb, vn;
+    napi_create_array_with_length(env, 2, &arr);
+    napi_create_uint32(env, b, &vb);
+    napi_create_uint32(env, n, &vn);
+    napi_set_element(env, arr, 0, vb);
+    napi_set_element(env, arr, 1, vn);
+    return arr;
+}
+
+static napi_value fn_upload_mesh(napi_env env, napi_callback_info info)
+{
+    ARGS(4);
+    CTX(0);
+    void *v, *j, *w;
+    size_t nv, nj, nw;
+    if (!get_ta(env, argv[1], napi_float32_array, 0, &v, &nv) || !get_ta(env, argv[2], napi_uint16_array, 0, &j, &nj) ||
+        !get_ta(env, argv[3], napi_uint8_array, 0, &w, &nw))
+        return throw_msg(env, "uploadMesh(ctx, Float32Array vertices8, Uint16Array joints4, Uint8Array weights4)");
+    if (nv % 8 || nj != nv / 8 * 4 || nw != nv / 8 * 4) return throw_msg(env, "uploadMesh: array lengths disagree");
+    int rc = rz_upload_mesh(ctx, (uint32_t)(nv / 8), (const float *)v, (const uint16_t *)j, (const uint8_t *)w);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_upload_mesh_soa(napi_env env, napi_callback_info info)
+{
+    ARGS(5);
+    CTX(0);
+    void *p, *n, *j, *w;
+    size_t np, nn, nj, nw;
+    if (!get_ta(env, argv[1], napi_float32_array, 0, &p, &np) || !get_ta(env, argv[2], napi_float32_array, 0, &n, &nn) ||
+        !get_ta(env, argv[3], napi_uint16_array, 0, &j, &nj) || !get_ta(env, argv[4], napi_uint8_array, 0, &w, &nw))
+        return throw_msg(env, "uploadMeshSoa(ctx, Float32Array pos3, Float32Array nrm3, Uint16Array joints4, Uint8Array weights4)");
+    if (np % 3 || nn != np || nj != np / 3 * 4 || nw != np / 3 * 4) return throw_msg(env, "uploadMeshSoa: array lengths disagree");
+    int rc = rz_upload_mesh_soa(ctx, (uint32_t)(np / 3), (const float *)p, (const float *)n, (const uint16_t *)j,
+                                (const uint8_t *)w);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_upload_skeleton(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    CTX(0);
+    void *ib;
+    size_t n;
+    if (!get_ta(env, argv[1], napi_float32_array, 0, &ib, &n) || n % 16)
+        return throw_msg(env, "uploadSkeleton(ctx, Float32Array inverseBind /* B*16 */)");
+    int rc = rz_upload_skeleton(ctx, (uint32_t)(n / 16), (const float *)ib);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_upload_morphs_dense(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    CTX(0);
+    uint32_t M;
+    void *d;
+    size_t n;
+    if (!get_u32(env, argv[1], &M) || !get_ta(env, argv[2], napi_float32_array, 1, &d, &n))
+        return throw_msg(env, "uploadMorphsDense(ctx, M, Float32Array deltas /* M*V*3 */)");
+    if (M && (!d || n % ((size_t)M * 3))) return throw_msg(env, "uploadMorphsDense: deltas length must be M*V*3");
+    int rc = rz_upload_morphs_dense(ctx, M, (const float *)d);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_upload_morphs_sparse(napi_env env, napi_callback_info info)
+{
+    ARGS(4);
+    CTX(0);
+    void *off, *idx, *d;
+    size_t noff, nidx, nd;
+    if (!get_ta(env, argv[1], napi_uint32_array, 0, &off, &noff) || !get_ta(env, argv[2], napi_uint32_array, 0, &idx, &nidx) ||
+        !get_ta(env, argv[3], napi_float32_array, 0, &d, &nd) || noff < 1)
+        return throw_msg(env, "uploadMorphsSparse(ctx, Uint32Array morphOffsets /* M+1 */, Uint32Array vertexIndex, Float32Array delta3)");
+    const uint32_t *o = (const uint32_t *)off;
+    if (o[noff - 1] > nidx || nd < (size_t)o[noff - 1] * 3) return throw_msg(env, "uploadMorphsSparse: entries shorter than the offsets claim");
+    int rc = rz_upload_morphs_sparse(ctx, (uint32_t)(noff - 1), o, (const uint32_t *)idx, (const float *)d);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_set_instances(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    CTX(0);
+    uint32_t I;
+    if (!get_u32(env, argv[1], &I)) return throw_msg(env, "setInstances(ctx, count)");
+    int rc = rz_set_instances(ctx, I);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_set_pose(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    CTX(0);
+    void *w, *mw = NULL;
+    size_t nw, nmw = 0;
+    if (!get_ta(env, argv[1], napi_float32_array, 0, &w, &nw)) return throw_msg(env, "setPose(ctx, Float32Array world, Float32Array|null morphWeights)");
+    if (argc > 2 && !get_ta(env, argv[2], napi_float32_array, 1, &mw, &nmw)) return throw_msg(env, "setPose: morphWeights must be a Float32Array or null");
+    /* lengths are validated against the uploaded skeleton / morph counts by querying them back */
+    int B = 0, M = 0, I = 0;
+    if (rz_get_tuning(ctx, "bones", &B) || rz_get_tuning(ctx, "morphs", &M) || rz_get_tuning(ctx, "instances", &I))
+        return throw_rz(env, RZ_ERR_INVALID);
+    if (nw != (size_t)I * B * 16) return throw_msg(env, "setPose: world must hold instances*bones*16 floats");
+    if (mw && nmw != (size_t)I * M) return throw_msg(env, "setPose: morphWeights must hold instances*morphs floats");
+    int rc = rz_set_pose(ctx, (const float *)w, (const float *)mw);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_deform(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    CTX(0);
+    int rc = rz_deform(ctx);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_deform_n(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    CTX(0);
+    uint32_t n;
+    if (!get_u32(env, argv[1], &n)) return throw_msg(env, "deformN(ctx, frames)");
+    int rc = rz_deform_n(ctx, n);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_sync(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    CTX(0);
+    int rc = rz_sync(ctx);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_read(napi_env env, napi_callback_info info)
+{
+    ARGS(6);
+    CTX(0);
+    uint32_t inst, v0, n;
+    void *p, *nr;
+    size_t np, nn;
+    if (!get_u32(env, argv[1], &inst) || !get_u32(env, argv[2], &v0) || !get_u32(env, argv[3], &n) ||
+        !get_ta(env, argv[4], napi_float32_array, 1, &p, &np) || !get_ta(env, argv[5], napi_float32_array, 1, &nr, &nn))
+        return throw_msg(env, "read(ctx, instance, v0, n, Float32Array|null pos3, Float32Array|null nrm3)");
+    if ((p && np < (size_t)n * 3) || (nr && nn < (size_t)n * 3)) return throw_msg(env, "read: output arrays too small");
+    int rc = rz_read(ctx, inst, v0, n, (float *)p, (float *)nr);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_read_palette(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    CTX(0);
+    uint32_t inst;
+    void *o;
+    size_t n;
+    int B = 0;
+    if (!get_u32(env, argv[1], &inst) || !get_ta(env, argv[2], napi_float32_array, 0, &o, &n))
+        return throw_msg(env, "readPalette(ctx, instance, Float32Array out /* B*12 */)");
+    if (rz_get_tuning(ctx, "bones", &B) || n < (size_t)B * 12) return throw_msg(env, "readPalette: output array too small");
+    int rc = rz_read_palette(ctx, inst, (float *)o);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static void set_num(napi_env env, napi_value obj, const char *k, double v)
+{
+    napi_value nv;
+    napi_create_double(env, v, &nv);
+    napi_set_named_property(env, obj, k, nv);
+}
+
+static napi_value fn_time_frames(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    CTX(0);
+    uint32_t n;
+    if (!get_u32(env, argv[1], &n)) return throw_msg(env, "timeFrames(ctx, frames)");
+    rz_timing t;
+    int rc = rz_time_frames(ctx, n, &t);
+    if (rc) return throw_rz(env, rc);
+    napi_value o;
+    napi_create_object(env, &o);
+    set_num(env, o, "frameMs", t.frame_ms);
+    set_num(env, o, "deformKernelMs", t.deform_kernel_ms);
+    set_num(env, o, "prepKernelMs", t.prep_kernel_ms);
+    set_num(env, o, "vertsPerFrame", (double)t.verts_per_frame);
+    set_num(env, o, "algorithmicBytesPerFrame", (double)t.algorithmic_bytes_per_frame);
+    set_num(env, o, "frames", t.frames);
+    return o;
+}
+
+static napi_value fn_set_tuning(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    CTX(0);
+    char key[64];
+    size_t kl = 0;
+    int32_t v;
+    if (napi_get_value_string_utf8(env, argv[1], key, sizeof key, &kl) != napi_ok || !get_i32(env, argv[2], &v))
+        return throw_msg(env, "setTuning(ctx, key, value)");
+    int rc = rz_set_tuning(ctx, key, v);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_get_tuning(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    CTX(0);
+    char key[64];
+    size_t kl = 0;
+    if (napi_get_value_string_utf8(env, argv[1], key, sizeof key, &kl) != napi_ok) return throw_msg(env, "getTuning(ctx, key)");
+    int v = 0;
+    int rc = rz_get_tuning(ctx, key, &v);
+    if (rc) return throw_rz(env, rc);
+    napi_value nv;
+    napi_create_int32(env, v, &nv);
+    return nv;
+}
+
+static napi_value fn_comm_unique_id(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    char id[128];
+    int rc = rz_comm_unique_id(id);
+    if (rc) return throw_rz(env, rc);
+    napi_value buf;
+    void *dst = NULL;
+    if (napi_create_buffer_copy(env, 128, id, &dst, &buf) != napi_ok) return throw_msg(env, "buffer alloc failed");
+    return buf;
+}
+
+static napi_value fn_comm_init(napi_env env, napi_callback_info info)
+{
+    ARGS(5);
+    CTX(0);
+    int32_t nr, r;
+    uint32_t vt;
+    void *id = NULL;
+    size_t idl = 0;
+    if (!get_i32(env, argv[1], &nr) || !get_i32(env, argv[2], &r) || napi_get_buffer_info(env, argv[3], &id, &idl) != napi_ok ||
+        idl != 128 || !get_u32(env, argv[4], &vt))
+        return throw_msg(env, "commInit(ctx, nranks, rank, Buffer id /* 128 B */, vTotal)");
+    int rc = rz_comm_init(ctx, nr, r, (const char *)id, vt);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_allgather(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    CTX(0);
+    bool wn = false;
+    if (argc > 1) napi_get_value_bool(env, argv[1], &wn);
+    int rc = rz_allgather(ctx, wn ? 1 : 0);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_read_gathered(napi_env env, napi_callback_info info)
+{
+    ARGS(5);
+    CTX(0);
+    uint32_t v0, n;
+    void *p, *nr;
+    size_t np, nn;
+    if (!get_u32(env, argv[1], &v0) || !get_u32(env, argv[2], &n) || !get_ta(env, argv[3], napi_float32_array, 1, &p, &np) ||
+        !get_ta(env, argv[4], napi_float32_array, 1, &nr, &nn))
+        return throw_msg(env, "readGathered(ctx, v0, n, Float32Array|null pos3, Float32Array|null nrm3)");
+    if ((p && np < (size_t)n * 3) || (nr && nn < (size_t)n * 3)) return throw_msg(env, "readGathered: output arrays too small");
+    int rc = rz_read_gathered(ctx, v0, n, (float *)p, (float *)nr);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value init(napi_env env, napi_value exports)
+{
+    static const struct { const char *name; napi_callback fn; } table[] = {
+        { "abiVersion", fn_abi_version }, { "deviceCount", fn_device_count }, { "create", fn_create },
+        { "destroy", fn_destroy }, { "shardRange", fn_shard_range }, { "uploadMesh", fn_upload_mesh },
+        { "uploadMeshSoa", fn_upload_mesh_soa }, { "uploadSkeleton", fn_upload_skeleton },
+        { "uploadMorphsDense", fn_upload_morphs_dense }, { "uploadMorphsSparse", fn_upload_morphs_sparse },
+        { "setInstances", fn_set_instances }, { "setPose", fn_set_pose }, { "deform", fn_deform },
+        { "deformN", fn_deform_n }, { "sync", fn_sync }, { "read", fn_read }, { "readPalette", fn_read_palette },
+        { "timeFrames", fn_time_frames }, { "setTuning", fn_set_tuning }, { "getTuning", fn_get_tuning },
+        { "commUniqueId", fn_comm_unique_id }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },
+        { "readGathered", fn_read_gathered },
+    };
+    for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
+        napi_value f;
+        if (napi_create_function(env, table[i].name, NAPI_AUTO_LENGTH, table[i].fn, NULL, &f) != napi_ok) return NULL;
+        napi_set_named_property(env, exports, table[i].name, f);
+    }
+    return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

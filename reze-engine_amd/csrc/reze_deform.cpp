@@ -222,7 +222,21 @@ int auto_split(const rz_ctx *c)
     return S;
 }
 
-struct Plan { RzVariant v; uint32_t grid_x, n_tiles; bool prep; };
+struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; };
+
+RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
+{
+    RzDeformParams p;
+    memset(&p, 0, sizeof p);
+    p.geom = c->geom; p.joints01 = c->j01; p.joints23 = c->j23; p.weights = c->wq;
+    p.palette = c->palette; p.world = c->world; p.inv_bind = c->inv_bind; p.dense = c->dense;
+    p.act_idx = c->act_idx; p.act_w = c->act_w; p.act_count = c->act_count; p.morph_w = c->morph_w;
+    p.sp_ptr = c->sp_ptr; p.sp_entries = c->sp_entries;
+    p.out_pos = c->out_pos; p.out_nrm = c->out_nrm;
+    p.Vp = c->Vp; p.n_quads = pl.n_quads; p.quads_per_wave = pl.quads_per_wave; p.dma = pl.dma ? 1 : 0;
+    p.B = (int)c->B; p.M = (int)c->M; p.Mpad = (int)c->Mpad;
+    return p;
+}
 
 Plan make_plan(const rz_ctx *c)
 {
@@ -237,25 +251,31 @@ Plan make_plan(const rz_ctx *c)
     // one-launch frame: single instance, and (dense) the active list fits the kernel arguments
     const bool can_fast = c->I == 1 && (v.mode != 1 || c->ml.count >= 0);
     v.fast = can_fast && c->t_fast != 0;
+    pl.dma = false;
+    pl.n_quads = (c->V + 3) / 4;
+    pl.quads_per_wave = 8;
+    pl.grid_x = 1;
+    if (v.fast) {
+        // raw matrices by LDS-DMA only while the workgroup still fits twice on a CU; a big skeleton reads them
+        // with plain loads instead, and one that does not fit at all takes the prep-kernel path
+        RzDeformParams probe = deform_params(c, pl);
+        probe.dma = 1;
+        if (rz_deform_lds_bytes(probe, v) <= 64 * 1024) pl.dma = true;
+        probe.dma = 0;
+        if (!pl.dma && rz_deform_lds_bytes(probe, v) > 160 * 1024) v.fast = false;
+    }
     pl.prep = !v.fast;
-    pl.n_tiles = (c->Vp / 4) / rz_quads_per_tile(v.S);
-    uint32_t cap = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : 8u * (uint32_t)c->n_cu;   // total workgroups
+    // persistent, balanced grid: `cap` workgroups in total, every wave owns an equal contiguous run of quads
+    const uint32_t waves_per_wg = 4, qpw_step = 64 / (uint32_t)v.S;
+    uint32_t cap = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : 2u * (uint32_t)c->n_cu;
     uint32_t gx = std::max<uint32_t>(1, cap / std::max<uint32_t>(1, c->I));
-    pl.grid_x = std::min(pl.n_tiles, gx);
+    const uint32_t max_useful = (pl.n_quads + waves_per_wg * qpw_step - 1) / (waves_per_wg * qpw_step);
+    gx = std::max<uint32_t>(1, std::min(gx, max_useful));
+    uint32_t per_wave = (pl.n_quads + gx * waves_per_wg - 1) / (gx * waves_per_wg);
+    per_wave = std::max<uint32_t>(8, round_up(per_wave, 8));
+    pl.quads_per_wave = per_wave;
+    pl.grid_x = std::max<uint32_t>(1, (pl.n_quads + per_wave * waves_per_wg - 1) / (per_wave * waves_per_wg));
     return pl;
-}
-
-RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
-{
-    RzDeformParams p;
-    memset(&p, 0, sizeof p);
-    p.geom = c->geom; p.joints01 = c->j01; p.joints23 = c->j23; p.weights = c->wq;
-    p.palette = c->palette; p.world = c->world; p.inv_bind = c->inv_bind; p.dense = c->dense;
-    p.act_idx = c->act_idx; p.act_w = c->act_w; p.act_count = c->act_count; p.morph_w = c->morph_w;
-    p.sp_ptr = c->sp_ptr; p.sp_entries = c->sp_entries;
-    p.out_pos = c->out_pos; p.out_nrm = c->out_nrm;
-    p.Vp = c->Vp; p.n_tiles = pl.n_tiles; p.B = (int)c->B; p.M = (int)c->M; p.Mpad = (int)c->Mpad;
-    return p;
 }
 
 RzPrepParams prep_params(const rz_ctx *c)

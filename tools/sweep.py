@@ -85,26 +85,25 @@ def main():
         return d
     if "c5" in which:
         setup(ctx, 1000000, 256, 64)
-        out += run(ctx, "C5 1M/256/64", 30, g(morph_split=[1, 2, 4], unroll=[4, 8], nt_store=[0, 1], geo_lds=[1, 0], fast=[1, 0]))
-        out += run(ctx, "C5 1M nt-load A/B", 30, g(morph_split=[1, 2], unroll=[8], nontemporal=[0, 1]))
-        out += run(ctx, "C5 1M grid", 30, g(morph_split=[1], grid_cap=[256, 512, 768, 1024]))
+        out += run(ctx, "C5 1M/256/64", 30, g(morph_split=[1, 2, 4], unroll=[4, 8], grid_cap=[256, 512, 768, 1024], nt_store=[0, 1]))
+        out += run(ctx, "C5 1M variants", 30, g(morph_split=[1, 2], unroll=[8], grid_cap=[256, 512], geo_lds=[0, 1], fast=[0, 1], nontemporal=[0, 1]))
     if "c5shard" in which:
-        b, n = rz.shard_range(1000000, 8, 0)
-        setup(ctx, n, 256, 64)
-        out += run(ctx, "C5 shard 1/8 (%d)" % n, 200, g(morph_split=[1, 2, 4, 8], unroll=[4, 8], geo_lds=[1, 0], fast=[1, 0]))
-        for nr in (2, 4):
+        for nr in (8, 4, 2):
             b, n = rz.shard_range(1000000, nr, 0)
             setup(ctx, n, 256, 64)
-            out += run(ctx, "C5 shard 1/%d (%d)" % (nr, n), 100, g(morph_split=[1, 2, 4], unroll=[4, 8]))
+            out += run(ctx, "C5 shard 1/%d (%d)" % (nr, n), 200 if nr == 8 else 100,
+                       g(morph_split=[1, 2, 4, 8], unroll=[4, 8], grid_cap=[256, 512, 1024], nt_store=[0, 1]))
+            if nr == 8:
+                out += run(ctx, "C5 shard 1/8 variants", 200, g(morph_split=[2, 4], unroll=[4], grid_cap=[256, 512], geo_lds=[0, 1], fast=[0, 1]))
     if "c4" in which:
         setup(ctx, 30000, 200, 0, I=256)
-        out += run(ctx, "C4 256x30k", 50, g(nt_store=[0, 1], geo_lds=[1, 0], grid_cap=[0, 1024, 4096, 8192]))
+        out += run(ctx, "C4 256x30k", 50, g(nt_store=[0, 1], geo_lds=[1, 0], grid_cap=[256, 512, 1024, 2048, 4096, 8192]))
     if "c3" in which:
         setup(ctx, 30000, 200, 64)
-        out += run(ctx, "C3 30k/200/64", 300, g(morph_split=[1, 2, 4, 8], unroll=[4, 8], fast=[1, 0]))
+        out += run(ctx, "C3 30k/200/64", 300, g(morph_split=[1, 2, 4, 8], unroll=[4, 8], fast=[1, 0], grid_cap=[256, 512]))
     if "c2" in which:
         setup(ctx, 30000, 200, 0)
-        out += run(ctx, "C2 30k/200/0", 300, g(geo_lds=[1, 0], fast=[1, 0], nt_store=[0, 1]))
+        out += run(ctx, "C2 30k/200/0", 300, g(geo_lds=[1, 0], fast=[1, 0], grid_cap=[64, 128, 256]))
     if "real" in which:
         setup_sparse(ctx, 28842, 349, 60)
         out += run(ctx, "demo-shaped 28842/349/60 sparse", 300, g(geo_lds=[1, 0], fast=[1, 0]))
