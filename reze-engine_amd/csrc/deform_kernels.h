@@ -50,10 +50,11 @@ struct RzDeformParams {
 // compacted on the host by rz_set_pose, so the frame needs no prep kernel and no dependent load
 // before the morph stream starts.
 constexpr int kKargMorphs = 128;
+constexpr int kKargPad = 8;          // the remainder loop may peek up to S-1 entries past `count`
 struct RzMorphList {
     int count;
-    uint16_t idx[kKargMorphs];
-    float w[kKargMorphs];
+    uint32_t idx[kKargMorphs + kKargPad];
+    float w[kKargMorphs + kKargPad];
 };
 
 // Compile-time variant selection of rz_deform_kernel (see deform_kernels.hip).

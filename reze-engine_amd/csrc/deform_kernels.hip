@@ -314,15 +314,32 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
 
         if (MODE == 1 && live) {
             const float4 *D = reinterpret_cast<const float4 *>(p.dense) + q;
-            int a = s;
-            // full groups of U morphs: 3*U independent 16-byte loads in flight per lane
-            for (; a + (U - 1) * S < count; a += U * S) {
+            // slice s of S accumulates the active morphs a = s, s+S, s+2S, ... in ascending order.
+            // The loop counter a0 is wave-uniform, so on the FAST path the list entries are fetched with
+            // scalar loads straight from the kernel arguments and each lane picks its slice's entry with
+            // v_cndmask — no vector-memory load sits in front of the morph stream.
+            auto entry = [&](int base, uint32_t &m, float &w) {
+                if (FAST) {
+                    m = (uint32_t)ml.idx[base]; w = ml.w[base];
+#pragma unroll
+                    for (int k = 1; k < S; ++k) {
+                        const uint32_t mk = (uint32_t)ml.idx[base + k];
+                        const float wk = ml.w[base + k];
+                        m = (s == k) ? mk : m; w = (s == k) ? wk : w;
+                    }
+                } else {
+                    m = s_idx[base + s]; w = s_w[base + s];
+                }
+            };
+            int a0 = 0;
+            // full groups of U morphs per slice: 3*U independent 16-byte loads in flight per lane
+            for (; a0 + U * S <= count; a0 += U * S) {
                 float4 dx[U], dy[U], dz[U];
                 float w[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const uint32_t m = FAST ? (uint32_t)ml.idx[a + u * S] : s_idx[a + u * S];
-                    w[u] = FAST ? ml.w[a + u * S] : s_w[a + u * S];
+                    uint32_t m;
+                    entry(a0 + u * S, m, w[u]);
                     const float4 *d = D + (size_t)m * 3 * plane4;
                     dx[u] = ld_stream(d, NT);
                     dy[u] = ld_stream(d + plane4, NT);
@@ -338,14 +355,17 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
                     az.z = fmaf(w[u], dz[u].z, az.z); az.w = fmaf(w[u], dz[u].w, az.w);
                 }
             }
-            for (; a < count; a += S) {     // remainder, one morph at a time
-                const uint32_t m = FAST ? (uint32_t)ml.idx[a] : s_idx[a];
-                const float w = FAST ? ml.w[a] : s_w[a];
-                const float4 *d = D + (size_t)m * 3 * plane4;
-                float4 dx = ld_stream(d, NT), dy = ld_stream(d + plane4, NT), dz = ld_stream(d + 2 * plane4, NT);
-                ax.x = fmaf(w, dx.x, ax.x); ax.y = fmaf(w, dx.y, ax.y); ax.z = fmaf(w, dx.z, ax.z); ax.w = fmaf(w, dx.w, ax.w);
-                ay.x = fmaf(w, dy.x, ay.x); ay.y = fmaf(w, dy.y, ay.y); ay.z = fmaf(w, dy.z, ay.z); ay.w = fmaf(w, dy.w, ay.w);
-                az.x = fmaf(w, dz.x, az.x); az.y = fmaf(w, dz.y, az.y); az.z = fmaf(w, dz.z, az.z); az.w = fmaf(w, dz.w, az.w);
+            for (; a0 < count; a0 += S) {     // remainder, one morph per slice at a time (list is zero-padded)
+                uint32_t m;
+                float w;
+                entry(a0, m, w);
+                if (a0 + s < count) {
+                    const float4 *d = D + (size_t)m * 3 * plane4;
+                    float4 dx = ld_stream(d, NT), dy = ld_stream(d + plane4, NT), dz = ld_stream(d + 2 * plane4, NT);
+                    ax.x = fmaf(w, dx.x, ax.x); ax.y = fmaf(w, dx.y, ax.y); ax.z = fmaf(w, dx.z, ax.z); ax.w = fmaf(w, dx.w, ax.w);
+                    ay.x = fmaf(w, dy.x, ay.x); ay.y = fmaf(w, dy.y, ay.y); ay.z = fmaf(w, dy.z, ay.z); ay.w = fmaf(w, dy.w, ay.w);
+                    az.x = fmaf(w, dz.x, az.x); az.y = fmaf(w, dz.y, az.y); az.z = fmaf(w, dz.z, az.z); az.w = fmaf(w, dz.w, az.w);
+                }
             }
         } else if (MODE == 2 && live) {
             // per-vertex CSR: entry = (dx,dy,dz, bits(morph)); entries of a vertex sorted by morph

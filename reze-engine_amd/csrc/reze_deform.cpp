@@ -104,7 +104,7 @@ struct rz_ctx {
 
     // morphs
     int morph_mode = 0;                 // 0 none, 1 dense, 2 sparse
-    uint32_t M = 0, Mpad = 4;
+    uint32_t M = 0, Mpad = 12;
     float *dense = nullptr;             // M x 3 x Vp
     uint32_t *sp_ptr = nullptr;         // Vp + 1
     float4 *sp_entries = nullptr;
@@ -137,7 +137,7 @@ struct rz_ctx {
     RzMorphList ml;
 
     // tuning (0 / -1 = automatic)
-    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = 1, t_geo = 1, t_fast = -1;
+    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1;
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -186,7 +186,7 @@ int ensure_pose_buffers(rz_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     dfree(c->world); dfree(c->palette); dfree(c->morph_w); dfree(c->act_idx); dfree(c->act_w); dfree(c->act_count);
     const size_t I = c->I, B = c->B;
-    const size_t Mpad = round_up(Mq, 4);
+    const size_t Mpad = round_up(Mq + 8, 4);
     HIP_TRY(hipMalloc(&c->world, I * B * 16 * sizeof(float)));
     HIP_TRY(hipMalloc(&c->palette, I * B * 3 * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->morph_w, I * Mq * sizeof(float)));
@@ -205,7 +205,7 @@ int ensure_pose_buffers(rz_ctx *c)
 void free_morphs(rz_ctx *c)
 {
     dfree(c->dense); dfree(c->sp_ptr); dfree(c->sp_entries);
-    c->morph_mode = 0; c->M = 0; c->Mpad = 4; c->sp_count = 0;
+    c->morph_mode = 0; c->M = 0; c->Mpad = 12; c->sp_count = 0;
     c->pose_set = false;                  // morph weights belong to the old target set
 }
 
@@ -246,7 +246,8 @@ Plan make_plan(const rz_ctx *c)
     v.S = (v.mode == 1) ? (c->t_split > 0 ? c->t_split : auto_split(c)) : 1;
     v.U = c->t_unroll > 0 ? c->t_unroll : (v.S <= 2 ? 8 : 4);
     v.nt = c->t_nt != 0;
-    v.nts = c->t_nts != 0;
+    // streaming stores pay once the frame's output no longer fits the L2s (measured: 1 M verts yes, 126 k no)
+    v.nts = c->t_nts < 0 ? ((uint64_t)c->V * c->I * 24 >= (16u << 20)) : c->t_nts != 0;
     v.geo = c->t_geo != 0;
     // one-launch frame: single instance, and (dense) the active list fits the kernel arguments
     const bool can_fast = c->I == 1 && (v.mode != 1 || c->ml.count >= 0);
@@ -518,7 +519,7 @@ int rz_upload_morphs_dense(rz_ctx *c, uint32_t M, const float *deltas)
     (void)hipFree(tmp);
     c->morph_mode = 1;
     c->M = M;
-    c->Mpad = round_up(M, 4);
+    c->Mpad = round_up(M + 8, 4);
     return ensure_pose_buffers(c);
 }
 
@@ -560,7 +561,7 @@ int rz_upload_morphs_sparse(rz_ctx *c, uint32_t M, const uint32_t *morph_off, co
     c->sp_count = kept;
     c->morph_mode = 2;
     c->M = M;
-    c->Mpad = round_up(M, 4);
+    c->Mpad = round_up(M + 8, 4);
     return ensure_pose_buffers(c);
 }
 
@@ -609,16 +610,16 @@ int rz_set_pose(rz_ctx *c, const float *world, const float *morph_weights)
     HIP_TRY(hipEventRecord(c->stage_ev[slot], c->stream));
     c->stage_used[slot] = true;
     // ordered compaction of the non-zero weights for the one-launch path (instance 0)
-    c->ml.count = 0;
+    memset(&c->ml, 0, sizeof c->ml);
     if (c->M > 0 && morph_weights && c->I == 1) {
         int n = 0;
         for (uint32_t m = 0; m < c->M; ++m) {
             const float w = morph_weights[m];
             if (w == 0.0f) continue;
-            if (n < kKargMorphs && m < 65536u) { c->ml.idx[n] = (uint16_t)m; c->ml.w[n] = w; }
+            if (n < kKargMorphs) { c->ml.idx[n] = m; c->ml.w[n] = w; }
             ++n;
         }
-        c->ml.count = (n <= kKargMorphs && c->M <= 65536u) ? n : -1;
+        c->ml.count = n <= kKargMorphs ? n : -1;
     }
     c->pose_set = true;
     return RZ_OK;
@@ -743,7 +744,7 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
     } else if (!strcmp(key, "geo_lds")) {
         c->t_geo = value ? 1 : 0;
     } else if (!strcmp(key, "nt_store")) {
-        c->t_nts = value ? 1 : 0;
+        c->t_nts = value < 0 ? -1 : (value ? 1 : 0);
     } else if (!strcmp(key, "fast")) {
         c->t_fast = value;        // -1 auto, 0 never (always prep kernel), 1 when possible
     } else {
@@ -760,6 +761,10 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "grid_cap")) *value = c->t_grid_cap;
     else if (!strcmp(key, "nontemporal")) *value = c->t_nt;
     else if (!strcmp(key, "geo_lds")) *value = c->t_geo;
+    else if (!strcmp(key, "bones")) *value = (int)c->B;
+    else if (!strcmp(key, "morphs")) *value = (int)c->M;
+    else if (!strcmp(key, "instances")) *value = (int)c->I;
+    else if (!strcmp(key, "verts")) *value = (int)c->V;
     else if (!strcmp(key, "nt_store")) *value = c->t_nts;
     else if (!strcmp(key, "fast")) *value = c->t_fast;
     else if (!strcmp(key, "effective_split")) *value = make_plan(c).v.S;

@@ -1,0 +1,286 @@
+'use strict'
+/*
+ * model.js — scene data + CPU pose solve (stays on the host, north star: "the PMX/VMD parsers and
+ * CPU bone-hierarchy solve stay in TypeScript").
+ *
+ * Mirrors the reference's class Model (engine/src/model.ts:70-421): same constructor argument
+ * order, same getters (getVertices / getSkinning / getSkeleton / getBoneWorldMatrices / ...),
+ * same rotateBones() tween semantics (:246-315), updateRotationTweens (:158-194) and forward
+ * kinematics with MMD append-rotation (:330-420), same typed-array state (SkeletonRuntime,
+ * :52-59). World matrices come out bit-identical to the reference because every intermediate
+ * matrix is stored to Float32Array at the same points.
+ *
+ * Additions the reference lacks (SURVEY §8b): an injectable clock (the reference reads
+ * performance.now(), model.ts:160,249 — not reproducible frame for frame) and vertex-morph state
+ * (names, sparse targets, weights, group-morph flattening) feeding the fused GPU kernel.
+ */
+const { Quat, easeInOut, kernels } = require('./math')
+const { slerpInto, mulInto, quatToMatInto, identityInto } = kernels
+
+const VERTEX_STRIDE = 8 // floats per vertex: x y z nx ny nz u v  (model.ts:4, :196-200)
+
+let defaultClock
+try {
+  const { performance } = require('perf_hooks')
+  defaultClock = () => performance.now()
+} catch (e) {
+  defaultClock = () => Date.now()
+}
+
+class Model {
+  /**
+   * @param {Float32Array} vertexData interleaved 8 floats / vertex
+   * @param {Uint32Array} indexData
+   * @param {Array} textures
+   * @param {Array} materials
+   * @param {{bones: Array, inverseBindMatrices: Float32Array}} skeleton
+   * @param {{joints: Uint16Array, weights: Uint8Array}} skinning
+   * @param {Array} [rigidbodies]
+   * @param {Array} [joints]
+   * @param {object|null} [morphs] { names, types, offsets:Uint32Array(M+1), vertexIndex:Uint32Array,
+   *                                 deltas:Float32Array(E*3), groups: Array<Array<[child, ratio]>|null> }
+   */
+  constructor(vertexData, indexData, textures, materials, skeleton, skinning, rigidbodies, joints, morphs) {
+    if (!skeleton || !skeleton.bones || skeleton.bones.length === 0) throw new Error('Model has no bones')
+    this.vertexData = vertexData
+    this.vertexCount = vertexData.length / VERTEX_STRIDE
+    this.indexData = indexData
+    this.textures = textures || []
+    this.materials = materials || []
+    this.skeleton = skeleton
+    this.skinning = skinning
+    this.rigidbodies = rigidbodies || []
+    this.joints = joints || []
+    this.clock = defaultClock
+
+    const n = skeleton.bones.length
+    const nameIndex = {}
+    for (let i = 0; i < n; i++) nameIndex[skeleton.bones[i].name] = i
+    const localRotations = new Float32Array(n * 4)
+    for (let i = 0; i < n; i++) localRotations[i * 4 + 3] = 1
+    this.runtimeSkeleton = {
+      nameIndex,
+      localRotations, // quat per bone (x,y,z,w)
+      localTranslations: new Float32Array(n * 3),
+      worldMatrices: new Float32Array(n * 16),
+      computedBones: new Array(n).fill(false),
+    }
+    this.rotTweenState = {
+      active: new Uint8Array(n),
+      startQuat: new Float32Array(n * 4),
+      targetQuat: new Float32Array(n * 4),
+      startTimeMs: new Float32Array(n),
+      durationMs: new Float32Array(n),
+    }
+    // parent-first evaluation order (the reference recurses; the result per bone is the same)
+    this.solveOrder = Model.parentFirstOrder(skeleton.bones)
+    // scratch matrices for the FK (no per-bone allocation)
+    this._rot = new Float32Array(16)
+    this._app = new Float32Array(16)
+    this._tmpA = new Float32Array(16)
+    this._tmpB = new Float32Array(16)
+    this._tr = new Float32Array(16)
+    this._q = [0, 0, 0, 1]
+
+    this.morphs = morphs || null
+    const m = this.morphs ? this.morphs.names.length : 0
+    this.morphWeights = new Float32Array(m) // as set by the user / animation (includes group morphs)
+    this.effectiveMorphWeights = new Float32Array(m) // group morphs flattened onto their children
+    this.morphNameIndex = {}
+    for (let i = 0; i < m; i++) this.morphNameIndex[this.morphs.names[i]] = i
+  }
+
+  static parentFirstOrder(bones) {
+    const n = bones.length
+    const state = new Uint8Array(n)
+    const order = []
+    for (let i = 0; i < n; i++) {
+      if (state[i]) continue
+      const chain = []
+      let b = i
+      while (b >= 0 && b < n && !state[b]) { state[b] = 1; chain.push(b); b = bones[b].parentIndex }
+      for (let k = chain.length - 1; k >= 0; k--) order.push(chain[k])
+    }
+    return order
+  }
+
+  /** Replace performance.now() (deterministic tests / offline stepping). */
+  setClock(fn) { this.clock = fn || defaultClock }
+
+  // ---- static data getters (model.ts:196-238) ----
+  getVertices() { return this.vertexData }
+  getTextures() { return this.textures }
+  getMaterials() { return this.materials }
+  getVertexCount() { return this.vertexCount }
+  getIndices() { return this.indexData }
+  getSkeleton() { return this.skeleton }
+  getSkinning() { return this.skinning }
+  getRigidbodies() { return this.rigidbodies }
+  getJoints() { return this.joints }
+  getBoneNames() { return this.skeleton.bones.map((b) => b.name) }
+  getBoneWorldMatrices() { return this.runtimeSkeleton.worldMatrices }
+  getBoneInverseBindMatrices() { return this.skeleton.inverseBindMatrices }
+
+  // ---- pose API ----
+  _tweenValue(idx, now, out) {
+    const st = this.rotTweenState
+    const qi = idx * 4
+    const dur = Math.max(1, st.durationMs[idx])
+    const t = Math.max(0, Math.min(1, (now - st.startTimeMs[idx]) / dur))
+    slerpInto(out, st.startQuat[qi], st.startQuat[qi + 1], st.startQuat[qi + 2], st.startQuat[qi + 3],
+      st.targetQuat[qi], st.targetQuat[qi + 1], st.targetQuat[qi + 2], st.targetQuat[qi + 3], easeInOut(t))
+    return t
+  }
+
+  /** model.ts:246-315 — immediate set (durationMs 0/undefined) or arm a quadratic-ease slerp tween. */
+  rotateBones(names, quats, durationMs) {
+    const st = this.rotTweenState
+    const rot = this.runtimeSkeleton.localRotations
+    const nameIndex = this.runtimeSkeleton.nameIndex
+    const now = this.clock()
+    const dur = durationMs && durationMs > 0 ? durationMs : 0
+    const cur = this._q
+    for (let i = 0; i < names.length; i++) {
+      const found = nameIndex[names[i]]
+      const idx = found === undefined || found === null ? -1 : found
+      if (idx < 0 || idx >= this.skeleton.bones.length) continue
+      const q = quats[i].normalize()
+      const qi = idx * 4
+      if (dur === 0) {
+        rot[qi] = q.x; rot[qi + 1] = q.y; rot[qi + 2] = q.z; rot[qi + 3] = q.w
+        st.active[idx] = 0
+        continue
+      }
+      // start from where the bone is now: the running tween's interpolated value, else the stored rotation
+      let sx = rot[qi], sy = rot[qi + 1], sz = rot[qi + 2], sw = rot[qi + 3]
+      if (st.active[idx] === 1) {
+        this._tweenValue(idx, now, cur)
+        sx = cur[0]; sy = cur[1]; sz = cur[2]; sw = cur[3]
+      }
+      st.startQuat[qi] = sx; st.startQuat[qi + 1] = sy; st.startQuat[qi + 2] = sz; st.startQuat[qi + 3] = sw
+      st.targetQuat[qi] = q.x; st.targetQuat[qi + 1] = q.y; st.targetQuat[qi + 2] = q.z; st.targetQuat[qi + 3] = q.w
+      st.startTimeMs[idx] = now
+      st.durationMs[idx] = dur
+      st.active[idx] = 1
+    }
+  }
+
+  /** model.ts:158-194 */
+  updateRotationTweens() {
+    const st = this.rotTweenState
+    const rot = this.runtimeSkeleton.localRotations
+    const now = this.clock()
+    const cur = this._q
+    for (let i = 0, n = this.skeleton.bones.length; i < n; i++) {
+      if (st.active[i] !== 1) continue
+      const t = this._tweenValue(i, now, cur)
+      const qi = i * 4
+      rot[qi] = cur[0]; rot[qi + 1] = cur[1]; rot[qi + 2] = cur[2]; rot[qi + 3] = cur[3]
+      if (t >= 1) st.active[i] = 0
+    }
+  }
+
+  /** model.ts:325-328 */
+  evaluatePose() {
+    this.updateRotationTweens()
+    this.computeWorldMatrices()
+  }
+
+  /**
+   * model.ts:330-420. Per bone: R = fromQuat(q); append-rotation R = fromQuat(slerp(I, +-q_append,
+   * |ratio|)) * R when appendRotate && valid parent && |clamp(ratio,-1,1)| > 1e-6; append-move only
+   * inside that branch; L = T(bind) * R * T(add); W = W_parent * L.
+   */
+  computeWorldMatrices() {
+    const bones = this.skeleton.bones
+    const n = bones.length
+    const rot = this.runtimeSkeleton.localRotations
+    const tra = this.runtimeSkeleton.localTranslations
+    const world = this.runtimeSkeleton.worldMatrices
+    const R = this._rot, A = this._app, T = this._tr, X = this._tmpA, L = this._tmpB
+    const q = this._q
+    for (let k = 0; k < n; k++) {
+      const i = this.solveOrder[k]
+      const b = bones[i]
+      if (b.parentIndex >= n) console.warn('[RZM] bone ' + i + ' parent out of range: ' + b.parentIndex)
+      const qi = i * 4
+      quatToMatInto(R, 0, rot[qi], rot[qi + 1], rot[qi + 2], rot[qi + 3])
+      let ax = 0, ay = 0, az = 0
+      let rotM = R
+      const ap = b.appendParentIndex
+      if (b.appendRotate && ap !== undefined && ap !== null && ap >= 0 && ap < n) {
+        const ratio = b.appendRatio === undefined || b.appendRatio === null ? 1 : Math.max(-1, Math.min(1, b.appendRatio))
+        if (Math.abs(ratio) > 1e-6) {
+          const aq = ap * 4
+          let qx = rot[aq], qy = rot[aq + 1], qz = rot[aq + 2]
+          const qw = rot[aq + 3]
+          if (ratio < 0) { qx = -qx; qy = -qy; qz = -qz }
+          slerpInto(q, 0, 0, 0, 1, qx, qy, qz, qw, ratio < 0 ? -ratio : ratio)
+          quatToMatInto(A, 0, q[0], q[1], q[2], q[3])
+          mulInto(X, 0, A, 0, R, 0)
+          rotM = X
+          if (b.appendMove) {
+            const r = b.appendRatio === undefined || b.appendRatio === null ? 1 : b.appendRatio
+            ax = tra[ap * 3] * r; ay = tra[ap * 3 + 1] * r; az = tra[ap * 3 + 2] * r
+          }
+        }
+      }
+      // L = T(bind) * rotM * T(add), each product stored as f32 like the reference's Mat4.multiply chain
+      identityInto(T, 0)
+      T[12] += b.bindTranslation[0]; T[13] += b.bindTranslation[1]; T[14] += b.bindTranslation[2]
+      mulInto(L, 0, T, 0, rotM, 0)
+      identityInto(T, 0)
+      T[12] += ax; T[13] += ay; T[14] += az
+      const L2 = rotM === X ? R : X // a free scratch matrix
+      mulInto(L2, 0, L, 0, T, 0)
+      const wo = i * 16
+      if (b.parentIndex >= 0) {
+        mulInto(T, 0, world, b.parentIndex * 16, L2, 0)
+        world.set(T, wo)
+      } else {
+        world.set(L2, wo)
+      }
+    }
+    this.runtimeSkeleton.computedBones.fill(true)
+  }
+
+  // ---- morphs (no reference counterpart; PMX layout per pmx-loader.ts:471-488) ----
+  getMorphNames() { return this.morphs ? this.morphs.names.slice() : [] }
+  getMorphCount() { return this.morphs ? this.morphs.names.length : 0 }
+  getMorphs() { return this.morphs }
+
+  /** names or indices + weights; unknown names are ignored like unknown bones in rotateBones. */
+  setMorphWeights(namesOrIndices, weights) {
+    if (!this.morphs) return
+    for (let i = 0; i < namesOrIndices.length; i++) {
+      const key = namesOrIndices[i]
+      const idx = typeof key === 'number' ? key : this.morphNameIndex[key]
+      if (idx === undefined || idx < 0 || idx >= this.morphWeights.length) continue
+      this.morphWeights[idx] = weights[i]
+    }
+  }
+
+  getMorphWeights() { return this.morphWeights }
+
+  /**
+   * Weights the GPU consumes: vertex morphs (type 1) keep their own weight plus, for every group
+   * morph (type 0) that lists them, w_group * ratio (pmx-loader.ts:479-482). Other morph types
+   * (bone / UV / material / flip / impulse) have no vertex deltas and contribute nothing.
+   */
+  getEffectiveMorphWeights() {
+    const out = this.effectiveMorphWeights
+    if (!this.morphs) return out
+    const { types, groups } = this.morphs
+    const w = this.morphWeights
+    for (let i = 0; i < out.length; i++) out[i] = types[i] === 1 ? w[i] : 0
+    for (let g = 0; g < out.length; g++) {
+      if (types[g] !== 0 || w[g] === 0 || !groups[g]) continue
+      for (const [child, ratio] of groups[g]) {
+        if (child >= 0 && child < out.length && types[child] === 1) out[child] += w[g] * ratio
+      }
+    }
+    return out
+  }
+}
+
+module.exports = { Model, VERTEX_STRIDE }
