@@ -11,6 +11,7 @@
 #include <node_api.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/reze_deform.h"
@@ -85,8 +86,6 @@ static void finalize_ctx(napi_env env, void *data, void *hint)
         free(slot);
     }
 }
-
-#include <stdlib.h>
 
 static napi_value fn_abi_version(napi_env env, napi_callback_info info)
 {

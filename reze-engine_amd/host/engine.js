@@ -1,0 +1,333 @@
+'use strict'
+/*
+ * engine.js — the Engine class with the reference's public surface (engine/src/engine.ts:35-185,
+ * 1419-1725): new Engine(canvas|null, options?), init(), loadModel(), loadAnimation(),
+ * playAnimation(), stopAnimation(), rotateBones(), render(), runRenderLoop(), stopRenderLoop(),
+ * getStats(), dispose(). What changes is what sits behind it: the WebGPU buffer uploads of
+ * setupModelBuffers() (:1728-1832) and the per-frame writeBuffer + palette dispatch of
+ * updateModelPose() (:2375-2402), and the skinning that the reference re-runs inside every vertex
+ * shader invocation (:253-272), become calls into the HIP addon: upload once, then per frame
+ * evaluatePose() on the CPU -> setPose(world matrices, morph weights) -> deform() on the MI355X.
+ * Rendering (pipelines, bloom, camera, textures) and physics are out of scope and absent.
+ *
+ * Additions (SURVEY §8b): setMorphWeights(), getDeformed(), step(timeMs) — a deterministic clock
+ * replacing performance.now()/window.setTimeout so a VMD can be stepped reproducibly — and
+ * options { device, morphLayout: 'sparse'|'dense', realtime }.
+ */
+const { Quat, Vec3 } = require('./math')
+const { PmxLoader } = require('./pmx-loader')
+const { VMDLoader } = require('./vmd-loader')
+const { requireAddon } = require('./addon')
+
+let wallClock
+try {
+  const { performance } = require('perf_hooks')
+  wallClock = () => performance.now()
+} catch (e) {
+  wallClock = () => Date.now()
+}
+
+class Engine {
+  constructor(canvas, options) {
+    this.canvas = canvas || null // accepted for signature compatibility; nothing is drawn
+    const o = options || {}
+    // render-only options are accepted and kept so existing call sites keep working (engine.ts:145-154)
+    this.ambient = o.ambient === undefined ? 1.0 : o.ambient
+    this.bloomIntensity = o.bloomIntensity === undefined ? 0.12 : o.bloomIntensity
+    this.rimLightIntensity = o.rimLightIntensity === undefined ? 0.45 : o.rimLightIntensity
+    this.cameraDistance = o.cameraDistance === undefined ? 26.6 : o.cameraDistance
+    this.cameraTarget = o.cameraTarget === undefined ? new Vec3(0, 12.5, 0) : o.cameraTarget
+    this.device = o.device === undefined ? 0 : o.device
+    this.morphLayout = o.morphLayout || 'sparse'
+    this.realtime = o.realtime !== false // false: time only advances through step()
+    this.native = null
+    this.ctx = null
+    this.currentModel = null
+    this.animationFrames = []
+    this.hasAnimation = false
+    this.playingAnimation = false
+    this.timers = [] // { due, fn, id, handle }
+    this.nextTimerId = 1
+    this.animationTimers = []
+    this.breathingTimer = null
+    this.breathingBaseRotations = new Map()
+    this.nowMs = 0 // manual clock value
+    this.loopHandle = null
+    this.renderLoopCallback = null
+    this.stats = { fps: 0, frameTime: 0, gpuMemory: 0, deformMs: 0, vertsPerSec: 0, hbmGBps: 0 }
+    this.frameTimeSamples = []
+    this.frameTimeSum = 0
+    this.framesSinceLastUpdate = 0
+    this.lastFpsUpdate = 0
+    this.outPos = null
+    this.outNrm = null
+  }
+
+  now() { return this.realtime ? wallClock() : this.nowMs }
+
+  // ---- lifecycle ----
+  /** engine.ts:157-185: acquire the device. Throws when the addon or an MI355X is not available. */
+  async init() {
+    this.native = requireAddon()
+    this.ctx = this.native.create(this.device)
+    this.lastFpsUpdate = this.now()
+  }
+
+  dispose() {
+    this.stopRenderLoop()
+    this.stopAnimation()
+    this.stopBreathing()
+    if (this.ctx) { this.native.destroy(this.ctx); this.ctx = null }
+  }
+
+  // ---- timers (window.setTimeout replacement that also works on a manual clock) ----
+  setTimer(fn, delayMs) {
+    const t = { due: this.now() + delayMs, fn, id: this.nextTimerId++, handle: null }
+    if (this.realtime) t.handle = setTimeout(() => { this.dropTimer(t.id); fn() }, delayMs)
+    this.timers.push(t)
+    return t.id
+  }
+
+  dropTimer(id) {
+    const i = this.timers.findIndex((t) => t.id === id)
+    if (i >= 0) { if (this.timers[i].handle) clearTimeout(this.timers[i].handle); this.timers.splice(i, 1) }
+  }
+
+  fireDueTimers() {
+    for (;;) { // earliest first; a callback may schedule more
+      let best = -1
+      for (let i = 0; i < this.timers.length; i++) {
+        if (this.timers[i].due <= this.nowMs && (best < 0 || this.timers[i].due < this.timers[best].due)) best = i
+      }
+      if (best < 0) return
+      const t = this.timers.splice(best, 1)[0]
+      t.fn()
+    }
+  }
+
+  // ---- model ----
+  /** engine.ts:1704-1721 */
+  async loadModel(path) {
+    const parts = path.split('/')
+    parts.pop()
+    this.modelDir = parts.join('/') + '/'
+    const model = await PmxLoader.load(path)
+    await this.setupModelBuffers(model)
+  }
+
+  /** engine.ts:1728-1832: one-off static upload (vertex / joints / weights / inverse bind [+ morph targets]). */
+  async setupModelBuffers(model) {
+    if (!this.ctx) throw new Error('Engine.init() has not been called')
+    this.currentModel = model
+    model.setClock(() => this.now())
+    const n = this.native, skinning = model.getSkinning(), skeleton = model.getSkeleton()
+    n.uploadMesh(this.ctx, model.getVertices(), skinning.joints, skinning.weights)
+    n.uploadSkeleton(this.ctx, skeleton.inverseBindMatrices)
+    const morphs = model.getMorphs()
+    const V = model.getVertexCount()
+    if (morphs && morphs.names.length > 0) {
+      if (this.morphLayout === 'dense') {
+        const M = morphs.names.length
+        const dense = new Float32Array(M * V * 3)
+        for (let m = 0; m < M; m++) {
+          for (let e = morphs.offsets[m]; e < morphs.offsets[m + 1]; e++) {
+            const d = (m * V + morphs.vertexIndex[e]) * 3
+            dense[d] += morphs.deltas[e * 3]; dense[d + 1] += morphs.deltas[e * 3 + 1]; dense[d + 2] += morphs.deltas[e * 3 + 2]
+          }
+        }
+        n.uploadMorphsDense(this.ctx, M, dense)
+      } else {
+        n.uploadMorphsSparse(this.ctx, morphs.offsets, morphs.vertexIndex, morphs.deltas)
+      }
+    }
+    this.outPos = new Float32Array(V * 3)
+    this.outNrm = new Float32Array(V * 3)
+    this.stats.gpuMemory = Math.round(((V * 60 + skeleton.bones.length * 176 +
+      (morphs ? morphs.vertexIndex.length * 16 + V * 4 : 0)) / 1024 / 1024) * 100) / 100
+  }
+
+  rotateBones(bones, rotations, durationMs) {
+    if (this.currentModel) this.currentModel.rotateBones(bones, rotations, durationMs)
+  }
+
+  setMorphWeights(namesOrIndices, weights) {
+    if (this.currentModel) this.currentModel.setMorphWeights(namesOrIndices, weights)
+  }
+
+  // ---- animation ("VMD step", engine.ts:1419-1662) ----
+  async loadAnimation(path) {
+    this.animationFrames = await VMDLoader.load(path)
+    this.hasAnimation = true
+  }
+
+  playAnimation(options) {
+    if (this.animationFrames.length === 0) return
+    this.stopAnimation()
+    this.stopBreathing()
+    this.playingAnimation = true
+    const opt = options || {}
+    let breathBones = []
+    let breathRanges
+    const enableBreath = opt.breathBones !== undefined && opt.breathBones !== null
+    if (enableBreath) {
+      if (Array.isArray(opt.breathBones)) breathBones = opt.breathBones
+      else { breathBones = Object.keys(opt.breathBones); breathRanges = opt.breathBones }
+    }
+    const breathDuration = opt.breathDuration === undefined || opt.breathDuration === null ? 4000 : opt.breathDuration
+
+    // per-bone key lists in time order
+    const byBone = new Map()
+    for (const kf of this.animationFrames) {
+      for (const bf of kf.boneFrames) {
+        if (!byBone.has(bf.boneName)) byBone.set(bf.boneName, [])
+        byBone.get(bf.boneName).push({ boneName: bf.boneName, time: kf.time, rotation: bf.rotation })
+      }
+    }
+    for (const keys of byBone.values()) keys.sort((a, b) => a.time - b.time)
+
+    if (this.currentModel) {
+      // time-0 keys apply instantly; every bone without one snaps to identity (:1474-1505)
+      const names0 = [], rots0 = [], has0 = new Set()
+      for (const [name, keys] of byBone.entries()) {
+        if (keys.length > 0 && keys[0].time === 0) { names0.push(name); rots0.push(keys[0].rotation); has0.add(name) }
+      }
+      if (names0.length > 0) this.rotateBones(names0, rots0, 0)
+      const reset = this.currentModel.getSkeleton().bones.map((b) => b.name).filter((n) => !has0.has(n))
+      if (reset.length > 0) this.rotateBones(reset, reset.map(() => new Quat(0, 0, 0, 1)), 0)
+    }
+
+    // later keys: a tween from the previous key's time lasting until this key's time (:1527-1553)
+    for (const keys of byBone.values()) {
+      for (let i = 0; i < keys.length; i++) {
+        const k = keys[i]
+        if (k.time === 0) continue
+        const prev = i > 0 ? keys[i - 1] : null
+        const durationMs = (prev ? k.time - prev.time : k.time) * 1000
+        const delayMs = (prev ? prev.time : 0) * 1000
+        if (delayMs <= 0) this.rotateBones([k.boneName], [k.rotation], durationMs)
+        else this.animationTimers.push(this.setTimer(() => this.rotateBones([k.boneName], [k.rotation], durationMs), delayMs))
+      }
+    }
+
+    // morph keys (no reference counterpart: its VMD loader never reads the block): step to each key's weight
+    const mf = this.animationFrames.morphFrames || []
+    for (const f of mf) {
+      const apply = () => this.setMorphWeights([f.morphName], [f.weight])
+      if (f.time <= 0) apply(); else this.animationTimers.push(this.setTimer(apply, f.time * 1000))
+    }
+
+    if (enableBreath && this.currentModel) {
+      let maxTime = 0
+      for (const kf of this.animationFrames) if (kf.time > maxTime) maxTime = kf.time
+      const last = new Map()
+      for (const bone of breathBones) {
+        const keys = byBone.get(bone)
+        if (keys && keys.length > 0) last.set(bone, keys[keys.length - 1].rotation)
+      }
+      this.breathingTimer = this.setTimer(() => this.startBreathing(breathBones, last, breathRanges, breathDuration), maxTime * 1000 + 200)
+    }
+  }
+
+  stopAnimation() {
+    for (const id of this.animationTimers) this.dropTimer(id)
+    this.animationTimers = []
+    this.playingAnimation = false
+  }
+
+  stopBreathing() {
+    if (this.breathingTimer !== null) { this.dropTimer(this.breathingTimer); this.breathingTimer = null }
+    this.breathingBaseRotations.clear()
+  }
+
+  startBreathing(bones, baseRotations, rotationRanges, durationMs) {
+    if (!this.currentModel) return
+    for (const b of bones) if (baseRotations.has(b)) this.breathingBaseRotations.set(b, baseRotations.get(b))
+    const half = (durationMs === undefined ? 4000 : durationMs) / 2
+    const swing = (inhale) => {
+      if (!this.currentModel) return
+      const names = [], quats = []
+      for (const b of bones) {
+        const base = this.breathingBaseRotations.get(b)
+        if (!base) continue
+        const range = rotationRanges && rotationRanges[b] !== undefined && rotationRanges[b] !== null ? rotationRanges[b] : 0.02
+        names.push(b)
+        quats.push(base.multiply(Quat.fromEuler(inhale ? range : -range, 0, 0)))
+      }
+      if (names.length > 0) this.rotateBones(names, quats, half)
+      this.breathingTimer = this.setTimer(() => swing(!inhale), half)
+    }
+    swing(false)
+  }
+
+  // ---- per frame ----
+  /** engine.ts:2124-2136 + 2375-2402 minus the draw calls: pose on the CPU, deformation on the GPU. */
+  render() {
+    if (!this.currentModel || !this.ctx) return
+    const t0 = wallClock()
+    const model = this.currentModel
+    model.evaluatePose()
+    const mw = model.getMorphCount() > 0 ? model.getEffectiveMorphWeights() : null
+    this.native.setPose(this.ctx, model.getBoneWorldMatrices(), mw)
+    this.native.deform(this.ctx)
+    this.updateStats(wallClock() - t0)
+  }
+
+  /** Deterministic stepping: move the clock to timeMs, fire the timers that came due, render one frame. */
+  step(timeMs) {
+    if (this.realtime) throw new Error('step() needs new Engine(canvas, { realtime: false })')
+    this.nowMs = timeMs
+    this.fireDueTimers()
+    this.render()
+  }
+
+  /** Blocking readback of the deformed mesh (the values the reference's vs() only ever feeds the rasteriser). */
+  getDeformed() {
+    if (!this.ctx || !this.currentModel) throw new Error('no model loaded')
+    this.native.read(this.ctx, 0, 0, this.currentModel.getVertexCount(), this.outPos, this.outNrm)
+    return { positions: this.outPos, normals: this.outNrm }
+  }
+
+  runRenderLoop(callback) {
+    this.renderLoopCallback = callback || null
+    const tick = () => {
+      this.render()
+      if (this.renderLoopCallback) this.renderLoopCallback()
+      this.loopHandle = setTimeout(tick, 0) // no requestAnimationFrame in Node: free-running
+    }
+    this.loopHandle = setTimeout(tick, 0)
+  }
+
+  stopRenderLoop() {
+    if (this.loopHandle !== null) { clearTimeout(this.loopHandle); this.loopHandle = null }
+    this.renderLoopCallback = null
+  }
+
+  /** engine.ts:2423-2445 (60-sample moving average, 1 Hz fps) + deformation figures. */
+  updateStats(frameTime) {
+    this.frameTimeSamples.push(frameTime)
+    this.frameTimeSum += frameTime
+    if (this.frameTimeSamples.length > 60) this.frameTimeSum -= this.frameTimeSamples.shift()
+    this.stats.frameTime = Math.round((this.frameTimeSum / this.frameTimeSamples.length) * 100) / 100
+    const now = wallClock()
+    this.framesSinceLastUpdate++
+    const elapsed = now - this.lastFpsUpdate
+    if (elapsed >= 1000) {
+      this.stats.fps = Math.round((this.framesSinceLastUpdate / elapsed) * 1000)
+      this.framesSinceLastUpdate = 0
+      this.lastFpsUpdate = now
+    }
+  }
+
+  /** Time `frames` back-to-back frames of the current pose on the GPU (HIP events) and fold them into getStats(). */
+  measure(frames) {
+    const t = this.native.timeFrames(this.ctx, frames || 100)
+    this.stats.deformMs = t.frameMs
+    this.stats.vertsPerSec = t.vertsPerFrame / (t.frameMs * 1e-3)
+    this.stats.hbmGBps = t.algorithmicBytesPerFrame / (t.deformKernelMs * 1e-3) / 1e9
+    return t
+  }
+
+  getStats() { return Object.assign({}, this.stats) }
+}
+
+module.exports = { Engine }

@@ -1,0 +1,60 @@
+// Typings for the host package; shapes follow the reference's engine/src/index.ts:1-2 exports.
+export class Vec3 {
+  x: number; y: number; z: number
+  constructor(x: number, y: number, z: number)
+  add(o: Vec3): Vec3; subtract(o: Vec3): Vec3; scale(k: number): Vec3; dot(o: Vec3): number; cross(o: Vec3): Vec3
+  length(): number; normalize(): Vec3; clone(): Vec3
+}
+export class Quat {
+  x: number; y: number; z: number; w: number
+  constructor(x: number, y: number, z: number, w: number)
+  add(o: Quat): Quat; clone(): Quat; multiply(o: Quat): Quat; conjugate(): Quat; length(): number; normalize(): Quat
+  rotateVec(v: Vec3): Vec3; rotate(v: Vec3): Vec3; toArray(): [number, number, number, number]; toEuler(): Vec3
+  static slerp(a: Quat, b: Quat, t: number): Quat
+  static fromEuler(rotX: number, rotY: number, rotZ: number): Quat
+  static fromTo(from: Vec3, to: Vec3): Quat
+}
+export class Mat4 {
+  values: Float32Array
+  constructor(values: Float32Array)
+  static identity(): Mat4
+  static perspective(fov: number, aspect: number, near: number, far: number): Mat4
+  static lookAt(eye: Vec3, target: Vec3, up: Vec3): Mat4
+  static fromQuat(x: number, y: number, z: number, w: number): Mat4
+  static fromPositionRotation(position: Vec3, rotation: Quat): Mat4
+  static multiplyArrays(a: Float32Array, aOffset: number, b: Float32Array, bOffset: number, out: Float32Array, outOffset: number): void
+  static toQuatFromArray(m: Float32Array, offset: number): Quat
+  multiply(other: Mat4): Mat4; clone(): Mat4; getPosition(): Vec3; toQuat(): Quat; setIdentity(): this
+  translateInPlace(tx: number, ty: number, tz: number): this; inverse(): Mat4
+}
+export interface EngineOptions {
+  ambient?: number; bloomIntensity?: number; rimLightIntensity?: number; cameraDistance?: number; cameraTarget?: Vec3
+  /** HIP device ordinal (default 0). */ device?: number
+  /** How PMX vertex morphs are laid out in HBM (default 'sparse'). */ morphLayout?: 'sparse' | 'dense'
+  /** false: time only advances through step(timeMs). */ realtime?: boolean
+}
+export interface EngineStats {
+  fps: number; frameTime: number; gpuMemory: number
+  deformMs: number; vertsPerSec: number; hbmGBps: number
+}
+export class Engine {
+  constructor(canvas: unknown | null, options?: EngineOptions)
+  init(): Promise<void>
+  loadModel(path: string): Promise<void>
+  loadAnimation(path: string): Promise<void>
+  playAnimation(options?: { breathBones?: string[] | Record<string, number>; breathDuration?: number }): void
+  stopAnimation(): void
+  rotateBones(bones: string[], rotations: Quat[], durationMs?: number): void
+  setMorphWeights(namesOrIndices: Array<string | number>, weights: number[]): void
+  render(): void
+  step(timeMs: number): void
+  getDeformed(): { positions: Float32Array; normals: Float32Array }
+  runRenderLoop(callback?: () => void): void
+  stopRenderLoop(): void
+  measure(frames?: number): { frameMs: number; deformKernelMs: number; prepKernelMs: number; vertsPerFrame: number; algorithmicBytesPerFrame: number; frames: number }
+  getStats(): EngineStats
+  dispose(): void
+}
+export class Model { [key: string]: any }
+export class PmxLoader { static load(path: string): Promise<Model>; static loadFromBuffer(buf: ArrayBuffer | Uint8Array): Model }
+export class VMDLoader { static load(path: string): Promise<any[]>; static loadFromBuffer(buf: ArrayBuffer | Uint8Array): any[] }

@@ -1,0 +1,8 @@
+'use strict'
+// Same export list as the reference's engine/src/index.ts:1-2 (+ loaders and Model for host-side use).
+const { Engine } = require('./engine')
+const { Vec3, Quat, Mat4 } = require('./math')
+const { Model } = require('./model')
+const { PmxLoader } = require('./pmx-loader')
+const { VMDLoader } = require('./vmd-loader')
+module.exports = { Engine, Vec3, Quat, Mat4, Model, PmxLoader, VMDLoader }

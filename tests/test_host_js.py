@@ -1,0 +1,291 @@
+"""CPU tests of the JavaScript host side (reze-engine_amd/host) under Node.
+
+Pins (tests/golden/, produced by tools/ref_erased_run.py from the reference's own code + assets):
+  * forward kinematics, append rotation and tween evaluation reproduce the reference's world
+    matrices BIT FOR BIT (real 349-bone skeleton, pool.vmd frame 0; a 400 ms tween at +150/+500 ms);
+  * when the reference's assets are present (this container only) the PMX/VMD parsers reproduce the
+    reference's parsed arrays by CRC32.
+Synthetic byte-level PMX / VMD files written here exercise every weight type, index width and
+morph type without touching the reference's model files."""
+import json
+import os
+import shutil
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+DUMP = os.path.join(ROOT, "tests", "js", "host_dump.js")
+ASSETS = "/root/reference/web/public"
+
+pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
+
+
+def node(*args):
+    subprocess.check_call(["node", DUMP] + list(args), timeout=120)
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "ref_c1_pose0.npz"))
+
+
+def test_fk_append_and_tweens_match_reference_bit_for_bit(gold, tmp_path):
+    """config C1: ~30k-vert PMX + VMD frame 0 — CPU bone hierarchy + palette inputs, host only."""
+    n = len(gold["parents"])
+    fx = dict(names=[str(s) for s in gold["bone_names"]], parents=gold["parents"].tolist(), bind=gold["bind"].tolist(),
+              appendParent=gold["append_parent"].tolist(), appendRatio=gold["append_ratio"].tolist(),
+              appendRotate=gold["append_rotate"].tolist(), appendMove=gold["append_move"].tolist(),
+              localRot=gold["local_rot_pose0"].astype(np.float64).tolist(),
+              tweenBones=["センター", "上半身", "首"],
+              tweenQuats=[[0.1, 0.2, 0.05, 0.97], [-0.2, 0.1, 0.0, 0.97], [0.0, -0.3, 0.1, 0.95]])
+    p = tmp_path / "fx.json"
+    p.write_text(json.dumps(fx), encoding="utf-8")
+    node("pose", str(p), str(tmp_path))
+    rd = lambda f: np.fromfile(str(tmp_path / f), dtype=np.float32)  # noqa: E731
+    assert n == 349 and int(gold["append_rotate"].sum()) == 26
+    assert np.array_equal(rd("world_pose0.f32").reshape(-1, 16), gold["world_pose0"])
+    assert np.array_equal(rd("localrot_tween150.f32").reshape(-1, 4), gold["local_rot_tween150"])
+    assert np.array_equal(rd("world_tween150.f32").reshape(-1, 16), gold["world_tween150"])
+    assert np.array_equal(rd("world_tween500.f32").reshape(-1, 16), gold["world_tween500"])
+    # frame 0 really poses the model: 36 keyed bones, world matrices differ from the bind pose
+    assert (np.abs(gold["local_rot_pose0"][:, :3]).sum(axis=1) > 0).sum() >= 30
+
+
+def test_numpy_fk_twin_agrees_with_reference_world_matrices(gold):
+    """The Python FK used to pose the synthetic bench skeleton is the same algorithm (no append bones there)."""
+    from reze_engine_amd import synth
+    parents = gold["parents"]
+    no_append = ~gold["append_rotate"]
+    world = synth.fk_world(parents, gold["bind"].astype(np.float32), gold["local_rot_pose0"])
+    # bones whose whole ancestor chain has no append rotation must match exactly
+    clean = no_append.copy()
+    for i in range(len(parents)):
+        p = parents[i]
+        if p >= 0:
+            clean[i] = clean[i] and clean[p]
+    assert clean.sum() > 200
+    assert np.array_equal(world[clean], gold["world_pose0"][clean])
+    ib = synth.inverse_bind_translation_only(parents, gold["bind"].astype(np.float32))
+    assert np.array_equal(ib, gold["inv_bind"])
+
+
+@pytest.mark.skipif(not os.path.isdir(ASSETS), reason="reference assets only exist in the build container")
+def test_parsers_reproduce_reference_arrays_on_real_assets(tmp_path, gold):
+    ref = json.load(open(os.path.join(GOLD, "ref_models.json")))
+    for tag, rel in (("m2", "models/塞尔凯特2/塞尔凯特2.pmx"), ("m1", "models/塞尔凯特/塞尔凯特.pmx"), ("w", "models/塞尔凯特/武器.pmx")):
+        out = tmp_path / tag
+        out.mkdir()
+        node("parse", os.path.join(ASSETS, rel), str(out))
+        info = json.load(open(out / "info.json"))
+        r = ref[tag]
+        for k in ("verts", "indices", "bones", "append", "materials"):
+            assert info[k] == r[k], (tag, k)
+        assert crc(np.fromfile(str(out / "vertices.f32"), dtype=np.uint8)) == r["crc_vertices"]
+        assert crc(np.fromfile(str(out / "joints.u16"), dtype=np.uint8)) == r["crc_joints"]
+        assert crc(np.fromfile(str(out / "weights.u8"), dtype=np.uint8)) == r["crc_weights"]
+        assert crc(np.fromfile(str(out / "invbind.f32"), dtype=np.uint8)) == r["crc_invbind"]
+        assert crc(np.fromfile(str(out / "indices.u32"), dtype=np.uint8)) == r["crc_indices"]
+        if tag != "w":      # the weapon carries a bone morph, which desynchronises the reference's skipper
+            assert info["rigidbodies"] == r["rigidbodies"] and info["joints"] == r["joints"]
+        w = np.fromfile(str(out / "weights.u8"), dtype=np.uint8).reshape(-1, 4)
+        assert (w.astype(int).sum(axis=1) == 255).all()                  # loader invariant, pmx-loader.ts:855-951
+        j = np.fromfile(str(out / "joints.u16"), dtype=np.uint16)
+        assert j.max() < info["bones"]
+        if tag == "m2":     # morph section statistics measured in SURVEY §4
+            types = np.array(info["morphTypes"])
+            assert len(types) == 72 and (types == 1).sum() == 60 and (types == 0).sum() == 11 and (types == 8).sum() == 1
+            off = np.fromfile(str(out / "morph_offsets.u32"), dtype=np.uint32)
+            assert off[-1] == 36397 and np.diff(off.astype(np.int64)).max() == 1718
+            sl = gold["slice_index"]
+            v = np.fromfile(str(out / "vertices.f32"), dtype=np.float32).reshape(-1, 8)
+            assert np.array_equal(v[sl], gold["slice_vertices"])
+    for name in ("pool", "boom"):
+        o = tmp_path / (name + ".json")
+        node("vmd", os.path.join(ASSETS, "animations", name + ".vmd"), str(o))
+        assert json.load(open(o))["keyTimes"] == ref[name]["keyTimes"]
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic byte-level files
+# ---------------------------------------------------------------------------------------------
+def pmx_text(s):
+    b = s.encode("utf-16le")
+    return struct.pack("<i", len(b)) + b
+
+
+def write_pmx(bone_index_size=1, vertex_index_size=2):
+    """A tiny PMX 2.0 file touching every branch of the parser. Returns (bytes, expectations)."""
+    rng = np.random.default_rng(7)
+    bi = {1: "<b", 2: "<h", 4: "<i"}[bone_index_size]
+    vi = {1: "<B", 2: "<H", 4: "<i"}[vertex_index_size]
+    out = bytearray(b"PMX ")
+    out += struct.pack("<f", 2.0) + bytes([8, 0, 1, vertex_index_size, 1, 1, bone_index_size, 1, 1])
+    out += pmx_text("model") + pmx_text("") + pmx_text("c") + pmx_text("")
+    n_bones = 5
+    kinds = [0, 1, 2, 3, 4, 1, 2, 0]                 # BDEF1, BDEF2, BDEF4, SDEF, QDEF ...
+    V = len(kinds)
+    exp_j = np.zeros((V, 4), dtype=np.uint16)
+    exp_w = np.zeros((V, 4), dtype=np.uint8)
+    pos = rng.normal(size=(V, 3)).astype(np.float32)
+    nrm = rng.normal(size=(V, 3)).astype(np.float32)
+    uv = rng.random((V, 2)).astype(np.float32)
+    out += struct.pack("<i", V)
+    for v, k in enumerate(kinds):
+        out += pos[v].tobytes() + nrm[v].tobytes() + uv[v].tobytes() + b"\0" * 16     # one extra vec4
+        out += bytes([k])
+        if k == 0:
+            j = [int(rng.integers(0, n_bones))]
+            out += struct.pack(bi, j[0])
+            exp_j[v, 0] = j[0]
+            exp_w[v] = [255, 0, 0, 0]
+        elif k in (1, 3):
+            j = [int(x) for x in rng.integers(0, n_bones, 2)]
+            w0 = np.float32(rng.random())
+            out += struct.pack(bi, j[0]) + struct.pack(bi, j[1]) + struct.pack("<f", w0)
+            if k == 3:
+                out += b"\0" * 36
+            q = int(np.floor(float(w0) * 255 + 0.5))
+            exp_j[v, :2] = j
+            exp_w[v] = [q, 255 - q, 0, 0]
+        else:
+            j = [int(x) for x in rng.integers(0, n_bones, 4)]
+            if v == 2:
+                j[3] = -1                             # negative index -> 0
+            wf = rng.random(4).astype(np.float32)
+            for x in j:
+                out += struct.pack(bi, x)
+            out += wf.tobytes()
+            w8 = np.floor(wf.astype(np.float64) * 255 + 0.5)
+            scale = 255.0 / w8.sum()
+            q = np.clip(np.floor(w8[:3] * scale + 0.5), 0, 255)
+            exp_j[v] = [max(x, 0) for x in j]
+            exp_w[v] = list(q) + [max(0, 255 - q.sum())]
+        out += struct.pack("<f", 1.0)
+    idx = [0, 1, 2, 2, 3, 4]
+    out += struct.pack("<i", len(idx)) + b"".join(struct.pack(vi, i) for i in idx)
+    out += struct.pack("<i", 1) + pmx_text("tex/a.png")
+    # one material
+    out += struct.pack("<i", 1) + pmx_text("hair_f") + pmx_text("") + struct.pack("<11f", *([0.5] * 11)) + bytes([0x10])
+    out += struct.pack("<5f", 0, 0, 0, 1, 1.0) + struct.pack("<b", 0) + struct.pack("<b", -1) + bytes([0, 1, 3])
+    out += pmx_text("") + struct.pack("<i", len(idx))
+    # bones: chain 0 <- 1 <- 2, 3 appended to 1 (rotate, ratio 0.5), 4 with IK block + axis limit + local axes
+    bpos = rng.normal(size=(n_bones, 3)).astype(np.float32)
+    parents = [-1, 0, 1, 0, 3]
+    out += struct.pack("<i", n_bones)
+    for b in range(n_bones):
+        flags = 0x0001 if b % 2 == 0 else 0
+        if b == 3:
+            flags |= 0x0100
+        if b == 4:
+            flags |= 0x0020 | 0x0400 | 0x0800 | 0x2000
+        out += pmx_text("bone%d" % b) + pmx_text("") + bpos[b].tobytes() + struct.pack(bi, parents[b]) + struct.pack("<i", 0)
+        out += struct.pack("<H", flags)
+        out += struct.pack(bi, 0) if flags & 1 else struct.pack("<3f", 0, 1, 0)
+        if flags & 0x0100:
+            out += struct.pack(bi, 1) + struct.pack("<f", 0.5)
+        if flags & 0x0400:
+            out += struct.pack("<3f", 1, 0, 0)
+        if flags & 0x0800:
+            out += struct.pack("<6f", 1, 0, 0, 0, 0, 1)
+        if flags & 0x2000:
+            out += struct.pack("<i", 0)
+        if flags & 0x0020:
+            out += struct.pack(bi, 2) + struct.pack("<if", 3, 0.1) + struct.pack("<i", 2)
+            out += struct.pack(bi, 1) + bytes([1]) + struct.pack("<6f", *([0.0] * 6))
+            out += struct.pack(bi, 0) + bytes([0])
+    # morphs: vertex, group, bone, uv, material, vertex
+    morphs = []
+    out += struct.pack("<i", 6)
+    d0 = rng.normal(size=(3, 3)).astype(np.float32)
+    out += pmx_text("smile") + pmx_text("") + bytes([1, 1]) + struct.pack("<i", 3)
+    for k, v in enumerate([1, 4, 6]):
+        out += struct.pack(vi, v) + d0[k].tobytes()
+    morphs.append(("smile", 1, [1, 4, 6], d0))
+    out += pmx_text("grp") + pmx_text("") + bytes([1, 0]) + struct.pack("<i", 2) + struct.pack("<bf", 0, 0.5) + struct.pack("<bf", 5, 2.0)
+    morphs.append(("grp", 0, [(0, 0.5), (5, 2.0)], None))
+    out += pmx_text("bonem") + pmx_text("") + bytes([1, 2]) + struct.pack("<i", 1) + struct.pack(bi, 1) + struct.pack("<7f", *([0.0] * 7))
+    morphs.append(("bonem", 2, [], None))
+    out += pmx_text("uvm") + pmx_text("") + bytes([1, 3]) + struct.pack("<i", 2) + (struct.pack(vi, 0) + struct.pack("<4f", 0, 0, 0, 0)) * 2
+    morphs.append(("uvm", 3, [], None))
+    out += pmx_text("matm") + pmx_text("") + bytes([1, 8]) + struct.pack("<i", 1) + struct.pack("<b", 0) + bytes([0]) + struct.pack("<28f", *([1.0] * 28))
+    morphs.append(("matm", 8, [], None))
+    d5 = rng.normal(size=(2, 3)).astype(np.float32)
+    out += pmx_text("blink") + pmx_text("") + bytes([1, 1]) + struct.pack("<i", 2)
+    for k, v in enumerate([0, 7]):
+        out += struct.pack(vi, v) + d5[k].tobytes()
+    morphs.append(("blink", 1, [0, 7], d5))
+    # display frames, rigid bodies, joints
+    out += struct.pack("<i", 1) + pmx_text("Root") + pmx_text("") + bytes([1]) + struct.pack("<i", 2) + bytes([0]) + struct.pack(bi, 0) + bytes([1]) + struct.pack("<b", 0)
+    out += struct.pack("<i", 1) + pmx_text("rb") + pmx_text("") + struct.pack(bi, 1) + bytes([0]) + struct.pack("<H", 0xFFFF) + bytes([0])
+    out += struct.pack("<9f", *([1.0] * 9)) + struct.pack("<5f", 1, 0.5, 0.5, 0, 0.5) + bytes([1])
+    out += struct.pack("<i", 1) + pmx_text("jt") + pmx_text("") + bytes([0]) + struct.pack("<bb", 0, 0) + struct.pack("<24f", *([0.0] * 24))
+    return bytes(out), dict(pos=pos, nrm=nrm, uv=uv, joints=exp_j, weights=exp_w, bpos=bpos, parents=parents, morphs=morphs, idx=idx)
+
+
+@pytest.mark.parametrize("bone_index_size,vertex_index_size", [(1, 1), (2, 2), (4, 4)])
+def test_pmx_parser_on_synthetic_file(tmp_path, bone_index_size, vertex_index_size):
+    data, exp = write_pmx(bone_index_size, vertex_index_size)
+    f = tmp_path / "t.pmx"
+    f.write_bytes(data)
+    node("parse", str(f), str(tmp_path))
+    info = json.load(open(tmp_path / "info.json"))
+    v = np.fromfile(str(tmp_path / "vertices.f32"), dtype=np.float32).reshape(-1, 8)
+    assert np.array_equal(v[:, 0:3], exp["pos"]) and np.array_equal(v[:, 3:6], exp["nrm"]) and np.array_equal(v[:, 6:8], exp["uv"])
+    j = np.fromfile(str(tmp_path / "joints.u16"), dtype=np.uint16).reshape(-1, 4)
+    w = np.fromfile(str(tmp_path / "weights.u8"), dtype=np.uint8).reshape(-1, 4)
+    assert (w.astype(int).sum(axis=1) == 255).all()
+    assert np.array_equal(w, exp["weights"]), (w, exp["weights"])
+    assert np.array_equal(j, exp["joints"])
+    assert np.fromfile(str(tmp_path / "indices.u32"), dtype=np.uint32).tolist() == exp["idx"]
+    assert info["bones"] == 5 and info["parents"] == exp["parents"] and info["append"] == 1
+    assert info["rigidbodies"] == 1 and info["joints"] == 1 and info["materials"] == 1
+    # bind translations are parent-relative differences of the absolute positions (pmx-loader.ts:416-442)
+    bp = exp["bpos"].astype(np.float64)
+    for b, p in enumerate(exp["parents"]):
+        ref = bp[b] - (bp[p] if p >= 0 else 0)
+        assert np.allclose(info["bind"][b], ref, atol=0)
+    # inverse bind = T(-sum of chain)
+    ib = np.fromfile(str(tmp_path / "invbind.f32"), dtype=np.float32).reshape(-1, 16)
+    assert np.allclose(ib[2, 12:15], -exp["bpos"][2], atol=1e-6) and (ib[:, [0, 5, 10, 15]] == 1).all()
+    # morph section
+    assert info["morphNames"] == [m[0] for m in exp["morphs"]]
+    assert info["morphTypes"] == [m[1] for m in exp["morphs"]]
+    off = np.fromfile(str(tmp_path / "morph_offsets.u32"), dtype=np.uint32)
+    vidx = np.fromfile(str(tmp_path / "morph_vidx.u32"), dtype=np.uint32)
+    dl = np.fromfile(str(tmp_path / "morph_deltas.f32"), dtype=np.float32).reshape(-1, 3)
+    assert off.tolist() == [0, 3, 3, 3, 3, 3, 5]
+    assert vidx.tolist() == [1, 4, 6, 0, 7]
+    assert np.array_equal(dl[:3], exp["morphs"][0][3]) and np.array_equal(dl[3:], exp["morphs"][5][3])
+    assert info["morphGroups"][1] == [[0, 0.5], [5, 2.0]]
+
+
+def test_vmd_parser_bone_and_morph_blocks(tmp_path):
+    def name15(s):
+        b = s.encode("shift-jis")
+        return b + b"\0" * (15 - len(b))
+    out = bytearray(b"Vocaloid Motion Data 0002" + b"\0" * 5) + bytearray(b"model" + b"\0" * 15)
+    frames = [("センター", 30, (0.0, 0.0, 0.0, 1.0)), ("右腕", 0, (0.1, 0.2, 0.3, 0.9)), ("センター", 0, (0.5, 0.5, 0.5, 0.5))]
+    out += struct.pack("<I", len(frames))
+    for n, f, q in frames:
+        out += name15(n) + struct.pack("<I", f) + struct.pack("<3f", 1, 2, 3) + struct.pack("<4f", *q) + bytes(range(64))
+    out += struct.pack("<I", 2) + name15("まばたき") + struct.pack("<If", 15, 0.75) + name15("あ") + struct.pack("<If", 0, 0.25)
+    f = tmp_path / "t.vmd"
+    f.write_bytes(bytes(out))
+    o = tmp_path / "o.json"
+    node("vmd", str(f), str(o))
+    r = json.load(open(o))
+    assert r["keyTimes"] == [[0, 2], [30, 1]]
+    assert [b["name"] for b in r["frames"][0]["bones"]] == ["右腕", "センター"]          # file order within a time
+    assert r["frames"][0]["bones"][0]["pos"] == [1, 2, 3]
+    assert np.allclose(r["frames"][1]["bones"][0]["rot"], [0, 0, 0, 1])
+    assert [(m["morphName"], m["frame"]) for m in r["morphFrames"]] == [("あ", 0), ("まばたき", 15)]
+    assert abs(r["morphFrames"][1]["weight"] - 0.75) < 1e-7
