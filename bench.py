@@ -126,7 +126,7 @@ def main():
 
     V_total = args.verts * (world_size if args.scaling == "weak" else 1)
     B, M, I = args.bones, args.morphs, args.instances
-    b, n = rz.shard_range(V_total, world_size, rank)
+    b, n, _chunk = rz.shard.shard_of(V_total, world_size, rank)
 
     # every rank generates the same full mesh deterministically and keeps its shard
     mesh = synth.make_mesh(V_total, B)
@@ -134,8 +134,7 @@ def main():
         deltas_full, mw = synth.make_morphs_dense(V_total, M)
     else:
         deltas_full, mw = None, None
-    shard = {k: np.ascontiguousarray(mesh[k][b:b + n]) for k in ("pos", "nrm", "joints", "weights")}
-    deltas = None if deltas_full is None else np.ascontiguousarray(deltas_full[:, b:b + n])
+    shard, deltas = rz.shard.cut_mesh(mesh, deltas_full, b, n)
 
     ctx = rz.DeformContext(local_rank)
     ctx.upload_mesh(shard["pos"], shard["nrm"], shard["joints"], shard["weights"])

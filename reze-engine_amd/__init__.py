@@ -8,7 +8,7 @@ Layout (only what the hot path needs):
 The directory name carries a hyphen (it is the name the build contract fixes); the importable
 Python package name is `reze_engine_amd`, provided by the shim module at the repo root.
 """
-from . import capi, synth  # noqa: F401
+from . import capi, shard, synth  # noqa: F401
 from .capi import DeformContext, RzError, device_count, shard_range  # noqa: F401
 
-__all__ = ["capi", "synth", "DeformContext", "RzError", "device_count", "shard_range"]
+__all__ = ["capi", "shard", "synth", "DeformContext", "RzError", "device_count", "shard_range"]

@@ -1,0 +1,39 @@
+'use strict'
+/* End-to-end through the N-API boundary: Engine (host JS) -> reze_deform.node -> libreze_deform.so -> MI355X.
+ * usage: node engine_e2e.js <model.pmx> <motion.vmd|-> <outdir> <morphLayout>
+ * Dumps, for three deterministic clock steps, the exact inputs the GPU consumed (world matrices, effective morph
+ * weights) and the deformed output it produced; pytest recomputes the frame with the CPU oracle from those inputs. */
+const fs = require('fs'), path = require('path')
+const { Engine, Quat } = require(path.join(__dirname, '..', '..', 'reze-engine_amd', 'host'))
+const [pmx, vmd, out, layout] = process.argv.slice(2)
+const dump = (name, ta) => fs.writeFileSync(path.join(out, name), Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength))
+;(async () => {
+  const quiet = console.warn; console.warn = () => {}
+  const engine = new Engine(null, { realtime: false, morphLayout: layout || 'sparse', ambient: 0.8 })
+  await engine.init()
+  await engine.loadModel(pmx)
+  const model = engine.currentModel
+  dump('vertices.f32', model.getVertices()); dump('joints.u16', model.getSkinning().joints)
+  dump('weights.u8', model.getSkinning().weights); dump('invbind.f32', model.getSkeleton().inverseBindMatrices)
+  const mo = model.getMorphs()
+  dump('morph_offsets.u32', mo.offsets); dump('morph_vidx.u32', mo.vertexIndex); dump('morph_deltas.f32', mo.deltas)
+  if (vmd !== '-') { await engine.loadAnimation(vmd); engine.playAnimation() }
+  const names = model.getBoneNames()
+  const steps = [0, 250, 1000]
+  for (let s = 0; s < steps.length; s++) {
+    if (s === 1) {
+      engine.rotateBones([names[1], names[2]], [new Quat(0.2, 0.1, -0.1, 0.96), new Quat(-0.3, 0.0, 0.2, 0.93)], 500)
+      engine.setMorphWeights(['grp', 'blink'], [0.6, 0.3])      // a group morph fans out onto its vertex morphs
+    }
+    engine.step(steps[s])
+    const d = engine.getDeformed()
+    dump('world_' + s + '.f32', model.getBoneWorldMatrices())
+    dump('mw_' + s + '.f32', model.getEffectiveMorphWeights())
+    dump('pos_' + s + '.f32', d.positions); dump('nrm_' + s + '.f32', d.normals)
+  }
+  const t = engine.measure(20)
+  const st = engine.getStats()
+  fs.writeFileSync(path.join(out, 'stats.json'), JSON.stringify({ t, st, names: mo.names }))
+  engine.dispose()
+  console.warn = quiet
+})().catch((e) => { console.error(e); process.exit(1) })

@@ -1,0 +1,48 @@
+'use strict'
+/* CPU test of the Engine's animation scheduler with a recording stand-in for the native addon (no GPU):
+ * checks the reference's playAnimation semantics (engine.ts:1425-1553) on a deterministic clock. */
+const path = require('path')
+const { Engine, Model, Quat } = require(path.join(__dirname, '..', '..', 'reze-engine_amd', 'host'))
+const calls = []
+const native = {
+  create: () => ({}), destroy: () => {}, uploadMesh: () => calls.push('uploadMesh'), uploadSkeleton: () => calls.push('uploadSkeleton'),
+  uploadMorphsSparse: () => calls.push('uploadMorphsSparse'), uploadMorphsDense: () => calls.push('uploadMorphsDense'),
+  setPose: (c, w, mw) => calls.push(['setPose', Array.from(w.slice(0, 16)), mw ? Array.from(mw) : null]), deform: () => calls.push('deform'),
+  read: () => {},
+}
+const bones = ['root', 'a', 'b'].map((name, i) => ({ name, parentIndex: i - 1, bindTranslation: [0, 1, 0], children: [] }))
+const morphs = { names: ['m0', 'g'], types: Uint8Array.from([1, 0]), panels: new Uint8Array(2), groups: [null, [[0, 0.5]]],
+  offsets: Uint32Array.from([0, 1, 1]), vertexIndex: Uint32Array.from([0]), deltas: Float32Array.from([1, 0, 0]) }
+const model = new Model(new Float32Array(8), new Uint32Array(3), [], [], { bones, inverseBindMatrices: new Float32Array(48) },
+  { joints: new Uint16Array(4), weights: Uint8Array.from([255, 0, 0, 0]) }, [], [], morphs)
+const q = (x, y, z, w) => new Quat(x, y, z, w)
+;(async () => {
+  const e = new Engine(null, { realtime: false })
+  e.native = native; e.ctx = {}
+  await e.setupModelBuffers(model)
+  const frames = [
+    { time: 0, boneFrames: [{ boneName: 'a', frame: 0, rotation: q(0, 0, 0.7071068, 0.7071068) }] },
+    { time: 1, boneFrames: [{ boneName: 'a', frame: 30, rotation: q(0, 0, 0, 1) }, { boneName: 'b', frame: 30, rotation: q(0.7071068, 0, 0, 0.7071068) }] },
+    { time: 2, boneFrames: [{ boneName: 'a', frame: 60, rotation: q(0, 0.7071068, 0, 0.7071068) }] },
+  ]
+  frames.morphFrames = [{ morphName: 'g', frame: 0, time: 0, weight: 1.0 }, { morphName: 'm0', frame: 30, time: 1, weight: 0.25 }]
+  e.animationFrames = frames
+  e.rotateBones(['b'], [q(0.5, 0.5, 0.5, 0.5)], 0)            // must be reset to identity by playAnimation (no time-0 key)
+  e.playAnimation()
+  const rot = model.runtimeSkeleton.localRotations
+  const out = {}
+  out.afterPlay = { a: Array.from(rot.slice(4, 8)), b: Array.from(rot.slice(8, 12)), timers: e.timers.length,
+    tweenA: model.rotTweenState.active[1], tweenB: model.rotTweenState.active[2] }
+  e.step(0); out.mw0 = Array.from(model.getEffectiveMorphWeights())
+  e.step(500); out.half = { a: Array.from(rot.slice(4, 8)), b: Array.from(rot.slice(8, 12)) }
+  e.step(1000); out.one = { a: Array.from(rot.slice(4, 8)), b: Array.from(rot.slice(8, 12)), timers: e.timers.length }
+  out.mw1 = Array.from(model.getEffectiveMorphWeights())
+  e.step(2000); out.two = { a: Array.from(rot.slice(4, 8)) }
+  e.stopAnimation(); out.afterStop = e.timers.length
+  out.calls = calls.filter((c) => typeof c === 'string')
+  out.lastPose = calls.filter((c) => Array.isArray(c)).pop()
+  let threw = false
+  try { new Engine(null).step(0) } catch (err) { threw = true }
+  out.realtimeStepThrows = threw
+  console.log(JSON.stringify(out))
+})().catch((err) => { console.error(err); process.exit(1) })

@@ -271,3 +271,49 @@ def test_error_paths(ctx, rz):
     with pytest.raises(rz.RzError):
         c._L.rz_read and c.read(v0=90, n=20)          # out of range
     c.close()
+
+
+def test_engine_through_napi_matches_oracle(tmp_path, oracle):
+    """The drop-in path end to end: host JS Engine (loadModel / loadAnimation / playAnimation / rotateBones /
+    setMorphWeights / step) -> reze_deform.node -> C ABI -> MI355X, against the oracle fed with the SAME
+    world matrices and effective morph weights the host produced. Sparse and dense morph layouts."""
+    import json
+    import shutil
+    import subprocess
+    import os
+    from pmx_synth import write_pmx, write_vmd
+    if shutil.which("node") is None:
+        pytest.skip("node is not installed on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "m.pmx").write_bytes(write_pmx())
+    s = 0.38268343
+    (tmp_path / "a.vmd").write_bytes(write_vmd(
+        [("bone1", 0, (0, 0, s, 0.92387953)), ("bone3", 0, (s, 0, 0, 0.92387953)), ("bone1", 15, (0, s, 0, 0.92387953)),
+         ("bone20", 30, (0, 0, -s, 0.92387953))], [("v1", 0, 0.8), ("v2", 6, 0.4)]))
+    for layout in ("sparse", "dense"):
+        out = tmp_path / layout
+        out.mkdir()
+        subprocess.check_call(["node", os.path.join(root, "tests", "js", "engine_e2e.js"), str(tmp_path / "m.pmx"),
+                               str(tmp_path / "a.vmd"), str(out), layout], timeout=300)
+        rd = lambda f, dt: np.fromfile(str(out / f), dtype=dt)  # noqa: E731
+        v = rd("vertices.f32", np.float32).reshape(-1, 8)
+        joints = rd("joints.u16", np.uint16).reshape(-1, 4)
+        weights = rd("weights.u8", np.uint8).reshape(-1, 4)
+        ib = rd("invbind.f32", np.float32).reshape(-1, 16)
+        off, vidx = rd("morph_offsets.u32", np.uint32), rd("morph_vidx.u32", np.uint32)
+        d3 = rd("morph_deltas.f32", np.float32).reshape(-1, 3)
+        seen_morph = False
+        for step in range(3):
+            world = rd("world_%d.f32" % step, np.float32).reshape(-1, 16)
+            mw = rd("mw_%d.f32" % step, np.float32)
+            pm = oracle.morph_sparse(len(v), off, vidx, d3, mw, v[:, 0:3])
+            S = oracle.palette(world, ib)
+            pr, nr = oracle.skin(pm, v[:, 3:6], joints, weights, S)
+            pg = rd("pos_%d.f32" % step, np.float32).reshape(-1, 3)
+            ng = rd("nrm_%d.f32" % step, np.float32).reshape(-1, 3)
+            assert_parity(pg, ng, pr, nr, "napi %s step %d" % (layout, step))
+            seen_morph = seen_morph or (mw != 0).sum() >= 3
+            assert not np.allclose(pg, v[:, 0:3])            # the pose really moved the mesh
+        assert seen_morph
+        st = json.load(open(out / "stats.json"))
+        assert st["t"]["frameMs"] > 0 and st["st"]["vertsPerSec"] > 0

@@ -289,3 +289,38 @@ def test_vmd_parser_bone_and_morph_blocks(tmp_path):
     assert np.allclose(r["frames"][1]["bones"][0]["rot"], [0, 0, 0, 1])
     assert [(m["morphName"], m["frame"]) for m in r["morphFrames"]] == [("あ", 0), ("まばたき", 15)]
     assert abs(r["morphFrames"][1]["weight"] - 0.75) < 1e-7
+
+
+def test_engine_animation_scheduler_on_a_manual_clock():
+    """playAnimation semantics of engine.ts:1425-1553 (time-0 keys instant, un-keyed bones reset, later keys as
+    eased tweens from the previous key) + morph keys, driven by step(timeMs) with a recording native stand-in."""
+    out = subprocess.check_output(["node", os.path.join(ROOT, "tests", "js", "engine_mock.js")], timeout=60)
+    r = json.loads(out.decode().strip().splitlines()[-1])
+    s = 0.7071067690849304
+    assert np.allclose(r["afterPlay"]["a"], [0, 0, s, s]) and r["afterPlay"]["b"] == [0, 0, 0, 1]
+    assert r["afterPlay"]["tweenA"] == 1 and r["afterPlay"]["tweenB"] == 1 and r["afterPlay"]["timers"] == 2
+    # easeInOut(0.5) = 0.5 -> half-way slerp of a 90 degree turn = 45 degrees
+    assert np.allclose(r["half"]["a"], [0, 0, np.sin(np.pi / 8), np.cos(np.pi / 8)], atol=1e-6)
+    assert np.allclose(r["half"]["b"], [np.sin(np.pi / 8), 0, 0, np.cos(np.pi / 8)], atol=1e-6)
+    assert np.allclose(r["one"]["a"], [0, 0, 0, 1], atol=1e-7) and np.allclose(r["one"]["b"], [s, 0, 0, s], atol=1e-7)
+    assert np.allclose(r["two"]["a"], [0, s, 0, s], atol=1e-7)
+    assert r["mw0"] == [0.5, 0] and r["mw1"] == [0.75, 0]               # group morph 'g' (x0.5) flattened onto 'm0'
+    assert r["one"]["timers"] == 0 and r["afterStop"] == 0
+    assert r["calls"][:3] == ["uploadMesh", "uploadSkeleton", "uploadMorphsSparse"] and r["calls"].count("deform") == 4
+    assert r["lastPose"][0] == "setPose" and len(r["lastPose"][1]) == 16
+    assert r["realtimeStepThrows"] is True
+
+
+def test_addon_exports_and_loud_failure_without_gpu():
+    """The N-API shim binds every data-path entry point of the C ABI and refuses to run without a device."""
+    js = ("const a=require('%s/reze-engine_amd/host/addon.js').requireAddon();"
+          "let msg='';try{a.create(0);msg='created'}catch(e){msg=e.message};"
+          "console.log(JSON.stringify({keys:Object.keys(a).sort(),abi:a.abiVersion(),n:a.deviceCount(),msg,"
+          "shard:a.shardRange(1000000,8,7)}))" % ROOT)
+    r = json.loads(subprocess.check_output(["node", "-e", js], timeout=60).decode().strip().splitlines()[-1])
+    for k in ("create", "destroy", "uploadMesh", "uploadSkeleton", "uploadMorphsDense", "uploadMorphsSparse", "setInstances",
+              "setPose", "deform", "sync", "read", "timeFrames", "commUniqueId", "commInit", "allgather", "shardRange"):
+        assert k in r["keys"], k
+    assert r["abi"] == 1 and r["shard"] == [881664, 118336]
+    if r["n"] == 0:
+        assert "no HIP device" in r["msg"] or "error -3" in r["msg"]

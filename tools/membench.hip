@@ -29,6 +29,15 @@ template <bool NT> __global__ void __launch_bounds__(256) k_fill(f4v *dst, size_
         if (NT) __builtin_nontemporal_store(v, dst + i); else dst[i] = v;
     }
 }
+// 12 bytes per lane, lanes contiguous: the store pattern of rz_deform_kernel's outputs (global_store_dwordx3)
+template <bool NT> __global__ void __launch_bounds__(256) k_fill3(float *dst, size_t nvert, float val)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvert; i += (size_t)gridDim.x * 256) {
+        float *d = dst + i * 3;
+        if (NT) { __builtin_nontemporal_store(val, d); __builtin_nontemporal_store(val, d + 1); __builtin_nontemporal_store(val, d + 2); }
+        else { d[0] = val; d[1] = val; d[2] = val; }
+    }
+}
 template <bool NT> __global__ void __launch_bounds__(256) k_copy(const f4v *__restrict__ src, f4v *dst, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -51,15 +60,22 @@ template <class F> double timeit(F f, int iters)
     }
     return best;
 }
-int main()
+int main(int argc, char **argv)
 {
-    const size_t sizes[] = {184u << 20, 828u << 20, 2048u << 20};
+    const bool quick = argc > 1;   // PMC calibration: one size, one launch geometry
+
+    const size_t sizes_full[] = {184u << 20, 828u << 20, 2048u << 20};
+    const size_t sizes_quick[] = {828u << 20};
+    const size_t *sizes_p = quick ? sizes_quick : sizes_full;
+    const int nsizes = quick ? 1 : 3;
     float *out; CK(hipMalloc(&out, 16));
-    for (size_t bytes : sizes) {
+    for (int si = 0; si < nsizes; ++si) {
+        const size_t bytes = sizes_p[si];
         f4v *a, *b; CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
         CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 0, bytes));
         const size_t n = bytes / 16;
         for (int grid : {1024, 2048, 4096, 8192}) {
+            if (quick && grid != 2048) continue;
             double t;
             t = timeit([&] { k_read<false, 4><<<grid, 256>>>(a, n, out); }, 20);
             printf("{\"op\":\"read\",\"nt\":0,\"U\":4,\"MB\":%zu,\"grid\":%d,\"us\":%.2f,\"GBps\":%.1f}\n", bytes >> 20, grid, t * 1e3, bytes / t / 1e6);
@@ -71,6 +87,10 @@ int main()
             printf("{\"op\":\"fill\",\"nt\":0,\"MB\":%zu,\"grid\":%d,\"us\":%.2f,\"GBps\":%.1f}\n", bytes >> 20, grid, t * 1e3, bytes / t / 1e6);
             t = timeit([&] { k_fill<true><<<grid, 256>>>(b, n, 1.f); }, 20);
             printf("{\"op\":\"fill\",\"nt\":1,\"MB\":%zu,\"grid\":%d,\"us\":%.2f,\"GBps\":%.1f}\n", bytes >> 20, grid, t * 1e3, bytes / t / 1e6);
+            t = timeit([&] { k_fill3<false><<<grid, 256>>>((float *)b, bytes / 12, 1.f); }, 20);
+            printf("{\"op\":\"fill3\",\"nt\":0,\"MB\":%zu,\"grid\":%d,\"us\":%.2f,\"GBps\":%.1f}\n", bytes >> 20, grid, t * 1e3, (bytes / 12 * 12) / t / 1e6);
+            t = timeit([&] { k_fill3<true><<<grid, 256>>>((float *)b, bytes / 12, 1.f); }, 20);
+            printf("{\"op\":\"fill3\",\"nt\":1,\"MB\":%zu,\"grid\":%d,\"us\":%.2f,\"GBps\":%.1f}\n", bytes >> 20, grid, t * 1e3, (bytes / 12 * 12) / t / 1e6);
             t = timeit([&] { k_copy<false><<<grid, 256>>>(a, b, n); }, 20);
             printf("{\"op\":\"copy\",\"nt\":0,\"MB\":%zu,\"grid\":%d,\"us\":%.2f,\"GBps\":%.1f}\n", bytes >> 20, grid, t * 1e3, 2.0 * bytes / t / 1e6);
             t = timeit([&] { k_copy<true><<<grid, 256>>>(a, b, n); }, 20);
