@@ -268,7 +268,8 @@ Plan make_plan(const rz_ctx *c)
     pl.prep = !v.fast;
     // persistent, balanced grid: `cap` workgroups in total, every wave owns an equal contiguous run of quads
     const uint32_t waves_per_wg = 4, qpw_step = 64 / (uint32_t)v.S;
-    uint32_t cap = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : 2u * (uint32_t)c->n_cu;
+    // measured (profiles/r1_*sweep*): 2 workgroups per CU for one big mesh, 8 per instance when instanced
+    uint32_t cap = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : std::max(2u * (uint32_t)c->n_cu, 8u * c->I);
     uint32_t gx = std::max<uint32_t>(1, cap / std::max<uint32_t>(1, c->I));
     const uint32_t max_useful = (pl.n_quads + waves_per_wg * qpw_step - 1) / (waves_per_wg * qpw_step);
     gx = std::max<uint32_t>(1, std::min(gx, max_useful));
