@@ -72,6 +72,9 @@ hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t
 hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, const RzVariant &v, uint32_t grid_x,
                             uint32_t instances, hipStream_t st);
 size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v);
+// instanced skin (no morphs): G poses per workgroup share one decode of each vertex
+hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
+                                    bool nts, hipStream_t st);
 uint32_t rz_quads_per_tile(int S);
 hipError_t rz_launch_deinterleave(const float *src, int stride, int offset, uint32_t n, float *px, float *py,
                                   float *pz, hipStream_t st);

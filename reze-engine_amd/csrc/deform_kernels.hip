@@ -447,6 +447,100 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
 }
 
 // ------------------------------------------------------------------------------------------------
+// instanced skin (MODE 0, I > 1 — BASELINE config C4: many poses of one static mesh).
+// A workgroup owns a run of vertices and a GROUP of G instances whose palettes it stages together in
+// LDS (LDS-DMA from the prep kernel's palette). Each lane decodes a vertex ONCE — rest position/normal,
+// the four joints as palette row offsets, the four weights as floats — and then loops over the G poses:
+// 12 ds_read_b128 + blend + transform + 24 B store per pose. The static mesh is read I/G times instead
+// of I times, and the per-pose body has no global load in front of it (the generic kernel was latency-
+// bound here: 43 % of wave time in s_waitcnt, VALU 30 %, LDS 31 % — profiles/r1_sq_counters.txt).
+// grid = (vertex runs, instance groups); block = 256; dynamic LDS = G * B * 48 bytes.
+// ------------------------------------------------------------------------------------------------
+template <bool NTS>
+__global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDeformParams p, int G, int n_inst,
+                                                                   uint32_t verts_per_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *pal = reinterpret_cast<float4 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int inst0 = blockIdx.y * G;
+    const int ng = min(G, n_inst - inst0);
+    const int rows = p.B * 3;                       // float4 per palette
+    {   // the group's palettes are contiguous in global memory: one linear LDS-DMA copy
+        const float4 *src = p.palette + (size_t)inst0 * rows;
+        const int n = ng * rows;
+        for (int c = wave * 64; c < n; c += kBlock) {
+            const int e = c + lane;
+            if (e < n) {
+                typedef const __attribute__((address_space(1))) void *gptr_t;
+                typedef __attribute__((address_space(3))) void *lptr_t;
+                __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(src + e), (lptr_t)(uint32_t)(uintptr_t)(pal + c), 16, 0, 0);
+            }
+        }
+    }
+    const size_t Vp = p.Vp;
+    const uint32_t v_begin = blockIdx.x * verts_per_wg;
+    const uint32_t v_end = min(p.n_quads * 4u, v_begin + verts_per_wg);
+    const uint32_t bmax = (uint32_t)(p.B - 1);
+    bool staged = false;
+    for (uint32_t v = v_begin + tid; v < v_end || !staged; v += kBlock) {
+        const bool live = v < v_end;
+        float x = 0, y = 0, z = 0, nx = 0, ny = 0, nz = 0;
+        uint32_t j01 = 0, j23 = 0, wq = 0;
+        if (live) {
+            x = p.geom[0 * Vp + v]; y = p.geom[1 * Vp + v]; z = p.geom[2 * Vp + v];
+            nx = p.geom[3 * Vp + v]; ny = p.geom[4 * Vp + v]; nz = p.geom[5 * Vp + v];
+            j01 = p.joints01[v]; j23 = p.joints23[v]; wq = p.weights[v];
+        }
+        if (!staged) {   // first trip (taken by every thread of the workgroup): palettes have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            staged = true;
+        }
+        if (!live) continue;
+        // decode once per vertex (engine.ts:255-258)
+        const uint32_t b0 = wq & 255u, b1 = (wq >> 8) & 255u, b2 = (wq >> 16) & 255u, b3 = wq >> 24;
+        const uint32_t isum = b0 + b1 + b2 + b3;
+        const bool ok = isum != 0u;
+        const float inv = __builtin_amdgcn_rcpf((float)(ok ? isum : 1u));
+        const float w0 = ok ? (float)b0 * inv : 1.0f, w1 = (float)b1 * inv, w2 = (float)b2 * inv, w3 = (float)b3 * inv;
+        const uint32_t o0 = min(j01 & 0xffffu, bmax) * 3u, o1 = min(j01 >> 16, bmax) * 3u,
+                       o2 = min(j23 & 0xffffu, bmax) * 3u, o3 = min(j23 >> 16, bmax) * 3u;
+        float *dp = p.out_pos + ((size_t)inst0 * Vp + v) * 3;
+        float *dn = p.out_nrm + ((size_t)inst0 * Vp + v) * 3;
+        const float4 *pg = pal;
+#pragma unroll 2
+        for (int g = 0; g < ng; ++g) {
+            const float4 a0 = pg[o0], a1 = pg[o0 + 1], a2 = pg[o0 + 2];
+            const float4 c0 = pg[o1], c1 = pg[o1 + 1], c2 = pg[o1 + 2];
+            const float4 d0 = pg[o2], d1 = pg[o2 + 1], d2 = pg[o2 + 2];
+            const float4 e0 = pg[o3], e1 = pg[o3 + 1], e2 = pg[o3 + 2];
+            float4 m0, m1, m2;
+            m0.x = fmaf(w3, e0.x, fmaf(w2, d0.x, fmaf(w1, c0.x, w0 * a0.x))); m0.y = fmaf(w3, e0.y, fmaf(w2, d0.y, fmaf(w1, c0.y, w0 * a0.y)));
+            m0.z = fmaf(w3, e0.z, fmaf(w2, d0.z, fmaf(w1, c0.z, w0 * a0.z))); m0.w = fmaf(w3, e0.w, fmaf(w2, d0.w, fmaf(w1, c0.w, w0 * a0.w)));
+            m1.x = fmaf(w3, e1.x, fmaf(w2, d1.x, fmaf(w1, c1.x, w0 * a1.x))); m1.y = fmaf(w3, e1.y, fmaf(w2, d1.y, fmaf(w1, c1.y, w0 * a1.y)));
+            m1.z = fmaf(w3, e1.z, fmaf(w2, d1.z, fmaf(w1, c1.z, w0 * a1.z))); m1.w = fmaf(w3, e1.w, fmaf(w2, d1.w, fmaf(w1, c1.w, w0 * a1.w)));
+            m2.x = fmaf(w3, e2.x, fmaf(w2, d2.x, fmaf(w1, c2.x, w0 * a2.x))); m2.y = fmaf(w3, e2.y, fmaf(w2, d2.y, fmaf(w1, c2.y, w0 * a2.y)));
+            m2.z = fmaf(w3, e2.z, fmaf(w2, d2.z, fmaf(w1, c2.z, w0 * a2.z))); m2.w = fmaf(w3, e2.w, fmaf(w2, d2.w, fmaf(w1, c2.w, w0 * a2.w)));
+            const float px = fmaf(m0.z, z, fmaf(m0.y, y, fmaf(m0.x, x, m0.w)));
+            const float py = fmaf(m1.z, z, fmaf(m1.y, y, fmaf(m1.x, x, m1.w)));
+            const float pz = fmaf(m2.z, z, fmaf(m2.y, y, fmaf(m2.x, x, m2.w)));
+            const float tx = fmaf(m0.z, nz, fmaf(m0.y, ny, m0.x * nx));
+            const float ty = fmaf(m1.z, nz, fmaf(m1.y, ny, m1.x * nx));
+            const float tz = fmaf(m2.z, nz, fmaf(m2.y, ny, m2.x * nx));
+            const float l2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+            const bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
+            const float rl = __builtin_amdgcn_rsqf(good ? l2 : 1.0f);
+            st3<NTS>(dp, px, py, pz);
+            st3<NTS>(dn, good ? tx * rl : nx, good ? ty * rl : ny, good ? tz * rl : nz);
+            pg += rows;
+            dp += Vp * 3;
+            dn += Vp * 3;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // upload-time re-layout kernels (one-off, not on the per-frame path)
 // ------------------------------------------------------------------------------------------------
 // packed [n][stride] floats -> planes; `stride` = 3 (packed xyz) or 8 (reference interleaved vertex)
@@ -547,6 +641,20 @@ hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, cons
     case 8: return launch_dense<8>(p, ml, v, grid, lds, st);
     default: return launch_dense<1>(p, ml, v, grid, lds, st);
     }
+}
+
+hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
+                                    bool nts, hipStream_t st)
+{
+    const size_t lds = (size_t)G * p.B * 48;
+    auto k = nts ? rz_skin_instances_kernel<true> : rz_skin_instances_kernel<false>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid(grid_x, (n_inst + G - 1) / G);
+    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p, G, n_inst, verts_per_wg);
+    return hipGetLastError();
 }
 
 hipError_t rz_launch_deinterleave(const float *src, int stride, int offset, uint32_t n, float *px, float *py,

@@ -137,7 +137,7 @@ struct rz_ctx {
     RzMorphList ml;
 
     // tuning (0 / -1 = automatic)
-    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1;
+    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1;
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -222,7 +222,7 @@ int auto_split(const rz_ctx *c)
     return S;
 }
 
-struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; };
+struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; };
 
 RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
 {
@@ -253,6 +253,8 @@ Plan make_plan(const rz_ctx *c)
     const bool can_fast = c->I == 1 && (v.mode != 1 || c->ml.count >= 0);
     v.fast = can_fast && c->t_fast != 0;
     pl.dma = false;
+    pl.inst_group = 0;
+    pl.verts_per_wg = 0;
     pl.n_quads = (c->V + 3) / 4;
     pl.quads_per_wave = 8;
     pl.grid_x = 1;
@@ -277,6 +279,21 @@ Plan make_plan(const rz_ctx *c)
     per_wave = std::max<uint32_t>(8, round_up(per_wave, 8));
     pl.quads_per_wave = per_wave;
     pl.grid_x = std::max<uint32_t>(1, (pl.n_quads + per_wave * waves_per_wg - 1) / (per_wave * waves_per_wg));
+    // instanced, morph-free frames: G poses per workgroup (palettes together <= 76.8 KB so two workgroups fit a CU)
+    if (v.mode == 0 && c->I > 1 && c->t_instloop != 0) {
+        int G = (int)std::min<uint32_t>(8, (80u * 1024u) / (c->B * 48u));
+        if (c->t_instloop > 0) G = std::min(G, c->t_instloop);
+        if (G >= 2) {
+            G = (int)std::min<uint32_t>((uint32_t)G, c->I);
+            const uint32_t groups = (c->I + G - 1) / G;
+            uint32_t total = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : 2u * (uint32_t)c->n_cu;
+            uint32_t gxi = std::max<uint32_t>(1, total / groups);
+            uint32_t per = round_up((c->V + gxi - 1) / gxi, 256);
+            pl.inst_group = G;
+            pl.verts_per_wg = per;
+            pl.grid_x = (c->V + per - 1) / per;
+        }
+    }
     return pl;
 }
 
@@ -307,6 +324,10 @@ int launch_prep(rz_ctx *c)
 int launch_deform(rz_ctx *c, const Plan &pl)
 {
     RzDeformParams p = deform_params(c, pl);
+    if (pl.inst_group > 0) {
+        HIP_TRY(rz_launch_skin_instances(p, pl.inst_group, (int)c->I, pl.verts_per_wg, pl.grid_x, pl.v.nts, c->stream));
+        return RZ_OK;
+    }
     size_t lds = rz_deform_lds_bytes(p, pl.v);
     if (lds > 160 * 1024) return fail(RZ_ERR_UNSUPPORTED, "skeleton too large for the LDS palette (%zu B)", lds);
     HIP_TRY(rz_launch_deform(p, c->ml, pl.v, pl.grid_x, c->I, c->stream));
@@ -746,6 +767,9 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
         c->t_geo = value ? 1 : 0;
     } else if (!strcmp(key, "nt_store")) {
         c->t_nts = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (!strcmp(key, "inst_loop")) {
+        if (value < -1 || value > 8) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off) or 2..8 poses per workgroup");
+        c->t_instloop = value;
     } else if (!strcmp(key, "fast")) {
         c->t_fast = value;        // -1 auto, 0 never (always prep kernel), 1 when possible
     } else {
@@ -771,6 +795,8 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "effective_split")) *value = make_plan(c).v.S;
     else if (!strcmp(key, "effective_unroll")) *value = make_plan(c).v.U;
     else if (!strcmp(key, "effective_fast")) *value = make_plan(c).v.fast ? 1 : 0;
+    else if (!strcmp(key, "inst_loop")) *value = c->t_instloop;
+    else if (!strcmp(key, "effective_inst_group")) *value = make_plan(c).inst_group;
     else if (!strcmp(key, "effective_grid")) *value = (int)make_plan(c).grid_x;
     else return fail(RZ_ERR_INVALID, "unknown tuning key '%s'", key);
     return RZ_OK;

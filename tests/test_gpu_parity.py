@@ -195,6 +195,30 @@ def test_c4_instances_each_match_their_own_pose(ctx, oracle):
     ctx.set_instances(1)
 
 
+@pytest.mark.parametrize("inst_loop", [-1, 0, 3])
+def test_c4_instance_loop_kernel_and_ragged_groups(ctx, oracle, inst_loop):
+    """19 poses do not divide into groups of 8: the pose-loop kernel (inst_loop != 0) and the generic kernel
+    (inst_loop = 0) must both match every pose; 471 bones forces a smaller group (LDS)."""
+    for V, B, I in ((7001, 64, 19), (3000, 471, 5)):
+        mesh = synth.make_mesh(V, B, seed=V)
+        worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=300 + i) for i in range(I)])
+        ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+        ctx.upload_skeleton(mesh["inv_bind"])
+        ctx.upload_morphs_dense(None)
+        ctx.set_instances(I)
+        ctx.set_tuning(inst_loop=inst_loop, grid_cap=0, nt_store=-1)
+        ctx.set_pose(worlds)
+        ctx.deform()
+        g = ctx.get_tuning("effective_inst_group")
+        assert (g == 0) if inst_loop == 0 else (2 <= g <= 8)
+        for i in range(I):
+            pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[i], mesh["inv_bind"])
+            pg, ng = ctx.read(instance=i)
+            assert_parity(pg, ng, pr, nr, "V=%d B=%d instance %d loop=%d" % (V, B, i, inst_loop))
+    ctx.set_tuning(inst_loop=-1)
+    ctx.set_instances(1)
+
+
 def test_instanced_morph_weights_are_per_instance(ctx, oracle):
     V, B, M, I = 5000, 40, 8, 3
     mesh = synth.make_mesh(V, B, seed=31)

@@ -6,7 +6,7 @@ top = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 rows = json.load(open(path))
 by = collections.OrderedDict()
 for r in rows: by.setdefault(r['config'], []).append(r)
-keep = ('morph_split','unroll','nontemporal','nt_store','geo_lds','grid_cap','fast','kernel_ms','frame_ms','gbps','S','U','F','grid')
+keep = ('inst_loop','morph_split','unroll','nontemporal','nt_store','geo_lds','grid_cap','fast','kernel_ms','frame_ms','gbps','S','U','F','grid')
 fmt = lambda r: ' '.join('%s=%s' % (k[:6], ('%.4f' % r[k] if isinstance(r[k], float) else r[k])) for k in keep if k in r)
 for k, v in by.items():
     print('==', k)

@@ -77,7 +77,7 @@ def main():
     ctx = rz.DeformContext(0)
     out = []
     t0 = time.time()
-    base = dict(morph_split=[0], unroll=[0], nontemporal=[1], nt_store=[1], geo_lds=[1], grid_cap=[0], fast=[-1])
+    base = dict(morph_split=[0], unroll=[0], nontemporal=[1], nt_store=[-1], geo_lds=[0], grid_cap=[0], fast=[-1], inst_loop=[-1])
 
     def g(**kw):
         d = dict(base)
@@ -97,7 +97,8 @@ def main():
                 out += run(ctx, "C5 shard 1/8 variants", 200, g(morph_split=[2, 4], unroll=[4], grid_cap=[256, 512], geo_lds=[0, 1], fast=[0, 1]))
     if "c4" in which:
         setup(ctx, 30000, 200, 0, I=256)
-        out += run(ctx, "C4 256x30k", 50, g(nt_store=[0, 1], geo_lds=[1, 0], grid_cap=[256, 512, 1024, 2048, 4096, 8192]))
+        out += run(ctx, "C4 256x30k pose-loop", 100, g(nt_store=[0, 1], inst_loop=[2, 4, 8], grid_cap=[256, 512, 768, 1024, 2048]))
+        out += run(ctx, "C4 256x30k generic", 100, g(nt_store=[1], inst_loop=[0], grid_cap=[1024, 2048, 4096]))
     if "c3" in which:
         setup(ctx, 30000, 200, 64)
         out += run(ctx, "C3 30k/200/64", 300, g(morph_split=[1, 2, 4, 8], unroll=[4, 8], fast=[1, 0], grid_cap=[256, 512]))
