@@ -482,22 +482,27 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
     const uint32_t v_begin = blockIdx.x * verts_per_wg;
     const uint32_t v_end = min(p.n_quads * 4u, v_begin + verts_per_wg);
     const uint32_t bmax = (uint32_t)(p.B - 1);
-    bool staged = false;
-    for (uint32_t v = v_begin + tid; v < v_end || !staged; v += kBlock) {
-        const bool live = v < v_end;
-        float x = 0, y = 0, z = 0, nx = 0, ny = 0, nz = 0;
-        uint32_t j01 = 0, j23 = 0, wq = 0;
-        if (live) {
-            x = p.geom[0 * Vp + v]; y = p.geom[1 * Vp + v]; z = p.geom[2 * Vp + v];
-            nx = p.geom[3 * Vp + v]; ny = p.geom[4 * Vp + v]; nz = p.geom[5 * Vp + v];
-            j01 = p.joints01[v]; j23 = p.joints23[v]; wq = p.weights[v];
+    // software-pipelined vertex loop: the next vertex's nine attribute loads are issued before the current
+    // vertex's pose loop, so their L2 latency hides behind 8 poses of LDS gathers + FMA
+    uint32_t v = v_begin + tid;
+    float x = 0, y = 0, z = 0, nx = 0, ny = 0, nz = 0;
+    uint32_t j01 = 0, j23 = 0, wq = 0;
+    if (v < v_end) {
+        x = p.geom[0 * Vp + v]; y = p.geom[1 * Vp + v]; z = p.geom[2 * Vp + v];
+        nx = p.geom[3 * Vp + v]; ny = p.geom[4 * Vp + v]; nz = p.geom[5 * Vp + v];
+        j01 = p.joints01[v]; j23 = p.joints23[v]; wq = p.weights[v];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // palettes (and the first vertex) have landed
+    __syncthreads();
+    for (; v < v_end; v += kBlock) {
+        const uint32_t vn = v + kBlock;
+        float xn = 0, yn = 0, zn = 0, nxn = 0, nyn = 0, nzn = 0;
+        uint32_t j01n = 0, j23n = 0, wqn = 0;
+        if (vn < v_end) {
+            xn = p.geom[0 * Vp + vn]; yn = p.geom[1 * Vp + vn]; zn = p.geom[2 * Vp + vn];
+            nxn = p.geom[3 * Vp + vn]; nyn = p.geom[4 * Vp + vn]; nzn = p.geom[5 * Vp + vn];
+            j01n = p.joints01[vn]; j23n = p.joints23[vn]; wqn = p.weights[vn];
         }
-        if (!staged) {   // first trip (taken by every thread of the workgroup): palettes have landed
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            staged = true;
-        }
-        if (!live) continue;
         // decode once per vertex (engine.ts:255-258)
         const uint32_t b0 = wq & 255u, b1 = (wq >> 8) & 255u, b2 = (wq >> 16) & 255u, b3 = wq >> 24;
         const uint32_t isum = b0 + b1 + b2 + b3;
@@ -537,6 +542,7 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
             dp += Vp * 3;
             dn += Vp * 3;
         }
+        x = xn; y = yn; z = zn; nx = nxn; ny = nyn; nz = nzn; j01 = j01n; j23 = j23n; wq = wqn;
     }
 }
 

@@ -247,7 +247,9 @@ Plan make_plan(const rz_ctx *c)
     v.U = c->t_unroll > 0 ? c->t_unroll : (v.S <= 2 ? 8 : 4);
     v.nt = c->t_nt != 0;
     // streaming stores pay once the frame's output no longer fits the L2s (measured: 1 M verts yes, 126 k no)
-    v.nts = c->t_nts < 0 ? ((uint64_t)c->V * c->I * 24 >= (16u << 20)) : c->t_nts != 0;
+    // and the morph stream is flowing too; a morph-free instanced frame (184 MB of output, MALL-absorbed) is faster
+    // with plain stores: 6.9 vs 5.7 TB/s in tools/membench
+    v.nts = c->t_nts < 0 ? (v.mode == 1 && (uint64_t)c->V * c->I * 24 >= (16u << 20)) : c->t_nts != 0;
     v.geo = c->t_geo != 0;
     // one-launch frame: single instance, and (dense) the active list fits the kernel arguments
     const bool can_fast = c->I == 1 && (v.mode != 1 || c->ml.count >= 0);
@@ -288,7 +290,7 @@ Plan make_plan(const rz_ctx *c)
             const uint32_t groups = (c->I + G - 1) / G;
             uint32_t total = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : 2u * (uint32_t)c->n_cu;
             uint32_t gxi = std::max<uint32_t>(1, total / groups);
-            uint32_t per = round_up((c->V + gxi - 1) / gxi, 256);
+            uint32_t per = round_up((c->V + gxi - 1) / gxi, 64);
             pl.inst_group = G;
             pl.verts_per_wg = per;
             pl.grid_x = (c->V + per - 1) / per;
