@@ -466,7 +466,8 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
     const int inst0 = blockIdx.y * G;
     const int ng = min(G, n_inst - inst0);
     const int rows = p.B * 3;                       // float4 per palette
-    {   // the group's palettes are contiguous in global memory: one linear LDS-DMA copy
+    if (p.dma) {
+        // prep-kernel path: the group's palettes are contiguous in global memory -> one linear LDS-DMA copy
         const float4 *src = p.palette + (size_t)inst0 * rows;
         const int n = ng * rows;
         for (int c = wave * 64; c < n; c += kBlock) {
@@ -475,6 +476,32 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
                 typedef const __attribute__((address_space(1))) void *gptr_t;
                 typedef __attribute__((address_space(3))) void *lptr_t;
                 __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(src + e), (lptr_t)(uint32_t)(uintptr_t)(pal + c), 16, 0, 0);
+            }
+        }
+    } else {
+        // one-launch frame: every workgroup forms its G palettes itself (rows 0..2 of world * inverseBind,
+        // engine.ts:926-928) — redundant across the vertex runs of a group but far cheaper than a prep launch
+        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind);
+        const float4 *gw = reinterpret_cast<const float4 *>(p.world) + (size_t)inst0 * p.B * 4;
+        const int n = ng * p.B;
+#pragma unroll 2
+        for (int idx = tid; idx < n; idx += kBlock) {
+            const int b = idx % p.B;
+            const float4 a0 = gw[idx * 4 + 0], a1 = gw[idx * 4 + 1], a2 = gw[idx * 4 + 2], a3 = gw[idx * 4 + 3];
+            float r0[4], r1[4], r2[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 bc = gi[b * 4 + c];
+                r0[c] = fmaf(a3.x, bc.w, fmaf(a2.x, bc.z, fmaf(a1.x, bc.y, a0.x * bc.x)));
+                r1[c] = fmaf(a3.y, bc.w, fmaf(a2.y, bc.z, fmaf(a1.y, bc.y, a0.y * bc.x)));
+                r2[c] = fmaf(a3.z, bc.w, fmaf(a2.z, bc.z, fmaf(a1.z, bc.y, a0.z * bc.x)));
+            }
+            const float4 q0 = make_float4(r0[0], r0[1], r0[2], r0[3]), q1 = make_float4(r1[0], r1[1], r1[2], r1[3]),
+                         q2 = make_float4(r2[0], r2[1], r2[2], r2[3]);
+            pal[idx * 3 + 0] = q0; pal[idx * 3 + 1] = q1; pal[idx * 3 + 2] = q2;
+            if (blockIdx.x == 0 && p.palette) {      // keep the skinMatrixBuffer observable (rz_read_palette)
+                float4 *gp = p.palette + ((size_t)inst0 * p.B + idx) * 3;
+                gp[0] = q0; gp[1] = q1; gp[2] = q2;
             }
         }
     }

@@ -293,6 +293,9 @@ Plan make_plan(const rz_ctx *c)
             uint32_t per = round_up((c->V + gxi - 1) / gxi, 64);
             pl.inst_group = G;
             pl.verts_per_wg = per;
+            // palettes formed inside the kernel unless the caller insists on the prep kernel (fast = 0)
+            pl.prep = c->t_fast == 0;
+            pl.dma = pl.prep;
             pl.grid_x = (c->V + per - 1) / per;
         }
     }

@@ -195,8 +195,9 @@ def test_c4_instances_each_match_their_own_pose(ctx, oracle):
     ctx.set_instances(1)
 
 
+@pytest.mark.parametrize("fast", [-1, 0])
 @pytest.mark.parametrize("inst_loop", [-1, 0, 3])
-def test_c4_instance_loop_kernel_and_ragged_groups(ctx, oracle, inst_loop):
+def test_c4_instance_loop_kernel_and_ragged_groups(ctx, oracle, inst_loop, fast):
     """19 poses do not divide into groups of 8: the pose-loop kernel (inst_loop != 0) and the generic kernel
     (inst_loop = 0) must both match every pose; 471 bones forces a smaller group (LDS)."""
     for V, B, I in ((7001, 64, 19), (3000, 471, 5)):
@@ -206,7 +207,7 @@ def test_c4_instance_loop_kernel_and_ragged_groups(ctx, oracle, inst_loop):
         ctx.upload_skeleton(mesh["inv_bind"])
         ctx.upload_morphs_dense(None)
         ctx.set_instances(I)
-        ctx.set_tuning(inst_loop=inst_loop, grid_cap=0, nt_store=-1)
+        ctx.set_tuning(inst_loop=inst_loop, grid_cap=0, nt_store=-1, fast=fast)
         ctx.set_pose(worlds)
         ctx.deform()
         g = ctx.get_tuning("effective_inst_group")
@@ -214,8 +215,11 @@ def test_c4_instance_loop_kernel_and_ragged_groups(ctx, oracle, inst_loop):
         for i in range(I):
             pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[i], mesh["inv_bind"])
             pg, ng = ctx.read(instance=i)
-            assert_parity(pg, ng, pr, nr, "V=%d B=%d instance %d loop=%d" % (V, B, i, inst_loop))
-    ctx.set_tuning(inst_loop=-1)
+            assert_parity(pg, ng, pr, nr, "V=%d B=%d instance %d loop=%d fast=%d" % (V, B, i, inst_loop, fast))
+            S = oracle.palette(worlds[i], mesh["inv_bind"]).reshape(-1, 4, 4)
+            rows = np.transpose(S, (0, 2, 1))[:, :3, :].reshape(-1, 12)
+            np.testing.assert_allclose(ctx.read_palette(i), rows, rtol=1e-6, atol=1e-6)
+    ctx.set_tuning(inst_loop=-1, fast=-1)
     ctx.set_instances(1)
 
 

@@ -97,7 +97,7 @@ def main():
                 out += run(ctx, "C5 shard 1/8 variants", 200, g(morph_split=[2, 4], unroll=[4], grid_cap=[256, 512], geo_lds=[0, 1], fast=[0, 1]))
     if "c4" in which:
         setup(ctx, 30000, 200, 0, I=256)
-        out += run(ctx, "C4 256x30k pose-loop", 100, g(nt_store=[0, 1], inst_loop=[2, 4, 8], grid_cap=[256, 512, 768, 1024, 2048]))
+        out += run(ctx, "C4 256x30k pose-loop", 100, g(fast=[-1, 0], inst_loop=[4, 8], grid_cap=[512, 768, 1024, 2048]))
         out += run(ctx, "C4 256x30k generic", 100, g(nt_store=[1], inst_loop=[0], grid_cap=[1024, 2048, 4096]))
     if "c3" in which:
         setup(ctx, 30000, 200, 64)
