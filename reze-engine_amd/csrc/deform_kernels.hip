@@ -456,6 +456,8 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
 // bound here: 43 % of wave time in s_waitcnt, VALU 30 %, LDS 31 % — profiles/r1_sq_counters.txt).
 // grid = (vertex runs, instance groups); block = 256; dynamic LDS = G * B * 48 bytes.
 // ------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <bool NTS>
 __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDeformParams p, int G, int n_inst,
                                                                    uint32_t verts_per_wg)
@@ -541,29 +543,30 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
         float *dp = p.out_pos + ((size_t)inst0 * Vp + v) * 3;
         float *dn = p.out_nrm + ((size_t)inst0 * Vp + v) * 3;
         const float4 *pg = pal;
+        // Packed-math form (v_pk_fma_f32 = two f32 FMAs per lane per instruction): palette rows are blended as
+        // (xy),(zw) register pairs straight out of ds_read_b128, and position + normal are transformed together
+        // as the pairs (x,nx),(y,ny),(z,nz),(1,0), so one FMA chain yields (p_r, n_r) for row r.
+        const f2 vx = {x, nx}, vy = {y, ny}, vz = {z, nz}, vw = {1.0f, 0.0f};
 #pragma unroll 2
         for (int g = 0; g < ng; ++g) {
-            const float4 a0 = pg[o0], a1 = pg[o0 + 1], a2 = pg[o0 + 2];
-            const float4 c0 = pg[o1], c1 = pg[o1 + 1], c2 = pg[o1 + 2];
-            const float4 d0 = pg[o2], d1 = pg[o2 + 1], d2 = pg[o2 + 2];
-            const float4 e0 = pg[o3], e1 = pg[o3 + 1], e2 = pg[o3 + 2];
-            float4 m0, m1, m2;
-            m0.x = fmaf(w3, e0.x, fmaf(w2, d0.x, fmaf(w1, c0.x, w0 * a0.x))); m0.y = fmaf(w3, e0.y, fmaf(w2, d0.y, fmaf(w1, c0.y, w0 * a0.y)));
-            m0.z = fmaf(w3, e0.z, fmaf(w2, d0.z, fmaf(w1, c0.z, w0 * a0.z))); m0.w = fmaf(w3, e0.w, fmaf(w2, d0.w, fmaf(w1, c0.w, w0 * a0.w)));
-            m1.x = fmaf(w3, e1.x, fmaf(w2, d1.x, fmaf(w1, c1.x, w0 * a1.x))); m1.y = fmaf(w3, e1.y, fmaf(w2, d1.y, fmaf(w1, c1.y, w0 * a1.y)));
-            m1.z = fmaf(w3, e1.z, fmaf(w2, d1.z, fmaf(w1, c1.z, w0 * a1.z))); m1.w = fmaf(w3, e1.w, fmaf(w2, d1.w, fmaf(w1, c1.w, w0 * a1.w)));
-            m2.x = fmaf(w3, e2.x, fmaf(w2, d2.x, fmaf(w1, c2.x, w0 * a2.x))); m2.y = fmaf(w3, e2.y, fmaf(w2, d2.y, fmaf(w1, c2.y, w0 * a2.y)));
-            m2.z = fmaf(w3, e2.z, fmaf(w2, d2.z, fmaf(w1, c2.z, w0 * a2.z))); m2.w = fmaf(w3, e2.w, fmaf(w2, d2.w, fmaf(w1, c2.w, w0 * a2.w)));
-            const float px = fmaf(m0.z, z, fmaf(m0.y, y, fmaf(m0.x, x, m0.w)));
-            const float py = fmaf(m1.z, z, fmaf(m1.y, y, fmaf(m1.x, x, m1.w)));
-            const float pz = fmaf(m2.z, z, fmaf(m2.y, y, fmaf(m2.x, x, m2.w)));
-            const float tx = fmaf(m0.z, nz, fmaf(m0.y, ny, m0.x * nx));
-            const float ty = fmaf(m1.z, nz, fmaf(m1.y, ny, m1.x * nx));
-            const float tz = fmaf(m2.z, nz, fmaf(m2.y, ny, m2.x * nx));
+            f2 r[3][2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 a = pg[o0 + k], c = pg[o1 + k], d = pg[o2 + k], e = pg[o3 + k];
+                const f2 axy = {a.x, a.y}, azw = {a.z, a.w}, cxy = {c.x, c.y}, czw = {c.z, c.w};
+                const f2 dxy = {d.x, d.y}, dzw = {d.z, d.w}, exy = {e.x, e.y}, ezw = {e.z, e.w};
+                r[k][0] = w3 * exy + (w2 * dxy + (w1 * cxy + w0 * axy));
+                r[k][1] = w3 * ezw + (w2 * dzw + (w1 * czw + w0 * azw));
+            }
+            // (p_r, t_r) = m_r.x*(x,nx) + m_r.y*(y,ny) + m_r.z*(z,nz) + m_r.w*(1,0)
+            const f2 q0 = r[0][0].x * vx + (r[0][0].y * vy + (r[0][1].x * vz + r[0][1].y * vw));
+            const f2 q1 = r[1][0].x * vx + (r[1][0].y * vy + (r[1][1].x * vz + r[1][1].y * vw));
+            const f2 q2 = r[2][0].x * vx + (r[2][0].y * vy + (r[2][1].x * vz + r[2][1].y * vw));
+            const float tx = q0.y, ty = q1.y, tz = q2.y;
             const float l2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
             const bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
             const float rl = __builtin_amdgcn_rsqf(good ? l2 : 1.0f);
-            st3<NTS>(dp, px, py, pz);
+            st3<NTS>(dp, q0.x, q1.x, q2.x);
             st3<NTS>(dn, good ? tx * rl : nx, good ? ty * rl : ny, good ? tz * rl : nz);
             pg += rows;
             dp += Vp * 3;
