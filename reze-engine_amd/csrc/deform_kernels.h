@@ -73,6 +73,9 @@ hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, cons
                             uint32_t instances, hipStream_t st);
 size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v);
 // instanced skin (no morphs): G poses per workgroup share one decode of each vertex
+// register-resident form: 2048 vertices per workgroup decoded once, poses streamed through a 2-deep LDS palette ring
+hipError_t rz_launch_skin_instances_reg(const RzDeformParams &p, int n_inst, int poses_per_wg, uint32_t grid_x, bool nts,
+                                        hipStream_t st);
 hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
                                     bool nts, hipStream_t st);
 uint32_t rz_quads_per_tile(int S);

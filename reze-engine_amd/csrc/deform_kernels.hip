@@ -577,6 +577,112 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
 }
 
 // ------------------------------------------------------------------------------------------------
+// instanced skin, register-resident form: a workgroup owns a run of KV*256 vertices and a RANGE of poses.
+// Each lane loads and decodes its KV vertices ONCE into registers (the static mesh is read once per
+// (run, pose range) instead of once per pose), then walks the poses: the palette of pose g+1 streams into
+// the other half of a 2-deep LDS ring by LDS-DMA while pose g is skinned, and every pose is written as one
+// contiguous KV*256*12-byte block per output array. LDS is only 2 palettes (19 KB at 200 bones).
+// grid = (vertex runs, pose ranges); block = 256.
+// ------------------------------------------------------------------------------------------------
+template <int KV, bool NTS>
+__global__ void __launch_bounds__(kBlock) rz_skin_instances_reg_kernel(const RzDeformParams p, int n_inst, int poses_per_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *ring = reinterpret_cast<float4 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows = p.B * 3;
+    const int inst0 = blockIdx.y * poses_per_wg;
+    const int ng = min(poses_per_wg, n_inst - inst0);
+    const size_t Vp = p.Vp;
+    const uint32_t v_lim = p.n_quads * 4u;
+    const uint32_t v0 = blockIdx.x * (KV * kBlock) + tid;
+    const uint32_t bmax = (uint32_t)(p.B - 1);
+
+    auto dma_palette = [&](int g) {
+        const float4 *src = p.palette + (size_t)(inst0 + g) * rows;
+        float4 *dst = ring + (size_t)(g & 1) * rows;
+        for (int c = wave * 64; c < rows; c += kBlock) {
+            const int e = c + lane;
+            if (e < rows) {
+                typedef const __attribute__((address_space(1))) void *gptr_t;
+                typedef __attribute__((address_space(3))) void *lptr_t;
+                __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(src + e), (lptr_t)(uint32_t)(uintptr_t)(dst + c), 16, 0, 0);
+            }
+        }
+    };
+    dma_palette(0);
+
+    // ---- decode KV vertices per lane, once ----
+    f2 vx[KV], vy[KV], vz[KV];
+    float w0[KV], w1[KV], w2[KV], w3[KV];
+    uint32_t j01[KV], j23[KV];
+    {
+        float x[KV], y[KV], z[KV], nx[KV], ny[KV], nz[KV];
+        uint32_t wq[KV];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const uint32_t v = v0 + k * kBlock;
+            const bool live = v < v_lim;
+            const size_t vs = live ? v : 0;
+            x[k] = p.geom[0 * Vp + vs]; y[k] = p.geom[1 * Vp + vs]; z[k] = p.geom[2 * Vp + vs];
+            nx[k] = p.geom[3 * Vp + vs]; ny[k] = p.geom[4 * Vp + vs]; nz[k] = p.geom[5 * Vp + vs];
+            j01[k] = p.joints01[vs]; j23[k] = p.joints23[vs]; wq[k] = p.weights[vs];
+        }
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const uint32_t b0 = wq[k] & 255u, b1 = (wq[k] >> 8) & 255u, b2 = (wq[k] >> 16) & 255u, b3 = wq[k] >> 24;
+            const uint32_t isum = b0 + b1 + b2 + b3;
+            const bool ok = isum != 0u;
+            const float inv = __builtin_amdgcn_rcpf((float)(ok ? isum : 1u));
+            w0[k] = ok ? (float)b0 * inv : 1.0f; w1[k] = (float)b1 * inv; w2[k] = (float)b2 * inv; w3[k] = (float)b3 * inv;
+            // joints -> clamped palette row offsets, two 16-bit fields per register (B*3 <= 65535 is checked on the host)
+            const uint32_t o0 = min(j01[k] & 0xffffu, bmax) * 3u, o1 = min(j01[k] >> 16, bmax) * 3u;
+            const uint32_t o2 = min(j23[k] & 0xffffu, bmax) * 3u, o3 = min(j23[k] >> 16, bmax) * 3u;
+            j01[k] = o0 | (o1 << 16); j23[k] = o2 | (o3 << 16);
+            vx[k] = f2{x[k], nx[k]}; vy[k] = f2{y[k], ny[k]}; vz[k] = f2{z[k], nz[k]};
+        }
+    }
+    const f2 vw = {1.0f, 0.0f};
+
+    for (int g = 0; g < ng; ++g) {
+        // pose g's palette has landed (own DMA drained, barrier publishes everyone's part and also retires
+        // every wave's reads of the other ring slot, which pose g+1 may now overwrite)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (g + 1 < ng) dma_palette(g + 1);
+        const float4 *pg = ring + (size_t)(g & 1) * rows;
+        float *op = p.out_pos + (size_t)(inst0 + g) * Vp * 3;
+        float *on = p.out_nrm + (size_t)(inst0 + g) * Vp * 3;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const uint32_t v = v0 + k * kBlock;
+            const uint32_t o0 = j01[k] & 0xffffu, o1 = j01[k] >> 16, o2 = j23[k] & 0xffffu, o3 = j23[k] >> 16;
+            f2 r[3][2];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float4 a = pg[o0 + q], c = pg[o1 + q], d = pg[o2 + q], e = pg[o3 + q];
+                const f2 axy = {a.x, a.y}, azw = {a.z, a.w}, cxy = {c.x, c.y}, czw = {c.z, c.w};
+                const f2 dxy = {d.x, d.y}, dzw = {d.z, d.w}, exy = {e.x, e.y}, ezw = {e.z, e.w};
+                r[q][0] = w3[k] * exy + (w2[k] * dxy + (w1[k] * cxy + w0[k] * axy));
+                r[q][1] = w3[k] * ezw + (w2[k] * dzw + (w1[k] * czw + w0[k] * azw));
+            }
+            const f2 q0 = r[0][0].x * vx[k] + (r[0][0].y * vy[k] + (r[0][1].x * vz[k] + r[0][1].y * vw));
+            const f2 q1 = r[1][0].x * vx[k] + (r[1][0].y * vy[k] + (r[1][1].x * vz[k] + r[1][1].y * vw));
+            const f2 q2 = r[2][0].x * vx[k] + (r[2][0].y * vy[k] + (r[2][1].x * vz[k] + r[2][1].y * vw));
+            const float tx = q0.y, ty = q1.y, tz = q2.y;
+            const float l2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+            const bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
+            const float rl = __builtin_amdgcn_rsqf(good ? l2 : 1.0f);
+            if (v < v_lim) {
+                st3<NTS>(op + (size_t)v * 3, q0.x, q1.x, q2.x);
+                st3<NTS>(on + (size_t)v * 3, good ? tx * rl : vx[k].y, good ? ty * rl : vy[k].y, good ? tz * rl : vz[k].y);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one vertex at a time: bounds the live palette rows (12 x float4)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // upload-time re-layout kernels (one-off, not on the per-frame path)
 // ------------------------------------------------------------------------------------------------
 // packed [n][stride] floats -> planes; `stride` = 3 (packed xyz) or 8 (reference interleaved vertex)
@@ -690,6 +796,21 @@ hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, 
     }
     dim3 grid(grid_x, (n_inst + G - 1) / G);
     hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p, G, n_inst, verts_per_wg);
+    return hipGetLastError();
+}
+
+hipError_t rz_launch_skin_instances_reg(const RzDeformParams &p, int n_inst, int poses_per_wg, uint32_t grid_x, bool nts,
+                                        hipStream_t st)
+{
+    constexpr int KV = 8;
+    const size_t lds = (size_t)2 * p.B * 48;
+    auto k = nts ? rz_skin_instances_reg_kernel<KV, true> : rz_skin_instances_reg_kernel<KV, false>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid(grid_x, (n_inst + poses_per_wg - 1) / poses_per_wg);
+    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p, n_inst, poses_per_wg);
     return hipGetLastError();
 }
 

@@ -222,7 +222,7 @@ int auto_split(const rz_ctx *c)
     return S;
 }
 
-struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; };
+struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; };
 
 RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
 {
@@ -257,6 +257,7 @@ Plan make_plan(const rz_ctx *c)
     pl.dma = false;
     pl.inst_group = 0;
     pl.verts_per_wg = 0;
+    pl.poses_per_wg = 0;
     pl.n_quads = (c->V + 3) / 4;
     pl.quads_per_wave = 8;
     pl.grid_x = 1;
@@ -284,7 +285,7 @@ Plan make_plan(const rz_ctx *c)
     // instanced, morph-free frames: G poses per workgroup (palettes together <= 76.8 KB so two workgroups fit a CU)
     if (v.mode == 0 && c->I > 1 && c->t_instloop != 0) {
         int G = (int)std::min<uint32_t>(8, (80u * 1024u) / (c->B * 48u));
-        if (c->t_instloop > 0) G = std::min(G, c->t_instloop);
+        if (c->t_instloop > 0 && c->t_instloop <= 8) G = std::min(G, c->t_instloop);
         if (G >= 2) {
             G = (int)std::min<uint32_t>((uint32_t)G, c->I);
             const uint32_t groups = (c->I + G - 1) / G;
@@ -299,6 +300,17 @@ Plan make_plan(const rz_ctx *c)
             pl.dma = pl.prep;
             pl.grid_x = (c->V + per - 1) / per;
         }
+    }
+    // register-resident instanced form (inst_loop = -1 auto / 9): 2048-vertex runs, pose ranges sized for ~2 WGs per CU
+    if (v.mode == 0 && c->I > 1 && (c->t_instloop == -1 || c->t_instloop == 9) && c->B * 3 <= 65535u) {
+        const uint32_t runs = (c->V + 2047) / 2048;
+        uint32_t total = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : 2u * (uint32_t)c->n_cu;
+        uint32_t ranges = std::max<uint32_t>(1, std::min<uint32_t>(c->I, total / std::max<uint32_t>(1, runs)));
+        pl.poses_per_wg = (int)((c->I + ranges - 1) / ranges);
+        pl.inst_group = 0;
+        pl.grid_x = runs;
+        pl.prep = true;
+        pl.dma = true;
     }
     return pl;
 }
@@ -330,6 +342,10 @@ int launch_prep(rz_ctx *c)
 int launch_deform(rz_ctx *c, const Plan &pl)
 {
     RzDeformParams p = deform_params(c, pl);
+    if (pl.poses_per_wg > 0) {
+        HIP_TRY(rz_launch_skin_instances_reg(p, (int)c->I, pl.poses_per_wg, pl.grid_x, pl.v.nts, c->stream));
+        return RZ_OK;
+    }
     if (pl.inst_group > 0) {
         HIP_TRY(rz_launch_skin_instances(p, pl.inst_group, (int)c->I, pl.verts_per_wg, pl.grid_x, pl.v.nts, c->stream));
         return RZ_OK;
@@ -774,7 +790,7 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
     } else if (!strcmp(key, "nt_store")) {
         c->t_nts = value < 0 ? -1 : (value ? 1 : 0);
     } else if (!strcmp(key, "inst_loop")) {
-        if (value < -1 || value > 8) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off) or 2..8 poses per workgroup");
+        if (value < -1 || value > 9) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off), 2..8 (poses per workgroup, LDS form) or 9 (register form)");
         c->t_instloop = value;
     } else if (!strcmp(key, "fast")) {
         c->t_fast = value;        // -1 auto, 0 never (always prep kernel), 1 when possible
@@ -803,6 +819,7 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "effective_fast")) *value = make_plan(c).v.fast ? 1 : 0;
     else if (!strcmp(key, "inst_loop")) *value = c->t_instloop;
     else if (!strcmp(key, "effective_inst_group")) *value = make_plan(c).inst_group;
+    else if (!strcmp(key, "effective_poses_per_wg")) *value = make_plan(c).poses_per_wg;
     else if (!strcmp(key, "effective_grid")) *value = (int)make_plan(c).grid_x;
     else return fail(RZ_ERR_INVALID, "unknown tuning key '%s'", key);
     return RZ_OK;

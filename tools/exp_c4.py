@@ -9,7 +9,7 @@ ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); ctx.
 ctx.set_instances(256)
 worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], 200, seed=1000 + i) for i in range(256)])
 ctx.set_pose(worlds)
-for il, cap in ((4, 2048), (8, 512), (0, 2048)):
+for il, cap in ((9, 512), (9, 1024), (9, 256), (8, 512), (0, 2048)):
     ctx.set_tuning(inst_loop=il, grid_cap=cap)
     for rep in range(4):
         t = ctx.time_frames(100)
