@@ -40,6 +40,7 @@ struct RzDeformParams {
     uint32_t Vp;                // padded vertex count (multiple of 1024)
     uint32_t n_quads;           // Vp / 4
     uint32_t quads_per_wave;    // contiguous run owned by each wave of the grid (multiple of 8)
+    int dbg;                    // ablation switch for profiling experiments (0 in production)
     int dma;                    // FAST: stage raw matrices by LDS-DMA (else plain loads after the first morph phase)
     int B;
     int M;

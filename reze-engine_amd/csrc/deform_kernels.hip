@@ -547,6 +547,14 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
         // (xy),(zw) register pairs straight out of ds_read_b128, and position + normal are transformed together
         // as the pairs (x,nx),(y,ny),(z,nz),(1,0), so one FMA chain yields (p_r, n_r) for row r.
         const f2 vx = {x, nx}, vy = {y, ny}, vz = {z, nz}, vw = {1.0f, 0.0f};
+        if (p.dbg == 2) {                        // dbg 2: ablation — the output stream without gathers / math
+            for (int g = 0; g < ng; ++g) {
+                st3<NTS>(dp, x, y, z); st3<NTS>(dn, nx, ny, nz);
+                dp += Vp * 3; dn += Vp * 3;
+            }
+            x = xn; y = yn; z = zn; nx = nxn; ny = nyn; nz = nzn; j01 = j01n; j23 = j23n; wq = wqn;
+            continue;
+        }
 #pragma unroll 2
         for (int g = 0; g < ng; ++g) {
             f2 r[3][2];
@@ -566,8 +574,10 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
             const float l2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
             const bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
             const float rl = __builtin_amdgcn_rsqf(good ? l2 : 1.0f);
-            st3<NTS>(dp, q0.x, q1.x, q2.x);
-            st3<NTS>(dn, good ? tx * rl : nx, good ? ty * rl : ny, good ? tz * rl : nz);
+            if (p.dbg != 1 || l2 == 1234.5f) {   // dbg 1: ablation — compute without the output stream
+                st3<NTS>(dp, q0.x, q1.x, q2.x);
+                st3<NTS>(dn, good ? tx * rl : nx, good ? ty * rl : ny, good ? tz * rl : nz);
+            }
             pg += rows;
             dp += Vp * 3;
             dn += Vp * 3;

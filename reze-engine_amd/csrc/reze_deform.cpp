@@ -137,7 +137,7 @@ struct rz_ctx {
     RzMorphList ml;
 
     // tuning (0 / -1 = automatic)
-    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1;
+    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0;
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -235,6 +235,7 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     p.out_pos = c->out_pos; p.out_nrm = c->out_nrm;
     p.Vp = c->Vp; p.n_quads = pl.n_quads; p.quads_per_wave = pl.quads_per_wave; p.dma = pl.dma ? 1 : 0;
     p.B = (int)c->B; p.M = (int)c->M; p.Mpad = (int)c->Mpad;
+    p.dbg = c->t_dbg;
     return p;
 }
 
@@ -301,8 +302,9 @@ Plan make_plan(const rz_ctx *c)
             pl.grid_x = (c->V + per - 1) / per;
         }
     }
-    // register-resident instanced form (inst_loop = -1 auto / 9): 2048-vertex runs, pose ranges sized for ~2 WGs per CU
-    if (v.mode == 0 && c->I > 1 && (c->t_instloop == -1 || c->t_instloop == 9) && c->B * 3 <= 65535u) {
+    // register-resident instanced form: 2048-vertex runs, pose ranges sized for ~2 WGs per CU
+    // (measured slower than the LDS pose-group form on C4 — 37 vs 34 us — so it is opt-in: inst_loop = 9)
+    if (v.mode == 0 && c->I > 1 && c->t_instloop == 9 && c->B * 3 <= 65535u) {
         const uint32_t runs = (c->V + 2047) / 2048;
         uint32_t total = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : 2u * (uint32_t)c->n_cu;
         uint32_t ranges = std::max<uint32_t>(1, std::min<uint32_t>(c->I, total / std::max<uint32_t>(1, runs)));
@@ -789,6 +791,8 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
         c->t_geo = value ? 1 : 0;
     } else if (!strcmp(key, "nt_store")) {
         c->t_nts = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (!strcmp(key, "dbg")) {
+        c->t_dbg = value;
     } else if (!strcmp(key, "inst_loop")) {
         if (value < -1 || value > 9) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off), 2..8 (poses per workgroup, LDS form) or 9 (register form)");
         c->t_instloop = value;

@@ -196,7 +196,7 @@ def test_c4_instances_each_match_their_own_pose(ctx, oracle):
 
 
 @pytest.mark.parametrize("fast", [-1, 0])
-@pytest.mark.parametrize("inst_loop", [-1, 0, 3, 8])
+@pytest.mark.parametrize("inst_loop", [-1, 0, 3, 9])
 def test_c4_instance_loop_kernel_and_ragged_groups(ctx, oracle, inst_loop, fast):
     """19 poses do not divide into groups of 8: the pose-loop kernel (inst_loop != 0) and the generic kernel
     (inst_loop = 0) must both match every pose; 471 bones forces a smaller group (LDS)."""
@@ -212,7 +212,7 @@ def test_c4_instance_loop_kernel_and_ragged_groups(ctx, oracle, inst_loop, fast)
         ctx.deform()
         g = ctx.get_tuning("effective_inst_group")
         pp = ctx.get_tuning("effective_poses_per_wg")
-        if inst_loop == -1:
+        if inst_loop == 9:
             assert pp >= 1 and g == 0                       # register-resident form
         elif inst_loop == 0:
             assert pp == 0 and g == 0                       # generic kernel, one pose per workgroup row

@@ -9,9 +9,9 @@ ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); ctx.
 ctx.set_instances(256)
 worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], 200, seed=1000 + i) for i in range(256)])
 ctx.set_pose(worlds)
-for il, cap in ((9, 512), (9, 1024), (9, 256), (8, 512), (0, 2048)):
-    ctx.set_tuning(inst_loop=il, grid_cap=cap)
-    for rep in range(4):
+for il, cap, dbg in ((8, 512, 0), (8, 512, 1), (8, 512, 2), (4, 2048, 0), (4, 2048, 1), (4, 2048, 2)):
+    ctx.set_tuning(inst_loop=il, grid_cap=cap, dbg=dbg)
+    for rep in range(2):
         t = ctx.time_frames(100)
         ctx.sync(); t0 = time.perf_counter(); ctx.deform_n(200); ctx.sync(); wall = (time.perf_counter() - t0) / 200 * 1e3
-        print(il, cap, rep, "frame %.4f kernel %.4f prep %.4f wall %.4f" % (t["frame_ms"], t["deform_kernel_ms"], t["prep_kernel_ms"], wall))
+        print(il, cap, "dbg", dbg, rep, "frame %.4f kernel %.4f prep %.4f wall %.4f" % (t["frame_ms"], t["deform_kernel_ms"], t["prep_kernel_ms"], wall))
