@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--bones", type=int, default=256)
     ap.add_argument("--morphs", type=int, default=64)
     ap.add_argument("--instances", type=int, default=1, help="C4-style instancing (single GPU only)")
+    ap.add_argument("--config", choices=["c5", "c4", "c3", "c2"], default=None,
+                    help="BASELINE.json shortcut: c5 = 1M/256/64 (default), c4 = 256 x 30k/200/0, c3 = 30k/200/64, c2 = 30k/200/0")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong: --verts is the whole mesh, sharded over ranks; weak: --verts per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -105,6 +107,12 @@ def cpu_baseline(args, mesh, deltas, mw):
 
 def main():
     args = parse_args()
+    if args.config == "c4":
+        args.verts, args.bones, args.morphs, args.instances = 30000, 200, 0, 256
+    elif args.config == "c3":
+        args.verts, args.bones, args.morphs, args.instances = 30000, 200, 64, 1
+    elif args.config == "c2":
+        args.verts, args.bones, args.morphs, args.instances = 30000, 200, 0, 1
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -235,8 +243,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "C5: %d-vert / %d-bone / %d-dense-morph synthetic PMX%s, vertex-sharded over %d GPU(s)"
-                            % (V_total, B, M, (" x %d instances" % I) if I > 1 else "", world_size),
+                "workload": "%s: %d-vert / %d-bone / %d-dense-morph synthetic PMX%s, vertex-sharded over %d GPU(s)"
+                            % ("C4" if I > 1 else ("C5" if (V_total, B, M) == (1000000, 256, 64) else "custom"), V_total, B, M,
+                               (" x %d instances (per-instance palette in LDS)" % I) if I > 1 else "", world_size),
                 "verts_total": V_total, "verts_per_gpu": n, "bones": B, "morphs": M, "instances": I,
                 "parallelism": "vertex-shard x%d" % world_size,
                 "morph_split": ctx.get_tuning("effective_split"),

@@ -18,12 +18,19 @@
  *                                                   :479-482): p~ = p + SUM_m w_m * delta_m[v], bind
  *                                                   space, before skinning, normals not morphed.
  *
- * PARITY STATUS: the reference is TypeScript + WGSL, has no tests, no golden vectors, and cannot
- * be executed in this image (no tsc, no WebGPU/WGSL executor). The skin/palette restatement is
- * pinned by analytic known-answer tests (identity pose => rest mesh, single-bone rigid motion,
- * hand-computed 2-bone blend) and by a bit-exact three-way agreement between this file, the
- * numpy twin (oracle/rz_oracle_np.py) and the JS Math.fround twin (oracle/js/skin_f32.js).
- * The morph half is PARITY UNPINNED against the reference (nothing to pin to).
+ * PARITY STATUS. The reference has no tests and no golden vectors for this path, its skinning is
+ * WGSL inside a vertex shader (engine.ts:245-276) whose outputs are never written to a buffer, and
+ * the image has no WebGPU / WGSL executor and no tsc. Therefore:
+ *   - rzo_palette / rzo_skin (rows a1-a3, a6): PARITY UNPINNED BY REFERENCE EXECUTION — nothing can
+ *     run the shader here. They are pinned by analytic known-answer tests (identity pose => rest
+ *     mesh, single-bone rigid motion about a pivot, hand-computed 2-bone blend, zero-weight and
+ *     zero-normal branches; tests/test_oracle.py) and by bit-exact three-way agreement between this
+ *     file, the NumPy twin (oracle/rz_oracle_np.py) and the JS Math.fround twin (oracle/js/skin_f32.js).
+ *   - the inputs they consume (world matrices, inverse bind, joints, weights: rows a9-a12) ARE pinned
+ *     to the reference's own code: tools/ref_erased_run.py runs math.ts/model.ts/pmx-loader.ts/
+ *     vmd-loader.ts with their TypeScript types erased on the reference's assets and stores numeric
+ *     fixtures in tests/golden/, which the host side reproduces bit for bit (tests/test_host_js.py).
+ *   - rzo_morph_*: PARITY UNPINNED — the reference has no morph implementation at all.
  *
  * Rounding model (the canonical evaluation the GPU kernel is compared with, tolerance 1e-4):
  * every operation is a single IEEE-754 binary32 operation, no FMA contraction (build with

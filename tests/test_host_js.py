@@ -324,3 +324,24 @@ def test_addon_exports_and_loud_failure_without_gpu():
     assert r["abi"] == 1 and r["shard"] == [881664, 118336]
     if r["n"] == 0:
         assert "no HIP device" in r["msg"] or "error -3" in r["msg"]
+
+
+def test_math_primitives_hand_computed():
+    """host/math.js (reference surface: math.ts Vec3 / Quat / Mat4 / easeInOut) against hand-computed values."""
+    out = subprocess.check_output(["node", os.path.join(ROOT, "tests", "js", "math_unit.js")], timeout=60, stderr=subprocess.DEVNULL)
+    r = json.loads(out.decode().strip().splitlines()[-1])
+    s = np.sqrt(0.5)
+    assert np.allclose(r["ease"], [0, 0.125, 0.5, 0.875, 1])
+    assert np.allclose(r["fromEulerZ"], [0, 0, s, s]) and np.allclose(r["rotX"], [0, 1, 0], atol=1e-12) and np.allclose(r["rotX2"], [0, 1, 0], atol=1e-12)
+    assert np.allclose(r["mulIdentity"], [0, 0, s, s]) and np.allclose(r["conj"], [0, 0, 0, 1], atol=1e-12)
+    assert np.allclose(r["slerpHalf"], [0, 0, np.sin(np.pi / 8), np.cos(np.pi / 8)]) and np.allclose(r["slerpNeg"], r["slerpHalf"])
+    assert abs(np.linalg.norm(r["slerpNear"]) - 1) < 1e-12
+    # toEuler mirrors the reference formula (math.ts:209-231), which inverts fromEuler per single axis
+    assert np.allclose(r["euler"], [0.3, 0, 0, 0, -0.2, 0], atol=1e-12) and np.allclose(r["fromTo"], [0, 0, s, s])
+    # column-major: first column = image of +X = +Y, translation in elements 12..14
+    assert np.allclose(r["matFromQuat"], [0, 1, 0, 0, -1, 0, 0, 0, 0, 0, 1, 0, 1, 2, 3, 1], atol=1e-7)
+    assert np.allclose(r["matInvProduct"], np.eye(4).reshape(-1), atol=1e-6) and np.allclose(r["matToQuat"], [0, 0, s, s], atol=1e-7)
+    assert r["translate"][12:15] == [4, 5, 6]
+    assert np.allclose(r["mulArrays"][12:15], [1, 3, 3], atol=1e-7)           # R * T(1,0,0) + t = (0,1,0) + (1,2,3)
+    assert np.allclose(r["singular"], np.eye(4).reshape(-1))
+    assert np.allclose(r["vec"], [5, 0.6, 4, 7, 0])
