@@ -18,5 +18,5 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/cal_write -o mb -- $R/tools/membench quick > $O/cal_write.log 2>&1
 echo "== shard (1/8) + C4 traces"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_shard -o bench -- python $R/bench.py --verts 125952 --steps 200 --warmup 20 --no-cpu-baseline > $O/trace_shard.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c4 -o bench -- python $R/bench.py --verts 30000 --bones 200 --morphs 0 --instances 256 --steps 100 --warmup 10 --no-cpu-baseline > $O/trace_c4.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c4 -o bench -- python $R/bench.py --config c4 --steps 100 --warmup 10 --no-cpu-baseline > $O/trace_c4.log 2>&1
 cd $R; find gpurun_out/prof -name "*.csv" | head -40; du -sh gpurun_out/prof
