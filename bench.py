@@ -122,7 +122,8 @@ def main():
 
     import torch
     dist = None
-    if world_size > 1:
+    # REZE_BENCH_FORCE_DIST=1 exercises the torch.distributed (RCCL) path with a single rank
+    if world_size > 1 or os.environ.get("REZE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -244,7 +245,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%s: %d-vert / %d-bone / %d-dense-morph synthetic PMX%s, vertex-sharded over %d GPU(s)"
-                            % ("C4" if I > 1 else ("C5" if (V_total, B, M) == (1000000, 256, 64) else "custom"), V_total, B, M,
+                            % ({(1000000, 256, 64, 1): "C5", (30000, 200, 0, 256): "C4", (30000, 200, 64, 1): "C3",
+                                (30000, 200, 0, 1): "C2"}.get((V_total, B, M, I), "custom"), V_total, B, M,
                                (" x %d instances (per-instance palette in LDS)" % I) if I > 1 else "", world_size),
                 "verts_total": V_total, "verts_per_gpu": n, "bones": B, "morphs": M, "instances": I,
                 "parallelism": "vertex-shard x%d" % world_size,
