@@ -148,6 +148,12 @@ int rz_comm_init(rz_ctx *ctx, int nranks, int rank, const char id[128], uint32_t
 int rz_allgather(rz_ctx *ctx, int with_normals);
 int rz_read_gathered(rz_ctx *ctx, uint32_t v0, uint32_t n, float *pos3, float *nrm3);
 
+/* Single-process form (one Node process driving several GPUs, one context each): ctxs[r] is rank r and
+ * must hold shard r of rz_shard_range(v_total, n, r). rz_comm_init_all = ncclCommInitAll; rz_allgather_all
+ * issues every rank's ncclAllGather inside one ncclGroupStart/End. */
+int rz_comm_init_all(rz_ctx **ctxs, int n, uint32_t v_total);
+int rz_allgather_all(rz_ctx **ctxs, int n, int with_normals);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,7 +18,7 @@ SYMBOLS = [
     "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
     "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
     "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_output_ptrs",
-    "rz_comm_unique_id", "rz_comm_init", "rz_allgather", "rz_read_gathered",
+    "rz_comm_unique_id", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all",
 ]
 
 
@@ -77,6 +77,8 @@ def load():
     L.rz_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, u32]
     L.rz_allgather.argtypes = [vp, ctypes.c_int]
     L.rz_read_gathered.argtypes = [vp, u32, u32, fp, fp]
+    L.rz_comm_init_all.argtypes = [ctypes.POINTER(vp), ctypes.c_int, u32]
+    L.rz_allgather_all.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int]
     for name in SYMBOLS:
         if name != "rz_last_error":
             getattr(L, name).restype = ctypes.c_int
@@ -115,6 +117,19 @@ def comm_unique_id():
     buf = ctypes.create_string_buffer(128)
     _chk(load().rz_comm_unique_id(buf))
     return buf.raw
+
+
+def comm_init_all(contexts, v_total):
+    """Single-process multi-GPU: contexts[r] is rank r (ncclCommInitAll)."""
+    arr = (ctypes.c_void_p * len(contexts))(*[c._h for c in contexts])
+    _chk(load().rz_comm_init_all(arr, len(contexts), int(v_total)))
+    for c in contexts:
+        c.v_total = int(v_total)
+
+
+def allgather_all(contexts, with_normals=False):
+    arr = (ctypes.c_void_p * len(contexts))(*[c._h for c in contexts])
+    _chk(load().rz_allgather_all(arr, len(contexts), 1 if with_normals else 0))
 
 
 class DeformContext:

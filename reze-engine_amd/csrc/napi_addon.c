@@ -398,6 +398,43 @@ static napi_value fn_allgather(napi_env env, napi_callback_info info)
     return rc ? throw_rz(env, rc) : undef(env);
 }
 
+/* JS array of context handles -> rz_ctx*[] (at most 64) */
+static int get_ctx_list(napi_env env, napi_value arr, rz_ctx **out, int *n)
+{
+    bool is_arr = false;
+    uint32_t len = 0;
+    if (napi_is_array(env, arr, &is_arr) != napi_ok || !is_arr || napi_get_array_length(env, arr, &len) != napi_ok || len < 1 || len > 64) return 0;
+    for (uint32_t i = 0; i < len; ++i) {
+        napi_value v;
+        if (napi_get_element(env, arr, i, &v) != napi_ok || !get_ctx(env, v, &out[i])) return 0;
+    }
+    *n = (int)len;
+    return 1;
+}
+
+static napi_value fn_comm_init_all(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    rz_ctx *list[64];
+    int n = 0;
+    uint32_t vt;
+    if (!get_ctx_list(env, argv[0], list, &n) || !get_u32(env, argv[1], &vt)) return throw_msg(env, "commInitAll(ctx[], vTotal)");
+    int rc = rz_comm_init_all(list, n, vt);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_allgather_all(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    rz_ctx *list[64];
+    int n = 0;
+    bool wn = false;
+    if (!get_ctx_list(env, argv[0], list, &n)) return throw_msg(env, "allgatherAll(ctx[], withNormals?)");
+    if (argc > 1) napi_get_value_bool(env, argv[1], &wn);
+    int rc = rz_allgather_all(list, n, wn ? 1 : 0);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
 static napi_value fn_read_gathered(napi_env env, napi_callback_info info)
 {
     ARGS(5);
@@ -424,7 +461,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "deformN", fn_deform_n }, { "sync", fn_sync }, { "read", fn_read }, { "readPalette", fn_read_palette },
         { "timeFrames", fn_time_frames }, { "setTuning", fn_set_tuning }, { "getTuning", fn_get_tuning },
         { "commUniqueId", fn_comm_unique_id }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },
-        { "readGathered", fn_read_gathered },
+        { "readGathered", fn_read_gathered }, { "commInitAll", fn_comm_init_all }, { "allgatherAll", fn_allgather_all },
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value f;

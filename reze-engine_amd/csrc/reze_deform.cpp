@@ -55,6 +55,9 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -72,7 +75,11 @@ int rccl_bind()
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString || !r.CommInitAll ||
+        !r.GroupStart || !r.GroupEnd)
         return fail(RZ_ERR_UNSUPPORTED, "RCCL symbols missing");
     g_rccl = r;
     return RZ_OK;
@@ -839,6 +846,8 @@ int rz_output_ptrs(rz_ctx *c, void **pos, void **nrm, uint32_t *v_padded)
     return RZ_OK;
 }
 
+static int comm_buffers(rz_ctx *c, int nranks, int rank, uint32_t v_total);
+
 int rz_comm_unique_id(char id[128])
 {
     if (!id) return fail(RZ_ERR_INVALID, "null id");
@@ -864,16 +873,7 @@ int rz_comm_init(rz_ctx *c, int nranks, int rank, const char id[128], uint32_t v
     ncclUniqueId u;
     memcpy(&u, id, 128);
     NCCL_TRY(g_rccl.CommInitRank(&c->comm, nranks, u, rank));
-    c->nranks = nranks; c->rank = rank; c->v_total = v_total;
-    uint32_t b0 = 0, n0 = 0;
-    rz_shard_range(v_total, nranks, 0, &b0, &n0);
-    c->chunk = round_up(n0, kVertPad);
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    dfree(c->g_pos); dfree(c->g_nrm);
-    const size_t g = (size_t)nranks * c->chunk * 3 * sizeof(float);
-    HIP_TRY(hipMalloc(&c->g_pos, g));
-    HIP_TRY(hipMalloc(&c->g_nrm, g));
-    return ensure_outputs(c);
+    return comm_buffers(c, nranks, rank, v_total);
 }
 
 int rz_allgather(rz_ctx *c, int with_normals)
@@ -883,6 +883,64 @@ int rz_allgather(rz_ctx *c, int with_normals)
     const size_t count = (size_t)c->chunk * 3;
     NCCL_TRY(g_rccl.AllGather(c->out_pos, c->g_pos, count, ncclFloat, c->comm, c->stream));
     if (with_normals) NCCL_TRY(g_rccl.AllGather(c->out_nrm, c->g_nrm, count, ncclFloat, c->comm, c->stream));
+    return RZ_OK;
+}
+
+static int comm_buffers(rz_ctx *c, int nranks, int rank, uint32_t v_total)
+{
+    c->nranks = nranks; c->rank = rank; c->v_total = v_total;
+    uint32_t b0 = 0, n0 = 0;
+    rz_shard_range(v_total, nranks, 0, &b0, &n0);
+    c->chunk = round_up(n0, kVertPad);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dfree(c->g_pos); dfree(c->g_nrm);
+    const size_t g = (size_t)nranks * c->chunk * 3 * sizeof(float);
+    HIP_TRY(hipMalloc(&c->g_pos, g));
+    HIP_TRY(hipMalloc(&c->g_nrm, g));
+    return ensure_outputs(c);
+}
+
+int rz_comm_init_all(rz_ctx **ctxs, int n, uint32_t v_total)
+{
+    if (!ctxs || n < 1 || n > 64) return fail(RZ_ERR_INVALID, "bad context list");
+    if (int r = rccl_bind()) return r;
+    int devs[64];
+    for (int r = 0; r < n; ++r) {
+        rz_ctx *c = ctxs[r];
+        if (!c) return fail(RZ_ERR_INVALID, "null context in list");
+        if (c->I != 1) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive");
+        uint32_t b = 0, cnt = 0;
+        if (int e = rz_shard_range(v_total, n, r, &b, &cnt)) return e;
+        if (cnt != c->V) return fail(RZ_ERR_INVALID, "context %d holds %u vertices but rz_shard_range assigns %u", r, c->V, cnt);
+        for (int k = 0; k < r; ++k)
+            if (devs[k] == c->device) return fail(RZ_ERR_INVALID, "contexts %d and %d share device %d: RCCL needs one GPU per rank", k, r, c->device);
+        devs[r] = c->device;
+        if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    }
+    ncclComm_t comms[64];
+    NCCL_TRY(g_rccl.CommInitAll(comms, n, devs));
+    for (int r = 0; r < n; ++r) {
+        ctxs[r]->comm = comms[r];
+        if (int e = comm_buffers(ctxs[r], n, r, v_total)) return e;
+    }
+    return RZ_OK;
+}
+
+int rz_allgather_all(rz_ctx **ctxs, int n, int with_normals)
+{
+    if (!ctxs || n < 1) return fail(RZ_ERR_INVALID, "bad context list");
+    for (int r = 0; r < n; ++r)
+        if (!ctxs[r] || !ctxs[r]->comm || ctxs[r]->nranks != n) return fail(RZ_ERR_INVALID, "rz_comm_init_all has not been called on this list");
+    NCCL_TRY(g_rccl.GroupStart());
+    for (int r = 0; r < n; ++r) {
+        rz_ctx *c = ctxs[r];
+        const size_t count = (size_t)c->chunk * 3;
+        ncclResult_t a = g_rccl.AllGather(c->out_pos, c->g_pos, count, ncclFloat, c->comm, c->stream);
+        if (a == ncclSuccess && with_normals) a = g_rccl.AllGather(c->out_nrm, c->g_nrm, count, ncclFloat, c->comm, c->stream);
+        if (a != ncclSuccess) { g_rccl.GroupEnd(); return fail(RZ_ERR_RCCL, "ncclAllGather failed: %s", g_rccl.GetErrorString(a)); }
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
     return RZ_OK;
 }
 

@@ -38,10 +38,14 @@ class Engine {
     this.cameraDistance = o.cameraDistance === undefined ? 26.6 : o.cameraDistance
     this.cameraTarget = o.cameraTarget === undefined ? new Vec3(0, 12.5, 0) : o.cameraTarget
     this.device = o.device === undefined ? 0 : o.device
+    // devices: [0,1,...]  one context per GPU in this process; the mesh is vertex-sharded across them (SURVEY §8e)
+    this.devices = Array.isArray(o.devices) && o.devices.length > 0 ? o.devices.slice() : [this.device]
+    this.gather = o.gather === true // all-gather deformed positions over RCCL after every frame (needs distinct GPUs)
     this.morphLayout = o.morphLayout || 'sparse'
     this.realtime = o.realtime !== false // false: time only advances through step()
     this.native = null
-    this.ctx = null
+    this.ctx = null // context of shard 0 (the only one on a single GPU)
+    this.shards = [] // [{ ctx, begin, count }]
     this.currentModel = null
     this.animationFrames = []
     this.hasAnimation = false
@@ -69,7 +73,8 @@ class Engine {
   /** engine.ts:157-185: acquire the device. Throws when the addon or an MI355X is not available. */
   async init() {
     this.native = requireAddon()
-    this.ctx = this.native.create(this.device)
+    this.shards = this.devices.map((d) => ({ ctx: this.native.create(d), begin: 0, count: 0 }))
+    this.ctx = this.shards[0].ctx
     this.lastFpsUpdate = this.now()
   }
 
@@ -77,7 +82,9 @@ class Engine {
     this.stopRenderLoop()
     this.stopAnimation()
     this.stopBreathing()
-    if (this.ctx) { this.native.destroy(this.ctx); this.ctx = null }
+    for (const s of this.shards) this.native.destroy(s.ctx)
+    this.shards = []
+    this.ctx = null
   }
 
   // ---- timers (window.setTimeout replacement that also works on a manual clock) ----
@@ -121,25 +128,47 @@ class Engine {
     this.currentModel = model
     model.setClock(() => this.now())
     const n = this.native, skinning = model.getSkinning(), skeleton = model.getSkeleton()
-    n.uploadMesh(this.ctx, model.getVertices(), skinning.joints, skinning.weights)
-    n.uploadSkeleton(this.ctx, skeleton.inverseBindMatrices)
     const morphs = model.getMorphs()
     const V = model.getVertexCount()
-    if (morphs && morphs.names.length > 0) {
-      if (this.morphLayout === 'dense') {
+    const G = this.shards.length
+    for (let r = 0; r < G; r++) {
+      const s = this.shards[r]
+      const range = n.shardRange(V, G, r)
+      s.begin = range[0]; s.count = range[1]
+      if (s.count === 0) continue
+      const b = s.begin, e = s.begin + s.count
+      // static data is cut once; subarray() views are zero-copy into the addon
+      n.uploadMesh(s.ctx, model.getVertices().subarray(b * 8, e * 8), skinning.joints.subarray(b * 4, e * 4), skinning.weights.subarray(b * 4, e * 4))
+      n.uploadSkeleton(s.ctx, skeleton.inverseBindMatrices)
+      if (morphs && morphs.names.length > 0) {
         const M = morphs.names.length
-        const dense = new Float32Array(M * V * 3)
-        for (let m = 0; m < M; m++) {
-          for (let e = morphs.offsets[m]; e < morphs.offsets[m + 1]; e++) {
-            const d = (m * V + morphs.vertexIndex[e]) * 3
-            dense[d] += morphs.deltas[e * 3]; dense[d + 1] += morphs.deltas[e * 3 + 1]; dense[d + 2] += morphs.deltas[e * 3 + 2]
+        if (this.morphLayout === 'dense') {
+          const dense = new Float32Array(M * s.count * 3)
+          for (let m = 0; m < M; m++) {
+            for (let k = morphs.offsets[m]; k < morphs.offsets[m + 1]; k++) {
+              const v = morphs.vertexIndex[k]
+              if (v < b || v >= e) continue
+              const d = (m * s.count + (v - b)) * 3
+              dense[d] += morphs.deltas[k * 3]; dense[d + 1] += morphs.deltas[k * 3 + 1]; dense[d + 2] += morphs.deltas[k * 3 + 2]
+            }
           }
+          n.uploadMorphsDense(s.ctx, M, dense)
+        } else if (G === 1) {
+          n.uploadMorphsSparse(s.ctx, morphs.offsets, morphs.vertexIndex, morphs.deltas)
+        } else { // re-base the sparse entries that fall inside this shard
+          const off = new Uint32Array(M + 1), vi = [], dl = []
+          for (let m = 0; m < M; m++) {
+            for (let k = morphs.offsets[m]; k < morphs.offsets[m + 1]; k++) {
+              const v = morphs.vertexIndex[k]
+              if (v >= b && v < e) { vi.push(v - b); dl.push(morphs.deltas[k * 3], morphs.deltas[k * 3 + 1], morphs.deltas[k * 3 + 2]) }
+            }
+            off[m + 1] = vi.length
+          }
+          n.uploadMorphsSparse(s.ctx, off, Uint32Array.from(vi), Float32Array.from(dl))
         }
-        n.uploadMorphsDense(this.ctx, M, dense)
-      } else {
-        n.uploadMorphsSparse(this.ctx, morphs.offsets, morphs.vertexIndex, morphs.deltas)
       }
     }
+    if (this.gather && G > 1) n.commInitAll(this.shards.map((s) => s.ctx), V)
     this.outPos = new Float32Array(V * 3)
     this.outNrm = new Float32Array(V * 3)
     this.stats.gpuMemory = Math.round(((V * 60 + skeleton.bones.length * 176 +
@@ -267,8 +296,13 @@ class Engine {
     const model = this.currentModel
     model.evaluatePose()
     const mw = model.getMorphCount() > 0 ? model.getEffectiveMorphWeights() : null
-    this.native.setPose(this.ctx, model.getBoneWorldMatrices(), mw)
-    this.native.deform(this.ctx)
+    // per-frame inputs are replicated to every shard (16-22 KB); launches are asynchronous, so the GPUs run concurrently
+    for (const s of this.shards) {
+      if (s.count === 0) continue
+      this.native.setPose(s.ctx, model.getBoneWorldMatrices(), mw)
+      this.native.deform(s.ctx)
+    }
+    if (this.gather && this.shards.length > 1) this.native.allgatherAll(this.shards.map((s) => s.ctx), true)
     this.updateStats(wallClock() - t0)
   }
 
@@ -283,7 +317,14 @@ class Engine {
   /** Blocking readback of the deformed mesh (the values the reference's vs() only ever feeds the rasteriser). */
   getDeformed() {
     if (!this.ctx || !this.currentModel) throw new Error('no model loaded')
-    this.native.read(this.ctx, 0, 0, this.currentModel.getVertexCount(), this.outPos, this.outNrm)
+    if (this.gather && this.shards.length > 1) { // every GPU holds the whole mesh after the all-gather: read it from shard 0
+      this.native.readGathered(this.ctx, 0, this.currentModel.getVertexCount(), this.outPos, this.outNrm)
+      return { positions: this.outPos, normals: this.outNrm }
+    }
+    for (const s of this.shards) {
+      if (s.count === 0) continue
+      this.native.read(s.ctx, 0, 0, s.count, this.outPos.subarray(s.begin * 3, (s.begin + s.count) * 3), this.outNrm.subarray(s.begin * 3, (s.begin + s.count) * 3))
+    }
     return { positions: this.outPos, normals: this.outNrm }
   }
 

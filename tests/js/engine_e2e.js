@@ -5,11 +5,12 @@
  * weights) and the deformed output it produced; pytest recomputes the frame with the CPU oracle from those inputs. */
 const fs = require('fs'), path = require('path')
 const { Engine, Quat } = require(path.join(__dirname, '..', '..', 'reze-engine_amd', 'host'))
-const [pmx, vmd, out, layout] = process.argv.slice(2)
+const [pmx, vmd, out, layout, devs] = process.argv.slice(2)
 const dump = (name, ta) => fs.writeFileSync(path.join(out, name), Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength))
 ;(async () => {
   const quiet = console.warn; console.warn = () => {}
-  const engine = new Engine(null, { realtime: false, morphLayout: layout || 'sparse', ambient: 0.8 })
+  const devices = (devs || '0').split(',').map(Number)   // '0,0' = two contexts (two vertex shards) on one GPU
+  const engine = new Engine(null, { realtime: false, morphLayout: layout || 'sparse', ambient: 0.8, devices })
   await engine.init()
   await engine.loadModel(pmx)
   const model = engine.currentModel

@@ -278,6 +278,27 @@ def test_c5_full_size_parity_and_properties(ctx, oracle, rz):
     np.testing.assert_allclose(pi, mesh["pos"], rtol=1e-6, atol=2e-5)
 
 
+def test_single_process_comm_init_all_one_rank(rz):
+    """ncclCommInitAll / grouped all-gather entry points (one Node process driving several GPUs) with one GPU."""
+    mesh = synth.make_mesh(3000, 10, seed=43)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    c.set_pose(mesh["world"])
+    c.deform()
+    pg, ng = c.read()
+    rz.capi.comm_init_all([c], 3000)
+    rz.capi.allgather_all([c], with_normals=True)
+    p2, n2 = c.read_gathered()
+    assert np.array_equal(p2, pg) and np.array_equal(n2, ng)
+    c2 = rz.DeformContext(0)
+    c2.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    with pytest.raises(rz.RzError):
+        rz.capi.comm_init_all([c, c2], 6000)          # two ranks on one GPU are refused, with a message
+    c.close()
+    c2.close()
+
+
 def test_allgather_single_rank_roundtrip(ctx, rz, oracle):
     """RCCL all-gather entry points with a world of 1: gathered buffer == local result."""
     mesh = synth.make_mesh(5000, 20, seed=41)
@@ -324,11 +345,12 @@ def test_engine_through_napi_matches_oracle(tmp_path, oracle):
     (tmp_path / "a.vmd").write_bytes(write_vmd(
         [("bone1", 0, (0, 0, s, 0.92387953)), ("bone3", 0, (s, 0, 0, 0.92387953)), ("bone1", 15, (0, s, 0, 0.92387953)),
          ("bone20", 30, (0, 0, -s, 0.92387953))], [("v1", 0, 0.8), ("v2", 6, 0.4)]))
-    for layout in ("sparse", "dense"):
-        out = tmp_path / layout
+    for layout, devs in (("sparse", "0"), ("dense", "0"), ("sparse", "0,0"), ("dense", "0,0,0")):
+        # "0,0": the Engine's multi-GPU sharding (one context per listed device) exercised as 2-3 shards on one GPU
+        out = tmp_path / (layout + devs.replace(",", "_"))
         out.mkdir()
         subprocess.check_call(["node", os.path.join(root, "tests", "js", "engine_e2e.js"), str(tmp_path / "m.pmx"),
-                               str(tmp_path / "a.vmd"), str(out), layout], timeout=300)
+                               str(tmp_path / "a.vmd"), str(out), layout, devs], timeout=300)
         rd = lambda f, dt: np.fromfile(str(out / f), dtype=dt)  # noqa: E731
         v = rd("vertices.f32", np.float32).reshape(-1, 8)
         joints = rd("joints.u16", np.uint16).reshape(-1, 4)
@@ -345,7 +367,7 @@ def test_engine_through_napi_matches_oracle(tmp_path, oracle):
             pr, nr = oracle.skin(pm, v[:, 3:6], joints, weights, S)
             pg = rd("pos_%d.f32" % step, np.float32).reshape(-1, 3)
             ng = rd("nrm_%d.f32" % step, np.float32).reshape(-1, 3)
-            assert_parity(pg, ng, pr, nr, "napi %s step %d" % (layout, step))
+            assert_parity(pg, ng, pr, nr, "napi %s devices %s step %d" % (layout, devs, step))
             seen_morph = seen_morph or (mw != 0).sum() >= 3
             assert not np.allclose(pg, v[:, 0:3])            # the pose really moved the mesh
         assert seen_morph
