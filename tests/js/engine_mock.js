@@ -8,7 +8,7 @@ const native = {
   create: () => ({}), destroy: () => {}, uploadMesh: () => calls.push('uploadMesh'), uploadSkeleton: () => calls.push('uploadSkeleton'),
   uploadMorphsSparse: () => calls.push('uploadMorphsSparse'), uploadMorphsDense: () => calls.push('uploadMorphsDense'),
   setPose: (c, w, mw) => calls.push(['setPose', Array.from(w.slice(0, 16)), mw ? Array.from(mw) : null]), deform: () => calls.push('deform'),
-  read: () => {},
+  read: () => {}, shardRange: (v) => [0, v],
 }
 const bones = ['root', 'a', 'b'].map((name, i) => ({ name, parentIndex: i - 1, bindTranslation: [0, 1, 0], children: [] }))
 const morphs = { names: ['m0', 'g'], types: Uint8Array.from([1, 0]), panels: new Uint8Array(2), groups: [null, [[0, 0.5]]],
@@ -18,7 +18,7 @@ const model = new Model(new Float32Array(8), new Uint32Array(3), [], [], { bones
 const q = (x, y, z, w) => new Quat(x, y, z, w)
 ;(async () => {
   const e = new Engine(null, { realtime: false })
-  e.native = native; e.ctx = {}
+  e.native = native; e.ctx = {}; e.shards = [{ ctx: e.ctx, begin: 0, count: 0 }]
   await e.setupModelBuffers(model)
   const frames = [
     { time: 0, boneFrames: [{ boneName: 'a', frame: 0, rotation: q(0, 0, 0.7071068, 0.7071068) }] },
