@@ -100,6 +100,20 @@ int rz_set_instances(rz_ctx *ctx, uint32_t I);
  * through pinned staging; the data is consumed by the next rz_deform(). */
 int rz_set_pose(rz_ctx *ctx, const float *world, const float *morph_weights);
 
+/* ---- forward kinematics on the device (optional) ----
+ * rz_upload_skeleton_topology hands over what Model.computeWorldMatrices (engine/src/model.ts:330-420) reads from
+ * the skeleton: parents[B] (-1 = root), bind_translation[B*3] (Bone.bindTranslation), and the append-rotation
+ * data of model.ts:355-386: append_parent[B] (-1 or NULL = none) and append_ratio[B] (NULL = all 1).
+ * rz_set_pose_local then replaces rz_set_pose: it uploads local rotations (I x B x 4, x y z w — the
+ * SkeletonRuntime.localRotations array, model.ts:55) instead of world matrices, and the frame computes the world
+ * matrices and the palette on the GPU (f32; the host solves in doubles with f32 stores, so results agree to
+ * ~1e-6, not bit for bit). 4x less per-frame upload; hierarchy solve for all instances in one launch. */
+int rz_upload_skeleton_topology(rz_ctx *ctx, uint32_t B, const int32_t *parents, const float *bind_translation3,
+                                const int32_t *append_parent, const float *append_ratio);
+int rz_set_pose_local(rz_ctx *ctx, const float *local_rotations4, const float *morph_weights);
+/* Blocking readback of one instance's world matrices (B x 16, column-major) as the frame used them. */
+int rz_read_world(rz_ctx *ctx, uint32_t instance, float *world16);
+
 /* computeSkinMatrices() dispatch  engine/src/engine.ts:2393-2402 (WGSL :906-930) followed by the
  * per-vertex body of vs()  engine/src/engine.ts:253-272 (copies :440-443/:700-703), executed
  * once per frame instead of once per draw pass. Enqueues the frame; asynchronous. */

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libreze_deform.so")
 SYMBOLS = [
     "rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_destroy", "rz_shard_range",
     "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
-    "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
+    "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_read_world", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
     "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_output_ptrs",
     "rz_comm_unique_id", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all",
 ]
@@ -64,6 +64,10 @@ def load():
     L.rz_upload_morphs_sparse.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), fp]
     L.rz_set_instances.argtypes = [vp, u32]
     L.rz_set_pose.argtypes = [vp, fp, fp]
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    L.rz_upload_skeleton_topology.argtypes = [vp, u32, i32p, fp, i32p, fp]
+    L.rz_set_pose_local.argtypes = [vp, fp, fp]
+    L.rz_read_world.argtypes = [vp, u32, fp]
     L.rz_deform.argtypes = [vp]
     L.rz_deform_n.argtypes = [vp, u32]
     L.rz_sync.argtypes = [vp]
@@ -219,6 +223,31 @@ class DeformContext:
             _chk(self._L.rz_set_pose(self._h, _fptr(w), _fptr(mw)))
         else:
             _chk(self._L.rz_set_pose(self._h, _fptr(w), None))
+
+    def upload_skeleton_topology(self, parents, bind_translation, append_parent=None, append_ratio=None):
+        par = np.ascontiguousarray(parents, dtype=np.int32)
+        bind = _f32(bind_translation).reshape(-1, 3)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        ap = None if append_parent is None else np.ascontiguousarray(append_parent, dtype=np.int32)
+        ar = None if append_ratio is None else _f32(append_ratio)
+        _chk(self._L.rz_upload_skeleton_topology(
+            self._h, len(par), par.ctypes.data_as(i32p), _fptr(bind),
+            None if ap is None else ap.ctypes.data_as(i32p), None if ar is None else _fptr(ar)))
+
+    def set_pose_local(self, local_rotations, morph_weights=None):
+        q = _f32(local_rotations).reshape(-1)
+        assert q.size == self.I * self.B * 4, (q.size, self.I, self.B)
+        if morph_weights is not None and self.M > 0:
+            mw = _f32(morph_weights).reshape(-1)
+            assert mw.size == self.I * self.M
+            _chk(self._L.rz_set_pose_local(self._h, _fptr(q), _fptr(mw)))
+        else:
+            _chk(self._L.rz_set_pose_local(self._h, _fptr(q), None))
+
+    def read_world(self, instance=0):
+        out = np.empty((self.B, 16), dtype=np.float32)
+        _chk(self._L.rz_read_world(self._h, int(instance), _fptr(out)))
+        return out
 
     def deform(self):
         _chk(self._L.rz_deform(self._h))

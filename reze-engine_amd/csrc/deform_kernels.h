@@ -19,6 +19,22 @@ struct RzPrepParams {
     int Mpad;
 };
 
+// rz_fk_kernel: forward kinematics + palette on the device (engine/src/model.ts:330-420, engine.ts:926-928).
+struct RzFkParams {
+    const float4 *local_q;      // [I][B] local rotations (x,y,z,w)
+    const int *parents;         // [B] -1 = root
+    const float *bind;          // [B][3] parent-relative bind translations
+    const int *append_parent;   // [B] -1 = no append rotation
+    const float *append_ratio;  // [B]
+    const int *order;           // [B] bones sorted by hierarchy level
+    const int *level_off;       // [n_levels + 1]
+    const float *inv_bind;      // [B][16]
+    float *world;               // [I][B][16] out
+    float4 *palette;            // [I][B][3] out
+    int B;
+    int n_levels;
+};
+
 // rz_deform_kernel: fused morph + 4-bone LBS (engine/src/engine.ts:253-272).
 struct RzDeformParams {
     const float *geom;          // 6 planes of Vp floats: x y z nx ny nz
@@ -70,6 +86,7 @@ struct RzVariant {
 };
 
 hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t st);
+hipError_t rz_launch_fk(const RzFkParams &p, uint32_t instances, hipStream_t st);
 hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, const RzVariant &v, uint32_t grid_x,
                             uint32_t instances, hipStream_t st);
 size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v);

@@ -110,6 +110,118 @@ __global__ void __launch_bounds__(kBlock) rz_prep_kernel(RzPrepParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward kinematics on the device: the reference's Model.computeWorldMatrices
+// (engine/src/model.ts:330-420) for I poses at once, fused with the palette product (engine.ts:926-928).
+// One workgroup per pose; bones are processed level by level (all bones of a level in parallel, one
+// barrier per level), parents are read back from LDS as 3x4 affine rows. Per bone:
+//   R = fromQuat(q)                                              math.ts:352-384
+//   append rotation: R = fromQuat(slerp(I, +-q_append, |ratio|)) * R    model.ts:359-386 (uses the append
+//                    parent's LOCAL rotation, so it adds no ordering dependency)
+//   L = T(bind) * R ;  W = W_parent * L                           model.ts:398-414
+// f32 throughout (the host computes in doubles with f32 stores): differences are ~1e-7 relative per level.
+// Writes world [I][B][16] column-major and palette [I][B][3] rows of W * inverseBind.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void quat_to_rows(float x, float y, float z, float w, float (&r)[9])
+{
+    const float x2 = x + x, y2 = y + y, z2 = z + z;
+    const float xx = x * x2, xy = x * y2, xz = x * z2, yy = y * y2, yz = y * z2, zz = z * z2;
+    const float wx = w * x2, wy = w * y2, wz = w * z2;
+    // row-major 3x3: r[row*3+col]; column-major source: out[0]=1-(yy+zz), out[1]=xy+wz, out[2]=xz-wy, out[4]=xy-wz ...
+    r[0] = 1.0f - (yy + zz); r[1] = xy - wz;          r[2] = xz + wy;
+    r[3] = xy + wz;          r[4] = 1.0f - (xx + zz); r[5] = yz - wx;
+    r[6] = xz - wy;          r[7] = yz + wx;          r[8] = 1.0f - (xx + yy);
+}
+
+__global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *wl = reinterpret_cast<float4 *>(smem);       // B x 3 rows of the world matrices of this pose
+    const int inst = blockIdx.x, tid = threadIdx.x;
+    const float4 *lq = p.local_q + (size_t)inst * p.B;
+    float *world = p.world + (size_t)inst * p.B * 16;
+    float4 *pal = p.palette + (size_t)inst * p.B * 3;
+    for (int l = 0; l < p.n_levels; ++l) {
+        const int lo = p.level_off[l], hi = p.level_off[l + 1];
+        for (int idx = lo + tid; idx < hi; idx += kBlock) {
+            const int b = p.order[idx];
+            const float4 q = lq[b];
+            float R[9];
+            quat_to_rows(q.x, q.y, q.z, q.w, R);
+            const int ap = p.append_parent[b];
+            if (ap >= 0) {
+                const float ratio = fminf(1.0f, fmaxf(-1.0f, p.append_ratio[b]));
+                if (fabsf(ratio) > 1e-6f) {
+                    float4 a = lq[ap];
+                    const float t = fabsf(ratio);
+                    if (ratio < 0.0f) { a.x = -a.x; a.y = -a.y; a.z = -a.z; }
+                    // Quat.slerp(identity, a, t)  (math.ts:156-189)
+                    float c = a.w;
+                    if (c < 0.0f) { c = -c; a.x = -a.x; a.y = -a.y; a.z = -a.z; a.w = -a.w; }
+                    float sx, sy, sz, sw;
+                    if (c > 0.9995f) {
+                        sx = t * a.x; sy = t * a.y; sz = t * a.z; sw = 1.0f + t * (a.w - 1.0f);
+                        const float il = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz + sw * sw);
+                        sx *= il; sy *= il; sz *= il; sw *= il;
+                    } else {
+                        const float th0 = acosf(c), sn = sinf(th0), th = th0 * t;
+                        const float s0 = sinf(th0 - th) / sn, s1 = sinf(th) / sn;
+                        sx = s1 * a.x; sy = s1 * a.y; sz = s1 * a.z; sw = s0 + s1 * a.w;
+                    }
+                    float A[9], X[9];
+                    quat_to_rows(sx, sy, sz, sw, A);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) X[i * 3 + j] = A[i * 3] * R[j] + A[i * 3 + 1] * R[3 + j] + A[i * 3 + 2] * R[6 + j];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) R[i] = X[i];
+                }
+            }
+            const float tx = p.bind[b * 3], ty = p.bind[b * 3 + 1], tz = p.bind[b * 3 + 2];
+            float W[12];   // 3 rows x 4
+            const int par = p.parents[b];
+            if (par >= 0) {
+                const float4 p0 = wl[par * 3], p1 = wl[par * 3 + 1], p2 = wl[par * 3 + 2];
+                const float P[12] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w };
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) W[i * 4 + j] = P[i * 4] * R[j] + P[i * 4 + 1] * R[3 + j] + P[i * 4 + 2] * R[6 + j];
+                    W[i * 4 + 3] = P[i * 4] * tx + P[i * 4 + 1] * ty + P[i * 4 + 2] * tz + P[i * 4 + 3];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { W[i * 4] = R[i * 3]; W[i * 4 + 1] = R[i * 3 + 1]; W[i * 4 + 2] = R[i * 3 + 2]; }
+                W[3] = tx; W[7] = ty; W[11] = tz;
+            }
+            wl[b * 3] = make_float4(W[0], W[1], W[2], W[3]);
+            wl[b * 3 + 1] = make_float4(W[4], W[5], W[6], W[7]);
+            wl[b * 3 + 2] = make_float4(W[8], W[9], W[10], W[11]);
+            // world, column-major 4x4 (what queue.writeBuffer(worldMatrixBuffer) would have carried)
+            float4 *wo = reinterpret_cast<float4 *>(world + (size_t)b * 16);
+            wo[0] = make_float4(W[0], W[4], W[8], 0.0f);
+            wo[1] = make_float4(W[1], W[5], W[9], 0.0f);
+            wo[2] = make_float4(W[2], W[6], W[10], 0.0f);
+            wo[3] = make_float4(W[3], W[7], W[11], 1.0f);
+            // palette rows 0..2 of W * IB (IB general 4x4, column-major)
+            const float4 *Im = reinterpret_cast<const float4 *>(p.inv_bind + (size_t)b * 16);
+            float r[3][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 bc = Im[c];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    r[i][c] = fmaf(W[i * 4 + 3], bc.w, fmaf(W[i * 4 + 2], bc.z, fmaf(W[i * 4 + 1], bc.y, W[i * 4] * bc.x)));
+            }
+            pal[b * 3] = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]);
+            pal[b * 3 + 1] = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]);
+            pal[b * 3 + 2] = make_float4(r[2][0], r[2][1], r[2][2], r[2][3]);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // helpers for the skin phase
 // ------------------------------------------------------------------------------------------------
 struct Skinned { float px, py, pz, nx, ny, nz; };
@@ -723,6 +835,17 @@ __global__ void rz_pack_skinning_kernel(const uint16_t *joints4, const uint8_t *
 hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t st)
 {
     hipLaunchKernelGGL(rz_prep_kernel, dim3(instances), dim3(kBlock), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t rz_launch_fk(const RzFkParams &p, uint32_t instances, hipStream_t st)
+{
+    const size_t lds = (size_t)p.B * 48;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rz_fk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(rz_fk_kernel, dim3(instances), dim3(kBlock), lds, st, p);
     return hipGetLastError();
 }
 

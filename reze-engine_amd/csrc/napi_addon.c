@@ -250,6 +250,51 @@ static napi_value fn_set_pose(napi_env env, napi_callback_info info)
     return rc ? throw_rz(env, rc) : undef(env);
 }
 
+static napi_value fn_upload_topology(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    CTX(0);
+    void *par, *bind, *ap = NULL, *ar = NULL;
+    size_t npar, nbind, nap = 0, nar = 0;
+    if (!get_ta(env, argv[1], napi_int32_array, 0, &par, &npar) || !get_ta(env, argv[2], napi_float32_array, 0, &bind, &nbind) || nbind != npar * 3)
+        return throw_msg(env, "uploadSkeletonTopology(ctx, Int32Array parents, Float32Array bindTranslation /* B*3 */, Int32Array|null appendParent, Float32Array|null appendRatio)");
+    if (argc > 3 && !get_ta(env, argv[3], napi_int32_array, 1, &ap, &nap)) return throw_msg(env, "appendParent must be an Int32Array or null");
+    if (argc > 4 && !get_ta(env, argv[4], napi_float32_array, 1, &ar, &nar)) return throw_msg(env, "appendRatio must be a Float32Array or null");
+    if ((ap && nap != npar) || (ar && nar != npar)) return throw_msg(env, "uploadSkeletonTopology: array lengths disagree");
+    int rc = rz_upload_skeleton_topology(ctx, (uint32_t)npar, (const int32_t *)par, (const float *)bind, (const int32_t *)ap, (const float *)ar);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_set_pose_local(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    CTX(0);
+    void *q, *mw = NULL;
+    size_t nq, nmw = 0;
+    if (!get_ta(env, argv[1], napi_float32_array, 0, &q, &nq)) return throw_msg(env, "setPoseLocal(ctx, Float32Array localRotations, Float32Array|null morphWeights)");
+    if (argc > 2 && !get_ta(env, argv[2], napi_float32_array, 1, &mw, &nmw)) return throw_msg(env, "setPoseLocal: morphWeights must be a Float32Array or null");
+    int B = 0, M = 0, I = 0;
+    if (rz_get_tuning(ctx, "bones", &B) || rz_get_tuning(ctx, "morphs", &M) || rz_get_tuning(ctx, "instances", &I)) return throw_rz(env, RZ_ERR_INVALID);
+    if (nq != (size_t)I * B * 4) return throw_msg(env, "setPoseLocal: localRotations must hold instances*bones*4 floats");
+    if (mw && nmw != (size_t)I * M) return throw_msg(env, "setPoseLocal: morphWeights must hold instances*morphs floats");
+    int rc = rz_set_pose_local(ctx, (const float *)q, (const float *)mw);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_read_world(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    CTX(0);
+    uint32_t inst;
+    void *o;
+    size_t n;
+    int B = 0;
+    if (!get_u32(env, argv[1], &inst) || !get_ta(env, argv[2], napi_float32_array, 0, &o, &n)) return throw_msg(env, "readWorld(ctx, instance, Float32Array out /* B*16 */)");
+    if (rz_get_tuning(ctx, "bones", &B) || n < (size_t)B * 16) return throw_msg(env, "readWorld: output array too small");
+    int rc = rz_read_world(ctx, inst, (float *)o);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
 static napi_value fn_deform(napi_env env, napi_callback_info info)
 {
     ARGS(1);
@@ -457,7 +502,8 @@ static napi_value init(napi_env env, napi_value exports)
         { "destroy", fn_destroy }, { "shardRange", fn_shard_range }, { "uploadMesh", fn_upload_mesh },
         { "uploadMeshSoa", fn_upload_mesh_soa }, { "uploadSkeleton", fn_upload_skeleton },
         { "uploadMorphsDense", fn_upload_morphs_dense }, { "uploadMorphsSparse", fn_upload_morphs_sparse },
-        { "setInstances", fn_set_instances }, { "setPose", fn_set_pose }, { "deform", fn_deform },
+        { "setInstances", fn_set_instances }, { "setPose", fn_set_pose }, { "uploadSkeletonTopology", fn_upload_topology },
+        { "setPoseLocal", fn_set_pose_local }, { "readWorld", fn_read_world }, { "deform", fn_deform },
         { "deformN", fn_deform_n }, { "sync", fn_sync }, { "read", fn_read }, { "readPalette", fn_read_palette },
         { "timeFrames", fn_time_frames }, { "setTuning", fn_set_tuning }, { "getTuning", fn_get_tuning },
         { "commUniqueId", fn_comm_unique_id }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },

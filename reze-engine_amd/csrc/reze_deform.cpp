@@ -108,6 +108,14 @@ struct rz_ctx {
     // skeleton
     uint32_t B = 0;
     float *inv_bind = nullptr;          // B x 16
+    // optional topology for on-device FK
+    bool has_topology = false;
+    int *fk_parents = nullptr, *fk_append_parent = nullptr, *fk_order = nullptr, *fk_level_off = nullptr;
+    float *fk_bind = nullptr, *fk_append_ratio = nullptr;
+    int fk_levels = 0;
+    float4 *local_q = nullptr;          // I x B
+    size_t local_q_alloc = 0;
+    bool pose_local = false;            // the current pose came from rz_set_pose_local
 
     // morphs
     int morph_mode = 0;                 // 0 none, 1 dense, 2 sparse
@@ -166,6 +174,13 @@ template <class T> void dfree(T *&p)
 {
     if (p) { (void)hipFree(p); p = nullptr; }
 }
+
+// upload-time scratch that is released on every exit path (HIP_TRY returns early on failure)
+template <class T> struct Scratch {
+    T *p = nullptr;
+    ~Scratch() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc(&p, count * sizeof(T)); }
+};
 
 int ensure_outputs(rz_ctx *c)
 {
@@ -342,6 +357,33 @@ int check_ready(rz_ctx *c)
     return RZ_OK;
 }
 
+int launch_prep(rz_ctx *c);
+
+int launch_fk(rz_ctx *c)
+{
+    RzFkParams p;
+    memset(&p, 0, sizeof p);
+    p.local_q = c->local_q; p.parents = c->fk_parents; p.bind = c->fk_bind; p.append_parent = c->fk_append_parent;
+    p.append_ratio = c->fk_append_ratio; p.order = c->fk_order; p.level_off = c->fk_level_off; p.inv_bind = c->inv_bind;
+    p.world = c->world; p.palette = c->palette; p.B = (int)c->B; p.n_levels = c->fk_levels;
+    HIP_TRY(rz_launch_fk(p, c->I, c->stream));
+    return RZ_OK;
+}
+
+// Everything a frame launches in front of the deform kernel: on-device FK (local-rotation poses) and/or the prep
+// kernel. The FK kernel already writes the palette, so prep is only still needed for its morph compaction.
+int launch_front(rz_ctx *c, const Plan &pl)
+{
+    if (c->pose_local) {
+        if (int r = launch_fk(c)) return r;
+        if (pl.prep && c->morph_mode == 1)
+            if (int r = launch_prep(c)) return r;
+        return RZ_OK;
+    }
+    if (pl.prep) return launch_prep(c);
+    return RZ_OK;
+}
+
 int launch_prep(rz_ctx *c)
 {
     HIP_TRY(rz_launch_prep(prep_params(c), c->I, c->stream));
@@ -378,16 +420,14 @@ uint64_t algorithmic_bytes(const rz_ctx *c)
 
 int upload_skinning(rz_ctx *c, uint32_t V, const uint16_t *joints4, const uint8_t *weights4)
 {
-    uint16_t *dj = nullptr;
-    uint8_t *dw = nullptr;
-    HIP_TRY(hipMalloc(&dj, (size_t)V * 8));
-    HIP_TRY(hipMalloc(&dw, (size_t)V * 4));
-    HIP_TRY(hipMemcpy(dj, joints4, (size_t)V * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dw, weights4, (size_t)V * 4, hipMemcpyHostToDevice));
-    HIP_TRY(rz_launch_pack_skinning(dj, dw, V, c->j01, c->j23, c->wq, c->stream));
+    Scratch<uint16_t> dj;
+    Scratch<uint8_t> dw;
+    HIP_TRY(dj.alloc((size_t)V * 4));
+    HIP_TRY(dw.alloc((size_t)V * 4));
+    HIP_TRY(hipMemcpy(dj.p, joints4, (size_t)V * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dw.p, weights4, (size_t)V * 4, hipMemcpyHostToDevice));
+    HIP_TRY(rz_launch_pack_skinning(dj.p, dw.p, V, c->j01, c->j23, c->wq, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(dj);
-    (void)hipFree(dw);
     return RZ_OK;
 }
 
@@ -467,6 +507,8 @@ int rz_destroy(rz_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->inv_bind);
+    dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind);
+    dfree(c->fk_append_ratio); dfree(c->local_q);
     free_morphs(c);
     dfree(c->world); dfree(c->palette); dfree(c->morph_w); dfree(c->act_idx); dfree(c->act_w); dfree(c->act_count);
     dfree(c->out_pos); dfree(c->out_nrm); dfree(c->g_pos); dfree(c->g_nrm);
@@ -499,14 +541,14 @@ int rz_upload_mesh(rz_ctx *c, uint32_t V, const float *interleaved8, const uint1
     if (int r = use(c)) return r;
     if (V == 0 || !interleaved8 || !joints4 || !weights4) return fail(RZ_ERR_INVALID, "rz_upload_mesh: empty mesh or null array");
     if (int r = alloc_mesh(c, V)) return r;
-    float *tmp = nullptr;
-    HIP_TRY(hipMalloc(&tmp, (size_t)V * 8 * sizeof(float)));
+    Scratch<float> scratch;
+    HIP_TRY(scratch.alloc((size_t)V * 8));
+    float *tmp = scratch.p;
     HIP_TRY(hipMemcpy(tmp, interleaved8, (size_t)V * 8 * sizeof(float), hipMemcpyHostToDevice));
     const size_t Vp = c->Vp;
     HIP_TRY(rz_launch_deinterleave(tmp, 8, 0, V, c->geom, c->geom + Vp, c->geom + 2 * Vp, c->stream));
     HIP_TRY(rz_launch_deinterleave(tmp, 8, 3, V, c->geom + 3 * Vp, c->geom + 4 * Vp, c->geom + 5 * Vp, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(tmp);
     if (int r = upload_skinning(c, V, joints4, weights4)) return r;
     return ensure_outputs(c);
 }
@@ -517,8 +559,9 @@ int rz_upload_mesh_soa(rz_ctx *c, uint32_t V, const float *pos3, const float *nr
     if (int r = use(c)) return r;
     if (V == 0 || !pos3 || !nrm3 || !joints4 || !weights4) return fail(RZ_ERR_INVALID, "rz_upload_mesh_soa: empty mesh or null array");
     if (int r = alloc_mesh(c, V)) return r;
-    float *tmp = nullptr;
-    HIP_TRY(hipMalloc(&tmp, (size_t)V * 3 * sizeof(float)));
+    Scratch<float> scratch;
+    HIP_TRY(scratch.alloc((size_t)V * 3));
+    float *tmp = scratch.p;
     const size_t Vp = c->Vp;
     HIP_TRY(hipMemcpy(tmp, pos3, (size_t)V * 3 * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(rz_launch_deinterleave(tmp, 3, 0, V, c->geom, c->geom + Vp, c->geom + 2 * Vp, c->stream));
@@ -526,7 +569,6 @@ int rz_upload_mesh_soa(rz_ctx *c, uint32_t V, const float *pos3, const float *nr
     HIP_TRY(hipMemcpy(tmp, nrm3, (size_t)V * 3 * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(rz_launch_deinterleave(tmp, 3, 0, V, c->geom + 3 * Vp, c->geom + 4 * Vp, c->geom + 5 * Vp, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(tmp);
     if (int r = upload_skinning(c, V, joints4, weights4)) return r;
     return ensure_outputs(c);
 }
@@ -542,6 +584,7 @@ int rz_upload_skeleton(rz_ctx *c, uint32_t B, const float *inverse_bind16)
     HIP_TRY(hipMemcpy(c->inv_bind, inverse_bind16, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice));
     c->B = B;
     c->pose_set = false;
+    c->has_topology = false;            // belongs to the previous skeleton
     return ensure_pose_buffers(c);
 }
 
@@ -558,8 +601,9 @@ int rz_upload_morphs_dense(rz_ctx *c, uint32_t M, const float *deltas)
     if (Vp != V) HIP_TRY(hipMemsetAsync(c->dense, 0, (size_t)M * 3 * Vp * sizeof(float), c->stream));
     // stream the host array through a bounded device staging buffer, re-laying each morph into planes
     const uint32_t batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(M, (64u << 20) / (V * 12)));
-    float *tmp = nullptr;
-    HIP_TRY(hipMalloc(&tmp, (size_t)batch * V * 3 * sizeof(float)));
+    Scratch<float> scratch;
+    HIP_TRY(scratch.alloc((size_t)batch * V * 3));
+    float *tmp = scratch.p;
     for (uint32_t m0 = 0; m0 < M; m0 += batch) {
         const uint32_t nb = std::min(batch, M - m0);
         HIP_TRY(hipMemcpy(tmp, deltas + (size_t)m0 * V * 3, (size_t)nb * V * 3 * sizeof(float), hipMemcpyHostToDevice));
@@ -569,7 +613,6 @@ int rz_upload_morphs_dense(rz_ctx *c, uint32_t M, const float *deltas)
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    (void)hipFree(tmp);
     c->morph_mode = 1;
     c->M = M;
     c->Mpad = round_up(M + 8, 4);
@@ -663,6 +706,7 @@ int rz_set_pose(rz_ctx *c, const float *world, const float *morph_weights)
     HIP_TRY(hipEventRecord(c->stage_ev[slot], c->stream));
     c->stage_used[slot] = true;
     // ordered compaction of the non-zero weights for the one-launch path (instance 0)
+    c->pose_local = false;
     memset(&c->ml, 0, sizeof c->ml);
     if (c->M > 0 && morph_weights && c->I == 1) {
         int n = 0;
@@ -678,14 +722,130 @@ int rz_set_pose(rz_ctx *c, const float *world, const float *morph_weights)
     return RZ_OK;
 }
 
+int rz_upload_skeleton_topology(rz_ctx *c, uint32_t B, const int32_t *parents, const float *bind_translation3,
+                                const int32_t *append_parent, const float *append_ratio)
+{
+    if (int r = use(c)) return r;
+    if (B == 0 || B != c->B) return fail(RZ_ERR_INVALID, "topology has %u bones but the uploaded skeleton has %u", B, c->B);
+    if (!parents || !bind_translation3) return fail(RZ_ERR_INVALID, "null topology arrays");
+    // hierarchy levels (parents may come in any order, like the reference's recursive solve; cycles are an error)
+    std::vector<int> level(B, -1);
+    for (uint32_t b = 0; b < B; ++b) {
+        if (parents[b] >= (int32_t)B) return fail(RZ_ERR_INVALID, "bone %u parent %d out of range", b, parents[b]);
+        std::vector<uint32_t> chain;
+        uint32_t cur = b;
+        while (level[cur] < 0) {
+            chain.push_back(cur);
+            if (chain.size() > B) return fail(RZ_ERR_INVALID, "bone hierarchy has a cycle through bone %u", b);
+            if (parents[cur] < 0) { level[cur] = 0; chain.pop_back(); break; }
+            cur = (uint32_t)parents[cur];
+        }
+        for (size_t k = chain.size(); k-- > 0;) level[chain[k]] = level[(uint32_t)parents[chain[k]]] + 1;
+    }
+    int n_levels = 0;
+    for (uint32_t b = 0; b < B; ++b) n_levels = std::max(n_levels, level[b] + 1);
+    std::vector<int> off(n_levels + 1, 0), order(B), ap(B, -1);
+    std::vector<float> ratio(B, 1.0f);
+    for (uint32_t b = 0; b < B; ++b) off[level[b] + 1]++;
+    for (int l = 0; l < n_levels; ++l) off[l + 1] += off[l];
+    std::vector<int> cur(off.begin(), off.end() - 1);
+    for (uint32_t b = 0; b < B; ++b) order[cur[level[b]]++] = (int)b;
+    for (uint32_t b = 0; b < B; ++b) {
+        if (append_parent && append_parent[b] >= 0 && append_parent[b] < (int32_t)B) ap[b] = append_parent[b];
+        if (append_ratio) ratio[b] = append_ratio[b];
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind); dfree(c->fk_append_ratio);
+    HIP_TRY(hipMalloc(&c->fk_parents, B * sizeof(int)));
+    HIP_TRY(hipMalloc(&c->fk_append_parent, B * sizeof(int)));
+    HIP_TRY(hipMalloc(&c->fk_order, B * sizeof(int)));
+    HIP_TRY(hipMalloc(&c->fk_level_off, (n_levels + 1) * sizeof(int)));
+    HIP_TRY(hipMalloc(&c->fk_bind, (size_t)B * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->fk_append_ratio, B * sizeof(float)));
+    HIP_TRY(hipMemcpy(c->fk_parents, parents, B * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->fk_append_parent, ap.data(), B * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->fk_order, order.data(), B * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->fk_level_off, off.data(), (n_levels + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->fk_bind, bind_translation3, (size_t)B * 3 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->fk_append_ratio, ratio.data(), B * sizeof(float), hipMemcpyHostToDevice));
+    c->fk_levels = n_levels;
+    c->has_topology = true;
+    return RZ_OK;
+}
+
+int rz_set_pose_local(rz_ctx *c, const float *local_rotations4, const float *morph_weights)
+{
+    if (int r = use(c)) return r;
+    if (!c->has_topology) return fail(RZ_ERR_INVALID, "rz_upload_skeleton_topology has not been called for this skeleton");
+    if (!local_rotations4) return fail(RZ_ERR_INVALID, "null local rotations");
+    if (int r = ensure_pose_buffers(c)) return r;
+    const size_t nq = (size_t)c->I * c->B;
+    if (nq > c->local_q_alloc) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        dfree(c->local_q);
+        HIP_TRY(hipMalloc(&c->local_q, nq * sizeof(float4)));
+        c->local_q_alloc = nq;
+    }
+    const size_t qb = nq * sizeof(float4);
+    const size_t mb = (size_t)c->I * c->M * sizeof(float);
+    const size_t need = std::max(qb + mb, (size_t)c->I * c->B * 64 + mb);
+    if (need > c->stage_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < kStageSlots; ++i) {
+            if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; }
+            HIP_TRY(hipHostMalloc(&c->stage[i], need, hipHostMallocDefault));
+            c->stage_used[i] = false;
+        }
+        c->stage_bytes = need;
+    }
+    const int slot = c->stage_next;
+    c->stage_next = (slot + 1) % kStageSlots;
+    if (c->stage_used[slot]) HIP_TRY(hipEventSynchronize(c->stage_ev[slot]));
+    char *s = static_cast<char *>(c->stage[slot]);
+    memcpy(s, local_rotations4, qb);
+    HIP_TRY(hipMemcpyAsync(c->local_q, s, qb, hipMemcpyHostToDevice, c->stream));
+    if (c->M > 0) {
+        if (morph_weights) {
+            memcpy(s + qb, morph_weights, mb);
+            HIP_TRY(hipMemcpyAsync(c->morph_w, s + qb, mb, hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIP_TRY(hipMemsetAsync(c->morph_w, 0, mb, c->stream));
+        }
+    }
+    HIP_TRY(hipEventRecord(c->stage_ev[slot], c->stream));
+    c->stage_used[slot] = true;
+    memset(&c->ml, 0, sizeof c->ml);
+    if (c->M > 0 && morph_weights && c->I == 1) {
+        int n = 0;
+        for (uint32_t m = 0; m < c->M; ++m) {
+            const float w = morph_weights[m];
+            if (w == 0.0f) continue;
+            if (n < kKargMorphs) { c->ml.idx[n] = m; c->ml.w[n] = w; }
+            ++n;
+        }
+        c->ml.count = n <= kKargMorphs ? n : -1;
+    }
+    c->pose_local = true;
+    c->pose_set = true;
+    return RZ_OK;
+}
+
+int rz_read_world(rz_ctx *c, uint32_t instance, float *world16)
+{
+    if (int r = use(c)) return r;
+    if (instance >= c->I || !world16 || !c->world) return fail(RZ_ERR_INVALID, "bad world read");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(world16, c->world + (size_t)instance * c->B * 16, (size_t)c->B * 16 * sizeof(float), hipMemcpyDeviceToHost));
+    return RZ_OK;
+}
+
 int rz_deform(rz_ctx *c)
 {
     if (int r = use(c)) return r;
     if (int r = check_ready(c)) return r;
     if (int r = ensure_outputs(c)) return r;
     const Plan pl = make_plan(c);
-    if (pl.prep)
-        if (int r = launch_prep(c)) return r;
+    if (int r = launch_front(c, pl)) return r;
     return launch_deform(c, pl);
 }
 
@@ -696,8 +856,7 @@ int rz_deform_n(rz_ctx *c, uint32_t frames)
     if (int r = ensure_outputs(c)) return r;
     const Plan pl = make_plan(c);
     for (uint32_t f = 0; f < frames; ++f) {
-        if (pl.prep)
-            if (int r = launch_prep(c)) return r;
+        if (int r = launch_front(c, pl)) return r;
         if (int r = launch_deform(c, pl)) return r;
     }
     return RZ_OK;
@@ -742,13 +901,11 @@ int rz_time_frames(rz_ctx *c, uint32_t frames, rz_timing *out)
     memset(out, 0, sizeof *out);
     float ms = 0.f;
     // whole frames (prep kernel when the plan needs one + fused kernel), back to back on the context's stream
-    if (pl.prep)
-        if (int r = launch_prep(c)) return r;     // !FAST: the deform-only loop below needs a palette
+    if (int r = launch_front(c, pl)) return r;    // the deform-only loop below needs a palette
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     for (uint32_t f = 0; f < frames; ++f) {
-        if (pl.prep)
-            if (int r = launch_prep(c)) return r;
+        if (int r = launch_front(c, pl)) return r;
         if (int r = launch_deform(c, pl)) return r;
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -764,10 +921,10 @@ int rz_time_frames(rz_ctx *c, uint32_t frames, rz_timing *out)
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     out->deform_kernel_ms = ms / frames;
     // the prep kernel alone (only part of the frame when the plan is not the one-launch FAST form)
-    if (pl.prep) {
+    if (pl.prep || c->pose_local) {
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
         for (uint32_t f = 0; f < frames; ++f)
-            if (int r = launch_prep(c)) return r;
+            if (int r = launch_front(c, pl)) return r;
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
         HIP_TRY(hipEventSynchronize(c->ev1));
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));

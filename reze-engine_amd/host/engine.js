@@ -40,6 +40,7 @@ class Engine {
     this.device = o.device === undefined ? 0 : o.device
     // devices: [0,1,...]  one context per GPU in this process; the mesh is vertex-sharded across them (SURVEY §8e)
     this.devices = Array.isArray(o.devices) && o.devices.length > 0 ? o.devices.slice() : [this.device]
+    this.deviceFK = o.deviceFK === true // forward kinematics on the GPU: upload local rotations instead of world matrices
     this.gather = o.gather === true // all-gather deformed positions over RCCL after every frame (needs distinct GPUs)
     this.morphLayout = o.morphLayout || 'sparse'
     this.realtime = o.realtime !== false // false: time only advances through step()
@@ -140,6 +141,19 @@ class Engine {
       // static data is cut once; subarray() views are zero-copy into the addon
       n.uploadMesh(s.ctx, model.getVertices().subarray(b * 8, e * 8), skinning.joints.subarray(b * 4, e * 4), skinning.weights.subarray(b * 4, e * 4))
       n.uploadSkeleton(s.ctx, skeleton.inverseBindMatrices)
+      if (this.deviceFK) {
+        const B = skeleton.bones.length
+        const parents = new Int32Array(B), bind = new Float32Array(B * 3), ap = new Int32Array(B).fill(-1), ar = new Float32Array(B).fill(1)
+        skeleton.bones.forEach((bn, i) => {
+          parents[i] = bn.parentIndex
+          bind.set(bn.bindTranslation, i * 3)
+          if (bn.appendRotate && bn.appendParentIndex !== undefined && bn.appendParentIndex !== null) {
+            ap[i] = bn.appendParentIndex
+            ar[i] = bn.appendRatio === undefined || bn.appendRatio === null ? 1 : bn.appendRatio
+          }
+        })
+        n.uploadSkeletonTopology(s.ctx, parents, bind, ap, ar)
+      }
       if (morphs && morphs.names.length > 0) {
         const M = morphs.names.length
         if (this.morphLayout === 'dense') {
@@ -294,12 +308,14 @@ class Engine {
     if (!this.currentModel || !this.ctx) return
     const t0 = wallClock()
     const model = this.currentModel
-    model.evaluatePose()
+    if (this.deviceFK) model.updateRotationTweens() // tweens stay on the host; the hierarchy solve moves to the GPU
+    else model.evaluatePose()
     const mw = model.getMorphCount() > 0 ? model.getEffectiveMorphWeights() : null
     // per-frame inputs are replicated to every shard (16-22 KB); launches are asynchronous, so the GPUs run concurrently
     for (const s of this.shards) {
       if (s.count === 0) continue
-      this.native.setPose(s.ctx, model.getBoneWorldMatrices(), mw)
+      if (this.deviceFK) this.native.setPoseLocal(s.ctx, model.runtimeSkeleton.localRotations, mw)
+      else this.native.setPose(s.ctx, model.getBoneWorldMatrices(), mw)
       this.native.deform(s.ctx)
     }
     if (this.gather && this.shards.length > 1) this.native.allgatherAll(this.shards.map((s) => s.ctx), true)

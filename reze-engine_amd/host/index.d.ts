@@ -30,6 +30,7 @@ export class Mat4 {
 export interface EngineOptions {
   ambient?: number; bloomIntensity?: number; rimLightIntensity?: number; cameraDistance?: number; cameraTarget?: Vec3
   /** HIP device ordinal (default 0). */ device?: number
+  /** Solve the bone hierarchy on the GPU (uploads local rotations instead of world matrices). */ deviceFK?: boolean
   /** One context per listed GPU; the mesh is vertex-sharded across them. */ devices?: number[]
   /** RCCL all-gather of the deformed mesh after every frame (distinct GPUs only). */ gather?: boolean
   /** How PMX vertex morphs are laid out in HBM (default 'sparse'). */ morphLayout?: 'sparse' | 'dense'

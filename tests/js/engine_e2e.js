@@ -9,8 +9,9 @@ const [pmx, vmd, out, layout, devs] = process.argv.slice(2)
 const dump = (name, ta) => fs.writeFileSync(path.join(out, name), Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength))
 ;(async () => {
   const quiet = console.warn; console.warn = () => {}
-  const devices = (devs || '0').split(',').map(Number)   // '0,0' = two contexts (two vertex shards) on one GPU
-  const engine = new Engine(null, { realtime: false, morphLayout: layout || 'sparse', ambient: 0.8, devices })
+  const deviceFK = /:fk$/.test(devs || '')
+  const devices = (devs || '0').replace(':fk', '').split(',').map(Number)   // '0,0' = two contexts (two vertex shards) on one GPU
+  const engine = new Engine(null, { realtime: false, morphLayout: layout || 'sparse', ambient: 0.8, devices, deviceFK })
   await engine.init()
   await engine.loadModel(pmx)
   const model = engine.currentModel
@@ -28,6 +29,12 @@ const dump = (name, ta) => fs.writeFileSync(path.join(out, name), Buffer.from(ta
     }
     engine.step(steps[s])
     const d = engine.getDeformed()
+    if (deviceFK) {   // the host did not solve the hierarchy this frame: do it now for the oracle, and fetch the GPU's solve
+      model.computeWorldMatrices()
+      const gw = new Float32Array(model.getBoneWorldMatrices().length)
+      engine.native.readWorld(engine.ctx, 0, gw)
+      dump('gpuworld_' + s + '.f32', gw)
+    }
     dump('world_' + s + '.f32', model.getBoneWorldMatrices())
     dump('mw_' + s + '.f32', model.getEffectiveMorphWeights())
     dump('pos_' + s + '.f32', d.positions); dump('nrm_' + s + '.f32', d.normals)

@@ -278,6 +278,50 @@ def test_c5_full_size_parity_and_properties(ctx, oracle, rz):
     np.testing.assert_allclose(pi, mesh["pos"], rtol=1e-6, atol=2e-5)
 
 
+def test_device_fk_matches_host_fk_and_reference_fixture(ctx, oracle):
+    """Row f1: Model.computeWorldMatrices (model.ts:330-420) on the GPU. (a) synthetic tree, 5 poses at once, against
+    the host-order FK twin; (b) the REAL 349-bone skeleton with its 26 append-rotation bones and pool.vmd frame 0,
+    against the world matrices the reference's own code produced (tests/golden/ref_c1_pose0.npz)."""
+    import os
+    V, B, I = 4000, 120, 5
+    mesh = synth.make_mesh(V, B, seed=61)
+    rng = np.random.default_rng(62)
+    quats = rng.normal(size=(I, B, 4)).astype(np.float32)
+    quats /= np.linalg.norm(quats, axis=2, keepdims=True)
+    ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    ctx.upload_skeleton(mesh["inv_bind"])
+    ctx.upload_morphs_dense(None)
+    ctx.set_instances(I)
+    ctx.set_tuning(inst_loop=-1, fast=-1, grid_cap=0)
+    ctx.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+    ctx.set_pose_local(quats)
+    ctx.deform()
+    for i in range(I):
+        world = synth.fk_world(mesh["parents"], mesh["bind"], quats[i])
+        np.testing.assert_allclose(ctx.read_world(i), world, rtol=2e-5, atol=2e-5)
+        pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], world, mesh["inv_bind"])
+        pg, ng = ctx.read(instance=i)
+        assert_parity(pg, ng, pr, nr, "device FK instance %d" % i)
+    ctx.set_instances(1)
+    # (b) reference fixture
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_c1_pose0.npz"))
+    B = len(g["parents"])
+    m2 = synth.make_mesh(6000, B, seed=63)
+    ctx.upload_mesh(m2["pos"], m2["nrm"], m2["joints"], m2["weights"])
+    ctx.upload_skeleton(g["inv_bind"])
+    ap = np.where(g["append_rotate"], g["append_parent"], -1)
+    ctx.upload_skeleton_topology(g["parents"], g["bind"], ap, g["append_ratio"])
+    for key_q, key_w in (("local_rot_pose0", "world_pose0"), ("local_rot_tween150", "world_tween150")):
+        ctx.set_pose_local(g[key_q])
+        ctx.deform()
+        np.testing.assert_allclose(ctx.read_world(0), g[key_w], rtol=3e-5, atol=3e-5)
+        pr, nr = oracle.deform(m2["pos"], m2["nrm"], m2["joints"], m2["weights"], g[key_w], g["inv_bind"])
+        pg, ng = ctx.read()
+        assert_parity(pg, ng, pr, nr, "device FK on the reference skeleton (%s)" % key_q)
+    with pytest.raises(Exception):
+        ctx.upload_skeleton_topology(np.array([1, 0] + [0] * (B - 2)), g["bind"])      # 0 <-> 1 cycle
+
+
 def test_single_process_comm_init_all_one_rank(rz):
     """ncclCommInitAll / grouped all-gather entry points (one Node process driving several GPUs) with one GPU."""
     mesh = synth.make_mesh(3000, 10, seed=43)
@@ -345,9 +389,9 @@ def test_engine_through_napi_matches_oracle(tmp_path, oracle):
     (tmp_path / "a.vmd").write_bytes(write_vmd(
         [("bone1", 0, (0, 0, s, 0.92387953)), ("bone3", 0, (s, 0, 0, 0.92387953)), ("bone1", 15, (0, s, 0, 0.92387953)),
          ("bone20", 30, (0, 0, -s, 0.92387953))], [("v1", 0, 0.8), ("v2", 6, 0.4)]))
-    for layout, devs in (("sparse", "0"), ("dense", "0"), ("sparse", "0,0"), ("dense", "0,0,0")):
+    for layout, devs in (("sparse", "0"), ("dense", "0"), ("sparse", "0,0"), ("dense", "0,0,0"), ("sparse", "0:fk"), ("dense", "0,0:fk")):
         # "0,0": the Engine's multi-GPU sharding (one context per listed device) exercised as 2-3 shards on one GPU
-        out = tmp_path / (layout + devs.replace(",", "_"))
+        out = tmp_path / (layout + devs.replace(",", "_").replace(":", "_"))
         out.mkdir()
         subprocess.check_call(["node", os.path.join(root, "tests", "js", "engine_e2e.js"), str(tmp_path / "m.pmx"),
                                str(tmp_path / "a.vmd"), str(out), layout, devs], timeout=300)
@@ -367,6 +411,8 @@ def test_engine_through_napi_matches_oracle(tmp_path, oracle):
             pr, nr = oracle.skin(pm, v[:, 3:6], joints, weights, S)
             pg = rd("pos_%d.f32" % step, np.float32).reshape(-1, 3)
             ng = rd("nrm_%d.f32" % step, np.float32).reshape(-1, 3)
+            if devs.endswith(":fk"):      # the GPU solved the hierarchy in f32: compare its world matrices with the host's
+                np.testing.assert_allclose(rd("gpuworld_%d.f32" % step, np.float32).reshape(-1, 16), world, rtol=3e-5, atol=3e-5)
             assert_parity(pg, ng, pr, nr, "napi %s devices %s step %d" % (layout, devs, step))
             seen_morph = seen_morph or (mw != 0).sum() >= 3
             assert not np.allclose(pg, v[:, 0:3])            # the pose really moved the mesh
