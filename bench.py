@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-verts", type=int, default=200000)
     ap.add_argument("--allgather", action="store_true", help="also time the RCCL all-gather of positions")
+    ap.add_argument("--device-fk", action="store_true",
+                    help="solve the bone hierarchy on the GPU: frames start from local rotations (rz_set_pose_local)")
     ap.add_argument("--tune", default="", help="comma list key=value passed to rz_set_tuning")
     return ap.parse_args()
 
@@ -160,7 +162,19 @@ def main():
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         ctx.set_tuning(**{k: int(v)})
-    ctx.set_pose(worlds, mws)
+    quats = None
+    if args.device_fk:
+        rng = np.random.default_rng(4242)
+        quats = rng.normal(size=(I, B, 4)).astype(np.float32)
+        quats /= np.linalg.norm(quats, axis=2, keepdims=True)
+        ctx.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+
+    def put_pose():
+        if quats is not None:
+            ctx.set_pose_local(quats, mws)
+        else:
+            ctx.set_pose(worlds, mws)
+    put_pose()
 
     def barrier():
         ctx.sync()
@@ -206,7 +220,7 @@ def main():
     barrier()
     tp0 = time.perf_counter()
     for _ in range(min(args.steps, 100)):
-        ctx.set_pose(worlds, mws)
+        put_pose()
         ctx.deform()
     ctx.sync()
     with_upload_ms = (time.perf_counter() - tp0) * 1e3 / min(args.steps, 100)
@@ -252,6 +266,7 @@ def main():
                                (" x %d instances (per-instance palette in LDS)" % I) if I > 1 else "", world_size),
                 "verts_total": V_total, "verts_per_gpu": n, "bones": B, "morphs": M, "instances": I,
                 "parallelism": "vertex-shard x%d" % world_size,
+                "bone_hierarchy_solve": "device (rz_fk_kernel)" if args.device_fk else "host",
                 "morph_split": ctx.get_tuning("effective_split"),
                 "grid": ctx.get_tuning("effective_grid"),
                 "frame_ms_events": timing["frame_ms"],
