@@ -136,22 +136,35 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *wl = reinterpret_cast<float4 *>(smem);       // B x 3 rows of the world matrices of this pose
+    float4 *sq = wl + (size_t)p.B * 3;                   // local rotations of this pose
+    int *s_par = reinterpret_cast<int *>(sq + p.B);
+    int *s_ap = s_par + p.B;
+    int *s_order = s_ap + p.B;
+    float *s_ratio = reinterpret_cast<float *>(s_order + p.B);
+    float *s_bind = s_ratio + p.B;
     const int inst = blockIdx.x, tid = threadIdx.x;
     const float4 *lq = p.local_q + (size_t)inst * p.B;
     float *world = p.world + (size_t)inst * p.B * 16;
     float4 *pal = p.palette + (size_t)inst * p.B * 3;
+    // one cooperative pass stages everything the level loop touches, so each level costs LDS latency + a barrier
+    // instead of two dependent global round trips
+    for (int i = tid; i < p.B; i += kBlock) {
+        sq[i] = lq[i]; s_par[i] = p.parents[i]; s_ap[i] = p.append_parent[i]; s_order[i] = p.order[i]; s_ratio[i] = p.append_ratio[i];
+        s_bind[i * 3] = p.bind[i * 3]; s_bind[i * 3 + 1] = p.bind[i * 3 + 1]; s_bind[i * 3 + 2] = p.bind[i * 3 + 2];
+    }
+    __syncthreads();
     for (int l = 0; l < p.n_levels; ++l) {
         const int lo = p.level_off[l], hi = p.level_off[l + 1];
         for (int idx = lo + tid; idx < hi; idx += kBlock) {
-            const int b = p.order[idx];
-            const float4 q = lq[b];
+            const int b = s_order[idx];
+            const float4 q = sq[b];
             float R[9];
             quat_to_rows(q.x, q.y, q.z, q.w, R);
-            const int ap = p.append_parent[b];
+            const int ap = s_ap[b];
             if (ap >= 0) {
-                const float ratio = fminf(1.0f, fmaxf(-1.0f, p.append_ratio[b]));
+                const float ratio = fminf(1.0f, fmaxf(-1.0f, s_ratio[b]));
                 if (fabsf(ratio) > 1e-6f) {
-                    float4 a = lq[ap];
+                    float4 a = sq[ap];
                     const float t = fabsf(ratio);
                     if (ratio < 0.0f) { a.x = -a.x; a.y = -a.y; a.z = -a.z; }
                     // Quat.slerp(identity, a, t)  (math.ts:156-189)
@@ -177,9 +190,9 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
                     for (int i = 0; i < 9; ++i) R[i] = X[i];
                 }
             }
-            const float tx = p.bind[b * 3], ty = p.bind[b * 3 + 1], tz = p.bind[b * 3 + 2];
+            const float tx = s_bind[b * 3], ty = s_bind[b * 3 + 1], tz = s_bind[b * 3 + 2];
             float W[12];   // 3 rows x 4
-            const int par = p.parents[b];
+            const int par = s_par[b];
             if (par >= 0) {
                 const float4 p0 = wl[par * 3], p1 = wl[par * 3 + 1], p2 = wl[par * 3 + 2];
                 const float P[12] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w };
@@ -197,27 +210,33 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
             wl[b * 3] = make_float4(W[0], W[1], W[2], W[3]);
             wl[b * 3 + 1] = make_float4(W[4], W[5], W[6], W[7]);
             wl[b * 3 + 2] = make_float4(W[8], W[9], W[10], W[11]);
-            // world, column-major 4x4 (what queue.writeBuffer(worldMatrixBuffer) would have carried)
-            float4 *wo = reinterpret_cast<float4 *>(world + (size_t)b * 16);
-            wo[0] = make_float4(W[0], W[4], W[8], 0.0f);
-            wo[1] = make_float4(W[1], W[5], W[9], 0.0f);
-            wo[2] = make_float4(W[2], W[6], W[10], 0.0f);
-            wo[3] = make_float4(W[3], W[7], W[11], 1.0f);
-            // palette rows 0..2 of W * IB (IB general 4x4, column-major)
-            const float4 *Im = reinterpret_cast<const float4 *>(p.inv_bind + (size_t)b * 16);
-            float r[3][4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 bc = Im[c];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    r[i][c] = fmaf(W[i * 4 + 3], bc.w, fmaf(W[i * 4 + 2], bc.z, fmaf(W[i * 4 + 1], bc.y, W[i * 4] * bc.x)));
-            }
-            pal[b * 3] = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]);
-            pal[b * 3 + 1] = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]);
-            pal[b * 3 + 2] = make_float4(r[2][0], r[2][1], r[2][2], r[2][3]);
         }
         __syncthreads();
+    }
+    // all levels solved: one parallel pass writes the world matrices and the palette (the inverse-bind loads of
+    // every bone are in flight together instead of once per level)
+    for (int b = tid; b < p.B; b += kBlock) {
+        const float4 w0 = wl[b * 3], w1 = wl[b * 3 + 1], w2 = wl[b * 3 + 2];
+        const float W[12] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w };
+        // world, column-major 4x4 (what queue.writeBuffer(worldMatrixBuffer) would have carried)
+        float4 *wo = reinterpret_cast<float4 *>(world + (size_t)b * 16);
+        wo[0] = make_float4(W[0], W[4], W[8], 0.0f);
+        wo[1] = make_float4(W[1], W[5], W[9], 0.0f);
+        wo[2] = make_float4(W[2], W[6], W[10], 0.0f);
+        wo[3] = make_float4(W[3], W[7], W[11], 1.0f);
+        // palette rows 0..2 of W * IB (IB general 4x4, column-major)
+        const float4 *Im = reinterpret_cast<const float4 *>(p.inv_bind + (size_t)b * 16);
+        float r[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 bc = Im[c];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                r[i][c] = fmaf(W[i * 4 + 3], bc.w, fmaf(W[i * 4 + 2], bc.z, fmaf(W[i * 4 + 1], bc.y, W[i * 4] * bc.x)));
+        }
+        pal[b * 3] = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]);
+        pal[b * 3 + 1] = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]);
+        pal[b * 3 + 2] = make_float4(r[2][0], r[2][1], r[2][2], r[2][3]);
     }
 }
 
@@ -840,7 +859,7 @@ hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t
 
 hipError_t rz_launch_fk(const RzFkParams &p, uint32_t instances, hipStream_t st)
 {
-    const size_t lds = (size_t)p.B * 48;
+    const size_t lds = (size_t)p.B * (48 + 16 + 4 * 4 + 12);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rz_fk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
