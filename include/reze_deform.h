@@ -131,6 +131,19 @@ int rz_read(rz_ctx *ctx, uint32_t instance, uint32_t v0, uint32_t n, float *pos3
  * world*inverseBind, row-major 3x4) — the skinMatrixBuffer of engine.ts:1770-1774. */
 int rz_read_palette(rz_ctx *ctx, uint32_t instance, float *rows3x4);
 
+/* ---- fused consumers of the deformed mesh (optional) ----
+ * rz_upload_edge_scale: per-vertex outline edge size (the material's edgeSize of the draw call that owns the
+ * vertex, engine/src/engine.ts:415-421). Once set, every frame also writes the outline pass's inverted hull
+ * expandedPos = worldPos + worldNormal * edgeSize * 0.01 (engine.ts:458-461, vertex shader :431-463) so the
+ * outline pipeline no longer re-skins; NULL turns it off. rz_read_hull reads it back.
+ * rz_enable_aabb: every frame also reduces the axis-aligned bounding box of the deformed positions of each
+ * instance inside the skin kernel (no extra pass over the mesh); rz_read_aabb returns min xyz, max xyz of the
+ * most recent frame. */
+int rz_upload_edge_scale(rz_ctx *ctx, uint32_t V, const float *edge_size);
+int rz_read_hull(rz_ctx *ctx, uint32_t instance, uint32_t v0, uint32_t n, float *pos3);
+int rz_enable_aabb(rz_ctx *ctx, int enable);
+int rz_read_aabb(rz_ctx *ctx, uint32_t instance, float min_max6[6]);
+
 /* Benchmark helper: enqueue `frames` back-to-back frames of the resident pose between two HIP
  * events on the context's stream, then (mode 1) time the deform kernel alone and (mode 2) the
  * prep kernel alone the same way. Blocking. */

@@ -40,6 +40,8 @@ def lib():
         L.rzo_deform.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp,
                                  ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint8),
                                  fp, fp, fp, fp, fp, fp, ctypes.c_int]
+        L.rzo_hull.argtypes = [ctypes.c_int, fp, fp, fp, fp]
+        L.rzo_hull.restype = None
         for f in (L.rzo_palette, L.rzo_skin, L.rzo_morph_dense, L.rzo_morph_sparse, L.rzo_deform):
             f.restype = None
         _LIB = L
@@ -98,6 +100,16 @@ def morph_sparse(n_verts, morph_off, vert_idx, delta3, weights, pos):
     u32 = ctypes.POINTER(ctypes.c_uint32)
     lib().rzo_morph_sparse(n_verts, len(mo) - 1, mo.ctypes.data_as(u32), vi.ctypes.data_as(u32),
                            dp, wp, pp, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return out
+
+
+def hull(pos, nrm, edge):
+    """Outline hull of engine.ts:458-461 from deformed positions / normals and a per-vertex edge size."""
+    p, pp = _f(pos)
+    n, npn = _f(nrm)
+    e, ep = _f(edge)
+    out = np.empty_like(p).reshape(-1, 3)
+    lib().rzo_hull(p.size // 3, pp, npn, ep, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
     return out
 
 

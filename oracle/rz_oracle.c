@@ -179,6 +179,16 @@ RZO_API void rzo_skin(int n_verts, const float *pos3, const float *nrm3, const u
     rzo_skin_range(0, (size_t)n_verts, pos3, nrm3, joints4, weights4, skin, out_pos3, out_nrm3);
 }
 
+/*
+ * Outline pass's inverted hull, engine.ts:458-461:  expandedPos = worldPos + worldNormal * edgeSize * 0.01
+ * (left to right: (N * edgeSize) * 0.01, then + P), with a per-vertex edge size.
+ */
+RZO_API void rzo_hull(int n_verts, const float *pos3, const float *nrm3, const float *edge, float *out3)
+{
+    for (size_t v = 0; v < (size_t)n_verts; ++v)
+        for (int k = 0; k < 3; ++k) out3[v * 3 + k] = pos3[v * 3 + k] + (nrm3[v * 3 + k] * edge[v]) * 0.01f;
+}
+
 /* ---- threaded whole-frame driver: used for full-size parity runs and as the C fallback of the
  * cpu_baseline leg when Node is unavailable (labelled "C stand-in" by bench.py). ---- */
 typedef struct {

@@ -90,6 +90,11 @@ def skin(pos, nrm, joints4, weights4, skin_mats):
     return np.stack(sp, axis=1), on.astype(F)
 
 
+def hull(pos, nrm, edge):
+    """engine.ts:458-461: worldPos + (worldNormal * edgeSize) * 0.01, f32 per op."""
+    return pos.astype(F) + (nrm.astype(F) * edge.astype(F)[:, None]) * F(0.01)
+
+
 def deform(pos, nrm, joints4, weights4, world, inv_bind, deltas=None, morph_w=None):
     """Whole frame: palette -> dense morph (optional) -> skin."""
     S = palette(world, inv_bind)

@@ -18,7 +18,7 @@ SYMBOLS = [
     "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
     "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_read_world", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
     "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_output_ptrs",
-    "rz_comm_unique_id", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all",
+    "rz_comm_unique_id", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all", "rz_upload_edge_scale", "rz_read_hull", "rz_enable_aabb", "rz_read_aabb",
 ]
 
 
@@ -81,6 +81,10 @@ def load():
     L.rz_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, u32]
     L.rz_allgather.argtypes = [vp, ctypes.c_int]
     L.rz_read_gathered.argtypes = [vp, u32, u32, fp, fp]
+    L.rz_upload_edge_scale.argtypes = [vp, u32, fp]
+    L.rz_read_hull.argtypes = [vp, u32, u32, u32, fp]
+    L.rz_enable_aabb.argtypes = [vp, ctypes.c_int]
+    L.rz_read_aabb.argtypes = [vp, u32, fp]
     L.rz_comm_init_all.argtypes = [ctypes.POINTER(vp), ctypes.c_int, u32]
     L.rz_allgather_all.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int]
     for name in SYMBOLS:
@@ -247,6 +251,27 @@ class DeformContext:
     def read_world(self, instance=0):
         out = np.empty((self.B, 16), dtype=np.float32)
         _chk(self._L.rz_read_world(self._h, int(instance), _fptr(out)))
+        return out
+
+    def upload_edge_scale(self, edge):
+        if edge is None:
+            _chk(self._L.rz_upload_edge_scale(self._h, 0, None))
+            return
+        e = _f32(edge).reshape(-1)
+        _chk(self._L.rz_upload_edge_scale(self._h, len(e), _fptr(e)))
+
+    def read_hull(self, instance=0, v0=0, n=None):
+        n = self.V - v0 if n is None else n
+        out = np.empty((n, 3), dtype=np.float32)
+        _chk(self._L.rz_read_hull(self._h, int(instance), int(v0), int(n), _fptr(out)))
+        return out
+
+    def enable_aabb(self, on=True):
+        _chk(self._L.rz_enable_aabb(self._h, 1 if on else 0))
+
+    def read_aabb(self, instance=0):
+        out = np.empty(6, dtype=np.float32)
+        _chk(self._L.rz_read_aabb(self._h, int(instance), _fptr(out)))
         return out
 
     def deform(self):

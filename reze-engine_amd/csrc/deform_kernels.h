@@ -53,8 +53,13 @@ struct RzDeformParams {
     const float4 *sp_entries;   // [E]      (dx,dy,dz,bits(morph))
     float *out_pos;             // [I][Vp][3]
     float *out_nrm;             // [I][Vp][3]
+    const float *edge;          // [Vp] per-vertex outline edge size, or null (hull epilogue off)
+    float *out_hull;            // [I][Vp][3] worldPos + worldNormal * edge * 0.01   (engine.ts:458-461)
+    uint32_t *aabb;             // [I][2 slots][6] order-preserving keys of min xyz / max xyz, or null
+    int aabb_slot;              // slot this launch accumulates into (the other one is re-armed)
     uint32_t Vp;                // padded vertex count (multiple of 1024)
-    uint32_t n_quads;           // Vp / 4
+    uint32_t n_verts;           // real vertex count V
+    uint32_t n_quads;           // ceil(V / 4)
     uint32_t quads_per_wave;    // contiguous run owned by each wave of the grid (multiple of 8)
     int dbg;                    // ablation switch for profiling experiments (0 in production)
     int dma;                    // FAST: stage raw matrices by LDS-DMA (else plain loads after the first morph phase)

@@ -384,6 +384,7 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
     float *opos = p.out_pos + (size_t)inst * Vp * 3;
     float *onrm = p.out_nrm + (size_t)inst * Vp * 3;
     bool need_palette = FAST;
+    float bb[6] = { __builtin_inff(), __builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
 
     // the raw matrices have landed (every wave drains its own DMA, the barrier publishes them): palette rows
     // 0..2 of world * inverseBind, out[c*4+r] = ((a0[r]*b0 + a1[r]*b1) + a2[r]*b2) + a3[r]*b3  (engine.ts:928)
@@ -570,11 +571,46 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
                 Skinned o = skin_vertex(pal, x, y, z, nx, ny, nz, j01, j23, wq, bmax);
                 st3<NTS>(opos + v * 3, o.px, o.py, o.pz);
                 st3<NTS>(onrm + v * 3, o.nx, o.ny, o.nz);
+                if (p.edge) {
+                    // fused consumer: the outline pass's inverted hull, engine.ts:458-461
+                    //   expandedPos = worldPos + worldNormal * edgeSize * 0.01
+                    const float e = p.edge[v];
+                    st3<NTS>(p.out_hull + ((size_t)inst * Vp + v) * 3, o.px + (o.nx * e) * 0.01f, o.py + (o.ny * e) * 0.01f,
+                             o.pz + (o.nz * e) * 0.01f);
+                }
+                if (p.aabb && v < p.n_verts) {       // padding vertices of the last quad stay out of the box
+                    bb[0] = fminf(bb[0], o.px); bb[1] = fminf(bb[1], o.py); bb[2] = fminf(bb[2], o.pz);
+                    bb[3] = fmaxf(bb[3], o.px); bb[4] = fmaxf(bb[4], o.py); bb[5] = fmaxf(bb[5], o.pz);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
     if (FAST && need_palette) stage_palette();   // a wave with an empty run still owes the workgroup its barriers
+    if (p.aabb) {
+        // fused per-frame bounding box: per-lane running min/max -> wave butterfly -> one atomic per wave and
+        // component on order-preserving integer keys. The kernel also re-arms the OTHER slot for the next frame,
+        // so no memset launch sits between frames.
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                bb[k] = fminf(bb[k], __shfl_xor(bb[k], off));
+                bb[3 + k] = fmaxf(bb[3 + k], __shfl_xor(bb[3 + k], off));
+            }
+        }
+        uint32_t *slot = p.aabb + ((size_t)inst * 2 + (p.aabb_slot & 1)) * 6;
+        if (lane < 6 && q_begin < q_end) {
+            const float sel = lane == 0 ? bb[0] : lane == 1 ? bb[1] : lane == 2 ? bb[2] : lane == 3 ? bb[3] : lane == 4 ? bb[4] : bb[5];
+            const uint32_t bits = __float_as_uint(sel);
+            const uint32_t key = bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);
+            if (lane < 3) atomicMin(slot + lane, key); else atomicMax(slot + lane, key);
+        }
+        if (blockIdx.x == 0 && tid < 6) {
+            uint32_t *next = p.aabb + ((size_t)inst * 2 + ((p.aabb_slot + 1) & 1)) * 6;
+            next[tid] = tid < 3 ? 0xffffffffu : 0u;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

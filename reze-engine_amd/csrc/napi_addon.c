@@ -295,6 +295,54 @@ static napi_value fn_read_world(napi_env env, napi_callback_info info)
     return rc ? throw_rz(env, rc) : undef(env);
 }
 
+static napi_value fn_upload_edge_scale(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    CTX(0);
+    void *e = NULL;
+    size_t n = 0;
+    if (!get_ta(env, argv[1], napi_float32_array, 1, &e, &n)) return throw_msg(env, "uploadEdgeScale(ctx, Float32Array|null edgeSizePerVertex)");
+    int rc = rz_upload_edge_scale(ctx, (uint32_t)n, (const float *)e);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_read_hull(napi_env env, napi_callback_info info)
+{
+    ARGS(5);
+    CTX(0);
+    uint32_t inst, v0, n;
+    void *o;
+    size_t no;
+    if (!get_u32(env, argv[1], &inst) || !get_u32(env, argv[2], &v0) || !get_u32(env, argv[3], &n) ||
+        !get_ta(env, argv[4], napi_float32_array, 0, &o, &no) || no < (size_t)n * 3)
+        return throw_msg(env, "readHull(ctx, instance, v0, n, Float32Array out /* n*3 */)");
+    int rc = rz_read_hull(ctx, inst, v0, n, (float *)o);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_enable_aabb(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    CTX(0);
+    bool on = false;
+    napi_get_value_bool(env, argv[1], &on);
+    int rc = rz_enable_aabb(ctx, on ? 1 : 0);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_read_aabb(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    CTX(0);
+    uint32_t inst;
+    void *o;
+    size_t no;
+    if (!get_u32(env, argv[1], &inst) || !get_ta(env, argv[2], napi_float32_array, 0, &o, &no) || no < 6)
+        return throw_msg(env, "readAabb(ctx, instance, Float32Array out /* 6 */)");
+    int rc = rz_read_aabb(ctx, inst, (float *)o);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
 static napi_value fn_deform(napi_env env, napi_callback_info info)
 {
     ARGS(1);
@@ -503,7 +551,8 @@ static napi_value init(napi_env env, napi_value exports)
         { "uploadMeshSoa", fn_upload_mesh_soa }, { "uploadSkeleton", fn_upload_skeleton },
         { "uploadMorphsDense", fn_upload_morphs_dense }, { "uploadMorphsSparse", fn_upload_morphs_sparse },
         { "setInstances", fn_set_instances }, { "setPose", fn_set_pose }, { "uploadSkeletonTopology", fn_upload_topology },
-        { "setPoseLocal", fn_set_pose_local }, { "readWorld", fn_read_world }, { "deform", fn_deform },
+        { "setPoseLocal", fn_set_pose_local }, { "readWorld", fn_read_world }, { "uploadEdgeScale", fn_upload_edge_scale },
+        { "readHull", fn_read_hull }, { "enableAabb", fn_enable_aabb }, { "readAabb", fn_read_aabb }, { "deform", fn_deform },
         { "deformN", fn_deform_n }, { "sync", fn_sync }, { "read", fn_read }, { "readPalette", fn_read_palette },
         { "timeFrames", fn_time_frames }, { "setTuning", fn_set_tuning }, { "getTuning", fn_get_tuning },
         { "commUniqueId", fn_comm_unique_id }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },

@@ -139,6 +139,14 @@ struct rz_ctx {
     // outputs
     float *out_pos = nullptr, *out_nrm = nullptr;
     size_t out_alloc_floats = 0;
+    // fused consumers
+    float *edge = nullptr;              // Vp
+    float *out_hull = nullptr;          // I x Vp x 3
+    size_t hull_alloc_floats = 0;
+    uint32_t *aabb = nullptr;           // I x 2 x 6 keys
+    size_t aabb_alloc_inst = 0;
+    bool aabb_on = false;
+    int aabb_slot = 0;                  // slot the NEXT frame accumulates into
 
     // pinned staging ring for rz_set_pose
     void *stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
@@ -196,6 +204,23 @@ int ensure_outputs(rz_ctx *c)
         HIP_TRY(hipMemsetAsync(c->out_pos, 0, need * sizeof(float), c->stream));
         HIP_TRY(hipMemsetAsync(c->out_nrm, 0, need * sizeof(float), c->stream));
         c->out_alloc_floats = need;
+    }
+    if (c->edge && need > c->hull_alloc_floats) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        dfree(c->out_hull);
+        HIP_TRY(hipMalloc(&c->out_hull, need * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(c->out_hull, 0, need * sizeof(float), c->stream));
+        c->hull_alloc_floats = need;
+    }
+    if (c->aabb_on && c->I > c->aabb_alloc_inst) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        dfree(c->aabb);
+        HIP_TRY(hipMalloc(&c->aabb, (size_t)c->I * 12 * sizeof(uint32_t)));
+        std::vector<uint32_t> init((size_t)c->I * 12);
+        for (size_t i = 0; i < init.size(); ++i) init[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+        HIP_TRY(hipMemcpy(c->aabb, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->aabb_alloc_inst = c->I;
+        c->aabb_slot = 0;
     }
     return RZ_OK;
 }
@@ -255,6 +280,8 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     p.act_idx = c->act_idx; p.act_w = c->act_w; p.act_count = c->act_count; p.morph_w = c->morph_w;
     p.sp_ptr = c->sp_ptr; p.sp_entries = c->sp_entries;
     p.out_pos = c->out_pos; p.out_nrm = c->out_nrm;
+    p.edge = c->edge; p.out_hull = c->out_hull; p.aabb = c->aabb_on ? c->aabb : nullptr; p.aabb_slot = c->aabb_slot;
+    p.n_verts = c->V;
     p.Vp = c->Vp; p.n_quads = pl.n_quads; p.quads_per_wave = pl.quads_per_wave; p.dma = pl.dma ? 1 : 0;
     p.B = (int)c->B; p.M = (int)c->M; p.Mpad = (int)c->Mpad;
     p.dbg = c->t_dbg;
@@ -306,7 +333,8 @@ Plan make_plan(const rz_ctx *c)
     pl.quads_per_wave = per_wave;
     pl.grid_x = std::max<uint32_t>(1, (pl.n_quads + per_wave * waves_per_wg - 1) / (per_wave * waves_per_wg));
     // instanced, morph-free frames: G poses per workgroup (palettes together <= 76.8 KB so two workgroups fit a CU)
-    if (v.mode == 0 && c->I > 1 && c->t_instloop != 0) {
+    const bool epilogues = c->edge != nullptr || c->aabb_on;   // only the generic kernel carries the fused consumers
+    if (v.mode == 0 && c->I > 1 && c->t_instloop != 0 && !epilogues) {
         int G = (int)std::min<uint32_t>(8, (80u * 1024u) / (c->B * 48u));
         if (c->t_instloop > 0 && c->t_instloop <= 8) G = std::min(G, c->t_instloop);
         if (G >= 2) {
@@ -326,7 +354,7 @@ Plan make_plan(const rz_ctx *c)
     }
     // register-resident instanced form: 2048-vertex runs, pose ranges sized for ~2 WGs per CU
     // (measured slower than the LDS pose-group form on C4 — 37 vs 34 us — so it is opt-in: inst_loop = 9)
-    if (v.mode == 0 && c->I > 1 && c->t_instloop == 9 && c->B * 3 <= 65535u) {
+    if (v.mode == 0 && c->I > 1 && c->t_instloop == 9 && c->B * 3 <= 65535u && !epilogues) {
         const uint32_t runs = (c->V + 2047) / 2048;
         uint32_t total = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : 2u * (uint32_t)c->n_cu;
         uint32_t ranges = std::max<uint32_t>(1, std::min<uint32_t>(c->I, total / std::max<uint32_t>(1, runs)));
@@ -404,6 +432,7 @@ int launch_deform(rz_ctx *c, const Plan &pl)
     size_t lds = rz_deform_lds_bytes(p, pl.v);
     if (lds > 160 * 1024) return fail(RZ_ERR_UNSUPPORTED, "skeleton too large for the LDS palette (%zu B)", lds);
     HIP_TRY(rz_launch_deform(p, c->ml, pl.v, pl.grid_x, c->I, c->stream));
+    if (c->aabb_on) c->aabb_slot ^= 1;     // this launch re-armed the other slot for the next frame
     return RZ_OK;
 }
 
@@ -434,7 +463,7 @@ int upload_skinning(rz_ctx *c, uint32_t V, const uint16_t *joints4, const uint8_
 int alloc_mesh(rz_ctx *c, uint32_t V)
 {
     HIP_TRY(hipStreamSynchronize(c->stream));
-    dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq);
+    dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->edge);
     free_morphs(c);                       // morph targets are per-vertex: a new mesh invalidates them
     c->V = V;
     c->Vp = round_up(V, kVertPad);
@@ -512,6 +541,7 @@ int rz_destroy(rz_ctx *c)
     free_morphs(c);
     dfree(c->world); dfree(c->palette); dfree(c->morph_w); dfree(c->act_idx); dfree(c->act_w); dfree(c->act_count);
     dfree(c->out_pos); dfree(c->out_nrm); dfree(c->g_pos); dfree(c->g_nrm);
+    dfree(c->edge); dfree(c->out_hull); dfree(c->aabb);
     for (int i = 0; i < kStageSlots; ++i) {
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
         if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
@@ -888,6 +918,52 @@ int rz_read_palette(rz_ctx *c, uint32_t instance, float *rows3x4)
     if (instance >= c->I || !rows3x4 || !c->palette) return fail(RZ_ERR_INVALID, "bad palette read");
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(rows3x4, c->palette + (size_t)instance * c->B * 3, (size_t)c->B * 12 * sizeof(float), hipMemcpyDeviceToHost));
+    return RZ_OK;
+}
+
+int rz_upload_edge_scale(rz_ctx *c, uint32_t V, const float *edge_size)
+{
+    if (int r = use(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!edge_size) { dfree(c->edge); return RZ_OK; }
+    if (V != c->V || V == 0) return fail(RZ_ERR_INVALID, "edge scale has %u entries but the mesh has %u vertices", V, c->V);
+    dfree(c->edge);
+    HIP_TRY(hipMalloc(&c->edge, (size_t)c->Vp * sizeof(float)));
+    HIP_TRY(hipMemset(c->edge, 0, (size_t)c->Vp * sizeof(float)));
+    HIP_TRY(hipMemcpy(c->edge, edge_size, (size_t)V * sizeof(float), hipMemcpyHostToDevice));
+    return ensure_outputs(c);
+}
+
+int rz_read_hull(rz_ctx *c, uint32_t instance, uint32_t v0, uint32_t n, float *pos3)
+{
+    if (int r = use(c)) return r;
+    if (!c->edge || !c->out_hull) return fail(RZ_ERR_INVALID, "the outline hull is off (rz_upload_edge_scale)");
+    if (instance >= c->I || (uint64_t)v0 + n > c->V || !pos3) return fail(RZ_ERR_INVALID, "bad hull read");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n) HIP_TRY(hipMemcpy(pos3, c->out_hull + ((size_t)instance * c->Vp + v0) * 3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return RZ_OK;
+}
+
+int rz_enable_aabb(rz_ctx *c, int enable)
+{
+    if (int r = use(c)) return r;
+    c->aabb_on = enable != 0;
+    return ensure_outputs(c);
+}
+
+int rz_read_aabb(rz_ctx *c, uint32_t instance, float min_max6[6])
+{
+    if (int r = use(c)) return r;
+    if (!c->aabb_on || !c->aabb) return fail(RZ_ERR_INVALID, "the bounding-box reduction is off (rz_enable_aabb)");
+    if (instance >= c->I || !min_max6) return fail(RZ_ERR_INVALID, "bad aabb read");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint32_t keys[6];
+    const int last = c->aabb_slot ^ 1;     // the slot the most recent frame accumulated into
+    HIP_TRY(hipMemcpy(keys, c->aabb + ((size_t)instance * 2 + last) * 6, sizeof keys, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t bits = (keys[k] & 0x80000000u) ? (keys[k] ^ 0x80000000u) : ~keys[k];
+        memcpy(&min_max6[k], &bits, 4);
+    }
     return RZ_OK;
 }
 

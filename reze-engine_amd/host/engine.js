@@ -41,6 +41,8 @@ class Engine {
     // devices: [0,1,...]  one context per GPU in this process; the mesh is vertex-sharded across them (SURVEY §8e)
     this.devices = Array.isArray(o.devices) && o.devices.length > 0 ? o.devices.slice() : [this.device]
     this.deviceFK = o.deviceFK === true // forward kinematics on the GPU: upload local rotations instead of world matrices
+    this.outline = o.outline === true // also produce the outline pass's inverted hull (engine.ts:458-461) every frame
+    this.bounds = o.bounds === true // also reduce the deformed mesh's bounding box every frame
     this.gather = o.gather === true // all-gather deformed positions over RCCL after every frame (needs distinct GPUs)
     this.morphLayout = o.morphLayout || 'sparse'
     this.realtime = o.realtime !== false // false: time only advances through step()
@@ -182,6 +184,21 @@ class Engine {
         }
       }
     }
+    if (this.outline) {
+      // per-vertex edge size = edgeSize of the material whose index range draws the vertex (edge flag 0x10), else 0
+      const edge = new Float32Array(V)
+      const indices = model.getIndices()
+      let first = 0
+      for (const mat of model.getMaterials()) {
+        const size = (mat.edgeFlag & 0x10) !== 0 ? mat.edgeSize : 0
+        for (let k = first; k < first + mat.vertexCount && k < indices.length; k++) edge[indices[k]] = size
+        first += mat.vertexCount
+      }
+      this.edgeScale = edge
+      for (const s of this.shards) if (s.count > 0) n.uploadEdgeScale(s.ctx, edge.subarray(s.begin, s.begin + s.count))
+      this.outHull = new Float32Array(V * 3)
+    }
+    if (this.bounds) for (const s of this.shards) if (s.count > 0) n.enableAabb(s.ctx, true)
     if (this.gather && G > 1) n.commInitAll(this.shards.map((s) => s.ctx), V)
     this.outPos = new Float32Array(V * 3)
     this.outNrm = new Float32Array(V * 3)
@@ -342,6 +359,26 @@ class Engine {
       this.native.read(s.ctx, 0, 0, s.count, this.outPos.subarray(s.begin * 3, (s.begin + s.count) * 3), this.outNrm.subarray(s.begin * 3, (s.begin + s.count) * 3))
     }
     return { positions: this.outPos, normals: this.outNrm }
+  }
+
+  /** Inverted-hull positions the outline pipeline draws: worldPos + worldNormal * edgeSize * 0.01 (needs { outline: true }). */
+  getOutlineHull() {
+    if (!this.outline) throw new Error('new Engine(canvas, { outline: true }) enables the outline hull')
+    for (const s of this.shards) if (s.count > 0) this.native.readHull(s.ctx, 0, 0, s.count, this.outHull.subarray(s.begin * 3, (s.begin + s.count) * 3))
+    return this.outHull
+  }
+
+  /** Axis-aligned bounds { min: [x,y,z], max: [x,y,z] } of the last deformed frame (needs { bounds: true }). */
+  getBounds() {
+    if (!this.bounds) throw new Error('new Engine(canvas, { bounds: true }) enables the bounding-box reduction')
+    const b = new Float32Array(6)
+    const min = [Infinity, Infinity, Infinity], max = [-Infinity, -Infinity, -Infinity]
+    for (const s of this.shards) {
+      if (s.count === 0) continue
+      this.native.readAabb(s.ctx, 0, b)
+      for (let k = 0; k < 3; k++) { min[k] = Math.min(min[k], b[k]); max[k] = Math.max(max[k], b[3 + k]) }
+    }
+    return { min, max }
   }
 
   runRenderLoop(callback) {

@@ -31,6 +31,8 @@ export interface EngineOptions {
   ambient?: number; bloomIntensity?: number; rimLightIntensity?: number; cameraDistance?: number; cameraTarget?: Vec3
   /** HIP device ordinal (default 0). */ device?: number
   /** Solve the bone hierarchy on the GPU (uploads local rotations instead of world matrices). */ deviceFK?: boolean
+  /** Also write the outline pass's inverted hull every frame. */ outline?: boolean
+  /** Also reduce the deformed mesh's bounding box every frame. */ bounds?: boolean
   /** One context per listed GPU; the mesh is vertex-sharded across them. */ devices?: number[]
   /** RCCL all-gather of the deformed mesh after every frame (distinct GPUs only). */ gather?: boolean
   /** How PMX vertex morphs are laid out in HBM (default 'sparse'). */ morphLayout?: 'sparse' | 'dense'
@@ -52,6 +54,8 @@ export class Engine {
   render(): void
   step(timeMs: number): void
   getDeformed(): { positions: Float32Array; normals: Float32Array }
+  getOutlineHull(): Float32Array
+  getBounds(): { min: number[]; max: number[] }
   runRenderLoop(callback?: () => void): void
   stopRenderLoop(): void
   measure(frames?: number): { frameMs: number; deformKernelMs: number; prepKernelMs: number; vertsPerFrame: number; algorithmicBytesPerFrame: number; frames: number }

@@ -11,7 +11,7 @@ const dump = (name, ta) => fs.writeFileSync(path.join(out, name), Buffer.from(ta
   const quiet = console.warn; console.warn = () => {}
   const deviceFK = /:fk$/.test(devs || '')
   const devices = (devs || '0').replace(':fk', '').split(',').map(Number)   // '0,0' = two contexts (two vertex shards) on one GPU
-  const engine = new Engine(null, { realtime: false, morphLayout: layout || 'sparse', ambient: 0.8, devices, deviceFK })
+  const engine = new Engine(null, { realtime: false, morphLayout: layout || 'sparse', ambient: 0.8, devices, deviceFK, outline: true, bounds: true })
   await engine.init()
   await engine.loadModel(pmx)
   const model = engine.currentModel
@@ -38,6 +38,9 @@ const dump = (name, ta) => fs.writeFileSync(path.join(out, name), Buffer.from(ta
     dump('world_' + s + '.f32', model.getBoneWorldMatrices())
     dump('mw_' + s + '.f32', model.getEffectiveMorphWeights())
     dump('pos_' + s + '.f32', d.positions); dump('nrm_' + s + '.f32', d.normals)
+    dump('hull_' + s + '.f32', engine.getOutlineHull())
+    const bb = engine.getBounds(); dump('bounds_' + s + '.f32', Float32Array.from(bb.min.concat(bb.max)))
+    if (s === 0) dump('edge.f32', engine.edgeScale)
   }
   const t = engine.measure(20)
   const st = engine.getStats()

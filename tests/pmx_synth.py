@@ -35,8 +35,8 @@ def write_pmx(V=5000, B=40, n_vertex_morphs=6, seed=5):
     tri = rng.integers(0, V, size=300).astype(np.int32)
     out += struct.pack("<i", len(tri)) + tri.tobytes()
     out += struct.pack("<i", 0)                                           # textures
-    out += struct.pack("<i", 1) + _text("body") + _text("") + struct.pack("<11f", *([0.5] * 11)) + bytes([0])
-    out += struct.pack("<5f", 0, 0, 0, 1, 1.0) + struct.pack("<bb", -1, -1) + bytes([0, 1, 0]) + _text("") + struct.pack("<i", len(tri))
+    out += struct.pack("<i", 1) + _text("body") + _text("") + struct.pack("<11f", *([0.5] * 11)) + bytes([0x10])
+    out += struct.pack("<5f", 0, 0, 0, 1, 1.25) + struct.pack("<bb", -1, -1) + bytes([0, 1, 0]) + _text("") + struct.pack("<i", len(tri))
     bpos = np.cumsum(rng.uniform(-1, 1, size=(B, 3)), axis=0).astype(np.float32)
     out += struct.pack("<i", B)
     for b in range(B):

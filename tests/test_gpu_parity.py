@@ -322,6 +322,49 @@ def test_device_fk_matches_host_fk_and_reference_fixture(ctx, oracle):
         ctx.upload_skeleton_topology(np.array([1, 0] + [0] * (B - 2)), g["bind"])      # 0 <-> 1 cycle
 
 
+def test_fused_outline_hull_and_bounding_box(ctx, oracle):
+    """Row f4: consumers of the deformed mesh fused into the skin kernel — the outline pass's inverted hull
+    (engine.ts:458-461) and a per-frame AABB — single pose with morphs, then 3 instances."""
+    V, B, M = 9001, 77, 6
+    mesh = synth.make_mesh(V, B, seed=71)
+    deltas, mw = synth.make_morphs_dense(V, M, seed=72)
+    edge = np.random.default_rng(73).uniform(0.0, 1.5, size=V).astype(np.float32)
+    edge[::4] = 0.0                                        # materials without the edge flag
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"], deltas, mw)
+    for split in (1, 4):
+        pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, morph_split=split)
+        ctx.upload_edge_scale(edge)
+        ctx.enable_aabb(True)
+        for _ in range(3):                                 # the box double-buffers across frames: stay consistent
+            ctx.deform()
+        pg, ng = ctx.read()
+        hg = ctx.read_hull()
+        assert_parity(pg, ng, pr, nr, "with epilogues S=%d" % split)
+        href = oracle.hull(pr, nr, edge)
+        assert np.abs(hg - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
+        assert np.array_equal(hg[::4], pg[::4])            # edge 0 => hull == position
+        box = ctx.read_aabb()
+        assert np.array_equal(box[:3], pg.min(axis=0)) and np.array_equal(box[3:], pg.max(axis=0))   # exact on the GPU's own output
+        np.testing.assert_allclose(box, np.r_[pr.min(axis=0), pr.max(axis=0)], rtol=1e-5, atol=1e-4)
+    # instanced: epilogues force the generic kernel; every instance gets its own box
+    I = 3
+    worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=400 + i) for i in range(I)])
+    ctx.upload_morphs_dense(None)
+    ctx.set_instances(I)
+    ctx.set_pose(worlds)
+    ctx.deform()
+    assert ctx.get_tuning("effective_inst_group") == 0
+    for i in range(I):
+        pg, ng = ctx.read(instance=i)
+        box = ctx.read_aabb(i)
+        assert np.array_equal(box[:3], pg.min(axis=0)) and np.array_equal(box[3:], pg.max(axis=0))
+        p_i, n_i = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[i], mesh["inv_bind"])
+        assert np.abs(ctx.read_hull(i) - oracle.hull(p_i, n_i, edge)).max() <= 1e-3
+    ctx.upload_edge_scale(None)
+    ctx.enable_aabb(False)
+    ctx.set_instances(1)
+
+
 def test_single_process_comm_init_all_one_rank(rz):
     """ncclCommInitAll / grouped all-gather entry points (one Node process driving several GPUs) with one GPU."""
     mesh = synth.make_mesh(3000, 10, seed=43)
@@ -414,6 +457,13 @@ def test_engine_through_napi_matches_oracle(tmp_path, oracle):
             if devs.endswith(":fk"):      # the GPU solved the hierarchy in f32: compare its world matrices with the host's
                 np.testing.assert_allclose(rd("gpuworld_%d.f32" % step, np.float32).reshape(-1, 16), world, rtol=3e-5, atol=3e-5)
             assert_parity(pg, ng, pr, nr, "napi %s devices %s step %d" % (layout, devs, step))
+            # fused consumers through the same boundary: outline hull and bounding box (multi-shard boxes are merged on the host)
+            edge = rd("edge.f32", np.float32)
+            assert (edge > 0).sum() > 0
+            hull = rd("hull_%d.f32" % step, np.float32).reshape(-1, 3)
+            assert np.abs(hull - oracle.hull(pr, nr, edge)).max() <= 1e-3
+            box = rd("bounds_%d.f32" % step, np.float32)
+            assert np.array_equal(box[:3], pg.min(axis=0)) and np.array_equal(box[3:], pg.max(axis=0))
             seen_morph = seen_morph or (mw != 0).sum() >= 3
             assert not np.allclose(pg, v[:, 0:3])            # the pose really moved the mesh
         assert seen_morph

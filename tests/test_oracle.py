@@ -147,3 +147,13 @@ def test_synthetic_mesh_respects_loader_invariants():
     np.testing.assert_allclose(np.linalg.norm(mesh["nrm"], axis=1), 1.0, atol=1e-6)
     # world matrices are affine (bottom row 0,0,0,1)
     np.testing.assert_array_equal(mesh["world"][:, [3, 7, 11, 15]], np.tile([0, 0, 0, 1], (200, 1)))
+
+
+def test_outline_hull_twins_agree(oracle):
+    rng = np.random.default_rng(4)
+    p = rng.normal(size=(500, 3)).astype(np.float32)
+    n = rng.normal(size=(500, 3)).astype(np.float32)
+    e = rng.uniform(0, 2, size=500).astype(np.float32)
+    a = oracle.hull(p, n, e)
+    assert np.array_equal(a, oracle.np_twin.hull(p, n, e))
+    np.testing.assert_allclose(a, p + n * e[:, None] * 0.01, rtol=1e-6, atol=1e-6)
