@@ -61,7 +61,6 @@ struct RzDeformParams {
     uint32_t n_verts;           // real vertex count V
     uint32_t n_quads;           // ceil(V / 4)
     uint32_t quads_per_wave;    // contiguous run owned by each wave of the grid (multiple of 8)
-    int tiled;                  // dense morph layout: 0 = planes D[m][3][Vp], 1 = tile-major D[m][Vp/256][3][256]
     int dbg;                    // ablation switch for profiling experiments (0 in production)
     int dma;                    // FAST: stage raw matrices by LDS-DMA (else plain loads after the first morph phase)
     int B;
@@ -105,6 +104,5 @@ hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, 
 uint32_t rz_quads_per_tile(int S);
 hipError_t rz_launch_deinterleave(const float *src, int stride, int offset, uint32_t n, float *px, float *py,
                                   float *pz, hipStream_t st);
-hipError_t rz_launch_deinterleave_tiled(const float *src, uint32_t n, float *dst, hipStream_t st);
 hipError_t rz_launch_pack_skinning(const uint16_t *joints4, const uint8_t *weights4, uint32_t n, uint32_t *j01,
                                    uint32_t *j23, uint32_t *wq, hipStream_t st);

@@ -445,10 +445,7 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
         }
 
         if (MODE == 1 && live) {
-            // morph targets: plane layout D[m][3][Vp] or tile-major D[m][Vp/256][3][256] (3 KB contiguous per
-            // morph and 256-vertex tile, so a wave's x/y/z reads of one morph share DRAM pages)
-            const float4 *D = reinterpret_cast<const float4 *>(p.dense) + (p.tiled ? (q >> 6) * 192 + (q & 63) : q);
-            const size_t ms4 = p.tiled ? (Vp / 256) * 192 : 3 * plane4, cs4 = p.tiled ? 64 : plane4;
+            const float4 *D = reinterpret_cast<const float4 *>(p.dense) + q;
             // slice s of S accumulates the active morphs a = s, s+S, s+2S, ... in ascending order.
             // The loop counter a0 is wave-uniform, so on the FAST path the list entries are fetched with
             // scalar loads straight from the kernel arguments and each lane picks its slice's entry with
@@ -475,10 +472,10 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
                 for (int u = 0; u < U; ++u) {
                     uint32_t m;
                     entry(a0 + u * S, m, w[u]);
-                    const float4 *d = D + (size_t)m * ms4;
+                    const float4 *d = D + (size_t)m * 3 * plane4;
                     dx[u] = ld_stream(d, NT);
-                    dy[u] = ld_stream(d + cs4, NT);
-                    dz[u] = ld_stream(d + 2 * cs4, NT);
+                    dy[u] = ld_stream(d + plane4, NT);
+                    dz[u] = ld_stream(d + 2 * plane4, NT);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -495,8 +492,8 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
                 float w;
                 entry(a0, m, w);
                 if (a0 + s < count) {
-                    const float4 *d = D + (size_t)m * ms4;
-                    float4 dx = ld_stream(d, NT), dy = ld_stream(d + cs4, NT), dz = ld_stream(d + 2 * cs4, NT);
+                    const float4 *d = D + (size_t)m * 3 * plane4;
+                    float4 dx = ld_stream(d, NT), dy = ld_stream(d + plane4, NT), dz = ld_stream(d + 2 * plane4, NT);
                     ax.x = fmaf(w, dx.x, ax.x); ax.y = fmaf(w, dx.y, ax.y); ax.z = fmaf(w, dx.z, ax.z); ax.w = fmaf(w, dx.w, ax.w);
                     ay.x = fmaf(w, dy.x, ay.x); ay.y = fmaf(w, dy.y, ay.y); ay.z = fmaf(w, dy.z, ay.z); ay.w = fmaf(w, dy.w, ay.w);
                     az.x = fmaf(w, dz.x, az.x); az.y = fmaf(w, dz.y, az.y); az.z = fmaf(w, dz.z, az.z); az.w = fmaf(w, dz.w, az.w);
@@ -875,16 +872,6 @@ __global__ void rz_deinterleave_kernel(const float *src, int stride, int offset,
     px[v] = s[0]; py[v] = s[1]; pz[v] = s[2];
 }
 
-// packed [n][3] morph deltas -> tile-major [Vp/256][3][256]
-__global__ void rz_deinterleave_tiled_kernel(const float *src, uint32_t n, float *dst)
-{
-    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    const float *s = src + (size_t)v * 3;
-    float *d = dst + (size_t)(v >> 8) * 768 + (v & 255u);
-    d[0] = s[0]; d[256] = s[1]; d[512] = s[2];
-}
-
 __global__ void rz_pack_skinning_kernel(const uint16_t *joints4, const uint8_t *weights4, uint32_t n,
                                         uint32_t *j01, uint32_t *j23, uint32_t *wq)
 {
@@ -1021,13 +1008,6 @@ hipError_t rz_launch_deinterleave(const float *src, int stride, int offset, uint
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(rz_deinterleave_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, stride, offset, n,
                        px, py, pz);
-    return hipGetLastError();
-}
-
-hipError_t rz_launch_deinterleave_tiled(const float *src, uint32_t n, float *dst, hipStream_t st)
-{
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(rz_deinterleave_tiled_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, n, dst);
     return hipGetLastError();
 }
 

@@ -160,8 +160,7 @@ struct rz_ctx {
     RzMorphList ml;
 
     // tuning (0 / -1 = automatic)
-    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_tiled = 0;
-    int dense_tiled = 0;               // layout the resident dense morph targets were uploaded in
+    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0;
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -286,7 +285,6 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     p.Vp = c->Vp; p.n_quads = pl.n_quads; p.quads_per_wave = pl.quads_per_wave; p.dma = pl.dma ? 1 : 0;
     p.B = (int)c->B; p.M = (int)c->M; p.Mpad = (int)c->Mpad;
     p.dbg = c->t_dbg;
-    p.tiled = c->dense_tiled;
     return p;
 }
 
@@ -641,13 +639,11 @@ int rz_upload_morphs_dense(rz_ctx *c, uint32_t M, const float *deltas)
         HIP_TRY(hipMemcpy(tmp, deltas + (size_t)m0 * V * 3, (size_t)nb * V * 3 * sizeof(float), hipMemcpyHostToDevice));
         for (uint32_t k = 0; k < nb; ++k) {
             float *pl = c->dense + (size_t)(m0 + k) * 3 * Vp;
-            if (c->t_tiled) HIP_TRY(rz_launch_deinterleave_tiled(tmp + (size_t)k * V * 3, (uint32_t)V, pl, c->stream));
-            else HIP_TRY(rz_launch_deinterleave(tmp + (size_t)k * V * 3, 3, 0, (uint32_t)V, pl, pl + Vp, pl + 2 * Vp, c->stream));
+            HIP_TRY(rz_launch_deinterleave(tmp + (size_t)k * V * 3, 3, 0, (uint32_t)V, pl, pl + Vp, pl + 2 * Vp, c->stream));
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     c->morph_mode = 1;
-    c->dense_tiled = c->t_tiled;
     c->M = M;
     c->Mpad = round_up(M + 8, 4);
     return ensure_pose_buffers(c);
@@ -1035,8 +1031,6 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
         c->t_geo = value ? 1 : 0;
     } else if (!strcmp(key, "nt_store")) {
         c->t_nts = value < 0 ? -1 : (value ? 1 : 0);
-    } else if (!strcmp(key, "morph_tiled")) {
-        c->t_tiled = value ? 1 : 0;       // takes effect at the next rz_upload_morphs_dense
     } else if (!strcmp(key, "dbg")) {
         c->t_dbg = value;
     } else if (!strcmp(key, "inst_loop")) {
