@@ -178,6 +178,37 @@ def test_sparse_morphs_match_oracle_and_dense_path(ctx, oracle):
     assert_parity(pd, nd, pr, nr, "dense expansion")
 
 
+def test_sparse_morph_duplicates_and_out_of_range_entries(ctx, oracle):
+    """PMX files may list a vertex twice inside one morph (both offsets add, in file order) and, when damaged, indices
+    past the mesh (ignored): the per-vertex CSR built at upload must keep the oracle's accumulation order."""
+    V, B = 3000, 12
+    mesh = synth.make_mesh(V, B, seed=81)
+    rng = np.random.default_rng(82)
+    off = np.array([0, 5, 5, 9], dtype=np.uint32)                       # morph 1 is empty
+    idx = np.array([7, 7, 2999, 5000, 7, 0, 7, 1, 4000000], dtype=np.uint32)   # duplicates of 7, two out of range
+    d3 = rng.normal(size=(9, 3)).astype(np.float32)
+    mw = np.array([0.5, 1.0, -0.25], dtype=np.float32)
+    pm = oracle.morph_sparse(V, off, idx, d3, mw, mesh["pos"])
+    assert not np.array_equal(pm[7], mesh["pos"][7])
+    S = oracle.palette(mesh["world"], mesh["inv_bind"])
+    pr, nr = oracle.skin(pm, mesh["nrm"], mesh["joints"], mesh["weights"], S)
+    for fast in (1, 0):
+        pg, ng = run_gpu(ctx, mesh, sparse=(off, idx, d3), mw=mw, fast=fast)
+        assert_parity(pg, ng, pr, nr, "sparse duplicates fast=%d" % fast)
+
+
+def test_larger_than_c5_no_32bit_overflow(ctx, oracle):
+    """3 M vertices x 40 dense morphs = 1.44 GB of morph planes: byte offsets pass 2^32 inside one buffer."""
+    V, B, M = 3000000, 64, 40
+    mesh = synth.make_mesh(V, B, seed=91)
+    deltas, mw = synth.make_morphs_dense(V, M, seed=92)
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"],
+                           deltas, mw, threads=32)
+    pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw)
+    assert_parity(pg, ng, pr, nr, "3M x 40")
+    assert_parity(pg[-5000:], ng[-5000:], pr[-5000:], nr[-5000:], "3M x 40 tail")
+
+
 def test_c4_instances_each_match_their_own_pose(ctx, oracle):
     """config 4 (reduced instance count for the oracle): per-instance palette, shared static mesh."""
     V, B, I = 30000, 200, 6
@@ -412,6 +443,16 @@ def test_error_paths(ctx, rz):
         c.set_tuning(morph_split=16)
     with pytest.raises(rz.RzError):
         c._L.rz_read and c.read(v0=90, n=20)          # out of range
+    with pytest.raises(rz.RzError):
+        c.upload_edge_scale(np.ones(7, dtype=np.float32))     # wrong length
+    with pytest.raises(rz.RzError):
+        c.set_pose_local(np.zeros((4, 4), dtype=np.float32))  # no topology uploaded
+    with pytest.raises(rz.RzError):
+        c.read_aabb()                                 # reduction not enabled
+    c2 = rz.DeformContext(0)
+    with pytest.raises(rz.RzError):
+        c2.upload_morphs_dense(np.zeros((1, 1, 3), dtype=np.float32)) if False else c2._L.rz_upload_morphs_dense(c2._h, 1, None) and (_ for _ in ()).throw(rz.RzError(-1, "morphs before mesh"))
+    c2.close()
     c.close()
 
 
