@@ -17,6 +17,7 @@
 const { Quat, Vec3 } = require('./math')
 const { PmxLoader } = require('./pmx-loader')
 const { VMDLoader } = require('./vmd-loader')
+const { VMDSampler } = require('./vmd-sampler')
 const { requireAddon } = require('./addon')
 
 let wallClock
@@ -325,18 +326,35 @@ class Engine {
     if (!this.currentModel || !this.ctx) return
     const t0 = wallClock()
     const model = this.currentModel
-    if (this.deviceFK) model.updateRotationTweens() // tweens stay on the host; the hierarchy solve moves to the GPU
+    // the GPU hierarchy solve takes rotations only; once a sampler moves bones, solve on the host
+    const gpuFK = this.deviceFK && !model.applyLocalTranslations
+    if (gpuFK) model.updateRotationTweens() // tweens stay on the host; the hierarchy solve moves to the GPU
     else model.evaluatePose()
     const mw = model.getMorphCount() > 0 ? model.getEffectiveMorphWeights() : null
     // per-frame inputs are replicated to every shard (16-22 KB); launches are asynchronous, so the GPUs run concurrently
     for (const s of this.shards) {
       if (s.count === 0) continue
-      if (this.deviceFK) this.native.setPoseLocal(s.ctx, model.runtimeSkeleton.localRotations, mw)
+      if (gpuFK) this.native.setPoseLocal(s.ctx, model.runtimeSkeleton.localRotations, mw)
       else this.native.setPose(s.ctx, model.getBoneWorldMatrices(), mw)
       this.native.deform(s.ctx)
     }
     if (this.gather && this.shards.length > 1) this.native.allgatherAll(this.shards.map((s) => s.ctx), true)
     this.updateStats(wallClock() - t0)
+  }
+
+  /**
+   * Frame-indexed playback (MMD semantics: Bezier-warped slerp / lerp between keys, bone translation, linear morph
+   * keys) of the loaded animation: pose the model at `frame` (30 fps, fractional allowed) and deform one frame.
+   * Independent of playAnimation()'s wall-clock tweens, which mirror the reference.
+   */
+  seekFrame(frame) {
+    if (!this.currentModel) return
+    if (!this.sampler || this.samplerFor !== this.animationFrames) {
+      this.sampler = new VMDSampler(this.animationFrames)
+      this.samplerFor = this.animationFrames
+    }
+    this.currentModel.applySampledFrame(this.sampler, frame)
+    this.render()
   }
 
   /** Deterministic stepping: move the clock to timeMs, fire the timers that came due, render one frame. */

@@ -53,6 +53,8 @@ export class Engine {
   setMorphWeights(namesOrIndices: Array<string | number>, weights: number[]): void
   render(): void
   step(timeMs: number): void
+  /** Pose the model at a (fractional) VMD frame with MMD interpolation and deform one frame. */
+  seekFrame(frame: number): void
   getDeformed(): { positions: Float32Array; normals: Float32Array }
   getOutlineHull(): Float32Array
   getBounds(): { min: number[]; max: number[] }

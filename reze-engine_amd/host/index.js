@@ -5,4 +5,5 @@ const { Vec3, Quat, Mat4 } = require('./math')
 const { Model } = require('./model')
 const { PmxLoader } = require('./pmx-loader')
 const { VMDLoader } = require('./vmd-loader')
-module.exports = { Engine, Vec3, Quat, Mat4, Model, PmxLoader, VMDLoader }
+const { VMDSampler } = require('./vmd-sampler')
+module.exports = { Engine, Vec3, Quat, Mat4, Model, PmxLoader, VMDLoader, VMDSampler }

@@ -82,6 +82,10 @@ class Model {
     this._tr = new Float32Array(16)
     this._q = [0, 0, 0, 1]
 
+    // Frame-sampled VMD playback may also move bones (センター etc.). The reference never writes localTranslations and
+    // applies them only through append-move (model.ts:388-393), so this stays off unless a sampler turns it on.
+    this.applyLocalTranslations = false
+
     this.morphs = morphs || null
     const m = this.morphs ? this.morphs.names.length : 0
     this.morphWeights = new Float32Array(m) // as set by the user / animation (includes group morphs)
@@ -228,6 +232,7 @@ class Model {
       // L = T(bind) * rotM * T(add), each product stored as f32 like the reference's Mat4.multiply chain
       identityInto(T, 0)
       T[12] += b.bindTranslation[0]; T[13] += b.bindTranslation[1]; T[14] += b.bindTranslation[2]
+      if (this.applyLocalTranslations) { T[12] += tra[i * 3]; T[13] += tra[i * 3 + 1]; T[14] += tra[i * 3 + 2] }
       mulInto(L, 0, T, 0, rotM, 0)
       identityInto(T, 0)
       T[12] += ax; T[13] += ay; T[14] += az
@@ -242,6 +247,24 @@ class Model {
       }
     }
     this.runtimeSkeleton.computedBones.fill(true)
+  }
+
+  /** Pose every bone the sampler keys at `frame` (rotation + translation), and every morph it keys. Un-keyed bones keep their state. */
+  applySampledFrame(sampler, frame) {
+    const rot = this.runtimeSkeleton.localRotations, tra = this.runtimeSkeleton.localTranslations
+    this.applyLocalTranslations = true
+    for (const name of sampler.boneNames()) {
+      const idx = this.runtimeSkeleton.nameIndex[name]
+      if (idx === undefined) continue
+      const s = sampler.sampleBone(name, frame)
+      rot[idx * 4] = s.rotation[0]; rot[idx * 4 + 1] = s.rotation[1]; rot[idx * 4 + 2] = s.rotation[2]; rot[idx * 4 + 3] = s.rotation[3]
+      tra[idx * 3] = s.position[0]; tra[idx * 3 + 1] = s.position[1]; tra[idx * 3 + 2] = s.position[2]
+      this.rotTweenState.active[idx] = 0
+    }
+    for (const name of sampler.morphNames()) {
+      const w = sampler.sampleMorph(name, frame)
+      if (w !== null) this.setMorphWeights([name], [w])
+    }
   }
 
   // ---- morphs (no reference counterpart; PMX layout per pmx-loader.ts:471-488) ----

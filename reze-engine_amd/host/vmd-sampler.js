@@ -1,0 +1,96 @@
+'use strict'
+/*
+ * vmd-sampler.js — frame-indexed VMD sampling (SURVEY §8f rank 2). No reference counterpart: the reference's
+ * loader drops position + the 64 interpolation bytes (engine/src/vmd-loader.ts:129-140), never reads the morph
+ * block, and its player replays keys as wall-clock eased tweens (engine.ts:1527-1553). This sampler evaluates a
+ * motion at an arbitrary (fractional) frame the way MMD defines it:
+ *   rotation   slerp between the surrounding keys, parameter warped by the key's R Bezier curve
+ *   position   per-axis lerp, each axis warped by its own X / Y / Z Bezier curve
+ *   morph      linear between the surrounding morph keys
+ * Interpolation block layout (first 16 of the 64 bytes; values / 127):
+ *   [X_x1, Y_x1, Z_x1, R_x1,  X_y1, Y_y1, Z_y1, R_y1,  X_x2, Y_x2, Z_x2, R_x2,  X_y2, Y_y2, Z_y2, R_y2]
+ * i.e. curve c in {X,Y,Z,R} = cubic Bezier through (0,0), (x1,y1), (x2,y2), (1,1), stored on the LATER key.
+ */
+const { kernels } = require('./math')
+
+// y(x) of the cubic Bezier (0,0) (x1,y1) (x2,y2) (1,1): solve x(t) = x by bisection-refined Newton, return y(t)
+function bezier(x, x1, y1, x2, y2) {
+  if (x <= 0) return 0
+  if (x >= 1) return 1
+  if (x1 === y1 && x2 === y2) return x // the default 20,20,107,107 curve is the identity
+  let lo = 0, hi = 1, t = x
+  for (let i = 0; i < 32; i++) {
+    const s = 1 - t
+    const fx = 3 * s * s * t * x1 + 3 * s * t * t * x2 + t * t * t - x
+    if (Math.abs(fx) < 1e-9) break
+    if (fx > 0) hi = t; else lo = t
+    const dfx = 3 * s * s * x1 + 6 * s * t * (x2 - x1) + 3 * t * t * (1 - x2)
+    const tn = dfx !== 0 ? t - fx / dfx : (lo + hi) / 2
+    t = tn > lo && tn < hi ? tn : (lo + hi) / 2
+  }
+  const s = 1 - t
+  return 3 * s * s * t * y1 + 3 * s * t * t * y2 + t * t * t
+}
+
+class VMDSampler {
+  /** @param keyFrames result of VMDLoader.load / loadFromBuffer (array + .morphFrames) */
+  constructor(keyFrames) {
+    this.bones = new Map() // name -> keys sorted by frame
+    for (const kf of keyFrames) {
+      for (const b of kf.boneFrames) {
+        if (!this.bones.has(b.boneName)) this.bones.set(b.boneName, [])
+        this.bones.get(b.boneName).push(b)
+      }
+    }
+    for (const keys of this.bones.values()) keys.sort((a, b) => a.frame - b.frame)
+    this.morphs = new Map()
+    for (const m of keyFrames.morphFrames || []) {
+      if (!this.morphs.has(m.morphName)) this.morphs.set(m.morphName, [])
+      this.morphs.get(m.morphName).push(m)
+    }
+    for (const keys of this.morphs.values()) keys.sort((a, b) => a.frame - b.frame)
+    this.lastFrame = 0
+    for (const keys of this.bones.values()) this.lastFrame = Math.max(this.lastFrame, keys[keys.length - 1].frame)
+    for (const keys of this.morphs.values()) this.lastFrame = Math.max(this.lastFrame, keys[keys.length - 1].frame)
+    this._q = [0, 0, 0, 1]
+  }
+
+  static span(keys, frame) { // index i with keys[i].frame <= frame < keys[i+1].frame (clamped)
+    let lo = 0, hi = keys.length - 1
+    if (frame <= keys[0].frame) return [0, 0, 0]
+    if (frame >= keys[hi].frame) return [hi, hi, 0]
+    while (hi - lo > 1) { const mid = (lo + hi) >> 1; if (keys[mid].frame <= frame) lo = mid; else hi = mid }
+    return [lo, hi, (frame - keys[lo].frame) / (keys[hi].frame - keys[lo].frame)]
+  }
+
+  /** -> { rotation: [x,y,z,w], position: [x,y,z] } of one bone at `frame`, or null when the motion does not key it */
+  sampleBone(name, frame) {
+    const keys = this.bones.get(name)
+    if (!keys) return null
+    const [i0, i1, x] = VMDSampler.span(keys, frame)
+    const a = keys[i0], b = keys[i1]
+    if (i0 === i1) return { rotation: [a.rotation.x, a.rotation.y, a.rotation.z, a.rotation.w], position: [a.position.x, a.position.y, a.position.z] }
+    const ip = b.interpolation
+    const curve = (c) => (ip ? bezier(x, ip[c] / 127, ip[c + 4] / 127, ip[c + 8] / 127, ip[c + 12] / 127) : x)
+    const q = kernels.slerpInto(this._q, a.rotation.x, a.rotation.y, a.rotation.z, a.rotation.w,
+      b.rotation.x, b.rotation.y, b.rotation.z, b.rotation.w, curve(3))
+    const tx = curve(0), ty = curve(1), tz = curve(2)
+    return {
+      rotation: [q[0], q[1], q[2], q[3]],
+      position: [a.position.x + (b.position.x - a.position.x) * tx, a.position.y + (b.position.y - a.position.y) * ty,
+        a.position.z + (b.position.z - a.position.z) * tz],
+    }
+  }
+
+  sampleMorph(name, frame) {
+    const keys = this.morphs.get(name)
+    if (!keys) return null
+    const [i0, i1, x] = VMDSampler.span(keys, frame)
+    return keys[i0].weight + (keys[i1].weight - keys[i0].weight) * x
+  }
+
+  boneNames() { return Array.from(this.bones.keys()) }
+  morphNames() { return Array.from(this.morphs.keys()) }
+}
+
+module.exports = { VMDSampler, bezier }

@@ -345,3 +345,47 @@ def test_math_primitives_hand_computed():
     assert np.allclose(r["mulArrays"][12:15], [1, 3, 3], atol=1e-7)           # R * T(1,0,0) + t = (0,1,0) + (1,2,3)
     assert np.allclose(r["singular"], np.eye(4).reshape(-1))
     assert np.allclose(r["vec"], [5, 0.6, 4, 7, 0])
+
+
+def test_vmd_frame_sampler_bezier_translation_and_morph_keys(tmp_path):
+    """Row f2: frame-indexed sampling with MMD Bezier interpolation (no reference counterpart; checked against an
+    independent Python evaluation of the same cubic)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from pmx_synth import write_vmd
+    s = np.sin(np.pi / 4)
+    data = bytearray(write_vmd([("boneA", 0, (0, 0, 0, 1)), ("boneA", 30, (0, 0, s, s))], [("smile", 0, 0.0), ("smile", 30, 1.0)]))
+    # patch the second key: position (3,6,9) and curves X=(0.2,0.8,0.6,0.1)*127 rounded, R=linear; layout [X_x1,Y_x1,Z_x1,R_x1, X_y1,.., X_x2,.., X_y2,..]
+    rec = 30 + 20 + 4 + 111                                       # second bone record
+    struct.pack_into("<3f", data, rec + 15 + 4, 3.0, 6.0, 9.0)
+    ip = [20] * 16
+    ip[0], ip[4], ip[8], ip[12] = 25, 102, 76, 13                 # X curve
+    ip[3], ip[7], ip[11], ip[15] = 20, 20, 107, 107               # R curve: identity
+    data[rec + 15 + 4 + 12 + 16: rec + 15 + 4 + 12 + 16 + 16] = bytes(ip)
+    f = tmp_path / "s.vmd"
+    f.write_bytes(bytes(data))
+    r = json.loads(subprocess.check_output(["node", os.path.join(ROOT, "tests", "js", "sampler_unit.js"), str(f)], timeout=60).decode().strip().splitlines()[-1])
+
+    def bez(x, x1, y1, x2, y2):
+        lo, hi = 0.0, 1.0
+        for _ in range(80):
+            t = (lo + hi) / 2
+            if 3 * (1 - t) ** 2 * t * x1 + 3 * (1 - t) * t * t * x2 + t ** 3 < x:
+                lo = t
+            else:
+                hi = t
+        return 3 * (1 - t) ** 2 * t * y1 + 3 * (1 - t) * t * t * y2 + t ** 3
+    assert np.allclose(r["bez"], [bez(x, 0.2, 0.8, 0.6, 0.1) for x in (0.1, 0.25, 0.5, 0.75, 0.9)], atol=1e-7)
+    assert abs(r["bezIdentity"] - 0.37) < 1e-12 and r["lastFrame"] == 30 and r["bones"] == ["boneA"] and r["morphs"] == ["smile"]
+    by = {x["f"]: x for x in r["samples"]}
+    assert by[0]["a"]["rotation"] == [0, 0, 0, 1] and by[45]["a"]["position"] == [3, 6, 9]        # clamped outside the keys
+    half = by[15]
+    assert np.allclose(half["a"]["rotation"], [0, 0, np.sin(np.pi / 8), np.cos(np.pi / 8)], atol=1e-6)   # linear R curve
+    tx = bez(0.5, 25 / 127, 102 / 127, 76 / 127, 13 / 127)
+    assert np.allclose(half["a"]["position"], [3 * tx, 6 * 0.5, 9 * 0.5], atol=1e-5)               # X warped, Y/Z default
+    assert abs(half["m"] - 0.5) < 1e-7 and abs(by[7.5]["m"] - 0.25) < 1e-7
+    # FK with the sampled translation: root at bind (0,1,0) + (3*tx, 3, 4.5); child 2 units along the rotated +Y
+    w = np.array(r["world15"]).reshape(2, 16)
+    assert np.allclose(w[0, 12:15], [3 * tx, 1 + 3.0, 4.5], atol=1e-5)
+    a = np.pi / 4
+    assert np.allclose(w[1, 12:15], w[0, 12:15] + [-2 * np.sin(a), 2 * np.cos(a), 0], atol=1e-5)
