@@ -298,13 +298,14 @@ __device__ __forceinline__ Skinned skin_vertex(const float4 *pal, float x, float
 //             the wave's LDS scratch; 0 = only the morphed position goes through LDS and the
 //             vertex-per-lane phase reads normal/joints/weights with 4-byte loads
 //   FAST  single-instance frame in ONE launch: the palette (world * inverseBind, engine.ts:926-928)
-//         is computed by every workgroup while it stages it into LDS — the raw matrices arrive by
-//         asynchronous global->LDS DMA that overlaps the first tile's morph stream — and the
-//         active-morph list comes in the kernel arguments (compacted on the host by rz_set_pose).
-//         !FAST reads the palette / list produced by rz_prep_kernel (instanced frames).
+//         is formed by every workgroup itself — each thread requests its bone's two matrices before
+//         anything else and does the 36 FMAs while the first group of morph loads is in flight, one
+//         barrier before the first skin phase publishes it — and the active-morph list comes in the
+//         kernel arguments (compacted on the host by rz_set_pose). No prep kernel, no launch boundary,
+//         no load in front of the morph stream. !FAST reads the palette / list produced by
+//         rz_prep_kernel (instanced frames, > 128 active morphs).
 // grid = (tiles capped, instances); block = 256.
-// dynamic LDS = palette | active-morph list (!FAST) | per-wave transpose
-//               scratch (aliased by the raw world/inverse-bind matrices during the prologue).
+// dynamic LDS = palette | active-morph list (!FAST) | per-wave transpose scratch.
 //
 // Two phases per tile, both fully coalesced:
 //   phase 1 (lane = quad of 4 vertices, slice s of S): stream the active morph planes with
@@ -342,25 +343,18 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
     const int inst = blockIdx.y;
     const int lane = tid & 63, wave = tid >> 6;
 
-    if (FAST && p.dma) {
-        // raw world (B*4 float4) then inverse bind (B*4 float4) -> scratch, by LDS-DMA: no VGPRs,
-        // in flight while the first tile's morph planes stream in
-        const float4 *gw = reinterpret_cast<const float4 *>(p.world);
-        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind);
-        const int n4 = p.B * 4;
-        for (int c = wave * 64; c < 2 * n4; c += kBlock) {
-            const int e = c + lane;
-            if (e < 2 * n4) {
-                const float4 *src = (e < n4) ? gw + e : gi + (e - n4);
-                typedef const __attribute__((address_space(1))) void *gptr_t;
-                typedef __attribute__((address_space(3))) void *lptr_t;
-                // LDS destination = wave-uniform base (+ lane * 16 added by the hardware)
-                __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)src,
-                                                 (lptr_t)(uint32_t)(uintptr_t)(reinterpret_cast<float4 *>(scratch_all) + c),
-                                                 16, 0, 0);
-            }
-        }
-    } else if (!FAST) {
+    // FAST: this thread's bone (tid < B covers the first 256 bones) — its world and inverse-bind matrices are
+    // requested FIRST, as plain loads into registers, so they are the oldest entries of the vmcnt queue: the palette
+    // math below only has to wait for them (a counted wait) while the morph loads issued after them stay in flight.
+    float4 ew0, ew1, ew2, ew3, ei0, ei1, ei2, ei3;
+    const bool early = FAST && tid < p.B && p.dbg != 3;      // dbg 3: ablation — no palette staging (output is garbage)
+    if (early) {
+        const float4 *gw = reinterpret_cast<const float4 *>(p.world) + tid * 4;
+        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + tid * 4;
+        ew0 = gw[0]; ew1 = gw[1]; ew2 = gw[2]; ew3 = gw[3];
+        ei0 = gi[0]; ei1 = gi[1]; ei2 = gi[2]; ei3 = gi[3];
+    }
+    if (!FAST) {
         const float4 *gpal = p.palette + (size_t)inst * p.B * 3;
         for (int i = tid; i < p.B * 3; i += kBlock) pal[i] = gpal[i];
         if (MODE == 1) {
@@ -383,41 +377,39 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
     const uint32_t bmax = (uint32_t)(p.B - 1);
     float *opos = p.out_pos + (size_t)inst * Vp * 3;
     float *onrm = p.out_nrm + (size_t)inst * Vp * 3;
-    bool need_palette = FAST;
+    bool need_palette = FAST && p.dbg != 3;
     float bb[6] = { __builtin_inff(), __builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
 
-    // the raw matrices have landed (every wave drains its own DMA, the barrier publishes them): palette rows
-    // 0..2 of world * inverseBind, out[c*4+r] = ((a0[r]*b0 + a1[r]*b1) + a2[r]*b2) + a3[r]*b3  (engine.ts:928)
-    auto stage_palette = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int n4 = p.B * 4;
-        const float4 *rw = p.dma ? reinterpret_cast<const float4 *>(scratch_all) : reinterpret_cast<const float4 *>(p.world);
-        const float4 *ri = p.dma ? rw + n4 : reinterpret_cast<const float4 *>(p.inv_bind);
-        for (int b0 = 0; b0 < p.B; b0 += kBlock) {
-            const int b = b0 + tid;
-            if (b < p.B) {
-                const float4 a0 = rw[b * 4 + 0], a1 = rw[b * 4 + 1], a2 = rw[b * 4 + 2], a3 = rw[b * 4 + 3];
-                float r0[4], r1[4], r2[4];
+    // palette rows 0..2 of world * inverseBind, out[c*4+r] = ((a0[r]*b0 + a1[r]*b1) + a2[r]*b2) + a3[r]*b3 (engine.ts:928)
+    auto palette_rows = [&](int b, const float4 &a0, const float4 &a1, const float4 &a2, const float4 &a3, const float4 &b0,
+                            const float4 &b1, const float4 &b2, const float4 &b3) {
+        const float4 bc[4] = { b0, b1, b2, b3 };
+        float r0[4], r1[4], r2[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float4 bc = ri[b * 4 + c];
-                    r0[c] = fmaf(a3.x, bc.w, fmaf(a2.x, bc.z, fmaf(a1.x, bc.y, a0.x * bc.x)));
-                    r1[c] = fmaf(a3.y, bc.w, fmaf(a2.y, bc.z, fmaf(a1.y, bc.y, a0.y * bc.x)));
-                    r2[c] = fmaf(a3.z, bc.w, fmaf(a2.z, bc.z, fmaf(a1.z, bc.y, a0.z * bc.x)));
-                }
-                const float4 q0 = make_float4(r0[0], r0[1], r0[2], r0[3]), q1 = make_float4(r1[0], r1[1], r1[2], r1[3]),
-                             q2 = make_float4(r2[0], r2[1], r2[2], r2[3]);
-                pal[b * 3 + 0] = q0; pal[b * 3 + 1] = q1; pal[b * 3 + 2] = q2;
-                if (blockIdx.x == 0 && p.palette) {      // keep the skinMatrixBuffer observable (rz_read_palette)
-                    float4 *gp = p.palette + (size_t)b * 3;
-                    gp[0] = q0; gp[1] = q1; gp[2] = q2;
-                }
-            }
+        for (int c = 0; c < 4; ++c) {
+            r0[c] = fmaf(a3.x, bc[c].w, fmaf(a2.x, bc[c].z, fmaf(a1.x, bc[c].y, a0.x * bc[c].x)));
+            r1[c] = fmaf(a3.y, bc[c].w, fmaf(a2.y, bc[c].z, fmaf(a1.y, bc[c].y, a0.y * bc[c].x)));
+            r2[c] = fmaf(a3.z, bc[c].w, fmaf(a2.z, bc[c].z, fmaf(a1.z, bc[c].y, a0.z * bc[c].x)));
         }
-        __syncthreads();      // palette visible; the raw region may now be reused as transpose scratch
+        const float4 q0 = make_float4(r0[0], r0[1], r0[2], r0[3]), q1 = make_float4(r1[0], r1[1], r1[2], r1[3]),
+                     q2 = make_float4(r2[0], r2[1], r2[2], r2[3]);
+        pal[b * 3 + 0] = q0; pal[b * 3 + 1] = q1; pal[b * 3 + 2] = q2;
+        if (blockIdx.x == 0 && p.palette) {      // keep the skinMatrixBuffer observable (rz_read_palette)
+            float4 *gp = p.palette + (size_t)b * 3;
+            gp[0] = q0; gp[1] = q1; gp[2] = q2;
+        }
+    };
+    // executed once per wave, wherever the first step has its loads in flight; no barrier here
+    auto form_palette = [&]() {
+        if (early) palette_rows(tid, ew0, ew1, ew2, ew3, ei0, ei1, ei2, ei3);
+        for (int b = tid + kBlock; b < p.B; b += kBlock) {      // skeletons beyond 256 bones: plain loads, late
+            const float4 *gw = reinterpret_cast<const float4 *>(p.world) + b * 4;
+            const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + b * 4;
+            palette_rows(b, gw[0], gw[1], gw[2], gw[3], gi[0], gi[1], gi[2], gi[3]);
+        }
         need_palette = false;
     };
+    bool need_sync = FAST && p.dbg != 3;          // one workgroup barrier publishes the palette before the first phase 2
 
     // persistent, evenly balanced partition: every wave of the grid owns one contiguous run of quads
     // (a multiple of 8 quads = 128 B per plane) and walks it QPW quads at a time; the last step is masked.
@@ -477,6 +469,7 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
                     dy[u] = ld_stream(d + plane4, NT);
                     dz[u] = ld_stream(d + 2 * plane4, NT);
                 }
+                if (FAST && need_palette) form_palette();    // first group only: overlaps the 3*U loads just issued
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     ax.x = fmaf(w[u], dx[u].x, ax.x); ax.y = fmaf(w[u], dx[u].y, ax.y);
@@ -532,7 +525,8 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
             }
         }
 
-        if (FAST && need_palette) stage_palette();
+        if (FAST && need_palette) form_palette();            // no morph group ran (MODE 0/2, or nothing active)
+        if (FAST && need_sync) { __syncthreads(); need_sync = false; }   // palette of every wave is in LDS
 
         // ---- park the quad in the wave's scratch: plane-major [NPL][VW] dwords ----
         if (s == 0 && live) {
@@ -586,7 +580,8 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (FAST && need_palette) stage_palette();   // a wave with an empty run still owes the workgroup its barriers
+    if (FAST && need_palette) form_palette();    // a wave with an empty run still owes the workgroup its bones ...
+    if (FAST && need_sync) __syncthreads();      // ... and its barrier
     if (p.aabb) {
         // fused per-frame bounding box: per-lane running min/max -> wave butterfly -> one atomic per wave and
         // component on order-preserving integer keys. The kernel also re-arms the OTHER slot for the next frame,
@@ -908,7 +903,6 @@ size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v)
 {
     const size_t vw = 256 / v.S;   // vertices per wave per tile
     size_t scratch = (size_t)(kBlock / 64) * (v.geo ? 9 : 3) * vw * 4;
-    if (v.fast && p.dma) scratch = std::max(scratch, (size_t)p.B * 128);  // raw world + inverse bind alias it
     const size_t list = (!v.fast && v.mode != 0) ? (size_t)p.Mpad * 8 : 0;
     return (size_t)p.B * 48 + list + scratch;
 }

@@ -311,15 +311,6 @@ Plan make_plan(const rz_ctx *c)
     pl.n_quads = (c->V + 3) / 4;
     pl.quads_per_wave = 8;
     pl.grid_x = 1;
-    if (v.fast) {
-        // raw matrices by LDS-DMA only while the workgroup still fits twice on a CU; a big skeleton reads them
-        // with plain loads instead, and one that does not fit at all takes the prep-kernel path
-        RzDeformParams probe = deform_params(c, pl);
-        probe.dma = 1;
-        if (rz_deform_lds_bytes(probe, v) <= 64 * 1024) pl.dma = true;
-        probe.dma = 0;
-        if (!pl.dma && rz_deform_lds_bytes(probe, v) > 160 * 1024) v.fast = false;
-    }
     pl.prep = !v.fast;
     // persistent, balanced grid: `cap` workgroups in total, every wave owns an equal contiguous run of quads
     const uint32_t waves_per_wg = 4, qpw_step = 64 / (uint32_t)v.S;
