@@ -85,16 +85,13 @@ def main():
         return d
     if "c5" in which:
         setup(ctx, 1000000, 256, 64)
-        out += run(ctx, "C5 1M/256/64", 30, g(morph_split=[1, 2, 4], unroll=[4, 8], grid_cap=[256, 512, 768, 1024], nt_store=[0, 1]))
-        out += run(ctx, "C5 1M variants", 30, g(morph_split=[1, 2], unroll=[8], grid_cap=[256, 512], geo_lds=[0, 1], fast=[0, 1], nontemporal=[0, 1]))
+        out += run(ctx, "C5 1M/256/64", 40, g(morph_split=[1, 2, 4], unroll=[4, 8], grid_cap=[256, 512, 768], nt_store=[0, 1]))
     if "c5shard" in which:
         for nr in (8, 4, 2):
             b, n = rz.shard_range(1000000, nr, 0)
             setup(ctx, n, 256, 64)
-            out += run(ctx, "C5 shard 1/%d (%d)" % (nr, n), 200 if nr == 8 else 100,
+            out += run(ctx, "C5 shard 1/%d (%d)" % (nr, n), 300 if nr == 8 else 100,
                        g(morph_split=[1, 2, 4, 8], unroll=[4, 8], grid_cap=[256, 512, 1024], nt_store=[0, 1]))
-            if nr == 8:
-                out += run(ctx, "C5 shard 1/8 variants", 200, g(morph_split=[2, 4], unroll=[4], grid_cap=[256, 512], geo_lds=[0, 1], fast=[0, 1]))
     if "c4" in which:
         setup(ctx, 30000, 200, 0, I=256)
         out += run(ctx, "C4 256x30k pose-loop", 100, g(fast=[-1, 0], inst_loop=[4, 8], grid_cap=[512, 768, 1024, 2048]))
