@@ -294,7 +294,7 @@ Plan make_plan(const rz_ctx *c)
     RzVariant &v = pl.v;
     v.mode = c->morph_mode;
     v.S = (v.mode == 1) ? (c->t_split > 0 ? c->t_split : auto_split(c)) : 1;
-    v.U = c->t_unroll > 0 ? c->t_unroll : (v.S <= 2 ? 8 : 4);
+    v.U = c->t_unroll > 0 ? c->t_unroll : 8;    // 24 loads in flight per lane: best or tied at every size measured
     v.nt = c->t_nt != 0;
     // streaming stores pay once the frame's output no longer fits the L2s (measured: 1 M verts yes, 126 k no)
     // and the morph stream is flowing too; a morph-free instanced frame (184 MB of output, MALL-absorbed) is faster
