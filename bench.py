@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--allgather", action="store_true", help="also time the RCCL all-gather of positions")
     ap.add_argument("--device-fk", action="store_true",
                     help="solve the bone hierarchy on the GPU: frames start from local rotations (rz_set_pose_local)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend for the barrier / max-reduce (gloo + --share-gpu lets a 1-GPU box rehearse N > 1)")
+    ap.add_argument("--share-gpu", action="store_true", help="map every rank onto GPU (local_rank %% visible devices)")
     ap.add_argument("--tune", default="", help="comma list key=value passed to rz_set_tuning")
     return ap.parse_args()
 
@@ -127,8 +130,13 @@ def main():
     # REZE_BENCH_FORCE_DIST=1 exercises the torch.distributed (RCCL) path with a single rank
     if world_size > 1 or os.environ.get("REZE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
+        if args.share_gpu:
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     elif torch.cuda.is_available():
         torch.cuda.set_device(0)
 
@@ -197,7 +205,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -1,3 +1,5 @@
+"""Ablation of the instanced (C4) skin kernel on one MI355X: dbg 0 = full kernel, 1 = gathers + math without the
+output stream, 2 = output stream without gathers / math; pose-group size G and grid swept."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,9 +11,8 @@ ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); ctx.
 ctx.set_instances(256)
 worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], 200, seed=1000 + i) for i in range(256)])
 ctx.set_pose(worlds)
-for il, cap, dbg in ((8, 512, 0), (8, 512, 1), (8, 512, 2), (4, 2048, 0), (4, 2048, 1), (4, 2048, 2)):
-    ctx.set_tuning(inst_loop=il, grid_cap=cap, dbg=dbg)
-    for rep in range(2):
-        t = ctx.time_frames(100)
-        ctx.sync(); t0 = time.perf_counter(); ctx.deform_n(200); ctx.sync(); wall = (time.perf_counter() - t0) / 200 * 1e3
-        print(il, cap, "dbg", dbg, rep, "frame %.4f kernel %.4f prep %.4f wall %.4f" % (t["frame_ms"], t["deform_kernel_ms"], t["prep_kernel_ms"], wall))
+for il, cap in ((8, 512), (4, 1024), (2, 2048), (8, 1024), (2, 4096)):
+    for dbg in (0, 1, 2):
+        ctx.set_tuning(inst_loop=il, grid_cap=cap, dbg=dbg)
+        t = min((ctx.time_frames(100) for _ in range(3)), key=lambda t: t["deform_kernel_ms"])
+        print("G=%d cap=%d dbg=%d kernel %.4f ms frame %.4f ms" % (il, cap, dbg, t["deform_kernel_ms"], t["frame_ms"]))
