@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
 
         // ---- phase 2: one vertex per lane ----
         const size_t vw0 = qw * 4;     // first vertex of this wave's step
-        const int v_live = (int)min((size_t)VW, (q_end - qw) * 4);
+        const int v_live = p.dbg == 4 ? 0 : (int)min((size_t)VW, (q_end - qw) * 4);   // dbg 4: ablation — morph phase only
 #pragma unroll 1
         for (int r = 0; r < ROUNDS; ++r) {
             const int vl = r * 64 + lane;
@@ -563,8 +563,10 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
                     j01 = p.joints01[v]; j23 = p.joints23[v]; wq = p.weights[v];
                 }
                 Skinned o = skin_vertex(pal, x, y, z, nx, ny, nz, j01, j23, wq, bmax);
-                st3<NTS>(opos + v * 3, o.px, o.py, o.pz);
-                st3<NTS>(onrm + v * 3, o.nx, o.ny, o.nz);
+                if (p.dbg != 5 || o.px == 1234.5f) {   // dbg 5: ablation — skin phase without its output stream
+                    st3<NTS>(opos + v * 3, o.px, o.py, o.pz);
+                    st3<NTS>(onrm + v * 3, o.nx, o.ny, o.nz);
+                }
                 if (p.edge) {
                     // fused consumer: the outline pass's inverted hull, engine.ts:458-461
                     //   expandedPos = worldPos + worldNormal * edgeSize * 0.01

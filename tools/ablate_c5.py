@@ -1,0 +1,16 @@
+"""Ablation of the fused morph+skin kernel (C5 and its 1/8 shard) on one MI355X. dbg 0 = full; 3 = no palette;
+4 = morph phase only (no skin phase, no stores); 5 = skin phase without its output stream."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import reze_engine_amd as rz
+from reze_engine_amd import synth
+ctx = rz.DeformContext(0)
+for V in (1000000, 125952):
+    mesh = synth.make_mesh(V, 256); deltas, mw = synth.make_morphs_dense(V, 64)
+    ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); ctx.upload_skeleton(mesh["inv_bind"])
+    ctx.upload_morphs_dense(deltas); ctx.set_pose(mesh["world"], mw)
+    for dbg in (0, 3, 4, 5, 0, 4):
+        ctx.set_tuning(dbg=dbg)
+        best = min(ctx.time_frames(300 if V < 500000 else 60)["frame_ms"] for _ in range(4))
+        print("V=%d dbg=%d frame %.4f ms" % (V, dbg, best))
