@@ -61,6 +61,7 @@ struct RzDeformParams {
     uint32_t n_verts;           // real vertex count V
     uint32_t n_quads;           // ceil(V / 4)
     uint32_t quads_per_wave;    // contiguous run owned by each wave of the grid (multiple of 8)
+    uint32_t out_cap;           // vertices buffered in LDS per wave before a 16-B/lane flush (0 = store directly)
     int dbg;                    // ablation switch for profiling experiments (0 in production)
     int dma;                    // FAST: stage raw matrices by LDS-DMA (else plain loads after the first morph phase)
     int B;

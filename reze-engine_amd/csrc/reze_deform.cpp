@@ -160,7 +160,7 @@ struct rz_ctx {
     RzMorphList ml;
 
     // tuning (0 / -1 = automatic)
-    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0;
+    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = 0;
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -269,7 +269,7 @@ int auto_split(const rz_ctx *c)
     return S;
 }
 
-struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; };
+struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; };
 
 RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
 {
@@ -285,6 +285,7 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     p.Vp = c->Vp; p.n_quads = pl.n_quads; p.quads_per_wave = pl.quads_per_wave; p.dma = pl.dma ? 1 : 0;
     p.B = (int)c->B; p.M = (int)c->M; p.Mpad = (int)c->Mpad;
     p.dbg = c->t_dbg;
+    p.out_cap = pl.out_cap;
     return p;
 }
 
@@ -308,6 +309,7 @@ Plan make_plan(const rz_ctx *c)
     pl.inst_group = 0;
     pl.verts_per_wg = 0;
     pl.poses_per_wg = 0;
+    pl.out_cap = 0;
     pl.n_quads = (c->V + 3) / 4;
     pl.quads_per_wave = 8;
     pl.grid_x = 1;
@@ -323,6 +325,12 @@ Plan make_plan(const rz_ctx *c)
     per_wave = std::max<uint32_t>(8, round_up(per_wave, 8));
     pl.quads_per_wave = per_wave;
     pl.grid_x = std::max<uint32_t>(1, (pl.n_quads + per_wave * waves_per_wg - 1) / (per_wave * waves_per_wg));
+    // LDS write batching: capacity = whole run when it fits 512 vertices (12 KB per wave), else 512; at least one step
+    if (c->t_outcap != 0) {
+        const uint32_t step = 256u / (uint32_t)v.S;
+        uint32_t cap_v = c->t_outcap > 0 ? (uint32_t)c->t_outcap : std::min<uint32_t>(512, round_up(pl.quads_per_wave * 4, 64));
+        pl.out_cap = std::max(round_up(cap_v, 64), step);
+    }
     // instanced, morph-free frames: G poses per workgroup (palettes together <= 76.8 KB so two workgroups fit a CU)
     const bool epilogues = c->edge != nullptr || c->aabb_on;   // only the generic kernel carries the fused consumers
     if (v.mode == 0 && c->I > 1 && c->t_instloop != 0 && !epilogues) {
@@ -1022,6 +1030,9 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
         c->t_geo = value ? 1 : 0;
     } else if (!strcmp(key, "nt_store")) {
         c->t_nts = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (!strcmp(key, "out_cap")) {
+        if (value < -1 || value > 2048) return fail(RZ_ERR_INVALID, "out_cap must be -1 (auto), 0 (off) or 64..2048 vertices per wave");
+        c->t_outcap = value;
     } else if (!strcmp(key, "dbg")) {
         c->t_dbg = value;
     } else if (!strcmp(key, "inst_loop")) {

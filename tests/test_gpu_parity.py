@@ -24,7 +24,7 @@ def run_gpu(ctx, mesh, world=None, deltas=None, mw=None, sparse=None, **tuning):
     elif sparse is not None:
         ctx.upload_morphs_sparse(*sparse)
     ctx.set_instances(1)
-    ctx.set_tuning(morph_split=0, unroll=0, nontemporal=1, nt_store=1, geo_lds=1, grid_cap=0, fast=-1)
+    ctx.set_tuning(morph_split=0, unroll=0, nontemporal=1, nt_store=1, geo_lds=1, grid_cap=0, fast=-1, out_cap=0)
     ctx.set_tuning(**tuning)
     ctx.set_pose(mesh["world"] if world is None else world, mw)
     ctx.deform()
@@ -176,6 +176,18 @@ def test_sparse_morphs_match_oracle_and_dense_path(ctx, oracle):
         assert_parity(pg, ng, pr, nr, "sparse fast=%d" % fast)
     pd, nd = run_gpu(ctx, mesh, deltas=synth.sparse_to_dense(V, off, idx, d3), mw=mw, morph_split=1)
     assert_parity(pd, nd, pr, nr, "dense expansion")
+
+
+@pytest.mark.parametrize("cap", [-1, 64, 192, 2048])
+def test_lds_batched_output_stores(ctx, oracle, cap):
+    """out_cap: outputs parked in a per-wave LDS buffer and flushed as 16-byte stores (full, partial and multi-flush runs)."""
+    for V, B, M, split in ((30000, 200, 64, 0), (70001, 33, 5, 1), (5000, 10, 0, 0)):
+        mesh = synth.make_mesh(V, B, seed=V)
+        deltas, mw = synth.make_morphs_dense(V, M, seed=7) if M else (None, None)
+        pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"], deltas, mw, threads=8)
+        for nts in (0, 1):
+            pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, morph_split=split, out_cap=cap, nt_store=nts, geo_lds=0)
+            assert_parity(pg, ng, pr, nr, "out_cap=%d V=%d nts=%d" % (cap, V, nts))
 
 
 def test_sparse_morph_duplicates_and_out_of_range_entries(ctx, oracle):

@@ -10,7 +10,7 @@ for V in (1000000, 125952):
     mesh = synth.make_mesh(V, 256); deltas, mw = synth.make_morphs_dense(V, 64)
     ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); ctx.upload_skeleton(mesh["inv_bind"])
     ctx.upload_morphs_dense(deltas); ctx.set_pose(mesh["world"], mw)
-    for dbg in (0, 3, 4, 5, 0, 4):
-        ctx.set_tuning(dbg=dbg)
+    for dbg, oc in ((0, 0), (0, -1), (0, 256), (5, 0), (0, 0), (0, -1)):
+        ctx.set_tuning(dbg=dbg, out_cap=oc)
         best = min(ctx.time_frames(300 if V < 500000 else 60)["frame_ms"] for _ in range(4))
-        print("V=%d dbg=%d frame %.4f ms" % (V, dbg, best))
+        print("V=%d dbg=%d out_cap=%d frame %.4f ms" % (V, dbg, oc, best))
