@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "deform_kernels.h"
 
@@ -324,8 +325,10 @@ template <bool NTS> __device__ __forceinline__ void st3(float *d, float a, float
     }
 }
 
+// __launch_bounds__(256, 2): the persistent grid is two workgroups per CU (2 waves per SIMD), so the register
+// allocator may use up to 256 VGPRs but not one more (a 257th would halve residency).
 template <int S, int U, int MODE, bool NT, bool NTS, bool GEO, bool FAST>
-__global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams p, const RzMorphList ml)
+__global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformParams p, const RzMorphList ml)
 {
     constexpr int QPW = 64 / S;              // quads per wave
     constexpr int VW = 4 * QPW;              // vertices per wave per tile
@@ -449,7 +452,10 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
         ob_fill = 0;
     };
 
-    for (size_t qw = q_begin; qw < q_end; qw += QPW) {
+    // One step = QPW quads. The body is instantiated twice: FIRST (the run's first step, which also forms the
+    // palette from the early-loaded matrices) and the steady-state form, where those 32 registers are dead.
+    auto step = [&](const size_t qw, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const size_t q = qw + qi;                                    // this lane's quad
         const bool live = q < q_end;
         float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), ay = ax, az = ax;
@@ -501,7 +507,7 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
                     dy[u] = ld_stream(d + plane4, NT);
                     dz[u] = ld_stream(d + 2 * plane4, NT);
                 }
-                if (FAST && need_palette) form_palette();    // first group only: overlaps the 3*U loads just issued
+                if (FAST && FIRST && need_palette) form_palette();    // first group of the first step: overlaps the 3*U loads just issued
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     ax.x = fmaf(w[u], dx[u].x, ax.x); ax.y = fmaf(w[u], dx[u].y, ax.y);
@@ -557,8 +563,8 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
             }
         }
 
-        if (FAST && need_palette) form_palette();            // no morph group ran (MODE 0/2, or nothing active)
-        if (FAST && need_sync) { __syncthreads(); need_sync = false; }   // palette of every wave is in LDS
+        if (FAST && FIRST && need_palette) form_palette();            // no morph group ran (MODE 0/2, or nothing active)
+        if (FAST && FIRST && need_sync) { __syncthreads(); need_sync = false; }   // palette of every wave is in LDS
 
         // ---- park the quad in the wave's scratch: plane-major [NPL][VW] dwords ----
         if (s == 0 && live) {
@@ -621,6 +627,11 @@ __global__ void __launch_bounds__(kBlock) rz_deform_kernel(const RzDeformParams 
             ob_fill += (uint32_t)v_live;
             if (ob_fill + VW > cap) flush_out();      // the next step might not fit
         }
+    };
+    {
+        size_t qw = q_begin;
+        if (qw < q_end) { step(qw, std::true_type{}); qw += QPW; }
+        for (; qw < q_end; qw += QPW) step(qw, std::false_type{});
     }
     if (cap && ob_fill) flush_out();
     if (FAST && need_palette) form_palette();    // a wave with an empty run still owes the workgroup its bones ...

@@ -329,7 +329,7 @@ Plan make_plan(const rz_ctx *c)
     if (c->t_outcap != 0) {
         const uint32_t step = 256u / (uint32_t)v.S;
         uint32_t cap_v = c->t_outcap > 0 ? (uint32_t)c->t_outcap : std::min<uint32_t>(512, round_up(pl.quads_per_wave * 4, 64));
-        pl.out_cap = std::max(round_up(cap_v, 64), step);
+        pl.out_cap = std::max(std::min<uint32_t>(round_up(cap_v, 64), 640), step);   // <= 15 KB per wave
     }
     // instanced, morph-free frames: G poses per workgroup (palettes together <= 76.8 KB so two workgroups fit a CU)
     const bool epilogues = c->edge != nullptr || c->aabb_on;   // only the generic kernel carries the fused consumers
