@@ -153,7 +153,8 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * per vertex quad), "unroll" (0,4,8 morphs in flight per lane), "grid_cap" (total workgroups),
  * "geo_lds" (0/1: rest geometry transposed through LDS vs 4-byte loads), "nontemporal" (0/1,
  * morph-stream loads), "nt_store" (0/1, output stores), "fast" (-1 auto, 0 always run the
- * separate prep kernel, 1 one-launch frame when possible), "inst_loop" (-1 auto, 0 off, 2..8 poses
+ * separate prep kernel, 1 one-launch frame when possible), "out_cap" (-1 auto, 0 off, else vertices a wave
+ * parks in LDS before writing them out in one burst), "inst_loop" (-1 auto, 0 off, 2..8 poses
  * per workgroup in instanced morph-free frames). rz_get_tuning also answers
  * "effective_split" / "effective_unroll" / "effective_grid" / "effective_fast".
  * Unknown keys return RZ_ERR_INVALID. */

@@ -160,7 +160,7 @@ struct rz_ctx {
     RzMorphList ml;
 
     // tuning (0 / -1 = automatic)
-    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = 0;
+    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1;
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -325,11 +325,14 @@ Plan make_plan(const rz_ctx *c)
     per_wave = std::max<uint32_t>(8, round_up(per_wave, 8));
     pl.quads_per_wave = per_wave;
     pl.grid_x = std::max<uint32_t>(1, (pl.n_quads + per_wave * waves_per_wg - 1) / (per_wave * waves_per_wg));
-    // LDS write batching: capacity = whole run when it fits 512 vertices (12 KB per wave), else 512; at least one step
-    if (c->t_outcap != 0) {
+    // LDS write batching. Measured (tools/ablate_c5.py): parking a wave's WHOLE run and writing it once at the end
+    // takes C5 from 127.6 to 124.5 us (the stores leave the read stream alone until the kernel's tail); flushing every
+    // step gains nothing. So automatic mode turns it on exactly when the run fits the buffer (<= 640 vertices per wave).
+    {
         const uint32_t step = 256u / (uint32_t)v.S;
-        uint32_t cap_v = c->t_outcap > 0 ? (uint32_t)c->t_outcap : std::min<uint32_t>(512, round_up(pl.quads_per_wave * 4, 64));
-        pl.out_cap = std::max(std::min<uint32_t>(round_up(cap_v, 64), 640), step);   // <= 15 KB per wave
+        const uint32_t run = round_up(pl.quads_per_wave * 4, 64);
+        if (c->t_outcap > 0) pl.out_cap = std::max(std::min<uint32_t>(round_up((uint32_t)c->t_outcap, 64), 640), step);
+        else if (c->t_outcap < 0 && run <= 640) pl.out_cap = std::max(run, step);
     }
     // instanced, morph-free frames: G poses per workgroup (palettes together <= 76.8 KB so two workgroups fit a CU)
     const bool epilogues = c->edge != nullptr || c->aabb_on;   // only the generic kernel carries the fused consumers
