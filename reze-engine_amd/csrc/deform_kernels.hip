@@ -683,7 +683,9 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int inst0 = blockIdx.y * G;
     const int ng = min(G, n_inst - inst0);
-    const int rows = p.B * 3;                       // float4 per palette
+    const int rows = p.B * 3;                       // float4 per palette in global memory
+    const int rstride = p.dma ? 3 : 4;              // float4 per palette slot in LDS
+    const int lrows = p.B * rstride;
     if (p.dma) {
         // prep-kernel path: the group's palettes are contiguous in global memory -> one linear LDS-DMA copy
         const float4 *src = p.palette + (size_t)inst0 * rows;
@@ -697,31 +699,26 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
             }
         }
     } else {
-        // one-launch frame: every workgroup forms its G palettes itself (rows 0..2 of world * inverseBind,
-        // engine.ts:926-928) — redundant across the vertex runs of a group but far cheaper than a prep launch
-        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind);
-        const float4 *gw = reinterpret_cast<const float4 *>(p.world) + (size_t)inst0 * p.B * 4;
-        const int n = ng * p.B;
-#pragma unroll 2
-        for (int idx = tid; idx < n; idx += kBlock) {
-            const int b = idx % p.B;
-            const float4 a0 = gw[idx * 4 + 0], a1 = gw[idx * 4 + 1], a2 = gw[idx * 4 + 2], a3 = gw[idx * 4 + 3];
-            float r0[4], r1[4], r2[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 bc = gi[b * 4 + c];
-                r0[c] = fmaf(a3.x, bc.w, fmaf(a2.x, bc.z, fmaf(a1.x, bc.y, a0.x * bc.x)));
-                r1[c] = fmaf(a3.y, bc.w, fmaf(a2.y, bc.z, fmaf(a1.y, bc.y, a0.y * bc.x)));
-                r2[c] = fmaf(a3.z, bc.w, fmaf(a2.z, bc.z, fmaf(a1.z, bc.y, a0.z * bc.x)));
-            }
-            const float4 q0 = make_float4(r0[0], r0[1], r0[2], r0[3]), q1 = make_float4(r1[0], r1[1], r1[2], r1[3]),
-                         q2 = make_float4(r2[0], r2[1], r2[2], r2[3]);
-            pal[idx * 3 + 0] = q0; pal[idx * 3 + 1] = q1; pal[idx * 3 + 2] = q2;
-            if (blockIdx.x == 0 && p.palette) {      // keep the skinMatrixBuffer observable (rz_read_palette)
-                float4 *gp = p.palette + ((size_t)inst0 * p.B + idx) * 3;
-                gp[0] = q0; gp[1] = q1; gp[2] = q2;
+        // one-launch frame: the group's WORLD matrices are staged instead, whole (64-byte slots, the same linear
+        // 16-byte LDS-DMA); the conversion pass below multiplies by the inverse bind matrix in place and leaves the
+        // palette rows in the first 48 bytes of each slot. (A compact 48-byte slot would need gfx950's 12-byte LDS-DMA
+        // to pack its cells — measured: it keeps a 16-byte lane stride — or loads + ds_write, measured 3 us slower.)
+        const float4 *src = reinterpret_cast<const float4 *>(p.world) + (size_t)inst0 * p.B * 4;
+        const int n = ng * p.B * 4;
+        for (int c = wave * 64; c < n; c += kBlock) {
+            const int e = c + lane;
+            if (e < n) {
+                typedef const __attribute__((address_space(1))) void *gptr_t;
+                typedef __attribute__((address_space(3))) void *lptr_t;
+                __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(src + e), (lptr_t)(uint32_t)(uintptr_t)(pal + c), 16, 0, 0);
             }
         }
+    }
+    // the inverse bind matrix of the bone this thread converts (one bone per thread across the group's poses)
+    float4 ib0 = {0, 0, 0, 0}, ib1 = ib0, ib2 = ib0, ib3 = ib0;
+    if (!p.dma && tid < p.B) {
+        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + tid * 4;
+        ib0 = gi[0]; ib1 = gi[1]; ib2 = gi[2]; ib3 = gi[3];
     }
     const size_t Vp = p.Vp;
     const uint32_t v_begin = blockIdx.x * verts_per_wg;
@@ -737,8 +734,48 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
         nx = p.geom[3 * Vp + v]; ny = p.geom[4 * Vp + v]; nz = p.geom[5 * Vp + v];
         j01 = p.joints01[v]; j23 = p.joints23[v]; wq = p.weights[v];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // palettes (and the first vertex) have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // palettes / world matrices (and the first vertex) have landed
     __syncthreads();
+    if (!p.dma) {
+        // in-place conversion: slot (g, b) = rows 0..2 of world * inverseBind (engine.ts:926-928). Packed math: the
+        // inverse bind matrix is held as column PAIRS (c0,c1),(c2,c3) per k, so each result row is two v_pk_fma
+        // chains; the next pose's cells are read before the current product is formed.
+        for (int b = tid; b < p.B; b += kBlock) {           // one trip unless the skeleton has > 256 bones
+            if (b != tid) {
+                const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + b * 4;
+                ib0 = gi[0]; ib1 = gi[1]; ib2 = gi[2]; ib3 = gi[3];
+            }
+            const f2 px01 = {ib0.x, ib1.x}, px23 = {ib2.x, ib3.x}, py01 = {ib0.y, ib1.y}, py23 = {ib2.y, ib3.y};
+            const f2 pz01 = {ib0.z, ib1.z}, pz23 = {ib2.z, ib3.z}, pw01 = {ib0.w, ib1.w}, pw23 = {ib2.w, ib3.w};
+            float4 *slot = pal + (size_t)b * 4;
+            float4 a0 = slot[0], a1 = slot[1], a2 = slot[2], a3 = slot[3];       // the world matrix's columns
+            for (int g = 0; g < ng; ++g) {
+                float4 *nxt = slot + lrows;
+                float4 n0 = a0, n1 = a1, n2 = a2, n3 = a3;
+                if (g + 1 < ng) { n0 = nxt[0]; n1 = nxt[1]; n2 = nxt[2]; n3 = nxt[3]; }
+                // row r of the product = a3[r]*P_w + (a2[r]*P_z + (a1[r]*P_y + a0[r]*P_x))
+                const f2 r0a = a3.x * pw01 + (a2.x * pz01 + (a1.x * py01 + a0.x * px01));
+                const f2 r0b = a3.x * pw23 + (a2.x * pz23 + (a1.x * py23 + a0.x * px23));
+                const f2 r1a = a3.y * pw01 + (a2.y * pz01 + (a1.y * py01 + a0.y * px01));
+                const f2 r1b = a3.y * pw23 + (a2.y * pz23 + (a1.y * py23 + a0.y * px23));
+                const f2 r2a = a3.z * pw01 + (a2.z * pz01 + (a1.z * py01 + a0.z * px01));
+                const f2 r2b = a3.z * pw23 + (a2.z * pz23 + (a1.z * py23 + a0.z * px23));
+                slot[0] = make_float4(r0a.x, r0a.y, r0b.x, r0b.y);
+                slot[1] = make_float4(r1a.x, r1a.y, r1b.x, r1b.y);
+                slot[2] = make_float4(r2a.x, r2a.y, r2b.x, r2b.y);
+                slot = nxt; a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+            }
+        }
+        __syncthreads();
+        if (p.palette) {
+            // keep the skinMatrixBuffer observable (rz_read_palette): the vertex runs of a pose group each copy one
+            // slice of the finished palettes out of LDS, coalesced
+            const int n = ng * rows, per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+            const int lo = (int)blockIdx.x * per, hi = min(n, lo + per);
+            float4 *gp = p.palette + (size_t)inst0 * rows;
+            for (int i = lo + tid; i < hi; i += kBlock) gp[i] = pal[(i / 3) * 4 + i % 3];
+        }
+    }
     for (; v < v_end; v += kBlock) {
         const uint32_t vn = v + kBlock;
         float xn = 0, yn = 0, zn = 0, nxn = 0, nyn = 0, nzn = 0;
@@ -754,8 +791,8 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
         const bool ok = isum != 0u;
         const float inv = __builtin_amdgcn_rcpf((float)(ok ? isum : 1u));
         const float w0 = ok ? (float)b0 * inv : 1.0f, w1 = (float)b1 * inv, w2 = (float)b2 * inv, w3 = (float)b3 * inv;
-        const uint32_t o0 = min(j01 & 0xffffu, bmax) * 3u, o1 = min(j01 >> 16, bmax) * 3u,
-                       o2 = min(j23 & 0xffffu, bmax) * 3u, o3 = min(j23 >> 16, bmax) * 3u;
+        const uint32_t o0 = min(j01 & 0xffffu, bmax) * rstride, o1 = min(j01 >> 16, bmax) * rstride,
+                       o2 = min(j23 & 0xffffu, bmax) * rstride, o3 = min(j23 >> 16, bmax) * rstride;
         float *dp = p.out_pos + ((size_t)inst0 * Vp + v) * 3;
         float *dn = p.out_nrm + ((size_t)inst0 * Vp + v) * 3;
         const float4 *pg = pal;
@@ -794,7 +831,7 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
                 st3<NTS>(dp, q0.x, q1.x, q2.x);
                 st3<NTS>(dn, good ? tx * rl : nx, good ? ty * rl : ny, good ? tz * rl : nz);
             }
-            pg += rows;
+            pg += lrows;
             dp += Vp * 3;
             dn += Vp * 3;
         }
@@ -1024,7 +1061,7 @@ hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, cons
 hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
                                     bool nts, hipStream_t st)
 {
-    const size_t lds = (size_t)G * p.B * 48;
+    const size_t lds = (size_t)G * p.B * (p.dma ? 48 : 64);
     auto k = nts ? rz_skin_instances_kernel<true> : rz_skin_instances_kernel<false>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

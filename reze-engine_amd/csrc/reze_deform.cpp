@@ -334,11 +334,20 @@ Plan make_plan(const rz_ctx *c)
         if (c->t_outcap > 0) pl.out_cap = std::max(std::min<uint32_t>(round_up((uint32_t)c->t_outcap, 64), 640), step);
         else if (c->t_outcap < 0 && run <= 640) pl.out_cap = std::max(run, step);
     }
-    // instanced, morph-free frames: G poses per workgroup (palettes together <= 76.8 KB so two workgroups fit a CU)
+    // instanced, morph-free frames: G poses per workgroup share one decode of each vertex, their palettes live in LDS.
+    // Where the palettes come from (measured on C4, tools/ablate_c4.py, frame = everything a frame launches):
+    //   prep kernel + 16-byte LDS-DMA of finished palettes (default, and always behind the on-device FK, which writes
+    //       the palettes itself): 38.7-39.5 us (kernel 34 + 2.7 us prep + launch boundary);
+    //   in-kernel (fast = 1): the skin kernel stages the group's world matrices (64-byte slots, same LDS-DMA) and
+    //       multiplies by the inverse bind matrices in place — one launch per frame, 39.6-40 us: the staging costs
+    //       what the extra launch did, so it is opt-in.
     const bool epilogues = c->edge != nullptr || c->aabb_on;   // only the generic kernel carries the fused consumers
     if (v.mode == 0 && c->I > 1 && c->t_instloop != 0 && !epilogues) {
-        int G = (int)std::min<uint32_t>(8, (80u * 1024u) / (c->B * 48u));
-        if (c->t_instloop > 0 && c->t_instloop <= 8) G = std::min(G, c->t_instloop);
+        const bool in_kernel = c->t_fast == 1 && !c->pose_local;
+        const uint32_t slot = in_kernel ? 64u : 48u;           // LDS bytes per bone per pose (deform_kernels.hip)
+        const uint32_t g_lds = (80u * 1024u) / (c->B * slot);  // two workgroups per CU must fit
+        int G = (int)std::min<uint32_t>(8, g_lds);
+        if (c->t_instloop > 0 && c->t_instloop <= 8) G = (int)std::min<uint32_t>(g_lds, (uint32_t)c->t_instloop);
         if (G >= 2) {
             G = (int)std::min<uint32_t>((uint32_t)G, c->I);
             const uint32_t groups = (c->I + G - 1) / G;
@@ -347,10 +356,8 @@ Plan make_plan(const rz_ctx *c)
             uint32_t per = round_up((c->V + gxi - 1) / gxi, 64);
             pl.inst_group = G;
             pl.verts_per_wg = per;
-            // palettes come from the prep kernel by LDS-DMA (measured faster: 39 vs 41-44 us per C4 frame); fast = 1
-            // forms them inside the kernel instead (one launch per frame)
-            pl.prep = c->t_fast != 1;
-            pl.dma = pl.prep;
+            pl.prep = !in_kernel;
+            pl.dma = !in_kernel;
             pl.grid_x = (c->V + per - 1) / per;
         }
     }

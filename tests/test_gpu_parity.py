@@ -238,11 +238,13 @@ def test_c4_instances_each_match_their_own_pose(ctx, oracle):
     ctx.set_instances(1)
 
 
-@pytest.mark.parametrize("fast", [-1, 0])
+@pytest.mark.parametrize("fast", [-1, 0, 1])
 @pytest.mark.parametrize("inst_loop", [-1, 0, 3, 9])
 def test_c4_instance_loop_kernel_and_ragged_groups(ctx, oracle, inst_loop, fast):
     """19 poses do not divide into groups of 8: the pose-loop kernel (inst_loop != 0) and the generic kernel
-    (inst_loop = 0) must both match every pose; 471 bones forces a smaller group (LDS)."""
+    (inst_loop = 0) must both match every pose; 471 bones forces a smaller group (LDS). fast = 1 makes the pose-group
+    kernel form its palettes itself (world matrices staged in LDS, converted in place) instead of reading
+    rz_prep_kernel's output."""
     for V, B, I in ((7001, 64, 19), (3000, 471, 5)):
         mesh = synth.make_mesh(V, B, seed=V)
         worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=300 + i) for i in range(I)])
