@@ -182,6 +182,20 @@ int rz_read_gathered(rz_ctx *ctx, uint32_t v0, uint32_t n, float *pos3, float *n
 int rz_comm_init_all(rz_ctx **ctxs, int n, uint32_t v_total);
 int rz_allgather_all(rz_ctx **ctxs, int n, int with_normals);
 
+/* Peer-direct gather ("peer-direct stores replacing the all-gather"), single-process form.
+ * The reference has one consumer of the deformed mesh — the rasteriser behind vs() (engine.ts:245-276) — so only ONE
+ * GPU (`root`, an index into ctxs) needs the whole mesh. rz_gather_direct allocates the [n x chunk][3] position and
+ * normal arrays on the root's GPU, enables peer access and re-points every context's output at its own slice of
+ * them: from then on each rz_deform stores its shard straight into the root's memory over xGMI while it computes —
+ * no collective, no second pass over the output, no RCCL. ctxs[r] must hold shard r of rz_shard_range(v_total, n, r);
+ * contexts may share a GPU (then no peer mapping is involved). rz_read() on a contributor still returns its shard.
+ * rz_gather_fence(root) makes the root's stream wait (hipStreamWaitEvent, nothing blocks on the host) for
+ * everything the other contexts have enqueued so far, so a consumer enqueued on the root's stream sees the whole
+ * frame; rz_read_gathered(root, ...) fences, synchronises and copies to the host. Uploading a new mesh to any of
+ * the contexts, or destroying the root, returns the contexts to their private output buffers. */
+int rz_gather_direct(rz_ctx **ctxs, int n, uint32_t v_total, int root);
+int rz_gather_fence(rz_ctx *root);
+
 #ifdef __cplusplus
 }
 #endif

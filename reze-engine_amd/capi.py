@@ -18,7 +18,7 @@ SYMBOLS = [
     "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
     "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_read_world", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
     "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_output_ptrs",
-    "rz_comm_unique_id", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all", "rz_upload_edge_scale", "rz_read_hull", "rz_enable_aabb", "rz_read_aabb",
+    "rz_comm_unique_id", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_gather_fence", "rz_upload_edge_scale", "rz_read_hull", "rz_enable_aabb", "rz_read_aabb",
 ]
 
 
@@ -87,6 +87,8 @@ def load():
     L.rz_read_aabb.argtypes = [vp, u32, fp]
     L.rz_comm_init_all.argtypes = [ctypes.POINTER(vp), ctypes.c_int, u32]
     L.rz_allgather_all.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int]
+    L.rz_gather_direct.argtypes = [ctypes.POINTER(vp), ctypes.c_int, u32, ctypes.c_int]
+    L.rz_gather_fence.argtypes = [vp]
     for name in SYMBOLS:
         if name != "rz_last_error":
             getattr(L, name).restype = ctypes.c_int
@@ -138,6 +140,15 @@ def comm_init_all(contexts, v_total):
 def allgather_all(contexts, with_normals=False):
     arr = (ctypes.c_void_p * len(contexts))(*[c._h for c in contexts])
     _chk(load().rz_allgather_all(arr, len(contexts), 1 if with_normals else 0))
+
+
+def gather_direct(contexts, v_total, root=0):
+    """Peer-direct gather: every context's kernels store their shard straight into contexts[root]'s gathered
+    buffer (no collective). contexts[r] holds shard r; read the whole mesh with contexts[root].read_gathered()."""
+    arr = (ctypes.c_void_p * len(contexts))(*[c._h for c in contexts])
+    _chk(load().rz_gather_direct(arr, len(contexts), int(v_total), int(root)))
+    for c in contexts:
+        c.v_total = int(v_total)
 
 
 class DeformContext:
@@ -324,6 +335,10 @@ class DeformContext:
 
     def allgather(self, with_normals=False):
         _chk(self._L.rz_allgather(self._h, 1 if with_normals else 0))
+
+    def gather_fence(self):
+        """Make this (root) context's stream wait for the frames the other contributors have enqueued."""
+        _chk(self._L.rz_gather_fence(self._h))
 
     def read_gathered(self, v0=0, n=None):
         n = self.v_total - v0 if n is None else n

@@ -528,6 +528,26 @@ static napi_value fn_allgather_all(napi_env env, napi_callback_info info)
     return rc ? throw_rz(env, rc) : undef(env);
 }
 
+static napi_value fn_gather_direct(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    rz_ctx *list[64];
+    int n = 0;
+    uint32_t vt, root;
+    if (!get_ctx_list(env, argv[0], list, &n) || !get_u32(env, argv[1], &vt) || !get_u32(env, argv[2], &root))
+        return throw_msg(env, "gatherDirect(ctx[], vTotal, root)");
+    int rc = rz_gather_direct(list, n, vt, (int)root);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_gather_fence(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    CTX(0);
+    int rc = rz_gather_fence(ctx);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
 static napi_value fn_read_gathered(napi_env env, napi_callback_info info)
 {
     ARGS(5);
@@ -557,6 +577,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "timeFrames", fn_time_frames }, { "setTuning", fn_set_tuning }, { "getTuning", fn_get_tuning },
         { "commUniqueId", fn_comm_unique_id }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },
         { "readGathered", fn_read_gathered }, { "commInitAll", fn_comm_init_all }, { "allgatherAll", fn_allgather_all },
+        { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value f;

@@ -167,6 +167,11 @@ struct rz_ctx {
     int nranks = 1, rank = 0;
     uint32_t v_total = 0, chunk = 0;
     float *g_pos = nullptr, *g_nrm = nullptr;   // nranks x chunk x 3
+    // peer-direct gather (rz_gather_direct): this context's kernels store straight into the root's gathered buffer
+    float *ext_pos = nullptr, *ext_nrm = nullptr;
+    rz_ctx *gather_root = nullptr;              // set on every contributor (the root contributes too)
+    std::vector<rz_ctx *> contributors;         // set on the root
+    hipEvent_t ev_done = nullptr;               // "my last frame has been enqueued up to here" for rz_gather_fence
 };
 
 namespace {
@@ -279,7 +284,7 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     p.palette = c->palette; p.world = c->world; p.inv_bind = c->inv_bind; p.dense = c->dense;
     p.act_idx = c->act_idx; p.act_w = c->act_w; p.act_count = c->act_count; p.morph_w = c->morph_w;
     p.sp_ptr = c->sp_ptr; p.sp_entries = c->sp_entries;
-    p.out_pos = c->out_pos; p.out_nrm = c->out_nrm;
+    p.out_pos = c->ext_pos ? c->ext_pos : c->out_pos; p.out_nrm = c->ext_nrm ? c->ext_nrm : c->out_nrm;
     p.edge = c->edge; p.out_hull = c->out_hull; p.aabb = c->aabb_on ? c->aabb : nullptr; p.aabb_slot = c->aabb_slot;
     p.n_verts = c->V;
     p.Vp = c->Vp; p.n_quads = pl.n_quads; p.quads_per_wave = pl.quads_per_wave; p.dma = pl.dma ? 1 : 0;
@@ -469,9 +474,30 @@ int upload_skinning(rz_ctx *c, uint32_t V, const uint16_t *joints4, const uint8_
     return RZ_OK;
 }
 
+// Undo rz_gather_direct for everything `c` takes part in: as a root, every contributor goes back to its own output
+// buffers (after draining, so no kernel is still storing into memory about to be freed); as a contributor, it leaves
+// the root's list.
+void drop_direct_gather(rz_ctx *c)
+{
+    for (rz_ctx *k : c->contributors) {
+        if (k != c) { (void)hipSetDevice(k->device); if (k->stream) (void)hipStreamSynchronize(k->stream); }
+        k->ext_pos = k->ext_nrm = nullptr;
+        k->gather_root = nullptr;
+    }
+    c->contributors.clear();
+    if (c->gather_root) {
+        auto &v = c->gather_root->contributors;
+        v.erase(std::remove(v.begin(), v.end(), c), v.end());
+        c->gather_root = nullptr;
+        c->ext_pos = c->ext_nrm = nullptr;
+    }
+    (void)hipSetDevice(c->device);
+}
+
 int alloc_mesh(rz_ctx *c, uint32_t V)
 {
     HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_direct_gather(c);                // shard sizes are about to change: back to private output buffers
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->edge);
     free_morphs(c);                       // morph targets are per-vertex: a new mesh invalidates them
     c->V = V;
@@ -543,6 +569,8 @@ int rz_destroy(rz_ctx *c)
     if (!c) return RZ_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_direct_gather(c);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->inv_bind);
     dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind);
@@ -704,7 +732,7 @@ int rz_set_instances(rz_ctx *c, uint32_t I)
 {
     if (int r = use(c)) return r;
     if (I == 0 || I > 65535) return fail(RZ_ERR_INVALID, "instance count must be 1..65535");
-    if (I > 1 && c->comm) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive");
+    if (I > 1 && (c->comm || c->gather_root)) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive");
     c->I = I;
     if (int r = ensure_pose_buffers(c)) return r;
     return ensure_outputs(c);
@@ -916,8 +944,9 @@ int rz_read(rz_ctx *c, uint32_t instance, uint32_t v0, uint32_t n, float *pos3, 
     if (!c->out_pos) return fail(RZ_ERR_INVALID, "nothing deformed yet");
     HIP_TRY(hipStreamSynchronize(c->stream));
     const size_t off = ((size_t)instance * c->Vp + v0) * 3;
-    if (pos3 && n) HIP_TRY(hipMemcpy(pos3, c->out_pos + off, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
-    if (nrm3 && n) HIP_TRY(hipMemcpy(nrm3, c->out_nrm + off, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    const float *sp = c->ext_pos ? c->ext_pos : c->out_pos, *sn = c->ext_nrm ? c->ext_nrm : c->out_nrm;
+    if (pos3 && n) HIP_TRY(hipMemcpy(pos3, sp + off, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (nrm3 && n) HIP_TRY(hipMemcpy(nrm3, sn + off, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return RZ_OK;
 }
 
@@ -1085,8 +1114,8 @@ int rz_output_ptrs(rz_ctx *c, void **pos, void **nrm, uint32_t *v_padded)
 {
     if (int r = use(c)) return r;
     if (int r = ensure_outputs(c)) return r;
-    if (pos) *pos = c->out_pos;
-    if (nrm) *nrm = c->out_nrm;
+    if (pos) *pos = c->ext_pos ? c->ext_pos : c->out_pos;
+    if (nrm) *nrm = c->ext_nrm ? c->ext_nrm : c->out_nrm;
     if (v_padded) *v_padded = c->Vp;
     return RZ_OK;
 }
@@ -1189,11 +1218,79 @@ int rz_allgather_all(rz_ctx **ctxs, int n, int with_normals)
     return RZ_OK;
 }
 
+int rz_gather_direct(rz_ctx **ctxs, int n, uint32_t v_total, int root)
+{
+    if (!ctxs || n < 1 || n > 64 || root < 0 || root >= n) return fail(RZ_ERR_INVALID, "bad context list / root");
+    for (int r = 0; r < n; ++r) {
+        rz_ctx *c = ctxs[r];
+        if (!c) return fail(RZ_ERR_INVALID, "null context in list");
+        if (c->I != 1) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive");
+        uint32_t b = 0, cnt = 0;
+        if (int e = rz_shard_range(v_total, n, r, &b, &cnt)) return e;
+        if (cnt != c->V) return fail(RZ_ERR_INVALID, "context %d holds %u vertices but rz_shard_range assigns %u", r, c->V, cnt);
+        for (int k = 0; k < r; ++k)
+            if (ctxs[k] == c) return fail(RZ_ERR_INVALID, "context listed twice");
+    }
+    rz_ctx *rt = ctxs[root];
+    for (int r = 0; r < n; ++r) drop_direct_gather(ctxs[r]);
+    // the gathered buffer lives on the root's GPU (rz_read_gathered, or a renderer there, consumes it)
+    rt->nranks = n; rt->rank = root; rt->v_total = v_total;
+    uint32_t b0 = 0, n0 = 0;
+    rz_shard_range(v_total, n, 0, &b0, &n0);
+    const uint32_t chunk = round_up(n0, kVertPad);
+    HIP_TRY(hipSetDevice(rt->device));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    dfree(rt->g_pos); dfree(rt->g_nrm);
+    const size_t g = (size_t)n * chunk * 3 * sizeof(float);
+    HIP_TRY(hipMalloc(&rt->g_pos, g));
+    HIP_TRY(hipMalloc(&rt->g_nrm, g));
+    HIP_TRY(hipMemset(rt->g_pos, 0, g));
+    HIP_TRY(hipMemset(rt->g_nrm, 0, g));
+    for (int r = 0; r < n; ++r) {
+        rz_ctx *c = ctxs[r];
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->device != rt->device) {
+            int can = 0;
+            HIP_TRY(hipDeviceCanAccessPeer(&can, c->device, rt->device));
+            if (!can) return fail(RZ_ERR_UNSUPPORTED, "GPU %d cannot store into GPU %d's memory (no peer access)", c->device, rt->device);
+            hipError_t pe = hipDeviceEnablePeerAccess(rt->device, 0);
+            if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            else if (pe != hipSuccess) return fail(RZ_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d): %s", c->device, rt->device, hipGetErrorString(pe));
+        }
+        if (!c->ev_done) HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+        c->nranks = n; c->rank = r; c->v_total = v_total; c->chunk = chunk;
+        c->ext_pos = rt->g_pos + (size_t)r * chunk * 3;
+        c->ext_nrm = rt->g_nrm + (size_t)r * chunk * 3;
+        c->gather_root = rt;
+        rt->contributors.push_back(c);
+    }
+    HIP_TRY(hipSetDevice(rt->device));
+    return RZ_OK;
+}
+
+int rz_gather_fence(rz_ctx *root)
+{
+    if (int r = use(root)) return r;
+    if (root->contributors.empty()) return fail(RZ_ERR_INVALID, "rz_gather_direct has not been called with this root");
+    for (rz_ctx *k : root->contributors) {
+        if (k == root) continue;
+        HIP_TRY(hipSetDevice(k->device));
+        HIP_TRY(hipEventRecord(k->ev_done, k->stream));
+        HIP_TRY(hipSetDevice(root->device));
+        HIP_TRY(hipStreamWaitEvent(root->stream, k->ev_done, 0));
+    }
+    HIP_TRY(hipSetDevice(root->device));
+    return RZ_OK;
+}
+
 int rz_read_gathered(rz_ctx *c, uint32_t v0, uint32_t n, float *pos3, float *nrm3)
 {
     if (int r = use(c)) return r;
     if (!c->g_pos) return fail(RZ_ERR_INVALID, "no gathered buffer");
     if ((uint64_t)v0 + n > c->v_total) return fail(RZ_ERR_INVALID, "range exceeds the full mesh");
+    if (!c->contributors.empty())
+        if (int r = rz_gather_fence(c)) return r;    // peer-direct: the other GPUs' frames must have landed
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (pos3 && n) HIP_TRY(hipMemcpy(pos3, c->g_pos + (size_t)v0 * 3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (nrm3 && n) HIP_TRY(hipMemcpy(nrm3, c->g_nrm + (size_t)v0 * 3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));

@@ -44,7 +44,9 @@ class Engine {
     this.deviceFK = o.deviceFK === true // forward kinematics on the GPU: upload local rotations instead of world matrices
     this.outline = o.outline === true // also produce the outline pass's inverted hull (engine.ts:458-461) every frame
     this.bounds = o.bounds === true // also reduce the deformed mesh's bounding box every frame
-    this.gather = o.gather === true // all-gather deformed positions over RCCL after every frame (needs distinct GPUs)
+    // gather: true = RCCL all-gather of the deformed mesh after every frame (needs distinct GPUs);
+    // 'direct' = every shard's kernel stores straight into GPU devices[0]'s buffer over xGMI (no collective)
+    this.gather = o.gather === 'direct' ? 'direct' : o.gather === true
     this.morphLayout = o.morphLayout || 'sparse'
     this.realtime = o.realtime !== false // false: time only advances through step()
     this.native = null
@@ -200,7 +202,8 @@ class Engine {
       this.outHull = new Float32Array(V * 3)
     }
     if (this.bounds) for (const s of this.shards) if (s.count > 0) n.enableAabb(s.ctx, true)
-    if (this.gather && G > 1) n.commInitAll(this.shards.map((s) => s.ctx), V)
+    if (this.gather === 'direct' && G > 1) n.gatherDirect(this.shards.map((s) => s.ctx), V, 0)
+    else if (this.gather && G > 1) n.commInitAll(this.shards.map((s) => s.ctx), V)
     this.outPos = new Float32Array(V * 3)
     this.outNrm = new Float32Array(V * 3)
     this.stats.gpuMemory = Math.round(((V * 60 + skeleton.bones.length * 176 +
@@ -338,7 +341,8 @@ class Engine {
       else this.native.setPose(s.ctx, model.getBoneWorldMatrices(), mw)
       this.native.deform(s.ctx)
     }
-    if (this.gather && this.shards.length > 1) this.native.allgatherAll(this.shards.map((s) => s.ctx), true)
+    if (this.gather === 'direct' && this.shards.length > 1) this.native.gatherFence(this.ctx)
+    else if (this.gather && this.shards.length > 1) this.native.allgatherAll(this.shards.map((s) => s.ctx), true)
     this.updateStats(wallClock() - t0)
   }
 
@@ -368,7 +372,7 @@ class Engine {
   /** Blocking readback of the deformed mesh (the values the reference's vs() only ever feeds the rasteriser). */
   getDeformed() {
     if (!this.ctx || !this.currentModel) throw new Error('no model loaded')
-    if (this.gather && this.shards.length > 1) { // every GPU holds the whole mesh after the all-gather: read it from shard 0
+    if (this.gather && this.shards.length > 1) { // shard 0's GPU holds the whole mesh (all-gather or peer-direct stores)
       this.native.readGathered(this.ctx, 0, this.currentModel.getVertexCount(), this.outPos, this.outNrm)
       return { positions: this.outPos, normals: this.outNrm }
     }

@@ -9,9 +9,11 @@ const [pmx, vmd, out, layout, devs] = process.argv.slice(2)
 const dump = (name, ta) => fs.writeFileSync(path.join(out, name), Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength))
 ;(async () => {
   const quiet = console.warn; console.warn = () => {}
-  const deviceFK = /:fk$/.test(devs || '')
-  const devices = (devs || '0').replace(':fk', '').split(',').map(Number)   // '0,0' = two contexts (two vertex shards) on one GPU
-  const engine = new Engine(null, { realtime: false, morphLayout: layout || 'sparse', ambient: 0.8, devices, deviceFK, outline: true, bounds: true })
+  const deviceFK = /:fk/.test(devs || '')
+  const direct = /:direct/.test(devs || '')      // peer-direct gather: every shard stores into shard 0's gathered buffer
+  const devices = (devs || '0').replace(':fk', '').replace(':direct', '').split(',').map(Number)   // '0,0' = two contexts (two vertex shards) on one GPU
+  const engine = new Engine(null, { realtime: false, morphLayout: layout || 'sparse', ambient: 0.8, devices, deviceFK, outline: true, bounds: true,
+    gather: direct ? 'direct' : false })
   await engine.init()
   await engine.loadModel(pmx)
   const model = engine.currentModel

@@ -442,6 +442,67 @@ def test_allgather_single_rank_roundtrip(ctx, rz, oracle):
     assert np.array_equal(p2, pg) and np.array_equal(n2, ng)
 
 
+def test_peer_direct_gather_three_shards(rz, oracle):
+    """rz_gather_direct: three contexts (three vertex shards; one GPU here, so no peer mapping but the same
+    pointers-into-the-root's-buffer mechanism) store their frames straight into the root's gathered arrays. The
+    gathered mesh must equal the oracle's whole-mesh result bit for bit with what each shard reads back itself;
+    re-uploading a mesh returns that context to its private output buffers."""
+    V, B, M, G, root = 10007, 40, 5, 3, 1
+    mesh = synth.make_mesh(V, B, seed=77)
+    deltas, mw = synth.make_morphs_dense(V, M, seed=78)
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"], deltas, mw)
+    ctxs = []
+    for r in range(G):
+        b, n, _ = rz.shard.shard_of(V, G, r)
+        shard, d = rz.shard.cut_mesh(mesh, deltas, b, n)
+        c = rz.DeformContext(0)
+        c.upload_mesh(shard["pos"], shard["nrm"], shard["joints"], shard["weights"])
+        c.upload_skeleton(mesh["inv_bind"])
+        c.upload_morphs_dense(d)
+        ctxs.append((c, b, n))
+    with pytest.raises(rz.RzError):
+        ctxs[0][0].gather_fence()                     # not a root yet
+    rz.capi.gather_direct([c for c, _, _ in ctxs], V, root=root)
+    for c, _, _ in ctxs:
+        c.set_pose(mesh["world"], mw)
+        c.deform()
+    pg, ng = ctxs[root][0].read_gathered()
+    assert_parity(pg, ng, pr, nr, "peer-direct gather")
+    for c, b, n in ctxs:                              # a contributor still reads its own shard (out of the root's buffer)
+        ps, ns = c.read()
+        assert np.array_equal(ps, pg[b:b + n]) and np.array_equal(ns, ng[b:b + n])
+    with pytest.raises(rz.RzError):
+        ctxs[0][0].set_instances(4)                   # instancing and sharding are exclusive
+    # a second frame with another pose lands in the same buffer
+    world2 = synth.make_pose(mesh["parents"], mesh["bind"], B, seed=5)
+    pr2, nr2 = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], world2, mesh["inv_bind"], deltas, mw)
+    for c, _, _ in ctxs:
+        c.set_pose(world2, mw)
+        c.deform()
+    ctxs[root][0].gather_fence()
+    pg2, ng2 = ctxs[root][0].read_gathered(v0=100, n=V - 100)
+    assert_parity(pg2, ng2, pr2[100:], nr2[100:], "peer-direct gather frame 2")
+    # a new mesh on shard 2 detaches it: its frames go to its own buffers again, the root's copy keeps the old data
+    c2, b2, n2 = ctxs[2]
+    small = synth.make_mesh(300, B, seed=3)
+    c2.upload_mesh(small["pos"], small["nrm"], small["joints"], small["weights"])
+    c2.upload_skeleton(small["inv_bind"])
+    c2.set_pose(small["world"])
+    c2.deform()
+    ps, ns = c2.read()
+    prs, nrs = oracle.deform(small["pos"], small["nrm"], small["joints"], small["weights"], small["world"], small["inv_bind"])
+    assert_parity(ps, ns, prs, nrs, "detached shard")
+    pg3, _ = ctxs[root][0].read_gathered()
+    assert np.array_equal(pg3[b2:b2 + n2], np.concatenate([pr2[:0], pg2[b2 - 100:b2 - 100 + n2]]))
+    ctxs[root][0].close()                             # destroying the root detaches the rest
+    c0 = ctxs[0][0]
+    c0.deform()
+    p0, n0 = c0.read()
+    assert_parity(p0, n0, pr2[:ctxs[0][2]], nr2[:ctxs[0][2]], "after the root is gone")
+    c0.close()
+    c2.close()
+
+
 def test_error_paths(ctx, rz):
     c = rz.DeformContext(0)
     with pytest.raises(rz.RzError):
@@ -487,7 +548,8 @@ def test_engine_through_napi_matches_oracle(tmp_path, oracle):
     (tmp_path / "a.vmd").write_bytes(write_vmd(
         [("bone1", 0, (0, 0, s, 0.92387953)), ("bone3", 0, (s, 0, 0, 0.92387953)), ("bone1", 15, (0, s, 0, 0.92387953)),
          ("bone20", 30, (0, 0, -s, 0.92387953))], [("v1", 0, 0.8), ("v2", 6, 0.4)]))
-    for layout, devs in (("sparse", "0"), ("dense", "0"), ("sparse", "0,0"), ("dense", "0,0,0"), ("sparse", "0:fk"), ("dense", "0,0:fk")):
+    for layout, devs in (("sparse", "0"), ("dense", "0"), ("sparse", "0,0"), ("dense", "0,0,0"), ("sparse", "0:fk"), ("dense", "0,0:fk"),
+                         ("sparse", "0,0:direct"), ("dense", "0,0,0:direct")):
         # "0,0": the Engine's multi-GPU sharding (one context per listed device) exercised as 2-3 shards on one GPU
         out = tmp_path / (layout + devs.replace(",", "_").replace(":", "_"))
         out.mkdir()
@@ -509,7 +571,7 @@ def test_engine_through_napi_matches_oracle(tmp_path, oracle):
             pr, nr = oracle.skin(pm, v[:, 3:6], joints, weights, S)
             pg = rd("pos_%d.f32" % step, np.float32).reshape(-1, 3)
             ng = rd("nrm_%d.f32" % step, np.float32).reshape(-1, 3)
-            if devs.endswith(":fk"):      # the GPU solved the hierarchy in f32: compare its world matrices with the host's
+            if ":fk" in devs:      # the GPU solved the hierarchy in f32: compare its world matrices with the host's
                 np.testing.assert_allclose(rd("gpuworld_%d.f32" % step, np.float32).reshape(-1, 16), world, rtol=3e-5, atol=3e-5)
             assert_parity(pg, ng, pr, nr, "napi %s devices %s step %d" % (layout, devs, step))
             # fused consumers through the same boundary: outline hull and bounding box (multi-shard boxes are merged on the host)
