@@ -51,7 +51,8 @@ def parse_args():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for the barrier / max-reduce (gloo + --share-gpu lets a 1-GPU box rehearse N > 1)")
     ap.add_argument("--share-gpu", action="store_true", help="map every rank onto GPU (local_rank %% visible devices)")
-    ap.add_argument("--tune", default="", help="comma list key=value passed to rz_set_tuning")
+    ap.add_argument("--tune", default="", help="comma list key=value passed to rz_set_tuning (disables the autotune pass)")
+    ap.add_argument("--no-autotune", action="store_true", help="skip rz_autotune (setup-time search over launch shapes) and use the built-in heuristics")
     return ap.parse_args()
 
 
@@ -183,6 +184,9 @@ def main():
         else:
             ctx.set_pose(worlds, mws)
     put_pose()
+    tuned = None
+    if not args.no_autotune and not args.tune:
+        tuned = ctx.autotune()          # setup-time search over launch shapes (untimed, like a GEMM library's find mode)
 
     def barrier():
         ctx.sync()
@@ -275,6 +279,7 @@ def main():
                 "verts_total": V_total, "verts_per_gpu": n, "bones": B, "morphs": M, "instances": I,
                 "parallelism": "vertex-shard x%d" % world_size,
                 "bone_hierarchy_solve": "device (rz_fk_kernel)" if args.device_fk else "host",
+                "autotune": tuned is not None,
                 "morph_split": ctx.get_tuning("effective_split"),
                 "grid": ctx.get_tuning("effective_grid"),
                 "frame_ms_events": timing["frame_ms"],

@@ -156,10 +156,18 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * separate prep kernel, 1 one-launch frame when possible), "out_cap" (-1 auto, 0 off, else vertices a wave
  * parks in LDS before writing them out in one burst), "inst_loop" (-1 auto, 0 off, 2..8 poses
  * per workgroup in instanced morph-free frames). rz_get_tuning also answers
- * "effective_split" / "effective_unroll" / "effective_grid" / "effective_fast".
+ * "effective_split" / "effective_unroll" / "effective_grid" / "effective_fast" / "effective_out_cap".
  * Unknown keys return RZ_ERR_INVALID. */
 int rz_set_tuning(rz_ctx *ctx, const char *key, int value);
 int rz_get_tuning(rz_ctx *ctx, const char *key, int *value);
+
+/* Setup-time search over launch shapes (like a GEMM library's "find" mode; no reference counterpart — WebGPU hides
+ * the dispatch shape, engine.ts:2393-2402): times `frames` frames (0 = 30) of every distinct plan among morph split
+ * {1,2,4,8} x {1,2,4} workgroups per CU (instanced frames: {4,8} poses per workgroup x {2,4} workgroups per CU) with
+ * the CURRENT mesh / morphs / pose on this GPU and keeps the fastest as the "morph_split" / "grid_cap" / "inst_loop"
+ * tuning values. Needs a pose; costs a few hundred frames; results stay within the parity tolerance for every
+ * candidate (tests cover them all). rz_set_tuning(key, 0 / -1) returns a key to its heuristic. */
+int rz_autotune(rz_ctx *ctx, uint32_t frames);
 
 /* Device pointers of the output buffers ([I][Vpad][3] floats each) and the padded vertex count,
  * so a host framework can wrap them without a copy. */

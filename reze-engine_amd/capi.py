@@ -17,7 +17,7 @@ SYMBOLS = [
     "rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_destroy", "rz_shard_range",
     "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
     "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_read_world", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
-    "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_output_ptrs",
+    "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_autotune", "rz_output_ptrs",
     "rz_comm_unique_id", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_gather_fence", "rz_upload_edge_scale", "rz_read_hull", "rz_enable_aabb", "rz_read_aabb",
 ]
 
@@ -74,6 +74,7 @@ def load():
     L.rz_read.argtypes = [vp, u32, u32, u32, fp, fp]
     L.rz_read_palette.argtypes = [vp, u32, fp]
     L.rz_time_frames.argtypes = [vp, u32, ctypes.POINTER(RzTiming)]
+    L.rz_autotune.argtypes = [vp, u32]
     L.rz_set_tuning.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
     L.rz_get_tuning.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     L.rz_output_ptrs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u32)]
@@ -305,6 +306,11 @@ class DeformContext:
         out = np.empty((self.B, 12), dtype=np.float32)
         _chk(self._L.rz_read_palette(self._h, int(instance), _fptr(out)))
         return out
+
+    def autotune(self, frames=0):
+        """Setup-time search over launch shapes with the current mesh / morphs / pose (rz_autotune)."""
+        _chk(self._L.rz_autotune(self._h, int(frames)))
+        return {k: self.get_tuning(k) for k in ("effective_split", "effective_grid", "effective_inst_group")}
 
     def time_frames(self, frames):
         t = RzTiming()

@@ -528,6 +528,16 @@ static napi_value fn_allgather_all(napi_env env, napi_callback_info info)
     return rc ? throw_rz(env, rc) : undef(env);
 }
 
+static napi_value fn_autotune(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    CTX(0);
+    uint32_t frames = 0;
+    if (argc > 1 && !get_u32(env, argv[1], &frames)) return throw_msg(env, "autotune(ctx, frames?)");
+    int rc = rz_autotune(ctx, frames);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
 static napi_value fn_gather_direct(napi_env env, napi_callback_info info)
 {
     ARGS(3);
@@ -577,7 +587,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "timeFrames", fn_time_frames }, { "setTuning", fn_set_tuning }, { "getTuning", fn_get_tuning },
         { "commUniqueId", fn_comm_unique_id }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },
         { "readGathered", fn_read_gathered }, { "commInitAll", fn_comm_init_all }, { "allgatherAll", fn_allgather_all },
-        { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
+        { "autotune", fn_autotune }, { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value f;

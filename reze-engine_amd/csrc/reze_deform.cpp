@@ -1050,6 +1050,65 @@ int rz_time_frames(rz_ctx *c, uint32_t frames, rz_timing *out)
     return RZ_OK;
 }
 
+int rz_autotune(rz_ctx *c, uint32_t frames)
+{
+    if (int r = use(c)) return r;
+    if (int r = check_ready(c)) return r;
+    if (int r = ensure_outputs(c)) return r;
+    if (frames == 0) frames = 30;
+    // candidates: morph split x workgroups per CU (single mesh), poses per workgroup x workgroups per CU (instanced).
+    // Every candidate is a legal plan; the search only picks among the variants the parity tests already cover.
+    struct Cand { int split, cap, loop; };
+    std::vector<Cand> cands;
+    const int ncu = c->n_cu;
+    const bool instanced = c->morph_mode == 0 && c->I > 1 && c->t_instloop != 0 && c->t_instloop != 9 && !(c->edge || c->aabb_on);
+    if (instanced) {
+        for (int loop : {8, 4})
+            for (int cap : {2 * ncu, 4 * ncu}) cands.push_back({0, cap, loop});
+    } else {
+        const int smax = c->morph_mode == 1 ? (int)std::min<uint32_t>(8, std::max<uint32_t>(1, c->M)) : 1;
+        for (int sp = 1; sp <= smax; sp <<= 1)
+            for (int cap : {ncu, 2 * ncu, 4 * ncu}) cands.push_back({sp, (int)(cap * c->I), 0});
+    }
+    const int keep_split = c->t_split, keep_cap = c->t_grid_cap, keep_loop = c->t_instloop;
+    float best_ms = 0.f;
+    int best = -1;
+    uint32_t seen_grid[32], seen_qpw[32];
+    int seen_s[32], seen_g[32], n_seen = 0;
+    for (size_t i = 0; i < cands.size(); ++i) {
+        c->t_split = cands[i].split; c->t_grid_cap = cands[i].cap;
+        if (instanced) c->t_instloop = cands[i].loop;
+        const Plan pl = make_plan(c);
+        bool dup = false;              // different requests often resolve to the same launch
+        for (int k = 0; k < n_seen; ++k)
+            dup |= seen_grid[k] == pl.grid_x && seen_qpw[k] == pl.quads_per_wave && seen_s[k] == pl.v.S && seen_g[k] == pl.inst_group;
+        if (dup) continue;
+        if (n_seen < 32) { seen_grid[n_seen] = pl.grid_x; seen_qpw[n_seen] = pl.quads_per_wave; seen_s[n_seen] = pl.v.S; seen_g[n_seen++] = pl.inst_group; }
+        float cand_ms = 0.f;
+        for (int rep = 0; rep < 2; ++rep) {        // best of two, the first pass also warms the variant up
+            for (uint32_t f = 0; f < 5; ++f) {
+                if (int r = launch_front(c, pl)) return r;
+                if (int r = launch_deform(c, pl)) return r;
+            }
+            HIP_TRY(hipEventRecord(c->ev0, c->stream));
+            for (uint32_t f = 0; f < frames; ++f) {
+                if (int r = launch_front(c, pl)) return r;
+                if (int r = launch_deform(c, pl)) return r;
+            }
+            HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            HIP_TRY(hipEventSynchronize(c->ev1));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            if (rep == 0 || ms < cand_ms) cand_ms = ms;
+        }
+        if (best < 0 || cand_ms < best_ms) { best = (int)i; best_ms = cand_ms; }
+    }
+    if (best < 0) { c->t_split = keep_split; c->t_grid_cap = keep_cap; c->t_instloop = keep_loop; return RZ_OK; }
+    c->t_split = cands[best].split; c->t_grid_cap = cands[best].cap;
+    c->t_instloop = instanced ? cands[best].loop : keep_loop;
+    return RZ_OK;
+}
+
 int rz_set_tuning(rz_ctx *c, const char *key, int value)
 {
     if (!c || !key) return fail(RZ_ERR_INVALID, "null argument");
@@ -1103,6 +1162,8 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "effective_unroll")) *value = make_plan(c).v.U;
     else if (!strcmp(key, "effective_fast")) *value = make_plan(c).v.fast ? 1 : 0;
     else if (!strcmp(key, "inst_loop")) *value = c->t_instloop;
+    else if (!strcmp(key, "out_cap")) *value = c->t_outcap;
+    else if (!strcmp(key, "effective_out_cap")) *value = (int)make_plan(c).out_cap;
     else if (!strcmp(key, "effective_inst_group")) *value = make_plan(c).inst_group;
     else if (!strcmp(key, "effective_poses_per_wg")) *value = make_plan(c).poses_per_wg;
     else if (!strcmp(key, "effective_grid")) *value = (int)make_plan(c).grid_x;

@@ -50,6 +50,8 @@ class Engine {
     this.morphLayout = o.morphLayout || 'sparse'
     this.realtime = o.realtime !== false // false: time only advances through step()
     this.native = null
+    this.autotune = o.autotune === true // search launch shapes once, on the first rendered frame (rz_autotune)
+    this.tuned = false
     this.ctx = null // context of shard 0 (the only one on a single GPU)
     this.shards = [] // [{ ctx, begin, count }]
     this.currentModel = null
@@ -204,6 +206,7 @@ class Engine {
     if (this.bounds) for (const s of this.shards) if (s.count > 0) n.enableAabb(s.ctx, true)
     if (this.gather === 'direct' && G > 1) n.gatherDirect(this.shards.map((s) => s.ctx), V, 0)
     else if (this.gather && G > 1) n.commInitAll(this.shards.map((s) => s.ctx), V)
+    this.tuned = false
     this.outPos = new Float32Array(V * 3)
     this.outNrm = new Float32Array(V * 3)
     this.stats.gpuMemory = Math.round(((V * 60 + skeleton.bones.length * 176 +
@@ -340,6 +343,10 @@ class Engine {
       if (gpuFK) this.native.setPoseLocal(s.ctx, model.runtimeSkeleton.localRotations, mw)
       else this.native.setPose(s.ctx, model.getBoneWorldMatrices(), mw)
       this.native.deform(s.ctx)
+    }
+    if (this.autotune && !this.tuned) { // the first frame supplied a pose: time the candidate launch shapes once per shard
+      for (const s of this.shards) if (s.count > 0) this.native.autotune(s.ctx, 0)
+      this.tuned = true
     }
     if (this.gather === 'direct' && this.shards.length > 1) this.native.gatherFence(this.ctx)
     else if (this.gather && this.shards.length > 1) this.native.allgatherAll(this.shards.map((s) => s.ctx), true)

@@ -13,7 +13,7 @@ const dump = (name, ta) => fs.writeFileSync(path.join(out, name), Buffer.from(ta
   const direct = /:direct/.test(devs || '')      // peer-direct gather: every shard stores into shard 0's gathered buffer
   const devices = (devs || '0').replace(':fk', '').replace(':direct', '').split(',').map(Number)   // '0,0' = two contexts (two vertex shards) on one GPU
   const engine = new Engine(null, { realtime: false, morphLayout: layout || 'sparse', ambient: 0.8, devices, deviceFK, outline: true, bounds: true,
-    gather: direct ? 'direct' : false })
+    gather: direct ? 'direct' : false, autotune: true })
   await engine.init()
   await engine.loadModel(pmx)
   const model = engine.currentModel

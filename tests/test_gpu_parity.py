@@ -442,6 +442,47 @@ def test_allgather_single_rank_roundtrip(ctx, rz, oracle):
     assert np.array_equal(p2, pg) and np.array_equal(n2, ng)
 
 
+def test_autotune_keeps_parity_and_picks_a_listed_plan(rz, oracle):
+    """rz_autotune times the candidate launch shapes and keeps one: the result must be one of the candidates, the
+    frame must still match the oracle, and 0 / -1 hands the keys back to the heuristics. Dense, morph-free and
+    instanced frames."""
+    ctx = rz.DeformContext(0)
+    V, B, M = 50000, 64, 16
+    mesh = synth.make_mesh(V, B, seed=21)
+    deltas, mw = synth.make_morphs_dense(V, M, seed=22)
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"], deltas, mw)
+    run_gpu(ctx, mesh, deltas=deltas, mw=mw)
+    got = ctx.autotune(10)
+    assert got["effective_split"] in (1, 2, 4, 8) and ctx.get_tuning("morph_split") == got["effective_split"]
+    assert ctx.get_tuning("grid_cap") in (256, 512, 1024)
+    ctx.deform()
+    pg, ng = ctx.read()
+    assert_parity(pg, ng, pr, nr, "after autotune (dense)")
+    ctx.set_tuning(morph_split=0, grid_cap=0)
+    # morph-free: only the grid is searched
+    pr0, nr0 = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"])
+    run_gpu(ctx, mesh)
+    got = ctx.autotune()
+    assert got["effective_split"] == 1
+    ctx.deform()
+    pg, ng = ctx.read()
+    assert_parity(pg, ng, pr0, nr0, "after autotune (no morphs)")
+    ctx.set_tuning(morph_split=0, grid_cap=0)
+    # instanced: poses per workgroup x workgroups per CU
+    I = 12
+    worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=900 + i) for i in range(I)])
+    ctx.set_instances(I)
+    ctx.set_pose(worlds)
+    got = ctx.autotune(5)
+    assert got["effective_inst_group"] in (4, 8) and ctx.get_tuning("inst_loop") in (4, 8)
+    ctx.deform()
+    for i in (0, 5, 11):
+        pri, nri = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[i], mesh["inv_bind"])
+        pg, ng = ctx.read(instance=i)
+        assert_parity(pg, ng, pri, nri, "after autotune (instance %d)" % i)
+    ctx.close()
+
+
 def test_peer_direct_gather_three_shards(rz, oracle):
     """rz_gather_direct: three contexts (three vertex shards; one GPU here, so no peer mapping but the same
     pointers-into-the-root's-buffer mechanism) store their frames straight into the root's gathered arrays. The

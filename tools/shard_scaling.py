@@ -1,0 +1,28 @@
+"""What each GPU runs at N = 1, 2, 4, 8 (strong scaling of C5): one shard of rz_shard_range(1 M, N, 0) on this GPU.
+Prints frame time, the projected N-GPU speed-up (t1 / tN) and the shard's algorithmic GB/s."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import reze_engine_amd as rz
+from reze_engine_amd import synth
+V, B, M = 1000000, 256, 64
+mesh = synth.make_mesh(V, B)
+deltas, mw = synth.make_morphs_dense(V, M)
+t1 = None
+for N in (1, 2, 4, 8):
+    b, n, _ = rz.shard.shard_of(V, N, 0)
+    shard, d = rz.shard.cut_mesh(mesh, deltas, b, n)
+    ctx = rz.DeformContext(0)
+    ctx.upload_mesh(shard["pos"], shard["nrm"], shard["joints"], shard["weights"]); ctx.upload_skeleton(mesh["inv_bind"])
+    ctx.upload_morphs_dense(d); ctx.set_pose(mesh["world"], mw)
+    ctx.deform_n(50)
+    t = min((ctx.time_frames(300) for _ in range(5)), key=lambda t: t["frame_ms"])
+    us = t["frame_ms"] * 1e3
+    t1 = t1 or us
+    print(json.dumps({"N": N, "shard_verts": n, "frame_us": round(us, 2), "GBps": round(t["algorithmic_bytes_per_frame"] / us / 1e3, 1),
+                      "projected_speedup": round(t1 / us, 2), "split": ctx.get_tuning("effective_split"), "grid": ctx.get_tuning("effective_grid"),
+                      "out_cap": ctx.get_tuning("effective_out_cap")}))
+    ctx.autotune()
+    t = min((ctx.time_frames(300) for _ in range(5)), key=lambda t: t["frame_ms"])
+    print(json.dumps({"N": N, "autotuned_frame_us": round(t["frame_ms"] * 1e3, 2), "split": ctx.get_tuning("effective_split"), "grid": ctx.get_tuning("effective_grid"), "projected_speedup_vs_untuned_t1": round(t1 / (t["frame_ms"] * 1e3), 2)}))
+    ctx.close()
