@@ -229,13 +229,18 @@ def main():
             traffic = None
 
     # per-frame pose upload included (PCIe-inclusive rate; never `value`)
+    n_up = min(args.steps, 200)
+    for _ in range(400):                # the upload path's own warm-up: pinned ring, upload stream (the HIP runtime
+                                        # stalls ~25 ms once, somewhere in the first few hundred two-stream frames)
+        put_pose()
+        ctx.deform()
     barrier()
     tp0 = time.perf_counter()
-    for _ in range(min(args.steps, 100)):
+    for _ in range(n_up):
         put_pose()
         ctx.deform()
     ctx.sync()
-    with_upload_ms = (time.perf_counter() - tp0) * 1e3 / min(args.steps, 100)
+    with_upload_ms = (time.perf_counter() - tp0) * 1e3 / n_up
 
     ag_ms = None
     if args.allgather and I == 1:

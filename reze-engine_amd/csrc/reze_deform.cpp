@@ -113,7 +113,8 @@ struct rz_ctx {
     int *fk_parents = nullptr, *fk_append_parent = nullptr, *fk_order = nullptr, *fk_level_off = nullptr;
     float *fk_bind = nullptr, *fk_append_ratio = nullptr;
     int fk_levels = 0;
-    float4 *local_q = nullptr;          // I x B
+    float4 *local_q = nullptr;          // I x B   (current pose slot)
+    float4 *local_q_buf[2] = {nullptr, nullptr};
     size_t local_q_alloc = 0;
     bool pose_local = false;            // the current pose came from rz_set_pose_local
 
@@ -127,9 +128,18 @@ struct rz_ctx {
 
     // per-frame state
     uint32_t I = 1;
-    float *world = nullptr;             // I x B x 16
+    float *world = nullptr;             // I x B x 16   (current pose slot)
+    // Per-frame INPUTS are double-buffered and uploaded on their own stream, so the upload of pose f+1 overlaps the
+    // kernels of pose f: ev_up[k] = slot k has landed (the compute stream waits for it), ev_free[k] = everything
+    // that reads slot k has been enqueued up to here (the upload stream waits for it before overwriting the slot).
+    float *world_buf[2] = {nullptr, nullptr};
+    float *morph_w_buf[2] = {nullptr, nullptr};
+    int pose_slot = 0;
+    hipStream_t up_stream = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    bool free_recorded[2] = {false, false};
     float4 *palette = nullptr;          // I x B x 3
-    float *morph_w = nullptr;           // I x M
+    float *morph_w = nullptr;           // I x M   (current pose slot)
     uint32_t *act_idx = nullptr;        // I x Mpad
     float *act_w = nullptr;             // I x Mpad
     int *act_count = nullptr;           // I
@@ -236,19 +246,27 @@ int ensure_pose_buffers(rz_ctx *c)
     const uint32_t Mq = std::max<uint32_t>(c->M, 1);
     if (c->I <= c->pose_alloc_I && c->B <= c->pose_alloc_B && Mq <= c->pose_alloc_M && c->world) return RZ_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    dfree(c->world); dfree(c->palette); dfree(c->morph_w); dfree(c->act_idx); dfree(c->act_w); dfree(c->act_count);
+    HIP_TRY(hipStreamSynchronize(c->up_stream));
+    for (int k = 0; k < 2; ++k) { dfree(c->world_buf[k]); dfree(c->morph_w_buf[k]); c->free_recorded[k] = false; }
+    c->world = nullptr; c->morph_w = nullptr;
+    dfree(c->palette); dfree(c->act_idx); dfree(c->act_w); dfree(c->act_count);
     const size_t I = c->I, B = c->B;
     const size_t Mpad = round_up(Mq + 8, 4);
-    HIP_TRY(hipMalloc(&c->world, I * B * 16 * sizeof(float)));
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipMalloc(&c->world_buf[k], I * B * 16 * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->morph_w_buf[k], I * Mq * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(c->morph_w_buf[k], 0, I * Mq * sizeof(float), c->stream));
+    }
+    c->pose_slot = 0;
+    c->world = c->world_buf[0]; c->morph_w = c->morph_w_buf[0];
     HIP_TRY(hipMalloc(&c->palette, I * B * 3 * sizeof(float4)));
-    HIP_TRY(hipMalloc(&c->morph_w, I * Mq * sizeof(float)));
     HIP_TRY(hipMalloc(&c->act_idx, I * Mpad * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->act_w, I * Mpad * sizeof(float)));
     HIP_TRY(hipMalloc(&c->act_count, I * sizeof(int)));
-    HIP_TRY(hipMemsetAsync(c->morph_w, 0, I * Mq * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->act_idx, 0, I * Mpad * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->act_w, 0, I * Mpad * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->act_count, 0, I * sizeof(int), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     c->pose_alloc_I = I; c->pose_alloc_B = B; c->pose_alloc_M = Mq;
     c->pose_set = false;
     return RZ_OK;
@@ -552,6 +570,11 @@ int rz_create(int device, rz_ctx **out)
     c->device = device;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && se == hipSuccess; ++k) {
+        se = hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming);
+        if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_free[k], hipEventDisableTiming);
+    }
     if (se == hipSuccess) se = hipEventCreate(&c->ev0);
     if (se == hipSuccess) se = hipEventCreate(&c->ev1);
     for (int i = 0; i < kStageSlots && se == hipSuccess; ++i)
@@ -569,14 +592,20 @@ int rz_destroy(rz_ctx *c)
     if (!c) return RZ_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
     drop_direct_gather(c);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->inv_bind);
     dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind);
-    dfree(c->fk_append_ratio); dfree(c->local_q);
+    dfree(c->fk_append_ratio); dfree(c->local_q_buf[0]); dfree(c->local_q_buf[1]);
     free_morphs(c);
-    dfree(c->world); dfree(c->palette); dfree(c->morph_w); dfree(c->act_idx); dfree(c->act_w); dfree(c->act_count);
+    for (int k = 0; k < 2; ++k) {
+        dfree(c->world_buf[k]); dfree(c->morph_w_buf[k]);
+        if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]);
+        if (c->ev_free[k]) (void)hipEventDestroy(c->ev_free[k]);
+    }
+    dfree(c->palette); dfree(c->act_idx); dfree(c->act_w); dfree(c->act_count);
     dfree(c->out_pos); dfree(c->out_nrm); dfree(c->g_pos); dfree(c->g_nrm);
     dfree(c->edge); dfree(c->out_hull); dfree(c->aabb);
     for (int i = 0; i < kStageSlots; ++i) {
@@ -585,6 +614,7 @@ int rz_destroy(rz_ctx *c)
     }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RZ_OK;
@@ -738,16 +768,15 @@ int rz_set_instances(rz_ctx *c, uint32_t I)
     return ensure_outputs(c);
 }
 
-int rz_set_pose(rz_ctx *c, const float *world, const float *morph_weights)
+// Shared tail of rz_set_pose / rz_set_pose_local. `primary` (world matrices or local rotations, `pbytes` long) and the
+// morph weights go through a pinned ring slot into the OTHER device slot on the upload stream, so this upload overlaps
+// whatever the compute stream is still running on the current slot; the compute stream then waits for the new slot.
+static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, bool local, const float *morph_weights)
 {
-    if (int r = use(c)) return r;
-    if (c->B == 0) return fail(RZ_ERR_INVALID, "no skeleton uploaded");
-    if (!world) return fail(RZ_ERR_INVALID, "null world matrices");
-    if (int r = ensure_pose_buffers(c)) return r;
-    const size_t wb = (size_t)c->I * c->B * 16 * sizeof(float);
     const size_t mb = (size_t)c->I * c->M * sizeof(float);
-    const size_t need = wb + mb;
+    const size_t need = std::max(pbytes, (size_t)c->I * c->B * 64) + mb;
     if (need > c->stage_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->up_stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         for (int i = 0; i < kStageSlots; ++i) {
             if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; }
@@ -759,21 +788,41 @@ int rz_set_pose(rz_ctx *c, const float *world, const float *morph_weights)
     const int slot = c->stage_next;
     c->stage_next = (slot + 1) % kStageSlots;
     if (c->stage_used[slot]) HIP_TRY(hipEventSynchronize(c->stage_ev[slot]));
-    char *s = static_cast<char *>(c->stage[slot]);
-    memcpy(s, world, wb);
-    HIP_TRY(hipMemcpyAsync(c->world, s, wb, hipMemcpyHostToDevice, c->stream));
+    // Small poses (one character: 16-22 KB) go down the compute stream itself — measured on C5, the two extra
+    // packets of the cross-stream hand-off (marker + barrier) cost 3 us more per frame than the copy they hide.
+    // Large ones (instanced crowds: MBs) take the upload stream: everything enqueued so far reads the current device
+    // slot, so mark it, fill the other slot once ITS last readers are done, and make the compute stream wait for it.
+    const int cur = c->pose_slot, k = cur ^ 1;
+    const bool piped = pbytes + mb > (256u << 10);
+    hipStream_t us = piped ? c->up_stream : c->stream;
+    if (piped) {
+        HIP_TRY(hipEventRecord(c->ev_free[cur], c->stream));
+        c->free_recorded[cur] = true;
+        if (c->free_recorded[k]) HIP_TRY(hipStreamWaitEvent(c->up_stream, c->ev_free[k], 0));
+    }
+    char *st = static_cast<char *>(c->stage[slot]);
+    memcpy(st, primary, pbytes);
+    void *dst = local ? static_cast<void *>(c->local_q_buf[k]) : static_cast<void *>(c->world_buf[k]);
+    HIP_TRY(hipMemcpyAsync(dst, st, pbytes, hipMemcpyHostToDevice, us));
     if (c->M > 0) {
         if (morph_weights) {
-            memcpy(s + wb, morph_weights, mb);
-            HIP_TRY(hipMemcpyAsync(c->morph_w, s + wb, mb, hipMemcpyHostToDevice, c->stream));
+            memcpy(st + pbytes, morph_weights, mb);
+            HIP_TRY(hipMemcpyAsync(c->morph_w_buf[k], st + pbytes, mb, hipMemcpyHostToDevice, us));
         } else {
-            HIP_TRY(hipMemsetAsync(c->morph_w, 0, mb, c->stream));
+            HIP_TRY(hipMemsetAsync(c->morph_w_buf[k], 0, mb, us));
         }
     }
-    HIP_TRY(hipEventRecord(c->stage_ev[slot], c->stream));
+    HIP_TRY(hipEventRecord(c->stage_ev[slot], us));
     c->stage_used[slot] = true;
+    if (piped) {
+        HIP_TRY(hipEventRecord(c->ev_up[k], c->up_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_up[k], 0));
+    }
+    c->pose_slot = k;
+    c->world = c->world_buf[k];
+    c->morph_w = c->morph_w_buf[k];
+    c->local_q = c->local_q_buf[k];
     // ordered compaction of the non-zero weights for the one-launch path (instance 0)
-    c->pose_local = false;
     memset(&c->ml, 0, sizeof c->ml);
     if (c->M > 0 && morph_weights && c->I == 1) {
         int n = 0;
@@ -785,8 +834,18 @@ int rz_set_pose(rz_ctx *c, const float *world, const float *morph_weights)
         }
         c->ml.count = n <= kKargMorphs ? n : -1;
     }
+    c->pose_local = local;
     c->pose_set = true;
     return RZ_OK;
+}
+
+int rz_set_pose(rz_ctx *c, const float *world, const float *morph_weights)
+{
+    if (int r = use(c)) return r;
+    if (c->B == 0) return fail(RZ_ERR_INVALID, "no skeleton uploaded");
+    if (!world) return fail(RZ_ERR_INVALID, "null world matrices");
+    if (int r = ensure_pose_buffers(c)) return r;
+    return upload_pose(c, world, (size_t)c->I * c->B * 16 * sizeof(float), false, morph_weights);
 }
 
 int rz_upload_skeleton_topology(rz_ctx *c, uint32_t B, const int32_t *parents, const float *bind_translation3,
@@ -849,52 +908,14 @@ int rz_set_pose_local(rz_ctx *c, const float *local_rotations4, const float *mor
     const size_t nq = (size_t)c->I * c->B;
     if (nq > c->local_q_alloc) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        dfree(c->local_q);
-        HIP_TRY(hipMalloc(&c->local_q, nq * sizeof(float4)));
+        HIP_TRY(hipStreamSynchronize(c->up_stream));
+        for (int k = 0; k < 2; ++k) {
+            dfree(c->local_q_buf[k]);
+            HIP_TRY(hipMalloc(&c->local_q_buf[k], nq * sizeof(float4)));
+        }
         c->local_q_alloc = nq;
     }
-    const size_t qb = nq * sizeof(float4);
-    const size_t mb = (size_t)c->I * c->M * sizeof(float);
-    const size_t need = std::max(qb + mb, (size_t)c->I * c->B * 64 + mb);
-    if (need > c->stage_bytes) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        for (int i = 0; i < kStageSlots; ++i) {
-            if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; }
-            HIP_TRY(hipHostMalloc(&c->stage[i], need, hipHostMallocDefault));
-            c->stage_used[i] = false;
-        }
-        c->stage_bytes = need;
-    }
-    const int slot = c->stage_next;
-    c->stage_next = (slot + 1) % kStageSlots;
-    if (c->stage_used[slot]) HIP_TRY(hipEventSynchronize(c->stage_ev[slot]));
-    char *s = static_cast<char *>(c->stage[slot]);
-    memcpy(s, local_rotations4, qb);
-    HIP_TRY(hipMemcpyAsync(c->local_q, s, qb, hipMemcpyHostToDevice, c->stream));
-    if (c->M > 0) {
-        if (morph_weights) {
-            memcpy(s + qb, morph_weights, mb);
-            HIP_TRY(hipMemcpyAsync(c->morph_w, s + qb, mb, hipMemcpyHostToDevice, c->stream));
-        } else {
-            HIP_TRY(hipMemsetAsync(c->morph_w, 0, mb, c->stream));
-        }
-    }
-    HIP_TRY(hipEventRecord(c->stage_ev[slot], c->stream));
-    c->stage_used[slot] = true;
-    memset(&c->ml, 0, sizeof c->ml);
-    if (c->M > 0 && morph_weights && c->I == 1) {
-        int n = 0;
-        for (uint32_t m = 0; m < c->M; ++m) {
-            const float w = morph_weights[m];
-            if (w == 0.0f) continue;
-            if (n < kKargMorphs) { c->ml.idx[n] = m; c->ml.w[n] = w; }
-            ++n;
-        }
-        c->ml.count = n <= kKargMorphs ? n : -1;
-    }
-    c->pose_local = true;
-    c->pose_set = true;
-    return RZ_OK;
+    return upload_pose(c, local_rotations4, nq * sizeof(float4), true, morph_weights);
 }
 
 int rz_read_world(rz_ctx *c, uint32_t instance, float *world16)
