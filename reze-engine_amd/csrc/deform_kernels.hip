@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     constexpr int VW = 4 * QPW;              // vertices per wave per tile
     constexpr int NPL = GEO ? 9 : 3;         // scratch planes per wave
     constexpr int ROUNDS = (VW + 63) / 64;
-    constexpr bool LDS_LIST = !FAST && MODE != 0;
+    constexpr bool LDS_LIST = MODE == 2 || (!FAST && MODE == 1);   // MODE 2 keeps all M weights in LDS on both paths
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *pal = reinterpret_cast<float4 *>(smem);                       // B*3 float4
@@ -368,6 +368,11 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
             const float *gw = p.morph_w + (size_t)inst * p.M;
             for (int i = tid; i < p.M; i += kBlock) s_w[i] = gw[i];
         }
+        __syncthreads();
+    }
+
+    if (FAST && MODE == 2) {
+        for (int i = tid; i < p.M; i += kBlock) s_w[i] = p.morph_w[i];
         __syncthreads();
     }
 
@@ -530,24 +535,6 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
                     az.x = fmaf(w, dz.x, az.x); az.y = fmaf(w, dz.y, az.y); az.z = fmaf(w, dz.z, az.z); az.w = fmaf(w, dz.w, az.w);
                 }
             }
-        } else if (MODE == 2 && live) {
-            // per-vertex CSR: entry = (dx,dy,dz, bits(morph)); entries of a vertex sorted by morph
-            const float *mwv = FAST ? p.morph_w : s_w;    // FAST: weights straight from global (L2-resident, tiny)
-            const uint32_t *ptr = p.sp_ptr + q * 4;
-            const uint4 lo = *reinterpret_cast<const uint4 *>(ptr);
-            const uint32_t b[5] = { lo.x, lo.y, lo.z, lo.w, ptr[4] };
-            float sx[4] = {0, 0, 0, 0}, sy[4] = {0, 0, 0, 0}, sz[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                for (uint32_t e = b[k]; e < b[k + 1]; ++e) {
-                    const float4 ent = p.sp_entries[e];
-                    const float w = mwv[__float_as_uint(ent.w)];
-                    sx[k] = fmaf(w, ent.x, sx[k]); sy[k] = fmaf(w, ent.y, sy[k]); sz[k] = fmaf(w, ent.z, sz[k]);
-                }
-            }
-            ax = make_float4(sx[0], sx[1], sx[2], sx[3]);
-            ay = make_float4(sy[0], sy[1], sy[2], sy[3]);
-            az = make_float4(sz[0], sz[1], sz[2], sz[3]);
         }
         if (MODE == 1 && S > 1) {
             // combine the S partial sums of each quad: __shfl_xor butterfly over the slice bits of the
@@ -589,7 +576,27 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
             const int vl = r * 64 + lane;
             if (vl < v_live) {
                 const size_t v = vw0 + vl;
-                const float x = scr[0 * VW + vl], y = scr[1 * VW + vl], z = scr[2 * VW + vl];
+                float x = scr[0 * VW + vl], y = scr[1 * VW + vl], z = scr[2 * VW + vl];
+                if (MODE == 2) {
+                    // sparse morph targets: this vertex's row of the vertex-ordered CSR, entry = (dx, dy, dz, bits(morph)),
+                    // ascending morph = the oracle's accumulation order. One vertex per lane and four independent entry
+                    // loads in flight, weights from LDS: a vertex carrying dozens of entries (the demo model's face —
+                    // all 60 expression morphs sit on the same ~600 vertices) is a short chain, and with S = 4 a wave
+                    // step is only 64 vertices, so such a region spreads over many waves.
+                    const uint32_t b0 = p.sp_ptr[v], b1 = p.sp_ptr[v + 1];
+                    float sx = 0.f, sy = 0.f, sz = 0.f;
+                    for (uint32_t e = b0; e < b1; e += 4) {
+                        float4 ent[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) ent[u] = e + u < b1 ? p.sp_entries[e + u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float w = e + u < b1 ? s_w[__float_as_uint(ent[u].w)] : 0.0f;
+                            sx = fmaf(w, ent[u].x, sx); sy = fmaf(w, ent[u].y, sy); sz = fmaf(w, ent[u].z, sz);
+                        }
+                    }
+                    x += sx; y += sy; z += sz;
+                }
                 float nx, ny, nz;
                 uint32_t j01, j23, wq;
                 if (GEO) {
@@ -994,7 +1001,7 @@ size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v)
 {
     const size_t vw = 256 / v.S;   // vertices per wave per tile
     size_t scratch = (size_t)(kBlock / 64) * (v.geo ? 9 : 3) * vw * 4;
-    const size_t list = (!v.fast && v.mode != 0) ? (size_t)p.Mpad * 8 : 0;
+    const size_t list = (v.mode == 2 || (!v.fast && v.mode == 1)) ? (size_t)p.Mpad * 8 : 0;
     return (size_t)p.B * 48 + list + scratch + (size_t)(kBlock / 64) * p.out_cap * 24;
 }
 
@@ -1049,7 +1056,7 @@ hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, cons
     const size_t lds = rz_deform_lds_bytes(p, v);
     dim3 grid(grid_x, instances);
     if (v.mode == 0) return launch_nt<1, 1, 0>(p, ml, v, grid, lds, st);
-    if (v.mode == 2) return launch_nt<1, 1, 2>(p, ml, v, grid, lds, st);
+    if (v.mode == 2) return v.S == 4 ? launch_nt<4, 1, 2>(p, ml, v, grid, lds, st) : launch_nt<1, 1, 2>(p, ml, v, grid, lds, st);
     switch (v.S) {
     case 2: return launch_dense<2>(p, ml, v, grid, lds, st);
     case 4: return launch_dense<4>(p, ml, v, grid, lds, st);

@@ -182,16 +182,21 @@ def make_morphs_dense(n_verts, n_morphs, seed=SEED + 1):
     return deltas, w
 
 
-def make_morphs_sparse(n_verts, n_morphs, density=0.02, seed=SEED + 2):
+def make_morphs_sparse(n_verts, n_morphs, density=0.02, seed=SEED + 2, region=None):
     """PMX on-disk form: morph_off [M+1], vert_idx [E] (unique, ascending within a morph),
-    delta3 [E,3]; weights [M]. density ~ 607/28842 of the demo model."""
+    delta3 [E,3]; weights [M]. density ~ 607/28842 of the demo model. `region` = (first, count) makes every
+    morph start inside the same vertex range — the demo model's shape, where all 60 vertex morphs are facial
+    expressions over the same ~600 vertices, i.e. a few vertices carry dozens of entries each."""
     rng = np.random.default_rng(seed)
     per = max(1, int(round(n_verts * density)))
     offs = [0]
     idx = []
     for _ in range(n_morphs):
         k = int(min(n_verts, max(1, rng.integers(per // 2, per * 3 // 2 + 1))))
-        start = int(rng.integers(0, max(1, n_verts - k)))
+        if region is not None:
+            start = int(region[0] + rng.integers(0, max(1, region[1] // 4)))
+        else:
+            start = int(rng.integers(0, max(1, n_verts - k)))
         # vertex morphs touch a locality (a face region): a run with random holes
         cand = np.arange(start, min(n_verts, start + 2 * k))
         pick = np.sort(rng.choice(cand, size=min(k, len(cand)), replace=False))

@@ -178,6 +178,34 @@ def test_sparse_morphs_match_oracle_and_dense_path(ctx, oracle):
     assert_parity(pd, nd, pr, nr, "dense expansion")
 
 
+def test_sparse_morphs_concentrated_on_a_face_region(ctx, oracle):
+    """The demo model's shape: every vertex morph is a facial expression over the same few hundred vertices, so some
+    vertices carry dozens of entries and most carry none. The tile-cooperative sparse path must match the oracle there
+    too — on ragged sizes, with a grid cap that gives waves several tiles, with instances that have their own weights,
+    and with out_cap on and off."""
+    for V, B, M, region in ((28842, 349, 60, (5000, 700)), (1000, 16, 40, (700, 300)), (70003, 64, 33, (69000, 1003))):
+        mesh = synth.make_mesh(V, B, seed=V + 1)
+        off, idx, d3, mw = synth.make_morphs_sparse(V, M, density=600.0 / V, region=region, seed=V + 2)
+        assert np.bincount(idx, minlength=V).max() >= 20
+        pm = oracle.morph_sparse(V, off, idx, d3, mw, mesh["pos"])
+        S = oracle.palette(mesh["world"], mesh["inv_bind"])
+        pr, nr = oracle.skin(pm, mesh["nrm"], mesh["joints"], mesh["weights"], S)
+        for fast, cap, oc in ((1, 0, -1), (0, 0, 0), (1, 16, -1), (1, 3, 0)):
+            pg, ng = run_gpu(ctx, mesh, sparse=(off, idx, d3), mw=mw, fast=fast, grid_cap=cap, out_cap=oc)
+            assert_parity(pg, ng, pr, nr, "face-concentrated sparse V=%d fast=%d cap=%d out_cap=%d" % (V, fast, cap, oc))
+    # two instances, the second with only three active expressions
+    mw2 = np.stack([mw, np.where(np.arange(M) < 3, mw, 0).astype(np.float32)])
+    ctx.set_instances(2)
+    ctx.set_pose(np.stack([mesh["world"], mesh["world"]]), mw2)
+    ctx.deform()
+    for i in range(2):
+        pm = oracle.morph_sparse(V, off, idx, d3, mw2[i], mesh["pos"])
+        pr, nr = oracle.skin(pm, mesh["nrm"], mesh["joints"], mesh["weights"], S)
+        pg, ng = ctx.read(instance=i)
+        assert_parity(pg, ng, pr, nr, "face-concentrated sparse, instance %d" % i)
+    ctx.set_instances(1)
+
+
 @pytest.mark.parametrize("cap", [0, 64, 192, 2048])
 def test_lds_batched_output_stores(ctx, oracle, cap):
     """out_cap: outputs parked in a per-wave LDS buffer and flushed as 16-byte stores (full, partial and multi-flush runs)."""
