@@ -1055,7 +1055,7 @@ hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, cons
 {
     const size_t lds = rz_deform_lds_bytes(p, v);
     dim3 grid(grid_x, instances);
-    if (v.mode == 0) return launch_nt<1, 1, 0>(p, ml, v, grid, lds, st);
+    if (v.mode == 0) return v.S == 4 ? launch_nt<4, 1, 0>(p, ml, v, grid, lds, st) : launch_nt<1, 1, 0>(p, ml, v, grid, lds, st);
     if (v.mode == 2) return v.S == 4 ? launch_nt<4, 1, 2>(p, ml, v, grid, lds, st) : launch_nt<1, 1, 2>(p, ml, v, grid, lds, st);
     switch (v.S) {
     case 2: return launch_dense<2>(p, ml, v, grid, lds, st);

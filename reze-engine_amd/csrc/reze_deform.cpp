@@ -317,10 +317,12 @@ Plan make_plan(const rz_ctx *c)
     Plan pl;
     RzVariant &v = pl.v;
     v.mode = c->morph_mode;
-    // sparse morphs: S = 4 makes a wave step 64 vertices, so a region where every vertex carries dozens of entries (a
-    // face) spreads over 4x as many waves; S only takes 1 or 4 there
+    // Without dense targets S only sets the size of a wave step: S = 4 makes it 64 vertices instead of 256, so a small
+    // mesh (one 30 k-vertex character is 118 wave steps at S = 1) reaches four times as many CUs, and a region where
+    // every vertex carries dozens of sparse entries (a face) spreads over four times as many waves. 1 or 4 there.
     v.S = (v.mode == 1) ? (c->t_split > 0 ? c->t_split : auto_split(c))
-          : (v.mode == 2) ? (c->t_split > 0 ? (c->t_split >= 4 ? 4 : 1) : ((uint64_t)c->V * c->I <= (256u << 10) ? 4 : 1)) : 1;
+                        : (c->t_split > 0 ? (c->t_split >= 4 ? 4 : 1)
+                                          : ((uint64_t)c->V * c->I <= (v.mode == 2 ? (256u << 10) : (64u << 10)) ? 4 : 1));   // measured: 30 k verts 5.5 -> 4.5 us, 126 k 6.0 -> 6.6
     v.U = c->t_unroll > 0 ? c->t_unroll : 8;    // 24 loads in flight per lane: best or tied at every size measured
     v.nt = c->t_nt != 0;
     // streaming stores pay once the frame's output no longer fits the L2s (measured: 1 M verts yes, 126 k no)
@@ -1090,7 +1092,7 @@ int rz_autotune(rz_ctx *c, uint32_t frames)
         for (int loop : {8, 4})
             for (int cap : {2 * ncu, 4 * ncu}) cands.push_back({0, cap, loop});
     } else {
-        const int smax = c->morph_mode == 1 ? (int)std::min<uint32_t>(8, std::max<uint32_t>(1, c->M)) : c->morph_mode == 2 ? 4 : 1;
+        const int smax = c->morph_mode == 1 ? (int)std::min<uint32_t>(8, std::max<uint32_t>(1, c->M)) : 4;
         for (int sp = 1; sp <= smax; sp <<= 1)
             for (int cap : {ncu, 2 * ncu, 4 * ncu}) cands.push_back({sp, (int)(cap * c->I), 0});
     }

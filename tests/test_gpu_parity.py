@@ -487,11 +487,11 @@ def test_autotune_keeps_parity_and_picks_a_listed_plan(rz, oracle):
     pg, ng = ctx.read()
     assert_parity(pg, ng, pr, nr, "after autotune (dense)")
     ctx.set_tuning(morph_split=0, grid_cap=0)
-    # morph-free: only the grid is searched
+    # morph-free: the split only sets the wave-step size there (256 or 64 vertices)
     pr0, nr0 = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"])
     run_gpu(ctx, mesh)
     got = ctx.autotune()
-    assert got["effective_split"] == 1
+    assert got["effective_split"] in (1, 4)
     ctx.deform()
     pg, ng = ctx.read()
     assert_parity(pg, ng, pr0, nr0, "after autotune (no morphs)")
