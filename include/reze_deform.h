@@ -166,7 +166,9 @@ int rz_get_tuning(rz_ctx *ctx, const char *key, int *value);
  * {1,2,4,8} x {1,2,4} workgroups per CU (instanced frames: {4,8} poses per workgroup x {2,4} workgroups per CU) with
  * the CURRENT mesh / morphs / pose on this GPU and keeps the fastest as the "morph_split" / "grid_cap" / "inst_loop"
  * tuning values. Needs a pose; costs a few hundred frames; results stay within the parity tolerance for every
- * candidate (tests cover them all). rz_set_tuning(key, 0 / -1) returns a key to its heuristic. */
+ * candidate (tests cover them all). The result belongs to the workload it was timed on: uploading another mesh or
+ * other morph targets, or changing the instance count, returns the three keys to their heuristics, and so does
+ * rz_set_tuning(key, 0 / -1). */
 int rz_autotune(rz_ctx *ctx, uint32_t frames);
 
 /* Device pointers of the output buffers ([I][Vpad][3] floats each) and the padded vertex count,

@@ -171,6 +171,7 @@ struct rz_ctx {
 
     // tuning (0 / -1 = automatic)
     int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1;
+    bool tuned_by_search = false;       // rz_autotune set morph_split / grid_cap / inst_loop for the CURRENT mesh, morphs and instance count
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -272,8 +273,17 @@ int ensure_pose_buffers(rz_ctx *c)
     return RZ_OK;
 }
 
+// A launch shape found by rz_autotune belongs to the workload it was timed on.
+void forget_search(rz_ctx *c)
+{
+    if (!c->tuned_by_search) return;
+    c->t_split = 0; c->t_grid_cap = 0; c->t_instloop = -1;
+    c->tuned_by_search = false;
+}
+
 void free_morphs(rz_ctx *c)
 {
+    forget_search(c);
     dfree(c->dense); dfree(c->sp_ptr); dfree(c->sp_entries);
     c->morph_mode = 0; c->M = 0; c->Mpad = 12; c->sp_count = 0;
     c->pose_set = false;                  // morph weights belong to the old target set
@@ -768,6 +778,7 @@ int rz_set_instances(rz_ctx *c, uint32_t I)
     if (int r = use(c)) return r;
     if (I == 0 || I > 65535) return fail(RZ_ERR_INVALID, "instance count must be 1..65535");
     if (I > 1 && (c->comm || c->gather_root)) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive");
+    if (I != c->I) forget_search(c);
     c->I = I;
     if (int r = ensure_pose_buffers(c)) return r;
     return ensure_outputs(c);
@@ -1132,12 +1143,14 @@ int rz_autotune(rz_ctx *c, uint32_t frames)
     if (best < 0) { c->t_split = keep_split; c->t_grid_cap = keep_cap; c->t_instloop = keep_loop; return RZ_OK; }
     c->t_split = cands[best].split; c->t_grid_cap = cands[best].cap;
     c->t_instloop = instanced ? cands[best].loop : keep_loop;
+    c->tuned_by_search = true;
     return RZ_OK;
 }
 
 int rz_set_tuning(rz_ctx *c, const char *key, int value)
 {
     if (!c || !key) return fail(RZ_ERR_INVALID, "null argument");
+    if (!strcmp(key, "morph_split") || !strcmp(key, "grid_cap") || !strcmp(key, "inst_loop")) c->tuned_by_search = false;   // the caller owns the shape now
     if (!strcmp(key, "morph_split")) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
             return fail(RZ_ERR_INVALID, "morph_split must be 0 (auto),1,2,4,8");
