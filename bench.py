@@ -264,7 +264,7 @@ def main():
     if rank == 0:
         verts = V_total * I * args.steps
         out = {
-            "metric": "deformed verts/sec (fused morph+skin); achieved HBM GB/s vs ~8 TB/s roofline",
+            "metric": "deformed verts/sec at 1/2/4/8 GPU; achieved HBM GB/s vs ~8 TB/s roofline",
             "value": verts / elapsed,
             "unit": "verts/s",
             "n_gpus": world_size,

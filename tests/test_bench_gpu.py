@@ -29,6 +29,8 @@ def _last_json(out):
 def _check(d, n_gpus, steps, verts):
     for k in REQUIRED:
         assert k in d, "missing key " + k
+    baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == baseline["metric"]           # the driver matches the line against BASELINE.json's metric
     assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["unit"] == "verts/s" and d["higher_is_better"] is True
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
