@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 1
+#define RZ_ABI_VERSION 2
 
 typedef struct rz_ctx rz_ctx;
 
@@ -102,15 +102,19 @@ int rz_set_pose(rz_ctx *ctx, const float *world, const float *morph_weights);
 
 /* ---- forward kinematics on the device (optional) ----
  * rz_upload_skeleton_topology hands over what Model.computeWorldMatrices (engine/src/model.ts:330-420) reads from
- * the skeleton: parents[B] (-1 = root), bind_translation[B*3] (Bone.bindTranslation), and the append-rotation
- * data of model.ts:355-386: append_parent[B] (-1 or NULL = none) and append_ratio[B] (NULL = all 1).
+ * the skeleton: parents[B] (-1 = root), bind_translation[B*3] (Bone.bindTranslation), and the append data of
+ * model.ts:355-393: append_parent[B] (-1 or NULL = no append rotation), append_ratio[B] (NULL = all 1) and
+ * append_move[B] (NULL = none; non-zero = the append parent's local translation * ratio is appended as well).
  * rz_set_pose_local then replaces rz_set_pose: it uploads local rotations (I x B x 4, x y z w — the
- * SkeletonRuntime.localRotations array, model.ts:55) instead of world matrices, and the frame computes the world
- * matrices and the palette on the GPU (f32; the host solves in doubles with f32 stores, so results agree to
- * ~1e-6, not bit for bit). 4x less per-frame upload; hierarchy solve for all instances in one launch. */
+ * SkeletonRuntime.localRotations array, model.ts:55) and, optionally, local translations (I x B x 3 —
+ * SkeletonRuntime.localTranslations, model.ts:56; NULL = all zero, which is all the reference ever has: nothing
+ * writes that array there, VMD bone translations are this build's row f2) instead of world matrices, and the frame
+ * computes L = T(bind + t) * R * T(add), W = W_parent * L and the palette on the GPU (f32; the host solves in
+ * doubles with f32 stores, so results agree to ~1e-6, not bit for bit). 4x less per-frame upload; hierarchy solve
+ * for all instances in one launch. */
 int rz_upload_skeleton_topology(rz_ctx *ctx, uint32_t B, const int32_t *parents, const float *bind_translation3,
-                                const int32_t *append_parent, const float *append_ratio);
-int rz_set_pose_local(rz_ctx *ctx, const float *local_rotations4, const float *morph_weights);
+                                const int32_t *append_parent, const float *append_ratio, const uint8_t *append_move);
+int rz_set_pose_local(rz_ctx *ctx, const float *local_rotations4, const float *local_translations3, const float *morph_weights);
 /* Blocking readback of one instance's world matrices (B x 16, column-major) as the frame used them. */
 int rz_read_world(rz_ctx *ctx, uint32_t instance, float *world16);
 

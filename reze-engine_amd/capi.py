@@ -65,8 +65,8 @@ def load():
     L.rz_set_instances.argtypes = [vp, u32]
     L.rz_set_pose.argtypes = [vp, fp, fp]
     i32p = ctypes.POINTER(ctypes.c_int32)
-    L.rz_upload_skeleton_topology.argtypes = [vp, u32, i32p, fp, i32p, fp]
-    L.rz_set_pose_local.argtypes = [vp, fp, fp]
+    L.rz_upload_skeleton_topology.argtypes = [vp, u32, i32p, fp, i32p, fp, ctypes.POINTER(ctypes.c_uint8)]
+    L.rz_set_pose_local.argtypes = [vp, fp, fp, fp]
     L.rz_read_world.argtypes = [vp, u32, fp]
     L.rz_deform.argtypes = [vp]
     L.rz_deform_n.argtypes = [vp, u32]
@@ -240,25 +240,30 @@ class DeformContext:
         else:
             _chk(self._L.rz_set_pose(self._h, _fptr(w), None))
 
-    def upload_skeleton_topology(self, parents, bind_translation, append_parent=None, append_ratio=None):
+    def upload_skeleton_topology(self, parents, bind_translation, append_parent=None, append_ratio=None, append_move=None):
         par = np.ascontiguousarray(parents, dtype=np.int32)
         bind = _f32(bind_translation).reshape(-1, 3)
         i32p = ctypes.POINTER(ctypes.c_int32)
         ap = None if append_parent is None else np.ascontiguousarray(append_parent, dtype=np.int32)
         ar = None if append_ratio is None else _f32(append_ratio)
+        am = None if append_move is None else np.ascontiguousarray(append_move, dtype=np.uint8)
         _chk(self._L.rz_upload_skeleton_topology(
             self._h, len(par), par.ctypes.data_as(i32p), _fptr(bind),
-            None if ap is None else ap.ctypes.data_as(i32p), None if ar is None else _fptr(ar)))
+            None if ap is None else ap.ctypes.data_as(i32p), None if ar is None else _fptr(ar),
+            None if am is None else am.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
 
-    def set_pose_local(self, local_rotations, morph_weights=None):
+    def set_pose_local(self, local_rotations, morph_weights=None, local_translations=None):
         q = _f32(local_rotations).reshape(-1)
         assert q.size == self.I * self.B * 4, (q.size, self.I, self.B)
+        t = None
+        if local_translations is not None:
+            t = _f32(local_translations).reshape(-1)
+            assert t.size == self.I * self.B * 3
+        mw = None
         if morph_weights is not None and self.M > 0:
             mw = _f32(morph_weights).reshape(-1)
             assert mw.size == self.I * self.M
-            _chk(self._L.rz_set_pose_local(self._h, _fptr(q), _fptr(mw)))
-        else:
-            _chk(self._L.rz_set_pose_local(self._h, _fptr(q), None))
+        _chk(self._L.rz_set_pose_local(self._h, _fptr(q), None if t is None else _fptr(t), None if mw is None else _fptr(mw)))
 
     def read_world(self, instance=0):
         out = np.empty((self.B, 16), dtype=np.float32)

@@ -22,6 +22,8 @@ struct RzPrepParams {
 // rz_fk_kernel: forward kinematics + palette on the device (engine/src/model.ts:330-420, engine.ts:926-928).
 struct RzFkParams {
     const float4 *local_q;      // [I][B] local rotations (x,y,z,w)
+    const float *local_t;       // [I][B][3] local translations (SkeletonRuntime.localTranslations) or nullptr = all zero
+    const unsigned char *append_move;   // [B] 1 = the append parent's local translation * ratio is appended too (model.ts:388-393)
     const int *parents;         // [B] -1 = root
     const float *bind;          // [B][3] parent-relative bind translations
     const int *append_parent;   // [B] -1 = no append rotation

@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
     float *s_bind = s_ratio + p.B;
     const int inst = blockIdx.x, tid = threadIdx.x;
     const float4 *lq = p.local_q + (size_t)inst * p.B;
+    const float *lt = p.local_t ? p.local_t + (size_t)inst * p.B * 3 : nullptr;
     float *world = p.world + (size_t)inst * p.B * 16;
     float4 *pal = p.palette + (size_t)inst * p.B * 3;
     // one cooperative pass stages everything the level loop touches, so each level costs LDS latency + a barrier
@@ -162,9 +163,14 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
             float R[9];
             quat_to_rows(q.x, q.y, q.z, q.w, R);
             const int ap = s_ap[b];
+            float ax = 0.0f, ay = 0.0f, az = 0.0f;       // append-move: T(add) of L = T(bind) * R * T(add)
             if (ap >= 0) {
                 const float ratio = fminf(1.0f, fmaxf(-1.0f, s_ratio[b]));
                 if (fabsf(ratio) > 1e-6f) {
+                    if (lt && p.append_move[b]) {            // model.ts:388-393 uses the UNclamped ratio here
+                        const float r = s_ratio[b];
+                        ax = lt[ap * 3] * r; ay = lt[ap * 3 + 1] * r; az = lt[ap * 3 + 2] * r;
+                    }
                     float4 a = sq[ap];
                     const float t = fabsf(ratio);
                     if (ratio < 0.0f) { a.x = -a.x; a.y = -a.y; a.z = -a.z; }
@@ -191,7 +197,14 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
                     for (int i = 0; i < 9; ++i) R[i] = X[i];
                 }
             }
-            const float tx = s_bind[b * 3], ty = s_bind[b * 3 + 1], tz = s_bind[b * 3 + 2];
+            // translation column of L = T(bind + local) * R * T(add)  =  bind + local + R * add
+            float tx = s_bind[b * 3], ty = s_bind[b * 3 + 1], tz = s_bind[b * 3 + 2];
+            if (lt) {
+                tx += lt[b * 3]; ty += lt[b * 3 + 1]; tz += lt[b * 3 + 2];
+                tx += R[0] * ax + R[1] * ay + R[2] * az;
+                ty += R[3] * ax + R[4] * ay + R[5] * az;
+                tz += R[6] * ax + R[7] * ay + R[8] * az;
+            }
             float W[12];   // 3 rows x 4
             const int par = s_par[b];
             if (par >= 0) {

@@ -254,14 +254,16 @@ static napi_value fn_upload_topology(napi_env env, napi_callback_info info)
 {
     ARGS(3);
     CTX(0);
-    void *par, *bind, *ap = NULL, *ar = NULL;
-    size_t npar, nbind, nap = 0, nar = 0;
+    void *par, *bind, *ap = NULL, *ar = NULL, *am = NULL;
+    size_t npar, nbind, nap = 0, nar = 0, nam = 0;
     if (!get_ta(env, argv[1], napi_int32_array, 0, &par, &npar) || !get_ta(env, argv[2], napi_float32_array, 0, &bind, &nbind) || nbind != npar * 3)
-        return throw_msg(env, "uploadSkeletonTopology(ctx, Int32Array parents, Float32Array bindTranslation /* B*3 */, Int32Array|null appendParent, Float32Array|null appendRatio)");
+        return throw_msg(env, "uploadSkeletonTopology(ctx, Int32Array parents, Float32Array bindTranslation /* B*3 */, Int32Array|null appendParent, Float32Array|null appendRatio, Uint8Array|null appendMove)");
     if (argc > 3 && !get_ta(env, argv[3], napi_int32_array, 1, &ap, &nap)) return throw_msg(env, "appendParent must be an Int32Array or null");
     if (argc > 4 && !get_ta(env, argv[4], napi_float32_array, 1, &ar, &nar)) return throw_msg(env, "appendRatio must be a Float32Array or null");
-    if ((ap && nap != npar) || (ar && nar != npar)) return throw_msg(env, "uploadSkeletonTopology: array lengths disagree");
-    int rc = rz_upload_skeleton_topology(ctx, (uint32_t)npar, (const int32_t *)par, (const float *)bind, (const int32_t *)ap, (const float *)ar);
+    if (argc > 5 && !get_ta(env, argv[5], napi_uint8_array, 1, &am, &nam)) return throw_msg(env, "appendMove must be a Uint8Array or null");
+    if ((ap && nap != npar) || (ar && nar != npar) || (am && nam != npar)) return throw_msg(env, "uploadSkeletonTopology: array lengths disagree");
+    int rc = rz_upload_skeleton_topology(ctx, (uint32_t)npar, (const int32_t *)par, (const float *)bind, (const int32_t *)ap, (const float *)ar,
+                                         (const uint8_t *)am);
     return rc ? throw_rz(env, rc) : undef(env);
 }
 
@@ -269,15 +271,17 @@ static napi_value fn_set_pose_local(napi_env env, napi_callback_info info)
 {
     ARGS(2);
     CTX(0);
-    void *q, *mw = NULL;
-    size_t nq, nmw = 0;
-    if (!get_ta(env, argv[1], napi_float32_array, 0, &q, &nq)) return throw_msg(env, "setPoseLocal(ctx, Float32Array localRotations, Float32Array|null morphWeights)");
+    void *q, *mw = NULL, *tr = NULL;
+    size_t nq, nmw = 0, ntr = 0;
+    if (!get_ta(env, argv[1], napi_float32_array, 0, &q, &nq)) return throw_msg(env, "setPoseLocal(ctx, Float32Array localRotations, Float32Array|null morphWeights, Float32Array|null localTranslations)");
     if (argc > 2 && !get_ta(env, argv[2], napi_float32_array, 1, &mw, &nmw)) return throw_msg(env, "setPoseLocal: morphWeights must be a Float32Array or null");
+    if (argc > 3 && !get_ta(env, argv[3], napi_float32_array, 1, &tr, &ntr)) return throw_msg(env, "setPoseLocal: localTranslations must be a Float32Array or null");
     int B = 0, M = 0, I = 0;
     if (rz_get_tuning(ctx, "bones", &B) || rz_get_tuning(ctx, "morphs", &M) || rz_get_tuning(ctx, "instances", &I)) return throw_rz(env, RZ_ERR_INVALID);
     if (nq != (size_t)I * B * 4) return throw_msg(env, "setPoseLocal: localRotations must hold instances*bones*4 floats");
     if (mw && nmw != (size_t)I * M) return throw_msg(env, "setPoseLocal: morphWeights must hold instances*morphs floats");
-    int rc = rz_set_pose_local(ctx, (const float *)q, (const float *)mw);
+    if (tr && ntr != (size_t)I * B * 3) return throw_msg(env, "setPoseLocal: localTranslations must hold instances*bones*3 floats");
+    int rc = rz_set_pose_local(ctx, (const float *)q, (const float *)tr, (const float *)mw);
     return rc ? throw_rz(env, rc) : undef(env);
 }
 

@@ -111,6 +111,8 @@ struct rz_ctx {
     // optional topology for on-device FK
     bool has_topology = false;
     int *fk_parents = nullptr, *fk_append_parent = nullptr, *fk_order = nullptr, *fk_level_off = nullptr;
+    unsigned char *fk_append_move = nullptr;
+    bool pose_local_t = false;          // the current local pose carries translations (behind the rotations in its slot)
     float *fk_bind = nullptr, *fk_append_ratio = nullptr;
     int fk_levels = 0;
     float4 *local_q = nullptr;          // I x B   (current pose slot)
@@ -438,7 +440,10 @@ int launch_fk(rz_ctx *c)
 {
     RzFkParams p;
     memset(&p, 0, sizeof p);
-    p.local_q = c->local_q; p.parents = c->fk_parents; p.bind = c->fk_bind; p.append_parent = c->fk_append_parent;
+    p.local_q = c->local_q;
+    p.local_t = c->pose_local_t ? reinterpret_cast<const float *>(c->local_q + (size_t)c->I * c->B) : nullptr;
+    p.append_move = c->fk_append_move;
+    p.parents = c->fk_parents; p.bind = c->fk_bind; p.append_parent = c->fk_append_parent;
     p.append_ratio = c->fk_append_ratio; p.order = c->fk_order; p.level_off = c->fk_level_off; p.inv_bind = c->inv_bind;
     p.world = c->world; p.palette = c->palette; p.B = (int)c->B; p.n_levels = c->fk_levels;
     HIP_TRY(rz_launch_fk(p, c->I, c->stream));
@@ -613,7 +618,7 @@ int rz_destroy(rz_ctx *c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->inv_bind);
     dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind);
-    dfree(c->fk_append_ratio); dfree(c->local_q_buf[0]); dfree(c->local_q_buf[1]);
+    dfree(c->fk_append_ratio); dfree(c->fk_append_move); dfree(c->local_q_buf[0]); dfree(c->local_q_buf[1]);
     free_morphs(c);
     for (int k = 0; k < 2; ++k) {
         dfree(c->world_buf[k]); dfree(c->morph_w_buf[k]);
@@ -787,8 +792,11 @@ int rz_set_instances(rz_ctx *c, uint32_t I)
 // Shared tail of rz_set_pose / rz_set_pose_local. `primary` (world matrices or local rotations, `pbytes` long) and the
 // morph weights go through a pinned ring slot into the OTHER device slot on the upload stream, so this upload overlaps
 // whatever the compute stream is still running on the current slot; the compute stream then waits for the new slot.
-static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, bool local, const float *morph_weights)
+static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void *secondary, size_t sbytes, bool local,
+                       const float *morph_weights)
 {
+    const size_t p1 = pbytes;           // `secondary` (local translations) rides right behind `primary` in the slot
+    pbytes += sbytes;
     const size_t mb = (size_t)c->I * c->M * sizeof(float);
     const size_t need = std::max(pbytes, (size_t)c->I * c->B * 64) + mb;
     if (need > c->stage_bytes) {
@@ -817,7 +825,8 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, bool local
         if (c->free_recorded[k]) HIP_TRY(hipStreamWaitEvent(c->up_stream, c->ev_free[k], 0));
     }
     char *st = static_cast<char *>(c->stage[slot]);
-    memcpy(st, primary, pbytes);
+    memcpy(st, primary, p1);
+    if (sbytes) memcpy(st + p1, secondary, sbytes);
     void *dst = local ? static_cast<void *>(c->local_q_buf[k]) : static_cast<void *>(c->world_buf[k]);
     HIP_TRY(hipMemcpyAsync(dst, st, pbytes, hipMemcpyHostToDevice, us));
     if (c->M > 0) {
@@ -861,11 +870,11 @@ int rz_set_pose(rz_ctx *c, const float *world, const float *morph_weights)
     if (c->B == 0) return fail(RZ_ERR_INVALID, "no skeleton uploaded");
     if (!world) return fail(RZ_ERR_INVALID, "null world matrices");
     if (int r = ensure_pose_buffers(c)) return r;
-    return upload_pose(c, world, (size_t)c->I * c->B * 16 * sizeof(float), false, morph_weights);
+    return upload_pose(c, world, (size_t)c->I * c->B * 16 * sizeof(float), nullptr, 0, false, morph_weights);
 }
 
 int rz_upload_skeleton_topology(rz_ctx *c, uint32_t B, const int32_t *parents, const float *bind_translation3,
-                                const int32_t *append_parent, const float *append_ratio)
+                                const int32_t *append_parent, const float *append_ratio, const uint8_t *append_move)
 {
     if (int r = use(c)) return r;
     if (B == 0 || B != c->B) return fail(RZ_ERR_INVALID, "topology has %u bones but the uploaded skeleton has %u", B, c->B);
@@ -888,6 +897,7 @@ int rz_upload_skeleton_topology(rz_ctx *c, uint32_t B, const int32_t *parents, c
     for (uint32_t b = 0; b < B; ++b) n_levels = std::max(n_levels, level[b] + 1);
     std::vector<int> off(n_levels + 1, 0), order(B), ap(B, -1);
     std::vector<float> ratio(B, 1.0f);
+    std::vector<unsigned char> mv(B, 0);
     for (uint32_t b = 0; b < B; ++b) off[level[b] + 1]++;
     for (int l = 0; l < n_levels; ++l) off[l + 1] += off[l];
     std::vector<int> cur(off.begin(), off.end() - 1);
@@ -895,9 +905,13 @@ int rz_upload_skeleton_topology(rz_ctx *c, uint32_t B, const int32_t *parents, c
     for (uint32_t b = 0; b < B; ++b) {
         if (append_parent && append_parent[b] >= 0 && append_parent[b] < (int32_t)B) ap[b] = append_parent[b];
         if (append_ratio) ratio[b] = append_ratio[b];
+        if (append_move) mv[b] = append_move[b] ? 1 : 0;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind); dfree(c->fk_append_ratio);
+    dfree(c->fk_append_move);
+    HIP_TRY(hipMalloc(&c->fk_append_move, B));
+    HIP_TRY(hipMemcpy(c->fk_append_move, mv.data(), B, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&c->fk_parents, B * sizeof(int)));
     HIP_TRY(hipMalloc(&c->fk_append_parent, B * sizeof(int)));
     HIP_TRY(hipMalloc(&c->fk_order, B * sizeof(int)));
@@ -915,7 +929,7 @@ int rz_upload_skeleton_topology(rz_ctx *c, uint32_t B, const int32_t *parents, c
     return RZ_OK;
 }
 
-int rz_set_pose_local(rz_ctx *c, const float *local_rotations4, const float *morph_weights)
+int rz_set_pose_local(rz_ctx *c, const float *local_rotations4, const float *local_translations3, const float *morph_weights)
 {
     if (int r = use(c)) return r;
     if (!c->has_topology) return fail(RZ_ERR_INVALID, "rz_upload_skeleton_topology has not been called for this skeleton");
@@ -927,11 +941,13 @@ int rz_set_pose_local(rz_ctx *c, const float *local_rotations4, const float *mor
         HIP_TRY(hipStreamSynchronize(c->up_stream));
         for (int k = 0; k < 2; ++k) {
             dfree(c->local_q_buf[k]);
-            HIP_TRY(hipMalloc(&c->local_q_buf[k], nq * sizeof(float4)));
+            HIP_TRY(hipMalloc(&c->local_q_buf[k], nq * (sizeof(float4) + 3 * sizeof(float))));   // rotations, then translations
         }
         c->local_q_alloc = nq;
     }
-    return upload_pose(c, local_rotations4, nq * sizeof(float4), true, morph_weights);
+    c->pose_local_t = local_translations3 != nullptr;
+    return upload_pose(c, local_rotations4, nq * sizeof(float4), local_translations3, local_translations3 ? nq * 3 * sizeof(float) : 0, true,
+                       morph_weights);
 }
 
 int rz_read_world(rz_ctx *c, uint32_t instance, float *world16)

@@ -151,15 +151,17 @@ class Engine {
       if (this.deviceFK) {
         const B = skeleton.bones.length
         const parents = new Int32Array(B), bind = new Float32Array(B * 3), ap = new Int32Array(B).fill(-1), ar = new Float32Array(B).fill(1)
+        const am = new Uint8Array(B)
         skeleton.bones.forEach((bn, i) => {
           parents[i] = bn.parentIndex
           bind.set(bn.bindTranslation, i * 3)
           if (bn.appendRotate && bn.appendParentIndex !== undefined && bn.appendParentIndex !== null) {
             ap[i] = bn.appendParentIndex
             ar[i] = bn.appendRatio === undefined || bn.appendRatio === null ? 1 : bn.appendRatio
+            am[i] = bn.appendMove ? 1 : 0
           }
         })
-        n.uploadSkeletonTopology(s.ctx, parents, bind, ap, ar)
+        n.uploadSkeletonTopology(s.ctx, parents, bind, ap, ar, am)
       }
       if (morphs && morphs.names.length > 0) {
         const M = morphs.names.length
@@ -332,15 +334,16 @@ class Engine {
     if (!this.currentModel || !this.ctx) return
     const t0 = wallClock()
     const model = this.currentModel
-    // the GPU hierarchy solve takes rotations only; once a sampler moves bones, solve on the host
-    const gpuFK = this.deviceFK && !model.applyLocalTranslations
+    const gpuFK = this.deviceFK
+    // VMD bone translations (seekFrame) travel with the rotations; the reference itself never writes localTranslations
+    const tra = gpuFK && model.applyLocalTranslations ? model.runtimeSkeleton.localTranslations : null
     if (gpuFK) model.updateRotationTweens() // tweens stay on the host; the hierarchy solve moves to the GPU
     else model.evaluatePose()
     const mw = model.getMorphCount() > 0 ? model.getEffectiveMorphWeights() : null
     // per-frame inputs are replicated to every shard (16-22 KB); launches are asynchronous, so the GPUs run concurrently
     for (const s of this.shards) {
       if (s.count === 0) continue
-      if (gpuFK) this.native.setPoseLocal(s.ctx, model.runtimeSkeleton.localRotations, mw)
+      if (gpuFK) this.native.setPoseLocal(s.ctx, model.runtimeSkeleton.localRotations, mw, tra)
       else this.native.setPose(s.ctx, model.getBoneWorldMatrices(), mw)
       this.native.deform(s.ctx)
     }

@@ -23,13 +23,13 @@ const dump = (name, ta) => fs.writeFileSync(path.join(out, name), Buffer.from(ta
   dump('morph_offsets.u32', mo.offsets); dump('morph_vidx.u32', mo.vertexIndex); dump('morph_deltas.f32', mo.deltas)
   if (vmd !== '-') { await engine.loadAnimation(vmd); engine.playAnimation() }
   const names = model.getBoneNames()
-  const steps = [0, 250, 1000]
+  const steps = [0, 250, 1000, -1]        // -1: a frame-indexed seek (MMD interpolation, bone translations) instead of a clock step
   for (let s = 0; s < steps.length; s++) {
     if (s === 1) {
       engine.rotateBones([names[1], names[2]], [new Quat(0.2, 0.1, -0.1, 0.96), new Quat(-0.3, 0.0, 0.2, 0.93)], 500)
       engine.setMorphWeights(['grp', 'blink'], [0.6, 0.3])      // a group morph fans out onto its vertex morphs
     }
-    engine.step(steps[s])
+    if (steps[s] < 0) { if (vmd === '-') break; engine.seekFrame(11.5) } else engine.step(steps[s])
     const d = engine.getDeformed()
     if (deviceFK) {   // the host did not solve the hierarchy this frame: do it now for the oracle, and fetch the GPU's solve
       model.computeWorldMatrices()

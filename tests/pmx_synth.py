@@ -41,11 +41,15 @@ def write_pmx(V=5000, B=40, n_vertex_morphs=6, seed=5):
     out += struct.pack("<i", B)
     for b in range(B):
         parent = -1 if b == 0 else int(rng.integers(max(0, b - 4), b))
-        flags = 0x0100 if b == B // 2 else 0
+        # one append-rotate bone, and one that appends its append parent's rotation AND translation (ratio beyond 1,
+        # so the clamp on the rotation ratio and the unclamped move ratio both show)
+        flags = 0x0100 if b == B // 2 else (0x0300 if b == B // 2 + 2 and B > 8 else 0)
         out += _text("bone%d" % b) + _text("") + bpos[b].tobytes() + struct.pack("<h", parent) + struct.pack("<i", 0)
         out += struct.pack("<H", flags) + struct.pack("<3f", 0, 1, 0)
-        if flags & 0x0100:
+        if flags == 0x0100:
             out += struct.pack("<hf", 1, 0.5)
+        elif flags == 0x0300:
+            out += struct.pack("<hf", 3, 1.5)
     names = ["v%d" % i for i in range(n_vertex_morphs)] + ["blink"]
     out += struct.pack("<i", len(names) + 1)
     for n in names:
@@ -62,14 +66,16 @@ def write_pmx(V=5000, B=40, n_vertex_morphs=6, seed=5):
 
 
 def write_vmd(bone_keys, morph_keys=()):
-    """bone_keys: [(name, frame, (x,y,z,w))]; morph_keys: [(name, frame, weight)]."""
+    """bone_keys: [(name, frame, (x,y,z,w))] or [(name, frame, (x,y,z,w), (px,py,pz))]; morph_keys: [(name, frame, weight)]."""
     def name15(s):
         b = s.encode("shift-jis")
         return b + b"\0" * (15 - len(b))
     out = bytearray(b"Vocaloid Motion Data 0002" + b"\0" * 5) + bytearray(b"model" + b"\0" * 15)
     out += struct.pack("<I", len(bone_keys))
-    for n, f, q in bone_keys:
-        out += name15(n) + struct.pack("<I", f) + struct.pack("<3f", 0, 0, 0) + struct.pack("<4f", *q) + bytes(64)
+    for key in bone_keys:
+        n, f, q = key[0], key[1], key[2]
+        pos = key[3] if len(key) > 3 else (0, 0, 0)
+        out += name15(n) + struct.pack("<I", f) + struct.pack("<3f", *pos) + struct.pack("<4f", *q) + bytes(64)
     out += struct.pack("<I", len(morph_keys))
     for n, f, w in morph_keys:
         out += name15(n) + struct.pack("<If", f, w)

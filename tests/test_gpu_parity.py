@@ -351,6 +351,52 @@ def test_c5_full_size_parity_and_properties(ctx, oracle, rz):
     np.testing.assert_allclose(pi, mesh["pos"], rtol=1e-6, atol=2e-5)
 
 
+def test_device_fk_local_translations_and_append_move(rz, oracle):
+    """Row f1 x f2: the GPU hierarchy solve with VMD bone translations (SkeletonRuntime.localTranslations) and bones that
+    append their append parent's rotation and movement (model.ts:355-393; clamped ratio for the rotation, raw ratio for the
+    move), three poses at once, against a float64 restatement; the deformed mesh against the oracle fed with those
+    world matrices. Parents deliberately come AFTER some children (the reference solves recursively)."""
+    from helpers import fk_reference
+    V, B, I = 3000, 90, 3
+    mesh = synth.make_mesh(V, B, seed=71)
+    rng = np.random.default_rng(72)
+    perm = rng.permutation(B)                      # shuffle bone ids so parents are not always earlier
+    inv = np.argsort(perm)
+    parents = np.array([(-1 if mesh["parents"][inv[j]] < 0 else perm[mesh["parents"][inv[j]]]) for j in range(B)], dtype=np.int32)
+    bind = mesh["bind"][inv]
+    quats = rng.normal(size=(I, B, 4)).astype(np.float32)
+    quats /= np.linalg.norm(quats, axis=2, keepdims=True)
+    trans = (rng.random((I, B, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(1.5)
+    ap = np.full(B, -1, dtype=np.int32)
+    ratio = np.ones(B, dtype=np.float32)
+    move = np.zeros(B, dtype=np.uint8)
+    for k, b in enumerate(rng.choice(B, size=12, replace=False)):
+        ap[b] = int(rng.integers(0, B))
+        ratio[b] = [0.5, -0.75, 1.5, 1e-7, -2.0, 1.0][k % 6]
+        move[b] = k % 2
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    ib = np.tile(np.eye(4, dtype=np.float32).reshape(1, 16), (B, 1))
+    ib[:, 12:15] = -rng.random((B, 3), dtype=np.float32)
+    c.upload_skeleton(ib)
+    c.set_instances(I)
+    c.upload_skeleton_topology(parents, bind, ap, ratio, move)
+    for with_t in (True, False):
+        c.set_pose_local(quats, local_translations=trans if with_t else None)
+        c.deform()
+        for i in range(I):
+            ref = fk_reference(parents, bind, quats[i], trans[i] if with_t else None, ap, ratio, move)
+            got = c.read_world(i)
+            scale = np.maximum(1.0, np.abs(ref).max())
+            assert np.abs(got - ref).max() <= 3e-5 * scale, "world matrices, pose %d translations=%s: %g" % (i, with_t, np.abs(got - ref).max())
+            pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], got, ib)
+            pg, ng = c.read(instance=i)
+            assert_parity(pg, ng, pr, nr, "device FK with translations, pose %d" % i)
+    # the two runs must differ (translations were really applied)
+    assert np.abs(fk_reference(parents, bind, quats[0], trans[0], ap, ratio, move) - fk_reference(parents, bind, quats[0], None, ap, ratio, move)).max() > 0.1
+    c.close()
+
+
 def test_device_fk_matches_host_fk_and_reference_fixture(ctx, oracle):
     """Row f1: Model.computeWorldMatrices (model.ts:330-420) on the GPU. (a) synthetic tree, 5 poses at once, against
     the host-order FK twin; (b) the REAL 349-bone skeleton with its 26 append-rotation bones and pool.vmd frame 0,
@@ -617,7 +663,8 @@ def test_engine_through_napi_matches_oracle(tmp_path, oracle):
     (tmp_path / "m.pmx").write_bytes(write_pmx())
     s = 0.38268343
     (tmp_path / "a.vmd").write_bytes(write_vmd(
-        [("bone1", 0, (0, 0, s, 0.92387953)), ("bone3", 0, (s, 0, 0, 0.92387953)), ("bone1", 15, (0, s, 0, 0.92387953)),
+        [("bone1", 0, (0, 0, s, 0.92387953)), ("bone3", 0, (s, 0, 0, 0.92387953), (0.3, -0.2, 0.1)), ("bone1", 15, (0, s, 0, 0.92387953)),
+         ("bone3", 20, (0, 0, s, 0.92387953), (-0.5, 0.4, 0.25)), ("bone0", 0, (0, 0, 0, 1), (0, 0.5, 0)), ("bone0", 25, (0, 0, 0, 1), (1.0, 0.25, -0.5)),
          ("bone20", 30, (0, 0, -s, 0.92387953))], [("v1", 0, 0.8), ("v2", 6, 0.4)]))
     for layout, devs in (("sparse", "0"), ("dense", "0"), ("sparse", "0,0"), ("dense", "0,0,0"), ("sparse", "0:fk"), ("dense", "0,0:fk"),
                          ("sparse", "0,0:direct"), ("dense", "0,0,0:direct")):
@@ -634,7 +681,7 @@ def test_engine_through_napi_matches_oracle(tmp_path, oracle):
         off, vidx = rd("morph_offsets.u32", np.uint32), rd("morph_vidx.u32", np.uint32)
         d3 = rd("morph_deltas.f32", np.float32).reshape(-1, 3)
         seen_morph = False
-        for step in range(3):
+        for step in range(4):
             world = rd("world_%d.f32" % step, np.float32).reshape(-1, 16)
             mw = rd("mw_%d.f32" % step, np.float32)
             pm = oracle.morph_sparse(len(v), off, vidx, d3, mw, v[:, 0:3])

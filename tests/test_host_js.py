@@ -319,9 +319,12 @@ def test_addon_exports_and_loud_failure_without_gpu():
           "shard:a.shardRange(1000000,8,7)}))" % ROOT)
     r = json.loads(subprocess.check_output(["node", "-e", js], timeout=60).decode().strip().splitlines()[-1])
     for k in ("create", "destroy", "uploadMesh", "uploadSkeleton", "uploadMorphsDense", "uploadMorphsSparse", "setInstances",
-              "setPose", "deform", "sync", "read", "timeFrames", "commUniqueId", "commInit", "allgather", "shardRange"):
+              "setPose", "deform", "sync", "read", "timeFrames", "commUniqueId", "commInit", "allgather", "shardRange",
+              "uploadSkeletonTopology", "setPoseLocal", "readWorld", "autotune", "gatherDirect", "gatherFence", "readGathered"):
         assert k in r["keys"], k
-    assert r["abi"] == 1 and r["shard"] == [881664, 118336]
+    import re
+    header = open(os.path.join(ROOT, "include", "reze_deform.h")).read()
+    assert r["abi"] == int(re.search(r"#define RZ_ABI_VERSION (\d+)", header).group(1)) and r["shard"] == [881664, 118336]
     if r["n"] == 0:
         assert "no HIP device" in r["msg"] or "error -3" in r["msg"]
 
