@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--allgather", action="store_true", help="also time the RCCL all-gather of positions")
     ap.add_argument("--device-fk", action="store_true",
                     help="solve the bone hierarchy on the GPU: frames start from local rotations (rz_set_pose_local)")
+    ap.add_argument("--device-sampling", action="store_true",
+                    help="with --device-fk: a synthetic motion is uploaded once and every frame sends ONE float per instance (rz_set_pose_sampled)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for the barrier / max-reduce (gloo + --share-gpu lets a 1-GPU box rehearse N > 1)")
     ap.add_argument("--share-gpu", action="store_true", help="map every rank onto GPU (local_rank %% visible devices)")
@@ -178,8 +180,24 @@ def main():
         quats /= np.linalg.norm(quats, axis=2, keepdims=True)
         ctx.upload_skeleton_topology(mesh["parents"], mesh["bind"])
 
+    frames = None
+    if args.device_sampling:
+        if not args.device_fk:
+            raise SystemExit("--device-sampling needs --device-fk")
+        rng = np.random.default_rng(777)
+        nk = 8                                              # keys per bone, every 10 frames, default (identity) curves
+        kq = rng.normal(size=(B, nk, 4)).astype(np.float32)
+        kq /= np.linalg.norm(kq, axis=2, keepdims=True)
+        ctx.upload_animation(np.arange(B), np.arange(B + 1) * nk, np.tile(np.arange(nk) * 10.0, B), kq,
+                             (rng.random((B, nk, 3), dtype=np.float32) - 0.5) * 0.2, np.tile(np.array([20] * 8 + [107] * 8, np.uint8), B * nk))
+        frames = rng.random(I).astype(np.float32) * 70.0
+        tick = [0]
+
     def put_pose():
-        if quats is not None:
+        if frames is not None:
+            tick[0] += 1
+            ctx.set_pose_sampled((frames + 0.5 * tick[0]) % 70.0)
+        elif quats is not None:
             ctx.set_pose_local(quats, mws)
         else:
             ctx.set_pose(worlds, mws)
@@ -283,7 +301,7 @@ def main():
                                (" x %d instances (per-instance palette in LDS)" % I) if I > 1 else "", world_size),
                 "verts_total": V_total, "verts_per_gpu": n, "bones": B, "morphs": M, "instances": I,
                 "parallelism": "vertex-shard x%d" % world_size,
-                "bone_hierarchy_solve": "device (rz_fk_kernel)" if args.device_fk else "host",
+                "bone_hierarchy_solve": ("device (motion sampling + hierarchy solve in rz_fk_kernel)" if args.device_sampling else "device (rz_fk_kernel)") if args.device_fk else "host",
                 "autotune": tuned is not None,
                 "morph_split": ctx.get_tuning("effective_split"),
                 "grid": ctx.get_tuning("effective_grid"),

@@ -115,6 +115,40 @@ int rz_set_pose(rz_ctx *ctx, const float *world, const float *morph_weights);
 int rz_upload_skeleton_topology(rz_ctx *ctx, uint32_t B, const int32_t *parents, const float *bind_translation3,
                                 const int32_t *append_parent, const float *append_ratio, const uint8_t *append_move);
 int rz_set_pose_local(rz_ctx *ctx, const float *local_rotations4, const float *local_translations3, const float *morph_weights);
+
+/* ---- motion sampling on the device (SURVEY §8f ranks 1 + 2 combined; optional) ----
+ * The caller of the path in the reference is Engine.playAnimation (engine/src/engine.ts:1515-1553) fed by
+ * VMDLoader (engine/src/vmd-loader.ts:95-160, which drops the key's position and interpolation bytes, :129-140).
+ * rz_upload_animation hands a whole flattened motion to the GPU once; rz_set_pose_sampled then replaces
+ * rz_set_pose_local: per frame the host sends ONE float per instance — the (fractional, 30 fps) frame that instance
+ * is posed at — and the frame samples every bone (slerp warped by the later key's R Bezier curve, per-axis lerp
+ * warped by the X / Y / Z curves) and every vertex morph (linear keys; group-morph tracks feed their children by
+ * ratio) on the device, then solves the hierarchy (needs rz_upload_skeleton_topology) and deforms. Bones and morphs
+ * the motion does not key are at rest. Same arithmetic as host/vmd-sampler.js in f32.
+ *   bone tracks : track_bone[n] (bone index, each bone at most once), key_off[n+1], and per key (ascending frame
+ *                 inside a track) key_frame, key_rot4 (x y z w), key_pos3, key_interp16 (the first 16 of the 64
+ *                 interpolation bytes: X_x1 Y_x1 Z_x1 R_x1 | ..y1 | ..x2 | ..y2; NULL = linear)
+ *   morph tracks: mkey_off[m+1], mkey_frame, mkey_weight; feeds per VERTEX MORPH of the uploaded morph set:
+ *                 feed_off[M+1], feed_track, feed_ratio — its own track (ratio 1) first, then the group-morph
+ *                 tracks that include it, ascending (the order Model.getEffectiveMorphWeights adds them in). */
+typedef struct rz_animation {
+    uint32_t n_bone_tracks;
+    const int32_t *track_bone;
+    const uint32_t *key_off;
+    const float *key_frame;
+    const float *key_rot4;
+    const float *key_pos3;
+    const uint8_t *key_interp16;
+    uint32_t n_morph_tracks;
+    const uint32_t *mkey_off;
+    const float *mkey_frame;
+    const float *mkey_weight;
+    const uint32_t *feed_off;
+    const int32_t *feed_track;
+    const float *feed_ratio;
+} rz_animation;
+int rz_upload_animation(rz_ctx *ctx, const rz_animation *anim);
+int rz_set_pose_sampled(rz_ctx *ctx, const float *frames);
 /* Blocking readback of one instance's world matrices (B x 16, column-major) as the frame used them. */
 int rz_read_world(rz_ctx *ctx, uint32_t instance, float *world16);
 

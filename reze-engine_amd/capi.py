@@ -16,10 +16,20 @@ LIB_PATH = os.path.join(_HERE, "libreze_deform.so")
 SYMBOLS = [
     "rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_destroy", "rz_shard_range",
     "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
-    "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_read_world", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
+    "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_upload_animation", "rz_set_pose_sampled", "rz_read_world", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
     "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_autotune", "rz_output_ptrs",
     "rz_comm_unique_id", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_gather_fence", "rz_upload_edge_scale", "rz_read_hull", "rz_enable_aabb", "rz_read_aabb",
 ]
+
+
+class RzAnimation(ctypes.Structure):
+    _fields_ = [("n_bone_tracks", ctypes.c_uint32), ("track_bone", ctypes.POINTER(ctypes.c_int32)),
+                ("key_off", ctypes.POINTER(ctypes.c_uint32)), ("key_frame", ctypes.POINTER(ctypes.c_float)),
+                ("key_rot4", ctypes.POINTER(ctypes.c_float)), ("key_pos3", ctypes.POINTER(ctypes.c_float)),
+                ("key_interp16", ctypes.POINTER(ctypes.c_uint8)), ("n_morph_tracks", ctypes.c_uint32),
+                ("mkey_off", ctypes.POINTER(ctypes.c_uint32)), ("mkey_frame", ctypes.POINTER(ctypes.c_float)),
+                ("mkey_weight", ctypes.POINTER(ctypes.c_float)), ("feed_off", ctypes.POINTER(ctypes.c_uint32)),
+                ("feed_track", ctypes.POINTER(ctypes.c_int32)), ("feed_ratio", ctypes.POINTER(ctypes.c_float))]
 
 
 class RzTiming(ctypes.Structure):
@@ -67,6 +77,8 @@ def load():
     i32p = ctypes.POINTER(ctypes.c_int32)
     L.rz_upload_skeleton_topology.argtypes = [vp, u32, i32p, fp, i32p, fp, ctypes.POINTER(ctypes.c_uint8)]
     L.rz_set_pose_local.argtypes = [vp, fp, fp, fp]
+    L.rz_upload_animation.argtypes = [vp, ctypes.POINTER(RzAnimation)]
+    L.rz_set_pose_sampled.argtypes = [vp, fp]
     L.rz_read_world.argtypes = [vp, u32, fp]
     L.rz_deform.argtypes = [vp]
     L.rz_deform_n.argtypes = [vp, u32]
@@ -264,6 +276,40 @@ class DeformContext:
             mw = _f32(morph_weights).reshape(-1)
             assert mw.size == self.I * self.M
         _chk(self._L.rz_set_pose_local(self._h, _fptr(q), None if t is None else _fptr(t), None if mw is None else _fptr(mw)))
+
+    def upload_animation(self, track_bone, key_off, key_frame, key_rot, key_pos, key_interp=None,
+                         mkey_off=None, mkey_frame=None, mkey_weight=None, feed_off=None, feed_track=None, feed_ratio=None):
+        """Flattened motion (rz_animation): bone tracks + optional morph tracks with their per-vertex-morph feeds."""
+        keep = []
+
+        def arr(x, dt, ct):
+            if x is None:
+                return None
+            a = np.ascontiguousarray(x, dtype=dt).reshape(-1)
+            keep.append(a)
+            return a.ctypes.data_as(ctypes.POINTER(ct))
+        a = RzAnimation()
+        a.n_bone_tracks = len(track_bone)
+        a.track_bone = arr(track_bone, np.int32, ctypes.c_int32)
+        a.key_off = arr(key_off, np.uint32, ctypes.c_uint32)
+        a.key_frame = arr(key_frame, np.float32, ctypes.c_float)
+        a.key_rot4 = arr(key_rot, np.float32, ctypes.c_float)
+        a.key_pos3 = arr(key_pos, np.float32, ctypes.c_float)
+        a.key_interp16 = arr(key_interp, np.uint8, ctypes.c_uint8)
+        a.n_morph_tracks = 0 if mkey_off is None else len(mkey_off) - 1
+        a.mkey_off = arr(mkey_off, np.uint32, ctypes.c_uint32)
+        a.mkey_frame = arr(mkey_frame, np.float32, ctypes.c_float)
+        a.mkey_weight = arr(mkey_weight, np.float32, ctypes.c_float)
+        a.feed_off = arr(feed_off, np.uint32, ctypes.c_uint32)
+        a.feed_track = arr(feed_track, np.int32, ctypes.c_int32)
+        a.feed_ratio = arr(feed_ratio, np.float32, ctypes.c_float)
+        _chk(self._L.rz_upload_animation(self._h, ctypes.byref(a)))
+
+    def set_pose_sampled(self, frames):
+        """One (fractional, 30 fps) frame per instance; bones, morph weights and the hierarchy are evaluated on the GPU."""
+        f = _f32(np.atleast_1d(frames)).reshape(-1)
+        assert f.size == self.I
+        _chk(self._L.rz_set_pose_sampled(self._h, _fptr(f)))
 
     def read_world(self, instance=0):
         out = np.empty((self.B, 16), dtype=np.float32)

@@ -20,6 +20,26 @@ struct RzPrepParams {
 };
 
 // rz_fk_kernel: forward kinematics + palette on the device (engine/src/model.ts:330-420, engine.ts:926-928).
+// motion sampling inside rz_fk_kernel: frame-indexed VMD sampling on the device (the GPU twin of host/vmd-sampler.js; the reference has no
+// counterpart — its loader drops positions and interpolation bytes, engine/src/vmd-loader.ts:129-140).
+struct RzSampleParams {
+    const float *frames;          // [I] fractional frame (30 fps) each instance is posed at; nullptr = no sampling
+    const int *bone_track;        // [B] track of each bone, -1 = the motion does not key it (identity / zero)
+    const uint32_t *key_off;      // [n_tracks + 1]
+    const float *key_frame;       // [K] ascending inside a track
+    const float4 *key_rot;        // [K]
+    const float *key_pos;         // [K][3]
+    const uint4 *key_interp;      // [K] first 16 interpolation bytes of each key (nullptr = linear)
+    const uint32_t *mkey_off;     // [n_morph_tracks + 1]
+    const float *mkey_frame;      // [Km]
+    const float *mkey_weight;     // [Km]
+    const uint32_t *feed_off;     // [M + 1] per vertex morph: the tracks that feed it ...
+    const int *feed_track;        //   ... own track first, then group-morph tracks in ascending group index
+    const float *feed_ratio;
+    float *morph_w;               // [I][M] out
+    int M;
+};
+
 struct RzFkParams {
     const float4 *local_q;      // [I][B] local rotations (x,y,z,w)
     const float *local_t;       // [I][B][3] local translations (SkeletonRuntime.localTranslations) or nullptr = all zero
@@ -35,6 +55,7 @@ struct RzFkParams {
     float4 *palette;            // [I][B][3] out
     int B;
     int n_levels;
+    RzSampleParams sample;      // sample.frames != nullptr: local_q / local_t are ignored, the pose is sampled in the kernel
 };
 
 // rz_deform_kernel: fused morph + 4-bone LBS (engine/src/engine.ts:253-272).

@@ -133,6 +133,96 @@ __device__ __forceinline__ void quat_to_rows(float x, float y, float z, float w,
     r[6] = xz - wy;          r[7] = yz + wx;          r[8] = 1.0f - (xx + yy);
 }
 
+// ------------------------------------------------------------------------------------------------
+// sample_bone / sample_morph — MMD motion sampling, run by rz_fk_kernel's staging pass for every (instance, bone) and
+// (instance, vertex morph) when the pose comes from rz_set_pose_sampled:
+//   rotation  slerp between the surrounding keys, parameter warped by the later key's R Bezier curve
+//   position  per-axis lerp, each axis warped by its own X / Y / Z curve
+//   morph     linear between the surrounding morph keys; a vertex morph sums its own track and the
+//             group-morph tracks that feed it (ratio-scaled), own first, groups ascending
+// Same arithmetic as host/vmd-sampler.js (doubles there, f32 here).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bezier_y(float x, float x1, float y1, float x2, float y2)
+{
+    if (x <= 0.0f) return 0.0f;
+    if (x >= 1.0f) return 1.0f;
+    if (x1 == y1 && x2 == y2) return x;           // the default 20,20,107,107 curve is the identity
+    float lo = 0.0f, hi = 1.0f, t = x;
+    for (int i = 0; i < 24; ++i) {                // bisection-guarded Newton on x(t) = x
+        const float s = 1.0f - t;
+        const float fx = 3.0f * s * s * t * x1 + 3.0f * s * t * t * x2 + t * t * t - x;
+        if (fabsf(fx) < 1e-7f) break;
+        if (fx > 0.0f) hi = t; else lo = t;
+        const float dfx = 3.0f * s * s * x1 + 6.0f * s * t * (x2 - x1) + 3.0f * t * t * (1.0f - x2);
+        const float tn = dfx != 0.0f ? t - fx / dfx : 0.5f * (lo + hi);
+        t = (tn > lo && tn < hi) ? tn : 0.5f * (lo + hi);
+    }
+    const float s = 1.0f - t;
+    return 3.0f * s * s * t * y1 + 3.0f * s * t * t * y2 + t * t * t;
+}
+
+// keys[lo] <= frame < keys[hi] (clamped to the ends); returns the linear parameter
+__device__ __forceinline__ float key_span(const float *kf, uint32_t b, uint32_t e, float frame, uint32_t &i0, uint32_t &i1)
+{
+    uint32_t lo = b, hi = e - 1;
+    if (frame <= kf[lo]) { i0 = i1 = lo; return 0.0f; }
+    if (frame >= kf[hi]) { i0 = i1 = hi; return 0.0f; }
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (kf[mid] <= frame) lo = mid; else hi = mid; }
+    i0 = lo; i1 = hi;
+    return (frame - kf[lo]) / (kf[hi] - kf[lo]);
+}
+
+__device__ __forceinline__ void sample_bone(const RzSampleParams &p, float frame, int bone, float4 &q, float &tx, float &ty, float &tz)
+{
+    const int tr = p.bone_track[bone];
+    q = make_float4(0.f, 0.f, 0.f, 1.f);
+    tx = ty = tz = 0.f;
+    if (tr < 0 || p.key_off[tr + 1] == p.key_off[tr]) return;
+    uint32_t i0, i1;
+    const float x = key_span(p.key_frame, p.key_off[tr], p.key_off[tr + 1], frame, i0, i1);
+    const float4 a = p.key_rot[i0];
+    const float *pa = p.key_pos + (size_t)i0 * 3;
+    if (i0 == i1) { q = a; tx = pa[0]; ty = pa[1]; tz = pa[2]; return; }
+    float cx = x, cy = x, cz = x, cr = x;
+    if (p.key_interp) {
+        const uint4 ip = p.key_interp[i1];          // bytes [X_x1 Y_x1 Z_x1 R_x1 | X_y1 .. | X_x2 .. | X_y2 ..]
+        auto byte = [](uint32_t w, int k) { return (float)((w >> (8 * k)) & 255u) * (1.0f / 127.0f); };
+        cx = bezier_y(x, byte(ip.x, 0), byte(ip.y, 0), byte(ip.z, 0), byte(ip.w, 0));
+        cy = bezier_y(x, byte(ip.x, 1), byte(ip.y, 1), byte(ip.z, 1), byte(ip.w, 1));
+        cz = bezier_y(x, byte(ip.x, 2), byte(ip.y, 2), byte(ip.z, 2), byte(ip.w, 2));
+        cr = bezier_y(x, byte(ip.x, 3), byte(ip.y, 3), byte(ip.z, 3), byte(ip.w, 3));
+    }
+    float4 b = p.key_rot[i1];
+    const float *pb = p.key_pos + (size_t)i1 * 3;
+    // Quat.slerp (math.ts:156-189)
+    float c = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    if (c < 0.0f) { c = -c; b.x = -b.x; b.y = -b.y; b.z = -b.z; b.w = -b.w; }
+    if (c > 0.9995f) {
+        q = make_float4(a.x + cr * (b.x - a.x), a.y + cr * (b.y - a.y), a.z + cr * (b.z - a.z), a.w + cr * (b.w - a.w));
+        const float il = 1.0f / sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        q.x *= il; q.y *= il; q.z *= il; q.w *= il;
+    } else {
+        const float th0 = acosf(c), sn = sinf(th0), th = th0 * cr;
+        const float ka = sinf(th0 - th) / sn, kb = sinf(th) / sn;
+        q = make_float4(ka * a.x + kb * b.x, ka * a.y + kb * b.y, ka * a.z + kb * b.z, ka * a.w + kb * b.w);
+    }
+    tx = pa[0] + (pb[0] - pa[0]) * cx; ty = pa[1] + (pb[1] - pa[1]) * cy; tz = pa[2] + (pb[2] - pa[2]) * cz;
+}
+
+__device__ __forceinline__ float sample_morph(const RzSampleParams &p, float frame, int m)
+{
+    float w = 0.0f;
+    for (uint32_t f = p.feed_off[m]; f < p.feed_off[m + 1]; ++f) {
+        const int tr = p.feed_track[f];
+        if (p.mkey_off[tr + 1] == p.mkey_off[tr]) continue;
+        uint32_t i0, i1;
+        const float x = key_span(p.mkey_frame, p.mkey_off[tr], p.mkey_off[tr + 1], frame, i0, i1);
+        const float wk = p.mkey_weight[i0] + (p.mkey_weight[i1] - p.mkey_weight[i0]) * x;
+        w += wk * p.feed_ratio[f];
+    }
+    return w;
+}
+
 __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -143,17 +233,33 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
     int *s_order = s_ap + p.B;
     float *s_ratio = reinterpret_cast<float *>(s_order + p.B);
     float *s_bind = s_ratio + p.B;
+    float *s_lt = s_bind + (size_t)p.B * 3;               // local translations of this pose
     const int inst = blockIdx.x, tid = threadIdx.x;
     const float4 *lq = p.local_q + (size_t)inst * p.B;
-    const float *lt = p.local_t ? p.local_t + (size_t)inst * p.B * 3 : nullptr;
+    const float *glt = p.local_t ? p.local_t + (size_t)inst * p.B * 3 : nullptr;
+    const bool sampled = p.sample.frames != nullptr;      // rz_set_pose_sampled: the pose is evaluated right here
+    const bool has_t = sampled || glt != nullptr;
+    const float *lt = has_t ? s_lt : nullptr;
+    const float frame = sampled ? p.sample.frames[inst] : 0.0f;
     float *world = p.world + (size_t)inst * p.B * 16;
     float4 *pal = p.palette + (size_t)inst * p.B * 3;
     // one cooperative pass stages everything the level loop touches, so each level costs LDS latency + a barrier
     // instead of two dependent global round trips
     for (int i = tid; i < p.B; i += kBlock) {
-        sq[i] = lq[i]; s_par[i] = p.parents[i]; s_ap[i] = p.append_parent[i]; s_order[i] = p.order[i]; s_ratio[i] = p.append_ratio[i];
+        s_par[i] = p.parents[i]; s_ap[i] = p.append_parent[i]; s_order[i] = p.order[i]; s_ratio[i] = p.append_ratio[i];
         s_bind[i * 3] = p.bind[i * 3]; s_bind[i * 3 + 1] = p.bind[i * 3 + 1]; s_bind[i * 3 + 2] = p.bind[i * 3 + 2];
+        if (sampled) {
+            float4 q;
+            float tx, ty, tz;
+            sample_bone(p.sample, frame, i, q, tx, ty, tz);
+            sq[i] = q; s_lt[i * 3] = tx; s_lt[i * 3 + 1] = ty; s_lt[i * 3 + 2] = tz;
+        } else {
+            sq[i] = lq[i];
+            if (glt) { s_lt[i * 3] = glt[i * 3]; s_lt[i * 3 + 1] = glt[i * 3 + 1]; s_lt[i * 3 + 2] = glt[i * 3 + 2]; }
+        }
     }
+    if (sampled)        // vertex-morph weights of this pose: consumed by the prep / deform kernels that follow
+        for (int m = tid; m < p.sample.M; m += kBlock) p.sample.morph_w[(size_t)inst * p.sample.M + m] = sample_morph(p.sample, frame, m);
     __syncthreads();
     for (int l = 0; l < p.n_levels; ++l) {
         const int lo = p.level_off[l], hi = p.level_off[l + 1];
@@ -1001,7 +1107,7 @@ hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t
 
 hipError_t rz_launch_fk(const RzFkParams &p, uint32_t instances, hipStream_t st)
 {
-    const size_t lds = (size_t)p.B * (48 + 16 + 4 * 4 + 12);
+    const size_t lds = (size_t)p.B * (48 + 16 + 4 * 4 + 12 + 12);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rz_fk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -285,6 +285,72 @@ static napi_value fn_set_pose_local(napi_env env, napi_callback_info info)
     return rc ? throw_rz(env, rc) : undef(env);
 }
 
+/* typed-array property of an object argument (or absent / null when optional) */
+static int get_prop_ta(napi_env env, napi_value obj, const char *name, napi_typedarray_type want, int optional, void **data, size_t *len)
+{
+    napi_value v;
+    bool has = false;
+    *data = NULL; *len = 0;
+    if (napi_has_named_property(env, obj, name, &has) != napi_ok) return 0;
+    if (!has) return optional;
+    if (napi_get_named_property(env, obj, name, &v) != napi_ok) return 0;
+    return get_ta(env, v, want, optional, data, len);
+}
+
+static napi_value fn_upload_animation(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    CTX(0);
+    napi_valuetype vt;
+    if (napi_typeof(env, argv[1], &vt) != napi_ok || vt != napi_object)
+        return throw_msg(env, "uploadAnimation(ctx, { trackBone, keyOff, keyFrame, keyRot, keyPos, keyInterp?, mkeyOff?, mkeyFrame?, mkeyWeight?, feedOff?, feedTrack?, feedRatio? })");
+    void *tb, *ko, *kf, *kr, *kp, *ki, *mo, *mf, *mw, *fo, *ft, *fr;
+    size_t ntb, nko, nkf, nkr, nkp, nki, nmo, nmf, nmw, nfo, nft, nfr;
+    napi_value o = argv[1];
+    if (!get_prop_ta(env, o, "trackBone", napi_int32_array, 0, &tb, &ntb) || !get_prop_ta(env, o, "keyOff", napi_uint32_array, 0, &ko, &nko) ||
+        !get_prop_ta(env, o, "keyFrame", napi_float32_array, 0, &kf, &nkf) || !get_prop_ta(env, o, "keyRot", napi_float32_array, 0, &kr, &nkr) ||
+        !get_prop_ta(env, o, "keyPos", napi_float32_array, 0, &kp, &nkp) || !get_prop_ta(env, o, "keyInterp", napi_uint8_array, 1, &ki, &nki) ||
+        !get_prop_ta(env, o, "mkeyOff", napi_uint32_array, 1, &mo, &nmo) || !get_prop_ta(env, o, "mkeyFrame", napi_float32_array, 1, &mf, &nmf) ||
+        !get_prop_ta(env, o, "mkeyWeight", napi_float32_array, 1, &mw, &nmw) || !get_prop_ta(env, o, "feedOff", napi_uint32_array, 1, &fo, &nfo) ||
+        !get_prop_ta(env, o, "feedTrack", napi_int32_array, 1, &ft, &nft) || !get_prop_ta(env, o, "feedRatio", napi_float32_array, 1, &fr, &nfr))
+        return throw_msg(env, "uploadAnimation: a field has the wrong typed-array type");
+    int M = 0;
+    if (rz_get_tuning(ctx, "morphs", &M)) return throw_rz(env, RZ_ERR_INVALID);
+    const size_t n = ntb;
+    if (nko != n + 1) return throw_msg(env, "uploadAnimation: keyOff must hold trackBone.length + 1 offsets");
+    const size_t K = n ? ((const uint32_t *)ko)[n] : 0;
+    if (nkf < K || nkr < K * 4 || nkp < K * 3 || (ki && nki < K * 16)) return throw_msg(env, "uploadAnimation: key arrays are shorter than keyOff says");
+    const size_t mt = mo ? (nmo ? nmo - 1 : 0) : 0;
+    const size_t Km = mt ? ((const uint32_t *)mo)[mt] : 0;
+    if (mt && (!mf || !mw || nmf < Km || nmw < Km)) return throw_msg(env, "uploadAnimation: morph key arrays are shorter than mkeyOff says");
+    if (mt && M > 0) {
+        if (!fo || nfo != (size_t)M + 1) return throw_msg(env, "uploadAnimation: feedOff must hold morphs + 1 offsets");
+        const size_t F = ((const uint32_t *)fo)[M];
+        if (F && (!ft || !fr || nft < F || nfr < F)) return throw_msg(env, "uploadAnimation: feed arrays are shorter than feedOff says");
+    }
+    rz_animation an;
+    memset(&an, 0, sizeof an);
+    an.n_bone_tracks = (uint32_t)n; an.track_bone = (const int32_t *)tb; an.key_off = (const uint32_t *)ko; an.key_frame = (const float *)kf;
+    an.key_rot4 = (const float *)kr; an.key_pos3 = (const float *)kp; an.key_interp16 = (const uint8_t *)ki;
+    an.n_morph_tracks = (uint32_t)mt; an.mkey_off = (const uint32_t *)mo; an.mkey_frame = (const float *)mf; an.mkey_weight = (const float *)mw;
+    an.feed_off = (const uint32_t *)fo; an.feed_track = (const int32_t *)ft; an.feed_ratio = (const float *)fr;
+    int rc = rz_upload_animation(ctx, &an);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_set_pose_sampled(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    CTX(0);
+    void *f;
+    size_t nf;
+    int I = 0;
+    if (!get_ta(env, argv[1], napi_float32_array, 0, &f, &nf)) return throw_msg(env, "setPoseSampled(ctx, Float32Array frames /* one per instance */)");
+    if (rz_get_tuning(ctx, "instances", &I) || nf != (size_t)I) return throw_msg(env, "setPoseSampled: frames must hold one float per instance");
+    int rc = rz_set_pose_sampled(ctx, (const float *)f);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
 static napi_value fn_read_world(napi_env env, napi_callback_info info)
 {
     ARGS(3);
@@ -591,7 +657,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "timeFrames", fn_time_frames }, { "setTuning", fn_set_tuning }, { "getTuning", fn_get_tuning },
         { "commUniqueId", fn_comm_unique_id }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },
         { "readGathered", fn_read_gathered }, { "commInitAll", fn_comm_init_all }, { "allgatherAll", fn_allgather_all },
-        { "autotune", fn_autotune }, { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
+        { "autotune", fn_autotune }, { "uploadAnimation", fn_upload_animation }, { "setPoseSampled", fn_set_pose_sampled }, { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value f;

@@ -112,7 +112,17 @@ struct rz_ctx {
     bool has_topology = false;
     int *fk_parents = nullptr, *fk_append_parent = nullptr, *fk_order = nullptr, *fk_level_off = nullptr;
     unsigned char *fk_append_move = nullptr;
-    bool pose_local_t = false;          // the current local pose carries translations (behind the rotations in its slot)
+    bool pose_local_t = false;
+    // device-side motion sampling (rz_upload_animation / rz_set_pose_sampled)
+    bool has_animation = false, pose_sampled = false;
+    int *an_bone_track = nullptr, *an_feed_track = nullptr;
+    uint32_t *an_key_off = nullptr, *an_mkey_off = nullptr, *an_feed_off = nullptr;
+    float *an_key_frame = nullptr, *an_key_pos = nullptr, *an_mkey_frame = nullptr, *an_mkey_weight = nullptr, *an_feed_ratio = nullptr;
+    float4 *an_key_rot = nullptr;
+    uint4 *an_key_interp = nullptr;
+    uint32_t an_M = 0;                  // vertex-morph count the feeds were built for
+    float *an_frames = nullptr;         // [I]
+    size_t an_frames_alloc = 0;          // the current local pose carries translations (behind the rotations in its slot)
     float *fk_bind = nullptr, *fk_append_ratio = nullptr;
     int fk_levels = 0;
     float4 *local_q = nullptr;          // I x B   (current pose slot)
@@ -272,6 +282,23 @@ int ensure_pose_buffers(rz_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->pose_alloc_I = I; c->pose_alloc_B = B; c->pose_alloc_M = Mq;
     c->pose_set = false;
+    return RZ_OK;
+}
+
+void free_animation(rz_ctx *c)
+{
+    dfree(c->an_bone_track); dfree(c->an_feed_track); dfree(c->an_key_off); dfree(c->an_mkey_off); dfree(c->an_feed_off);
+    dfree(c->an_key_frame); dfree(c->an_key_pos); dfree(c->an_mkey_frame); dfree(c->an_mkey_weight); dfree(c->an_feed_ratio);
+    dfree(c->an_key_rot); dfree(c->an_key_interp);
+    c->has_animation = false;
+    if (c->pose_sampled) { c->pose_sampled = false; c->pose_set = false; }
+}
+
+template <typename T> int to_device(T **dst, const void *src, size_t count)
+{
+    *dst = nullptr;
+    HIP_TRY(hipMalloc(dst, std::max<size_t>(count, 1) * sizeof(T)));
+    if (count) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
     return RZ_OK;
 }
 
@@ -446,6 +473,14 @@ int launch_fk(rz_ctx *c)
     p.parents = c->fk_parents; p.bind = c->fk_bind; p.append_parent = c->fk_append_parent;
     p.append_ratio = c->fk_append_ratio; p.order = c->fk_order; p.level_off = c->fk_level_off; p.inv_bind = c->inv_bind;
     p.world = c->world; p.palette = c->palette; p.B = (int)c->B; p.n_levels = c->fk_levels;
+    if (c->pose_sampled) {
+        RzSampleParams &q = p.sample;
+        q.frames = c->an_frames; q.bone_track = c->an_bone_track; q.key_off = c->an_key_off; q.key_frame = c->an_key_frame;
+        q.key_rot = c->an_key_rot; q.key_pos = c->an_key_pos; q.key_interp = c->an_key_interp;
+        q.mkey_off = c->an_mkey_off; q.mkey_frame = c->an_mkey_frame; q.mkey_weight = c->an_mkey_weight;
+        q.feed_off = c->an_feed_off; q.feed_track = c->an_feed_track; q.feed_ratio = c->an_feed_ratio;
+        q.morph_w = c->morph_w; q.M = (int)c->M;
+    }
     HIP_TRY(rz_launch_fk(p, c->I, c->stream));
     return RZ_OK;
 }
@@ -618,6 +653,7 @@ int rz_destroy(rz_ctx *c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->inv_bind);
     dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind);
+    free_animation(c); dfree(c->an_frames);
     dfree(c->fk_append_ratio); dfree(c->fk_append_move); dfree(c->local_q_buf[0]); dfree(c->local_q_buf[1]);
     free_morphs(c);
     for (int k = 0; k < 2; ++k) {
@@ -789,16 +825,9 @@ int rz_set_instances(rz_ctx *c, uint32_t I)
     return ensure_outputs(c);
 }
 
-// Shared tail of rz_set_pose / rz_set_pose_local. `primary` (world matrices or local rotations, `pbytes` long) and the
-// morph weights go through a pinned ring slot into the OTHER device slot on the upload stream, so this upload overlaps
-// whatever the compute stream is still running on the current slot; the compute stream then waits for the new slot.
-static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void *secondary, size_t sbytes, bool local,
-                       const float *morph_weights)
+// Pinned staging ring for per-frame inputs: a slot is reused only after the copy that read it has completed.
+static int stage_acquire(rz_ctx *c, size_t need, int *slot_out)
 {
-    const size_t p1 = pbytes;           // `secondary` (local translations) rides right behind `primary` in the slot
-    pbytes += sbytes;
-    const size_t mb = (size_t)c->I * c->M * sizeof(float);
-    const size_t need = std::max(pbytes, (size_t)c->I * c->B * 64) + mb;
     if (need > c->stage_bytes) {
         HIP_TRY(hipStreamSynchronize(c->up_stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -812,6 +841,21 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
     const int slot = c->stage_next;
     c->stage_next = (slot + 1) % kStageSlots;
     if (c->stage_used[slot]) HIP_TRY(hipEventSynchronize(c->stage_ev[slot]));
+    *slot_out = slot;
+    return RZ_OK;
+}
+
+// Shared tail of rz_set_pose / rz_set_pose_local. `primary` (world matrices or local rotations, `pbytes` long) and the
+// morph weights go through a pinned ring slot into the OTHER device slot on the upload stream, so this upload overlaps
+// whatever the compute stream is still running on the current slot; the compute stream then waits for the new slot.
+static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void *secondary, size_t sbytes, bool local,
+                       const float *morph_weights)
+{
+    const size_t p1 = pbytes;           // `secondary` (local translations) rides right behind `primary` in the slot
+    pbytes += sbytes;
+    const size_t mb = (size_t)c->I * c->M * sizeof(float);
+    int slot = 0;
+    if (int r = stage_acquire(c, std::max(pbytes, (size_t)c->I * c->B * 64) + mb, &slot)) return r;
     // Small poses (one character: 16-22 KB) go down the compute stream itself — measured on C5, the two extra
     // packets of the cross-stream hand-off (marker + barrier) cost 3 us more per frame than the copy they hide.
     // Large ones (instanced crowds: MBs) take the upload stream: everything enqueued so far reads the current device
@@ -860,6 +904,7 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
         c->ml.count = n <= kKargMorphs ? n : -1;
     }
     c->pose_local = local;
+    c->pose_sampled = false;
     c->pose_set = true;
     return RZ_OK;
 }
@@ -948,6 +993,103 @@ int rz_set_pose_local(rz_ctx *c, const float *local_rotations4, const float *loc
     c->pose_local_t = local_translations3 != nullptr;
     return upload_pose(c, local_rotations4, nq * sizeof(float4), local_translations3, local_translations3 ? nq * 3 * sizeof(float) : 0, true,
                        morph_weights);
+}
+
+int rz_upload_animation(rz_ctx *c, const rz_animation *a)
+{
+    if (int r = use(c)) return r;
+    if (!a) return fail(RZ_ERR_INVALID, "null animation");
+    if (c->B == 0) return fail(RZ_ERR_INVALID, "upload the skeleton before a motion");
+    const uint32_t n = a->n_bone_tracks, mt = a->n_morph_tracks;
+    if (n && (!a->track_bone || !a->key_off || !a->key_frame || !a->key_rot4 || !a->key_pos3)) return fail(RZ_ERR_INVALID, "null bone-track arrays");
+    if (mt && (!a->mkey_off || !a->mkey_frame || !a->mkey_weight)) return fail(RZ_ERR_INVALID, "null morph-track arrays");
+    if (c->M && mt && (!a->feed_off || (a->feed_off[c->M] && (!a->feed_track || !a->feed_ratio)))) return fail(RZ_ERR_INVALID, "null morph feeds");
+    std::vector<int> bone_track(c->B, -1);
+    const uint32_t K = n ? a->key_off[n] : 0;
+    for (uint32_t t = 0; t < n; ++t) {
+        if (a->key_off[t] > a->key_off[t + 1]) return fail(RZ_ERR_INVALID, "key offsets must be non-decreasing");
+        const int32_t b = a->track_bone[t];
+        if (b < 0 || (uint32_t)b >= c->B) continue;                      // a motion may key bones this model lacks
+        if (bone_track[b] >= 0) return fail(RZ_ERR_INVALID, "bone %d is driven by two tracks", b);
+        for (uint32_t k = a->key_off[t] + 1; k < a->key_off[t + 1]; ++k)
+            if (!(a->key_frame[k] > a->key_frame[k - 1])) return fail(RZ_ERR_INVALID, "track %u: key frames must ascend", t);
+        bone_track[b] = (int)t;
+    }
+    const uint32_t Km = mt ? a->mkey_off[mt] : 0;
+    for (uint32_t t = 0; t < mt; ++t) {
+        if (a->mkey_off[t] > a->mkey_off[t + 1]) return fail(RZ_ERR_INVALID, "morph key offsets must be non-decreasing");
+        for (uint32_t k = a->mkey_off[t] + 1; k < a->mkey_off[t + 1]; ++k)
+            if (!(a->mkey_frame[k] > a->mkey_frame[k - 1])) return fail(RZ_ERR_INVALID, "morph track %u: key frames must ascend", t);
+    }
+    std::vector<uint32_t> feed_off(c->M + 1, 0);
+    uint32_t F = 0;
+    if (c->M && mt) {
+        for (uint32_t m = 0; m <= c->M; ++m) feed_off[m] = a->feed_off[m];
+        F = feed_off[c->M];
+        for (uint32_t m = 0; m < c->M; ++m)
+            if (feed_off[m] > feed_off[m + 1]) return fail(RZ_ERR_INVALID, "feed offsets must be non-decreasing");
+        for (uint32_t f = 0; f < F; ++f)
+            if (a->feed_track[f] < 0 || (uint32_t)a->feed_track[f] >= mt) return fail(RZ_ERR_INVALID, "feed %u names morph track %d of %u", f, a->feed_track[f], mt);
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_animation(c);
+    const uint32_t zero_off[2] = {0, 0};
+    if (int r = to_device(&c->an_bone_track, bone_track.data(), c->B)) return r;
+    if (int r = to_device(&c->an_key_off, n ? a->key_off : zero_off, (size_t)n + 1)) return r;
+    if (int r = to_device(&c->an_key_frame, a->key_frame, K)) return r;
+    if (int r = to_device(&c->an_key_rot, a->key_rot4, K)) return r;
+    if (int r = to_device(&c->an_key_pos, a->key_pos3, (size_t)K * 3)) return r;
+    if (a->key_interp16 && K)
+        if (int r = to_device(&c->an_key_interp, a->key_interp16, K)) return r;
+    if (int r = to_device(&c->an_mkey_off, mt ? a->mkey_off : zero_off, (size_t)mt + 1)) return r;
+    if (int r = to_device(&c->an_mkey_frame, a->mkey_frame, Km)) return r;
+    if (int r = to_device(&c->an_mkey_weight, a->mkey_weight, Km)) return r;
+    if (int r = to_device(&c->an_feed_off, feed_off.data(), (size_t)c->M + 1)) return r;
+    if (int r = to_device(&c->an_feed_track, a->feed_track, F)) return r;
+    if (int r = to_device(&c->an_feed_ratio, a->feed_ratio, F)) return r;
+    c->an_M = c->M;
+    c->has_animation = true;
+    return RZ_OK;
+}
+
+int rz_set_pose_sampled(rz_ctx *c, const float *frames)
+{
+    if (int r = use(c)) return r;
+    if (!c->has_animation) return fail(RZ_ERR_INVALID, "rz_upload_animation has not been called");
+    if (!c->has_topology) return fail(RZ_ERR_INVALID, "rz_upload_skeleton_topology has not been called for this skeleton");
+    if (c->an_M != c->M) return fail(RZ_ERR_INVALID, "the motion's morph feeds were built for %u vertex morphs, the context holds %u", c->an_M, c->M);
+    if (!frames) return fail(RZ_ERR_INVALID, "null frames");
+    if (int r = ensure_pose_buffers(c)) return r;
+    const size_t nq = (size_t)c->I * c->B;
+    if (nq > c->local_q_alloc) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->up_stream));
+        for (int k = 0; k < 2; ++k) {
+            dfree(c->local_q_buf[k]);
+            HIP_TRY(hipMalloc(&c->local_q_buf[k], nq * (sizeof(float4) + 3 * sizeof(float))));
+        }
+        c->local_q_alloc = nq;
+    }
+    if (c->I > c->an_frames_alloc) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        dfree(c->an_frames);
+        HIP_TRY(hipMalloc(&c->an_frames, (size_t)c->I * sizeof(float)));
+        c->an_frames_alloc = c->I;
+    }
+    int slot = 0;
+    if (int r = stage_acquire(c, std::max<size_t>((size_t)c->I * sizeof(float), 4096), &slot)) return r;
+    memcpy(c->stage[slot], frames, (size_t)c->I * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(c->an_frames, c->stage[slot], (size_t)c->I * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->stage_ev[slot], c->stream));
+    c->stage_used[slot] = true;
+    c->local_q = c->local_q_buf[c->pose_slot];
+    c->pose_sampled = true;
+    c->pose_local = true;
+    c->pose_local_t = true;
+    memset(&c->ml, 0, sizeof c->ml);
+    if (c->M > 0) c->ml.count = -1;          // the weights only exist on the device: the prep kernel compacts them
+    c->pose_set = true;
+    return RZ_OK;
 }
 
 int rz_read_world(rz_ctx *c, uint32_t instance, float *world16)

@@ -50,6 +50,9 @@ class Engine {
     this.morphLayout = o.morphLayout || 'sparse'
     this.realtime = o.realtime !== false // false: time only advances through step()
     this.native = null
+    // deviceSampling (needs deviceFK): seekFrame() sends one float — the frame — and the motion is sampled on the GPU
+    this.deviceSampling = o.deviceSampling === true && o.deviceFK === true
+    this.animationOnDevice = null
     this.autotune = o.autotune === true // search launch shapes once, on the first rendered frame (rz_autotune)
     this.tuned = false
     this.ctx = null // context of shard 0 (the only one on a single GPU)
@@ -367,8 +370,30 @@ class Engine {
       this.sampler = new VMDSampler(this.animationFrames)
       this.samplerFor = this.animationFrames
     }
+    if (this.deviceSampling) return this.seekFrameOnDevice(frame)
     this.currentModel.applySampledFrame(this.sampler, frame)
     this.render()
+  }
+
+  /** seekFrame with { deviceFK, deviceSampling }: upload the flattened motion once, then one float per frame. */
+  seekFrameOnDevice(frame) {
+    const model = this.currentModel
+    if (this.animationOnDevice !== this.animationFrames || this.animationFor !== model) {
+      const flat = this.sampler.flatten(model.runtimeSkeleton.nameIndex, model.getMorphCount() > 0 ? model.getMorphs() : null)
+      for (const s of this.shards) if (s.count > 0) this.native.uploadAnimation(s.ctx, flat)
+      this.animationOnDevice = this.animationFrames
+      this.animationFor = model
+    }
+    const t0 = wallClock()
+    const f = new Float32Array([frame])
+    for (const s of this.shards) {
+      if (s.count === 0) continue
+      this.native.setPoseSampled(s.ctx, f)
+      this.native.deform(s.ctx)
+    }
+    if (this.gather === 'direct' && this.shards.length > 1) this.native.gatherFence(this.ctx)
+    else if (this.gather && this.shards.length > 1) this.native.allgatherAll(this.shards.map((s) => s.ctx), true)
+    this.updateStats(wallClock() - t0)
   }
 
   /** Deterministic stepping: move the clock to timeMs, fire the timers that came due, render one frame. */

@@ -34,6 +34,7 @@ export interface EngineOptions {
   /** Also write the outline pass's inverted hull every frame. */ outline?: boolean
   /** Also reduce the deformed mesh's bounding box every frame. */ bounds?: boolean
   /** One context per listed GPU; the mesh is vertex-sharded across them. */ devices?: number[]
+  /** With deviceFK: seekFrame() samples the motion on the GPU (rz_upload_animation once, one float per frame). */ deviceSampling?: boolean
   /** Search launch shapes (morph split, workgroups per CU) once on the first rendered frame. */ autotune?: boolean
   /** true: RCCL all-gather of the deformed mesh after every frame (distinct GPUs only); 'direct': every shard's kernel stores
    *  straight into the first GPU's gathered buffer over xGMI — no collective, GPUs may repeat in `devices`. */ gather?: boolean | 'direct'

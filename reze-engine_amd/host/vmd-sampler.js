@@ -89,6 +89,70 @@ class VMDSampler {
     return keys[i0].weight + (keys[i1].weight - keys[i0].weight) * x
   }
 
+  /**
+   * Flatten the motion for the device sampler (rz_upload_animation): one track per bone of `boneNameIndex` the motion
+   * keys, one track per keyed morph, and for every morph of the model the tracks that feed its GPU weight in the order
+   * Model.getEffectiveMorphWeights adds them — its own track (vertex morphs only), then the group morphs that list it,
+   * ascending. `morphs` is Model.getMorphs() ({ names, types, groups }) or null.
+   */
+  flatten(boneNameIndex, morphs) {
+    const tracks = []
+    for (const [name, keys] of this.bones) {
+      const b = boneNameIndex[name]
+      if (b !== undefined) tracks.push([b, keys])
+    }
+    let K = 0
+    for (const t of tracks) K += t[1].length
+    const out = {
+      trackBone: new Int32Array(tracks.length), keyOff: new Uint32Array(tracks.length + 1), keyFrame: new Float32Array(K),
+      keyRot: new Float32Array(K * 4), keyPos: new Float32Array(K * 3), keyInterp: new Uint8Array(K * 16),
+    }
+    let k = 0
+    tracks.forEach(([b, keys], t) => {
+      out.trackBone[t] = b
+      out.keyOff[t] = k
+      for (const key of keys) {
+        out.keyFrame[k] = key.frame
+        out.keyRot.set([key.rotation.x, key.rotation.y, key.rotation.z, key.rotation.w], k * 4)
+        out.keyPos.set([key.position.x, key.position.y, key.position.z], k * 3)
+        if (key.interpolation) for (let i = 0; i < 16; i++) out.keyInterp[k * 16 + i] = key.interpolation[i]
+        else out.keyInterp.set([20, 20, 20, 20, 20, 20, 20, 20, 107, 107, 107, 107, 107, 107, 107, 107], k * 16) // identity curves
+        k++
+      }
+    })
+    out.keyOff[tracks.length] = k
+    if (!morphs || morphs.names.length === 0) return out
+    const M = morphs.names.length
+    const trackOf = new Int32Array(M).fill(-1)
+    const mtracks = []
+    morphs.names.forEach((name, i) => {
+      if (this.morphs.has(name) && trackOf[i] < 0) { trackOf[i] = mtracks.length; mtracks.push(this.morphs.get(name)) }
+    })
+    let Km = 0
+    for (const keys of mtracks) Km += keys.length
+    out.mkeyOff = new Uint32Array(mtracks.length + 1); out.mkeyFrame = new Float32Array(Km); out.mkeyWeight = new Float32Array(Km)
+    k = 0
+    mtracks.forEach((keys, t) => {
+      out.mkeyOff[t] = k
+      for (const key of keys) { out.mkeyFrame[k] = key.frame; out.mkeyWeight[k] = key.weight; k++ }
+    })
+    out.mkeyOff[mtracks.length] = k
+    const feeds = []
+    out.feedOff = new Uint32Array(M + 1)
+    for (let i = 0; i < M; i++) {
+      out.feedOff[i] = feeds.length
+      if (morphs.types[i] !== 1) continue // only vertex morphs carry deltas
+      if (trackOf[i] >= 0) feeds.push([trackOf[i], 1])
+      for (let g = 0; g < M; g++) {
+        if (morphs.types[g] !== 0 || trackOf[g] < 0 || !morphs.groups[g]) continue
+        for (const [child, ratio] of morphs.groups[g]) if (child === i) feeds.push([trackOf[g], ratio])
+      }
+    }
+    out.feedOff[M] = feeds.length
+    out.feedTrack = Int32Array.from(feeds.map((f) => f[0])); out.feedRatio = Float32Array.from(feeds.map((f) => f[1]))
+    return out
+  }
+
   boneNames() { return Array.from(this.bones.keys()) }
   morphNames() { return Array.from(this.morphs.keys()) }
 }

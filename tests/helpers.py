@@ -83,3 +83,89 @@ def fk_reference(parents, bind, quats, trans=None, append_parent=None, append_ra
     for i in range(B):
         solve(i)
     return np.transpose(world, (0, 2, 1)).reshape(B, 16)
+
+
+def bezier_reference(x, x1, y1, x2, y2):
+    """host/vmd-sampler.js bezier() in float64: y(x) of the cubic (0,0) (x1,y1) (x2,y2) (1,1)."""
+    if x <= 0:
+        return 0.0
+    if x >= 1:
+        return 1.0
+    if x1 == y1 and x2 == y2:
+        return x
+    lo, hi, t = 0.0, 1.0, x
+    for _ in range(64):
+        s = 1 - t
+        fx = 3 * s * s * t * x1 + 3 * s * t * t * x2 + t ** 3 - x
+        if abs(fx) < 1e-12:
+            break
+        if fx > 0:
+            hi = t
+        else:
+            lo = t
+        d = 3 * s * s * x1 + 6 * s * t * (x2 - x1) + 3 * t * t * (1 - x2)
+        tn = t - fx / d if d != 0 else (lo + hi) / 2
+        t = tn if lo < tn < hi else (lo + hi) / 2
+    s = 1 - t
+    return 3 * s * s * t * y1 + 3 * s * t * t * y2 + t ** 3
+
+
+def sample_reference(anim, frame, n_bones, n_morphs):
+    """MMD motion sampling in float64 (the arithmetic of host/vmd-sampler.js): returns (quats [B,4], trans [B,3],
+    morph weights [M]) at `frame` for a flattened motion dict with the rz_animation field names."""
+    import numpy as np
+
+    def span(kf, b, e, f):
+        lo, hi = b, e - 1
+        if f <= kf[lo]:
+            return lo, lo, 0.0
+        if f >= kf[hi]:
+            return hi, hi, 0.0
+        while hi - lo > 1:
+            mid = (lo + hi) >> 1
+            if kf[mid] <= f:
+                lo = mid
+            else:
+                hi = mid
+        return lo, hi, (f - kf[lo]) / (kf[hi] - kf[lo])
+
+    q = np.tile(np.array([0.0, 0, 0, 1]), (n_bones, 1))
+    t = np.zeros((n_bones, 3))
+    kf = np.asarray(anim["key_frame"], dtype=np.float64)
+    rot = np.asarray(anim["key_rot"], dtype=np.float64).reshape(-1, 4)
+    pos = np.asarray(anim["key_pos"], dtype=np.float64).reshape(-1, 3)
+    ip = None if anim.get("key_interp") is None else np.asarray(anim["key_interp"], dtype=np.float64).reshape(-1, 16) / 127.0
+    for tr, b in enumerate(anim["track_bone"]):
+        lo, hi = int(anim["key_off"][tr]), int(anim["key_off"][tr + 1])
+        if b < 0 or b >= n_bones or hi == lo:
+            continue
+        i0, i1, x = span(kf, lo, hi, frame)
+        if i0 == i1:
+            q[b], t[b] = rot[i0], pos[i0]
+            continue
+        c = [x] * 4 if ip is None else [bezier_reference(x, ip[i1][k], ip[i1][k + 4], ip[i1][k + 8], ip[i1][k + 12]) for k in range(4)]
+        a, bq = rot[i0].copy(), rot[i1].copy()
+        d = float(a @ bq)
+        if d < 0:
+            d, bq = -d, -bq
+        if d > 0.9995:
+            r = a + c[3] * (bq - a)
+            r /= np.linalg.norm(r)
+        else:
+            th0 = np.arccos(d)
+            r = (np.sin(th0 - th0 * c[3]) * a + np.sin(th0 * c[3]) * bq) / np.sin(th0)
+        q[b] = r
+        t[b] = pos[i0] + (pos[i1] - pos[i0]) * np.array(c[:3])
+    w = np.zeros(n_morphs)
+    if n_morphs and anim.get("mkey_off") is not None:
+        mkf = np.asarray(anim["mkey_frame"], dtype=np.float64)
+        mw = np.asarray(anim["mkey_weight"], dtype=np.float64)
+        for m in range(n_morphs):
+            for f in range(int(anim["feed_off"][m]), int(anim["feed_off"][m + 1])):
+                tr = int(anim["feed_track"][f])
+                lo, hi = int(anim["mkey_off"][tr]), int(anim["mkey_off"][tr + 1])
+                if hi == lo:
+                    continue
+                i0, i1, x = span(mkf, lo, hi, frame)
+                w[m] += (mw[i0] + (mw[i1] - mw[i0]) * x) * float(anim["feed_ratio"][f])
+    return q, t, w

@@ -66,7 +66,7 @@ def write_pmx(V=5000, B=40, n_vertex_morphs=6, seed=5):
 
 
 def write_vmd(bone_keys, morph_keys=()):
-    """bone_keys: [(name, frame, (x,y,z,w))] or [(name, frame, (x,y,z,w), (px,py,pz))]; morph_keys: [(name, frame, weight)]."""
+    """bone_keys: [(name, frame, (x,y,z,w)[, (px,py,pz)[, 64 interpolation bytes]])]; morph_keys: [(name, frame, weight)]."""
     def name15(s):
         b = s.encode("shift-jis")
         return b + b"\0" * (15 - len(b))
@@ -75,7 +75,8 @@ def write_vmd(bone_keys, morph_keys=()):
     for key in bone_keys:
         n, f, q = key[0], key[1], key[2]
         pos = key[3] if len(key) > 3 else (0, 0, 0)
-        out += name15(n) + struct.pack("<I", f) + struct.pack("<3f", *pos) + struct.pack("<4f", *q) + bytes(64)
+        interp = key[4] if len(key) > 4 else bytes([20] * 8 + [107] * 8) + bytes(48)
+        out += name15(n) + struct.pack("<I", f) + struct.pack("<3f", *pos) + struct.pack("<4f", *q) + interp
     out += struct.pack("<I", len(morph_keys))
     for n, f, w in morph_keys:
         out += name15(n) + struct.pack("<If", f, w)

@@ -397,6 +397,121 @@ def test_device_fk_local_translations_and_append_move(rz, oracle):
     c.close()
 
 
+def test_engine_device_sampling_matches_host_sampling_through_napi(tmp_path):
+    """new Engine(null, { deviceFK, deviceSampling }).seekFrame(f) — motion flattened by host/vmd-sampler.js, sampled,
+    solved and deformed on the GPU from one float — against the host sampler + host FK engine on the same synthetic
+    PMX + VMD (bone translations, custom interpolation curves, a group morph, an append-move bone), one and two shards."""
+    import json
+    import shutil
+    import subprocess
+    import os
+    from pmx_synth import write_pmx, write_vmd
+    if shutil.which("node") is None:
+        pytest.skip("node is not installed on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "m.pmx").write_bytes(write_pmx())
+    s = 0.38268343
+    curve = bytes([10, 30, 50, 100, 90, 70, 5, 20, 60, 80, 100, 127, 120, 40, 110, 64]) + bytes(48)
+    (tmp_path / "a.vmd").write_bytes(write_vmd(
+        [("bone1", 0, (0, 0, s, 0.92387953)), ("bone1", 15, (0, s, 0, 0.92387953), (0, 0, 0), curve), ("bone1", 30, (s, 0, 0, 0.92387953)),
+         ("bone3", 0, (s, 0, 0, 0.92387953), (0.3, -0.2, 0.1)), ("bone3", 20, (0, 0, s, 0.92387953), (-0.5, 0.4, 0.25), curve),
+         ("bone0", 0, (0, 0, 0, 1), (0, 0.5, 0)), ("bone0", 25, (0, 0, 0, 1), (1.0, 0.25, -0.5), curve), ("bone20", 30, (0, 0, -s, 0.92387953)),
+         ("nosuchbone", 5, (0, 0, 0, 1))],
+        [("v1", 0, 0.8), ("v1", 20, 0.1), ("v2", 6, 0.4), ("grp", 0, 0.0), ("grp", 30, 1.0), ("blink", 10, 0.5)]))
+    for layout, devs in (("sparse", "0"), ("dense", "0,0")):
+        out = tmp_path / (layout + devs.replace(",", "_"))
+        out.mkdir()
+        subprocess.check_call(["node", os.path.join(root, "tests", "js", "sampled_e2e.js"), str(tmp_path / "m.pmx"), str(tmp_path / "a.vmd"),
+                               str(out), layout, devs], timeout=300)
+        frames = json.load(open(str(out / "frames.json")))
+        rd = lambda f: np.fromfile(str(out / f), dtype=np.float32)  # noqa: E731
+        moved = 0.0
+        for i in range(len(frames)):
+            wa, wb = rd("a_world_%d.f32" % i).reshape(-1, 16), rd("b_world_%d.f32" % i).reshape(-1, 16)
+            assert np.abs(wa - wb).max() <= 5e-5 * max(1.0, np.abs(wa).max()), "world matrices at frame %g: %g" % (frames[i], np.abs(wa - wb).max())
+            pa, na = rd("a_pos_%d.f32" % i).reshape(-1, 3), rd("a_nrm_%d.f32" % i).reshape(-1, 3)
+            pb, nb = rd("b_pos_%d.f32" % i).reshape(-1, 3), rd("b_nrm_%d.f32" % i).reshape(-1, 3)
+            assert_parity(pb, nb, pa, na, "device sampling vs host sampling, %s %s frame %g" % (layout, devs, frames[i]))
+            moved = max(moved, float(np.abs(pa - rd("a_pos_0.f32").reshape(-1, 3)).max()))
+            assert (rd("a_mw_%d.f32" % i) != 0).sum() >= 1
+        assert moved > 0.2                     # the motion really moves the mesh between the sampled frames
+
+
+def test_device_motion_sampling_matches_the_float64_sampler(rz, oracle):
+    """rz_upload_animation + rz_set_pose_sampled: MMD sampling (Bezier-warped slerp / lerp, linear morph keys, group
+    feeds) + hierarchy solve + morph + skin all on the GPU from ONE float per instance. Every instance sits at its own
+    frame — before the first key, on a key, between keys with linear, default and sharp curves, past the last key."""
+    from helpers import fk_reference, sample_reference
+    V, B, M, I = 4000, 48, 6, 7
+    mesh = synth.make_mesh(V, B, seed=31)
+    deltas, _ = synth.make_morphs_dense(V, M, seed=32)
+    rng = np.random.default_rng(33)
+    tracked = rng.choice(B, size=30, replace=False)
+    track_bone = np.concatenate([tracked, [B + 5]]).astype(np.int32)        # one track for a bone this model lacks
+    key_off, kfs, rots, poss, ips = [0], [], [], [], []
+    for tr in range(len(track_bone)):
+        nk = int(rng.integers(1, 6))
+        frames = np.sort(rng.choice(np.arange(0, 60), size=nk, replace=False)).astype(np.float32)
+        q = rng.normal(size=(nk, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+        if nk > 2:
+            q[2] = q[1] + 1e-3 * rng.normal(size=4); q[2] /= np.linalg.norm(q[2])    # nearly equal keys: the lerp branch
+        kfs.append(frames); rots.append(q); poss.append(rng.normal(size=(nk, 3)) * 0.5)
+        ip = np.tile(np.array([20, 20, 20, 20, 20, 20, 20, 20, 107, 107, 107, 107, 107, 107, 107, 107], dtype=np.uint8), (nk, 1))
+        for k in range(nk):
+            if rng.random() < 0.6:
+                ip[k] = rng.integers(0, 128, size=16)
+        ips.append(ip)
+        key_off.append(key_off[-1] + nk)
+    anim = dict(track_bone=track_bone, key_off=np.array(key_off, np.uint32), key_frame=np.concatenate(kfs), key_rot=np.concatenate(rots).astype(np.float32),
+                key_pos=np.concatenate(poss).astype(np.float32), key_interp=np.concatenate(ips))
+    # morph tracks: 0..3 drive vertex morphs 0..3, track 4 is a group feeding morphs 1 and 5, morph 4 is never keyed
+    mk = [np.array([0, 10, 40], np.float32), np.array([5], np.float32), np.array([0, 30], np.float32), np.array([2, 3, 50], np.float32), np.array([0, 20], np.float32)]
+    mwk = [rng.random(len(k)).astype(np.float32) for k in mk]
+    anim.update(mkey_off=np.cumsum([0] + [len(k) for k in mk]).astype(np.uint32), mkey_frame=np.concatenate(mk), mkey_weight=np.concatenate(mwk))
+    feeds = [[(0, 1.0)], [(1, 1.0), (4, 0.5)], [(2, 1.0)], [(3, 1.0)], [], [(4, -0.25)]]
+    anim.update(feed_off=np.cumsum([0] + [len(f) for f in feeds]).astype(np.uint32), feed_track=np.array([t for f in feeds for t, _ in f], np.int32),
+                feed_ratio=np.array([r for f in feeds for _, r in f], np.float32))
+    ap = np.full(B, -1, dtype=np.int32); ap[7] = 3; ap[20] = 11
+    ratio = np.ones(B, dtype=np.float32); ratio[7] = 0.5; ratio[20] = -1.0
+    move = np.zeros(B, dtype=np.uint8); move[20] = 1
+    frames = np.array([-3.0, 0.0, 7.25, 19.0, 33.5, 58.999, 400.0], dtype=np.float32)
+    for morphs in ("dense", "none"):
+        c = rz.DeformContext(0)
+        c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+        c.upload_skeleton(mesh["inv_bind"])
+        if morphs == "dense":
+            c.upload_morphs_dense(deltas)
+        Mq = M if morphs == "dense" else 0
+        c.set_instances(I)
+        c.upload_skeleton_topology(mesh["parents"], mesh["bind"], ap, ratio, move)
+        with pytest.raises(rz.RzError):
+            c.set_pose_sampled(frames)                                    # no motion uploaded yet
+        a = dict(anim)
+        if Mq == 0:
+            for k in ("mkey_off", "mkey_frame", "mkey_weight", "feed_off", "feed_track", "feed_ratio"):
+                a[k] = None
+        c.upload_animation(a["track_bone"], a["key_off"], a["key_frame"], a["key_rot"], a["key_pos"], a["key_interp"],
+                           a["mkey_off"], a["mkey_frame"], a["mkey_weight"], a["feed_off"], a["feed_track"], a["feed_ratio"])
+        c.set_pose_sampled(frames)
+        c.deform()
+        for i in range(I):
+            q, t, w = sample_reference(a, float(frames[i]), B, Mq)
+            ref = fk_reference(mesh["parents"], mesh["bind"], q, t, ap, ratio, move)
+            got = c.read_world(i)
+            assert np.abs(got - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), "world, instance %d frame %g: %g" % (i, frames[i], np.abs(got - ref).max())
+            pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], got, mesh["inv_bind"],
+                                   deltas if Mq else None, w.astype(np.float32) if Mq else None)
+            pg, ng = c.read(instance=i)
+            assert_parity(pg, ng, pr, nr, "sampled pose, %s morphs, instance %d" % (morphs, i))
+        # a host-supplied pose takes over again
+        c.set_pose(np.stack([mesh["world"]] * I), None)
+        c.deform()
+        pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"])
+        pg, ng = c.read(instance=I - 1)
+        assert_parity(pg, ng, pr, nr, "back to a host pose")
+        c.close()
+
+
 def test_device_fk_matches_host_fk_and_reference_fixture(ctx, oracle):
     """Row f1: Model.computeWorldMatrices (model.ts:330-420) on the GPU. (a) synthetic tree, 5 poses at once, against
     the host-order FK twin; (b) the REAL 349-bone skeleton with its 26 append-rotation bones and pool.vmd frame 0,
