@@ -13,4 +13,9 @@ const bones = [{ name: 'boneA', parentIndex: -1, bindTranslation: [0, 1, 0], chi
 const model = new Model(new Float32Array(8), new Uint32Array(3), [], [], { bones, inverseBindMatrices: new Float32Array(32) }, { joints: new Uint16Array(4), weights: new Uint8Array(4) })
 model.applySampledFrame(s, 15); model.evaluatePose()
 out.world15 = Array.from(model.getBoneWorldMatrices())
+// the flattened form the device sampler consumes (rz_upload_animation): bone 'tip' is not keyed, 'boneA' is;
+// morph set = [vertex 'smile', group 'grp' -> smile x0.5 twice, vertex 'other' (never keyed)]
+const flat = s.flatten({ boneA: 0, tip: 1 }, { names: ['smile', 'grp', 'other'], types: [1, 0, 1], groups: [null, [[0, 0.5], [0, 0.25]], null] })
+out.flat = {}
+for (const k2 of Object.keys(flat)) out.flat[k2] = Array.from(flat[k2])
 console.log(JSON.stringify(out))

@@ -392,3 +392,9 @@ def test_vmd_frame_sampler_bezier_translation_and_morph_keys(tmp_path):
     assert np.allclose(w[0, 12:15], [3 * tx, 1 + 3.0, 4.5], atol=1e-5)
     a = np.pi / 4
     assert np.allclose(w[1, 12:15], w[0, 12:15] + [-2 * np.sin(a), 2 * np.cos(a), 0], atol=1e-5)
+    # flatten(): what rz_upload_animation receives
+    fl = r["flat"]
+    assert fl["trackBone"] == [0] and fl["keyOff"] == [0, 2] and fl["keyFrame"] == [0, 30] and len(fl["keyRot"]) == 8 and len(fl["keyPos"]) == 6
+    assert fl["keyPos"][3:] == [3, 6, 9] and fl["keyInterp"][16:32] == list(ip) and fl["keyInterp"][:16] == [20] * 8 + [107] * 8
+    assert fl["mkeyOff"] == [0, 2] and fl["mkeyFrame"] == [0, 30] and fl["mkeyWeight"] == [0, 1]          # only 'smile' is keyed
+    assert fl["feedOff"] == [0, 1, 1, 1] and fl["feedTrack"] == [0] and fl["feedRatio"] == [1]              # the group has no track: no feed
