@@ -52,6 +52,7 @@ class Engine {
     this.native = null
     // deviceSampling (needs deviceFK): seekFrame() sends one float — the frame — and the motion is sampled on the GPU
     this.deviceSampling = o.deviceSampling === true && o.deviceFK === true
+    this.instances = 1
     this.animationOnDevice = null
     this.autotune = o.autotune === true // search launch shapes once, on the first rendered frame (rz_autotune)
     this.tuned = false
@@ -385,7 +386,9 @@ class Engine {
       this.animationFor = model
     }
     const t0 = wallClock()
-    const f = new Float32Array([frame])
+    // a crowd (setInstanceCount) takes one frame per instance; a single number poses every instance at that frame
+    const f = typeof frame === 'number' ? new Float32Array(this.instances).fill(frame) : Float32Array.from(frame)
+    if (f.length !== this.instances) throw new Error('seekFrame: ' + f.length + ' frames for ' + this.instances + ' instances')
     for (const s of this.shards) {
       if (s.count === 0) continue
       this.native.setPoseSampled(s.ctx, f)
@@ -404,9 +407,31 @@ class Engine {
     this.render()
   }
 
-  /** Blocking readback of the deformed mesh (the values the reference's vs() only ever feeds the rasteriser). */
-  getDeformed() {
+  /**
+   * A crowd of `n` independently posed copies of the loaded model (BASELINE config 4; the reference draws one model).
+   * Needs { deviceFK, deviceSampling } — every instance is posed on the GPU at its own frame of the loaded motion,
+   * seekFrame([f0, f1, ...]) — and a single GPU (instancing and vertex sharding are exclusive).
+   */
+  setInstanceCount(n) {
     if (!this.ctx || !this.currentModel) throw new Error('no model loaded')
+    if (!this.deviceSampling) throw new Error('setInstanceCount needs new Engine(canvas, { deviceFK: true, deviceSampling: true })')
+    if (this.shards.length > 1) throw new Error('instancing and vertex sharding are exclusive')
+    if (this.outline || this.bounds) throw new Error('the outline hull and bounds are single-instance consumers')
+    this.native.setInstances(this.ctx, n)
+    this.instances = n
+    this.tuned = false
+  }
+
+  /** Blocking readback of the deformed mesh (the values the reference's vs() only ever feeds the rasteriser). */
+  getDeformed(instance) {
+    if (!this.ctx || !this.currentModel) throw new Error('no model loaded')
+    if (instance !== undefined && instance !== 0) {
+      if (!(instance > 0 && instance < this.instances)) throw new Error('instance ' + instance + ' out of range')
+      const V = this.currentModel.getVertexCount()
+      const pos = new Float32Array(V * 3), nrm = new Float32Array(V * 3)
+      this.native.read(this.ctx, instance, 0, V, pos, nrm)
+      return { positions: pos, normals: nrm }
+    }
     if (this.gather && this.shards.length > 1) { // shard 0's GPU holds the whole mesh (all-gather or peer-direct stores)
       this.native.readGathered(this.ctx, 0, this.currentModel.getVertexCount(), this.outPos, this.outNrm)
       return { positions: this.outPos, normals: this.outNrm }

@@ -57,8 +57,11 @@ export class Engine {
   render(): void
   step(timeMs: number): void
   /** Pose the model at a (fractional) VMD frame with MMD interpolation and deform one frame. */
-  seekFrame(frame: number): void
-  getDeformed(): { positions: Float32Array; normals: Float32Array }
+  /** MMD-interpolated pose at a (fractional, 30 fps) frame; with a crowd (setInstanceCount) one frame per instance. */
+  seekFrame(frame: number | ArrayLike<number>): void
+  /** n independently posed copies of the model (needs { deviceFK, deviceSampling }, one GPU). */
+  setInstanceCount(n: number): void
+  getDeformed(instance?: number): { positions: Float32Array; normals: Float32Array }
   getOutlineHull(): Float32Array
   getBounds(): { min: number[]; max: number[] }
   runRenderLoop(callback?: () => void): void

@@ -27,6 +27,13 @@ const dump = (name, ta) => fs.writeFileSync(path.join(out, name), Buffer.from(ta
     dump('b_world_' + i + '.f32', gw)
     dump('a_mw_' + i + '.f32', A.currentModel.getEffectiveMorphWeights())
   })
+  // a crowd: three copies of the model, each at its own frame, posed + deformed by one launch chain
+  if (devices.length === 1) {
+    const crowd = [3.5, 22.75, 11.5]
+    B.setInstanceCount(crowd.length)
+    B.seekFrame(crowd)
+    crowd.forEach((f, k) => { const d = B.getDeformed(k); dump('crowd_pos_' + frames.indexOf(f) + '.f32', d.positions); dump('crowd_nrm_' + frames.indexOf(f) + '.f32', d.normals) })
+  }
   A.dispose(); B.dispose()
   console.warn = quiet
 })().catch((e) => { console.error(e); process.exit(1) })

@@ -435,6 +435,10 @@ def test_engine_device_sampling_matches_host_sampling_through_napi(tmp_path):
             moved = max(moved, float(np.abs(pa - rd("a_pos_0.f32").reshape(-1, 3)).max()))
             assert (rd("a_mw_%d.f32" % i) != 0).sum() >= 1
         assert moved > 0.2                     # the motion really moves the mesh between the sampled frames
+        if devs == "0":                        # the crowd: instance k at frames[i] must equal the single-instance result
+            for i in (1, 2, 4):
+                pc, nc = rd("crowd_pos_%d.f32" % i).reshape(-1, 3), rd("crowd_nrm_%d.f32" % i).reshape(-1, 3)
+                assert_parity(pc, nc, rd("a_pos_%d.f32" % i).reshape(-1, 3), rd("a_nrm_%d.f32" % i).reshape(-1, 3), "crowd instance at frame %g" % frames[i])
 
 
 def test_device_motion_sampling_matches_the_float64_sampler(rz, oracle):
