@@ -243,6 +243,13 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
     const float frame = sampled ? p.sample.frames[inst] : 0.0f;
     float *world = p.world + (size_t)inst * p.B * 16;
     float4 *pal = p.palette + (size_t)inst * p.B * 3;
+    // this thread's inverse bind matrix (consumed after the level loop) is requested first, so its latency hides
+    // behind the staging pass and the level loop instead of sitting in front of the output pass
+    float4 pib0 = make_float4(0.f, 0.f, 0.f, 0.f), pib1 = pib0, pib2 = pib0, pib3 = pib0;
+    if (tid < p.B) {
+        const float4 *Im = reinterpret_cast<const float4 *>(p.inv_bind + (size_t)tid * 16);
+        pib0 = Im[0]; pib1 = Im[1]; pib2 = Im[2]; pib3 = Im[3];
+    }
     // one cooperative pass stages everything the level loop touches, so each level costs LDS latency + a barrier
     // instead of two dependent global round trips
     for (int i = tid; i < p.B; i += kBlock) {
@@ -261,71 +268,76 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
     if (sampled)        // vertex-morph weights of this pose: consumed by the prep / deform kernels that follow
         for (int m = tid; m < p.sample.M; m += kBlock) p.sample.morph_w[(size_t)inst * p.sample.M + m] = sample_morph(p.sample, frame, m);
     __syncthreads();
-    for (int l = 0; l < p.n_levels; ++l) {
+    // Pass A, every bone in parallel: its LOCAL matrix L = T(bind + t) * R * T(add) (rows 0..2), parked in the slot that
+    // will hold its world matrix. The level loop below is then only W = W_parent * L — the quaternion / append / slerp
+    // math is off the level-by-level critical path.
+    for (int b = tid; b < p.B; b += kBlock) {
+        const float4 q = sq[b];
+        float R[9];
+        quat_to_rows(q.x, q.y, q.z, q.w, R);
+        const int ap = s_ap[b];
+        float ax = 0.0f, ay = 0.0f, az = 0.0f;       // append-move: T(add) of L = T(bind) * R * T(add)
+        if (ap >= 0) {
+            const float ratio = fminf(1.0f, fmaxf(-1.0f, s_ratio[b]));
+            if (fabsf(ratio) > 1e-6f) {
+                if (lt && p.append_move[b]) {            // model.ts:388-393 uses the UNclamped ratio here
+                    const float r = s_ratio[b];
+                    ax = lt[ap * 3] * r; ay = lt[ap * 3 + 1] * r; az = lt[ap * 3 + 2] * r;
+                }
+                float4 a = sq[ap];
+                const float t = fabsf(ratio);
+                if (ratio < 0.0f) { a.x = -a.x; a.y = -a.y; a.z = -a.z; }
+                // Quat.slerp(identity, a, t)  (math.ts:156-189)
+                float c = a.w;
+                if (c < 0.0f) { c = -c; a.x = -a.x; a.y = -a.y; a.z = -a.z; a.w = -a.w; }
+                float sx, sy, sz, sw;
+                if (c > 0.9995f) {
+                    sx = t * a.x; sy = t * a.y; sz = t * a.z; sw = 1.0f + t * (a.w - 1.0f);
+                    const float il = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz + sw * sw);
+                    sx *= il; sy *= il; sz *= il; sw *= il;
+                } else {
+                    const float th0 = acosf(c), sn = sinf(th0), th = th0 * t;
+                    const float s0 = sinf(th0 - th) / sn, s1 = sinf(th) / sn;
+                    sx = s1 * a.x; sy = s1 * a.y; sz = s1 * a.z; sw = s0 + s1 * a.w;
+                }
+                float A[9], X[9];
+                quat_to_rows(sx, sy, sz, sw, A);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) X[i * 3 + j] = A[i * 3] * R[j] + A[i * 3 + 1] * R[3 + j] + A[i * 3 + 2] * R[6 + j];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) R[i] = X[i];
+            }
+        }
+        // translation column of L = T(bind + local) * R * T(add)  =  bind + local + R * add
+        float tx = s_bind[b * 3], ty = s_bind[b * 3 + 1], tz = s_bind[b * 3 + 2];
+        if (lt) {
+            tx += lt[b * 3]; ty += lt[b * 3 + 1]; tz += lt[b * 3 + 2];
+            tx += R[0] * ax + R[1] * ay + R[2] * az;
+            ty += R[3] * ax + R[4] * ay + R[5] * az;
+            tz += R[6] * ax + R[7] * ay + R[8] * az;
+        }
+        wl[b * 3] = make_float4(R[0], R[1], R[2], tx);
+        wl[b * 3 + 1] = make_float4(R[3], R[4], R[5], ty);
+        wl[b * 3 + 2] = make_float4(R[6], R[7], R[8], tz);
+    }
+    __syncthreads();
+    for (int l = 1; l < p.n_levels; ++l) {          // level 0 = roots: W = L already
         const int lo = p.level_off[l], hi = p.level_off[l + 1];
         for (int idx = lo + tid; idx < hi; idx += kBlock) {
             const int b = s_order[idx];
-            const float4 q = sq[b];
-            float R[9];
-            quat_to_rows(q.x, q.y, q.z, q.w, R);
-            const int ap = s_ap[b];
-            float ax = 0.0f, ay = 0.0f, az = 0.0f;       // append-move: T(add) of L = T(bind) * R * T(add)
-            if (ap >= 0) {
-                const float ratio = fminf(1.0f, fmaxf(-1.0f, s_ratio[b]));
-                if (fabsf(ratio) > 1e-6f) {
-                    if (lt && p.append_move[b]) {            // model.ts:388-393 uses the UNclamped ratio here
-                        const float r = s_ratio[b];
-                        ax = lt[ap * 3] * r; ay = lt[ap * 3 + 1] * r; az = lt[ap * 3 + 2] * r;
-                    }
-                    float4 a = sq[ap];
-                    const float t = fabsf(ratio);
-                    if (ratio < 0.0f) { a.x = -a.x; a.y = -a.y; a.z = -a.z; }
-                    // Quat.slerp(identity, a, t)  (math.ts:156-189)
-                    float c = a.w;
-                    if (c < 0.0f) { c = -c; a.x = -a.x; a.y = -a.y; a.z = -a.z; a.w = -a.w; }
-                    float sx, sy, sz, sw;
-                    if (c > 0.9995f) {
-                        sx = t * a.x; sy = t * a.y; sz = t * a.z; sw = 1.0f + t * (a.w - 1.0f);
-                        const float il = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz + sw * sw);
-                        sx *= il; sy *= il; sz *= il; sw *= il;
-                    } else {
-                        const float th0 = acosf(c), sn = sinf(th0), th = th0 * t;
-                        const float s0 = sinf(th0 - th) / sn, s1 = sinf(th) / sn;
-                        sx = s1 * a.x; sy = s1 * a.y; sz = s1 * a.z; sw = s0 + s1 * a.w;
-                    }
-                    float A[9], X[9];
-                    quat_to_rows(sx, sy, sz, sw, A);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) X[i * 3 + j] = A[i * 3] * R[j] + A[i * 3 + 1] * R[3 + j] + A[i * 3 + 2] * R[6 + j];
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) R[i] = X[i];
-                }
-            }
-            // translation column of L = T(bind + local) * R * T(add)  =  bind + local + R * add
-            float tx = s_bind[b * 3], ty = s_bind[b * 3 + 1], tz = s_bind[b * 3 + 2];
-            if (lt) {
-                tx += lt[b * 3]; ty += lt[b * 3 + 1]; tz += lt[b * 3 + 2];
-                tx += R[0] * ax + R[1] * ay + R[2] * az;
-                ty += R[3] * ax + R[4] * ay + R[5] * az;
-                tz += R[6] * ax + R[7] * ay + R[8] * az;
-            }
-            float W[12];   // 3 rows x 4
             const int par = s_par[b];
-            if (par >= 0) {
-                const float4 p0 = wl[par * 3], p1 = wl[par * 3 + 1], p2 = wl[par * 3 + 2];
-                const float P[12] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w };
+            const float4 l0 = wl[b * 3], l1 = wl[b * 3 + 1], l2 = wl[b * 3 + 2];
+            const float4 p0 = wl[par * 3], p1 = wl[par * 3 + 1], p2 = wl[par * 3 + 2];
+            const float P[12] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w };
+            float W[12];   // 3 rows x 4:  W = P * L  (bottom rows 0 0 0 1)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) W[i * 4 + j] = P[i * 4] * R[j] + P[i * 4 + 1] * R[3 + j] + P[i * 4 + 2] * R[6 + j];
-                    W[i * 4 + 3] = P[i * 4] * tx + P[i * 4 + 1] * ty + P[i * 4 + 2] * tz + P[i * 4 + 3];
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { W[i * 4] = R[i * 3]; W[i * 4 + 1] = R[i * 3 + 1]; W[i * 4 + 2] = R[i * 3 + 2]; }
-                W[3] = tx; W[7] = ty; W[11] = tz;
+            for (int i = 0; i < 3; ++i) {
+                W[i * 4 + 0] = P[i * 4] * l0.x + P[i * 4 + 1] * l1.x + P[i * 4 + 2] * l2.x;
+                W[i * 4 + 1] = P[i * 4] * l0.y + P[i * 4 + 1] * l1.y + P[i * 4 + 2] * l2.y;
+                W[i * 4 + 2] = P[i * 4] * l0.z + P[i * 4 + 1] * l1.z + P[i * 4 + 2] * l2.z;
+                W[i * 4 + 3] = P[i * 4] * l0.w + P[i * 4 + 1] * l1.w + P[i * 4 + 2] * l2.w + P[i * 4 + 3];
             }
             wl[b * 3] = make_float4(W[0], W[1], W[2], W[3]);
             wl[b * 3 + 1] = make_float4(W[4], W[5], W[6], W[7]);
@@ -346,10 +358,12 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
         wo[3] = make_float4(W[3], W[7], W[11], 1.0f);
         // palette rows 0..2 of W * IB (IB general 4x4, column-major)
         const float4 *Im = reinterpret_cast<const float4 *>(p.inv_bind + (size_t)b * 16);
+        const bool mine = b == tid;
+        const float4 ibm[4] = { mine ? pib0 : Im[0], mine ? pib1 : Im[1], mine ? pib2 : Im[2], mine ? pib3 : Im[3] };
         float r[3][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float4 bc = Im[c];
+            const float4 bc = ibm[c];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 r[i][c] = fmaf(W[i * 4 + 3], bc.w, fmaf(W[i * 4 + 2], bc.z, fmaf(W[i * 4 + 1], bc.y, W[i * 4] * bc.x)));
