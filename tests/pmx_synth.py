@@ -9,7 +9,7 @@ def _text(s):
     return struct.pack("<i", len(b)) + b
 
 
-def write_pmx(V=5000, B=40, n_vertex_morphs=6, seed=5):
+def write_pmx(V=5000, B=40, n_vertex_morphs=6, seed=5, max_depth=None):
     """A PMX with V vertices (BDEF1/2/4 mix), a B-bone tree (one append-rotate bone), `n_vertex_morphs`
     sparse vertex morphs named v0.., plus 'blink' (vertex) and 'grp' (group of v0 x0.5 + blink x1.0)."""
     rng = np.random.default_rng(seed)
@@ -39,8 +39,13 @@ def write_pmx(V=5000, B=40, n_vertex_morphs=6, seed=5):
     out += struct.pack("<5f", 0, 0, 0, 1, 1.25) + struct.pack("<bb", -1, -1) + bytes([0, 1, 0]) + _text("") + struct.pack("<i", len(tri))
     bpos = np.cumsum(rng.uniform(-1, 1, size=(B, 3)), axis=0).astype(np.float32)
     out += struct.pack("<i", B)
+    depth = []
     for b in range(B):
         parent = -1 if b == 0 else int(rng.integers(max(0, b - 4), b))
+        if max_depth is not None and b > 0:        # a humanoid-like tree (the demo model is ~15 levels deep), not a chain
+            while depth[parent] >= max_depth - 1:
+                parent = int(rng.integers(0, b))
+        depth.append(0 if parent < 0 else depth[parent] + 1)
         # one append-rotate bone, and one that appends its append parent's rotation AND translation (ratio beyond 1,
         # so the clamp on the rotation ratio and the unclamped move ratio both show)
         flags = 0x0100 if b == B // 2 else (0x0300 if b == B // 2 + 2 and B > 8 else 0)
