@@ -78,6 +78,20 @@ def test_numpy_fk_twin_agrees_with_reference_world_matrices(gold):
     assert np.array_equal(ib, gold["inv_bind"])
 
 
+def test_float64_fk_restatement_is_pinned_by_the_reference_fixture(gold):
+    """tests/helpers.py: fk_reference — the float64 restatement the device hierarchy solve and the device motion sampler are
+    checked against — must itself reproduce the world matrices the reference's own code produced for the real 349-bone
+    skeleton (26 append-rotation bones), at pose 0 and mid-tween."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import fk_reference
+    ap = np.where(gold["append_rotate"], gold["append_parent"], -1)
+    for quats, world in ((gold["local_rot_pose0"], gold["world_pose0"]), (gold["local_rot_tween150"], gold["world_tween150"])):
+        ref = fk_reference(gold["parents"], gold["bind"], quats, None, ap, gold["append_ratio"], gold["append_move"])
+        assert np.abs(ref - world).max() <= 2e-5 * max(1.0, np.abs(world).max())
+    assert gold["append_rotate"].sum() >= 20
+
+
 @pytest.mark.skipif(not os.path.isdir(ASSETS), reason="reference assets only exist in the build container")
 def test_parsers_reproduce_reference_arrays_on_real_assets(tmp_path, gold):
     ref = json.load(open(os.path.join(GOLD, "ref_models.json")))
@@ -398,3 +412,13 @@ def test_vmd_frame_sampler_bezier_translation_and_morph_keys(tmp_path):
     assert fl["keyPos"][3:] == [3, 6, 9] and fl["keyInterp"][16:32] == list(ip) and fl["keyInterp"][:16] == [20] * 8 + [107] * 8
     assert fl["mkeyOff"] == [0, 2] and fl["mkeyFrame"] == [0, 30] and fl["mkeyWeight"] == [0, 1]          # only 'smile' is keyed
     assert fl["feedOff"] == [0, 1, 1, 1] and fl["feedTrack"] == [0] and fl["feedRatio"] == [1]              # the group has no track: no feed
+    # the float64 restatement the DEVICE sampler is tested against (tests/helpers.py: sample_reference), fed with that
+    # flattened motion, must agree with the JS sampler frame by frame
+    from helpers import sample_reference
+    anim = dict(track_bone=fl["trackBone"], key_off=fl["keyOff"], key_frame=fl["keyFrame"], key_rot=fl["keyRot"], key_pos=fl["keyPos"],
+                key_interp=fl["keyInterp"], mkey_off=fl["mkeyOff"], mkey_frame=fl["mkeyFrame"], mkey_weight=fl["mkeyWeight"],
+                feed_off=fl["feedOff"], feed_track=fl["feedTrack"], feed_ratio=fl["feedRatio"])
+    for smp in r["samples"]:
+        q, t, w = sample_reference(anim, smp["f"], 2, 3)
+        assert np.allclose(q[0], smp["a"]["rotation"], atol=1e-9) and np.allclose(t[0], smp["a"]["position"], atol=1e-7), smp["f"]
+        assert abs(w[0] - smp["m"]) < 1e-9 and w[1] == 0 and w[2] == 0 and np.allclose(q[1], [0, 0, 0, 1])
