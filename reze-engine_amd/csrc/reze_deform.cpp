@@ -866,7 +866,14 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
     if (piped) {
         HIP_TRY(hipEventRecord(c->ev_free[cur], c->stream));
         c->free_recorded[cur] = true;
-        if (c->free_recorded[k]) HIP_TRY(hipStreamWaitEvent(c->up_stream, c->ev_free[k], 0));
+        // Slot k was last current two uploads ago; its readers (and the FK kernel that WRITES its world matrices) were
+        // all enqueued before the upload after it. If that upload was a piped one it left ev_free[k] behind them; if it
+        // was a small in-stream one it recorded nothing, so fall back to "everything enqueued so far" (no overlap for
+        // this one frame, but never a torn or clobbered pose).
+        if (!c->free_recorded[k]) HIP_TRY(hipEventRecord(c->ev_free[k], c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->up_stream, c->ev_free[k], 0));
+    } else {
+        c->free_recorded[cur] = false;      // the slot's readers are about to be enqueued and nothing will mark their end
     }
     char *st = static_cast<char *>(c->stage[slot]);
     memcpy(st, primary, p1);
@@ -888,6 +895,7 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_up[k], 0));
     }
     c->pose_slot = k;
+    c->free_recorded[k] = false;            // slot k gets new readers from here on: its old end-of-readers mark is void
     c->world = c->world_buf[k];
     c->morph_w = c->morph_w_buf[k];
     c->local_q = c->local_q_buf[k];

@@ -351,6 +351,52 @@ def test_c5_full_size_parity_and_properties(ctx, oracle, rz):
     np.testing.assert_allclose(pi, mesh["pos"], rtol=1e-6, atol=2e-5)
 
 
+def test_pose_upload_pipeline_never_serves_a_stale_or_torn_pose(rz, oracle):
+    """Per-frame inputs are double-buffered and large uploads ride a second stream (pinned 4-slot ring, ev_up / ev_free
+    hand-off). Hammer it: 300 frames cycling through four crowd poses — world matrices, local rotations, back and forth,
+    with and without a deform between two uploads — and check, whenever a frame is read back, that it is exactly the
+    frame of the pose that was set last (bit-identical to the same pose computed in isolation)."""
+    V, B, I = 6000, 160, 48                           # 48 x 160 x 64 B = 480 KB per world upload: the piped path
+    mesh = synth.make_mesh(V, B, seed=5)
+    rng = np.random.default_rng(6)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    c.set_instances(I)
+    c.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+    poses = []
+    for k in range(4):
+        q = rng.normal(size=(I, B, 4)).astype(np.float32)
+        q /= np.linalg.norm(q, axis=2, keepdims=True)
+        w = np.stack([synth.fk_world(mesh["parents"], mesh["bind"], q[i]) for i in (0, I - 1)])
+        poses.append((q, w))
+    worlds = [np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=40 + 7 * k + i) for i in range(I)]) for k in range(4)]
+    # isolated results: instance 0 and I-1 of every pose, both kinds
+    iso = {}
+    for k in range(4):
+        c.set_pose(worlds[k]); c.deform(); iso[("w", k)] = (c.read(instance=0), c.read(instance=I - 1))
+        c.set_pose_local(poses[k][0]); c.deform(); iso[("l", k)] = (c.read(instance=0), c.read(instance=I - 1))
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[2][I - 1], mesh["inv_bind"])
+    assert_parity(iso[("w", 2)][1][0], iso[("w", 2)][1][1], pr, nr, "isolated world pose")
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], poses[1][1][0], mesh["inv_bind"])
+    assert_parity(iso[("l", 1)][0][0], iso[("l", 1)][0][1], pr, nr, "isolated local pose")
+    checks = 0
+    for f in range(300):
+        kind = "w" if rng.random() < 0.5 else "l"
+        k = int(rng.integers(0, 4))
+        if rng.random() < 0.2:                         # an upload that is overwritten before any frame consumes it
+            c.set_pose(worlds[(k + 1) % 4]) if rng.random() < 0.5 else c.set_pose_local(poses[(k + 2) % 4][0])
+        c.set_pose(worlds[k]) if kind == "w" else c.set_pose_local(poses[k][0])
+        c.deform()
+        if f % 7 == 0 or f > 290:
+            for inst, want in ((0, iso[(kind, k)][0]), (I - 1, iso[(kind, k)][1])):
+                got = c.read(instance=inst)
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), "frame %d (%s%d) instance %d" % (f, kind, k, inst)
+            checks += 1
+    assert checks > 40
+    c.close()
+
+
 def test_device_fk_local_translations_and_append_move(rz, oracle):
     """Row f1 x f2: the GPU hierarchy solve with VMD bone translations (SkeletonRuntime.localTranslations) and bones that
     append their append parent's rotation and movement (model.ts:355-393; clamped ratio for the rotation, raw ratio for the
