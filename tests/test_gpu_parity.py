@@ -353,8 +353,8 @@ def test_c5_full_size_parity_and_properties(ctx, oracle, rz):
 
 def test_pose_upload_pipeline_never_serves_a_stale_or_torn_pose(rz, oracle):
     """Per-frame inputs are double-buffered and large uploads ride a second stream (pinned 4-slot ring, ev_up / ev_free
-    hand-off). Hammer it: 300 frames cycling through four crowd poses — world matrices, local rotations, back and forth,
-    with and without a deform between two uploads — and check, whenever a frame is read back, that it is exactly the
+    hand-off). Hammer it: 400 frames cycling through four crowd poses — world matrices, local rotations, back and forth,
+    and poses sampled on the device, with and without a deform between two uploads — and check, whenever a frame is read back, that it is exactly the
     frame of the pose that was set last (bit-identical to the same pose computed in isolation)."""
     V, B, I = 6000, 160, 48                           # 48 x 160 x 64 B = 480 KB per world upload: the piped path
     mesh = synth.make_mesh(V, B, seed=5)
@@ -380,15 +380,29 @@ def test_pose_upload_pipeline_never_serves_a_stale_or_torn_pose(rz, oracle):
     assert_parity(iso[("w", 2)][1][0], iso[("w", 2)][1][1], pr, nr, "isolated world pose")
     pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], poses[1][1][0], mesh["inv_bind"])
     assert_parity(iso[("l", 1)][0][0], iso[("l", 1)][0][1], pr, nr, "isolated local pose")
+    # a third kind: poses sampled on the device from an uploaded motion (writes the current slot's world matrices itself)
+    nk = 4
+    kq = rng.normal(size=(B, nk, 4)).astype(np.float32)
+    kq /= np.linalg.norm(kq, axis=2, keepdims=True)
+    c.upload_animation(np.arange(B), np.arange(B + 1) * nk, np.tile(np.arange(nk) * 10.0, B), kq, (rng.random((B, nk, 3), dtype=np.float32) - 0.5) * 0.3)
+    frames = [rng.random(I).astype(np.float32) * 30 for _ in range(4)]
+    for k in range(4):
+        c.set_pose_sampled(frames[k]); c.deform(); iso[("s", k)] = (c.read(instance=0), c.read(instance=I - 1))
+    assert not np.array_equal(iso[("s", 0)][0][0], iso[("s", 1)][0][0])
     checks = 0
-    for f in range(300):
-        kind = "w" if rng.random() < 0.5 else "l"
+    for f in range(400):
+        kind = "wls"[int(rng.integers(0, 3))]
         k = int(rng.integers(0, 4))
         if rng.random() < 0.2:                         # an upload that is overwritten before any frame consumes it
             c.set_pose(worlds[(k + 1) % 4]) if rng.random() < 0.5 else c.set_pose_local(poses[(k + 2) % 4][0])
-        c.set_pose(worlds[k]) if kind == "w" else c.set_pose_local(poses[k][0])
+        if kind == "w":
+            c.set_pose(worlds[k])
+        elif kind == "l":
+            c.set_pose_local(poses[k][0])
+        else:
+            c.set_pose_sampled(frames[k])
         c.deform()
-        if f % 7 == 0 or f > 290:
+        if f % 7 == 0 or f > 390:
             for inst, want in ((0, iso[(kind, k)][0]), (I - 1, iso[(kind, k)][1])):
                 got = c.read(instance=inst)
                 assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), "frame %d (%s%d) instance %d" % (f, kind, k, inst)
