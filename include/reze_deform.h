@@ -14,7 +14,8 @@
  *   - "host" pointers are caller-owned and are copied (or fully consumed) before the call returns.
  *   - one rz_ctx drives ONE GPU (one process — or one context — per GPU); calls on a context are
  *     serialised by the caller (Node's main thread). Work is enqueued on the context's own HIP
- *     stream and is asynchronous unless stated; rz_sync() drains it.
+ *     streams (compute, plus an upload stream for large per-frame inputs) and is asynchronous
+ *     unless stated; rz_sync() drains it.
  *   - matrices are column-major float[16] exactly as engine/src/math.ts stores them.
  *   - a context owns a contiguous vertex shard [v_begin, v_begin + V) of a mesh of v_total
  *     vertices (v_begin = 0, v_total = V on a single GPU).
@@ -67,7 +68,7 @@ int rz_create(int device, rz_ctx **out);
 int rz_destroy(rz_ctx *ctx);
 
 /* Pure helper: contiguous shard of rank `rank` of `nranks` over v_total vertices.
- * Shards are equal-sized (a multiple of 256 vertices) except the last; *count may be 0. */
+ * Shards are equal-sized (a multiple of 1024 vertices) except the last; *count may be 0. */
 int rz_shard_range(uint32_t v_total, int nranks, int rank, uint32_t *begin, uint32_t *count);
 
 /* setupModelBuffers()  engine/src/engine.ts:1734-1765: vertex buffer in the reference's
@@ -188,12 +189,12 @@ int rz_read_aabb(rz_ctx *ctx, uint32_t instance, float min_max6[6]);
 int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
 
 /* Tuning knobs (bench sweeps / tests); 0 / -1 = automatic. Keys: "morph_split" (0,1,2,4,8 lanes
- * per vertex quad), "unroll" (0,4,8 morphs in flight per lane), "grid_cap" (total workgroups),
+ * per vertex quad; without dense targets it only sets the wave step: 1 -> 256 vertices, >= 4 -> 64), "unroll" (0,4,8 morphs in flight per lane), "grid_cap" (total workgroups),
  * "geo_lds" (0/1: rest geometry transposed through LDS vs 4-byte loads), "nontemporal" (0/1,
  * morph-stream loads), "nt_store" (0/1, output stores), "fast" (-1 auto, 0 always run the
  * separate prep kernel, 1 one-launch frame when possible), "out_cap" (-1 auto, 0 off, else vertices a wave
  * parks in LDS before writing them out in one burst), "inst_loop" (-1 auto, 0 off, 2..8 poses
- * per workgroup in instanced morph-free frames). rz_get_tuning also answers
+ * per workgroup in instanced morph-free frames, 9 = the register-resident form). rz_get_tuning also answers
  * "effective_split" / "effective_unroll" / "effective_grid" / "effective_fast" / "effective_out_cap".
  * Unknown keys return RZ_ERR_INVALID. */
 int rz_set_tuning(rz_ctx *ctx, const char *key, int value);
@@ -239,8 +240,9 @@ int rz_allgather_all(rz_ctx **ctxs, int n, int with_normals);
  * contexts may share a GPU (then no peer mapping is involved). rz_read() on a contributor still returns its shard.
  * rz_gather_fence(root) makes the root's stream wait (hipStreamWaitEvent, nothing blocks on the host) for
  * everything the other contexts have enqueued so far, so a consumer enqueued on the root's stream sees the whole
- * frame; rz_read_gathered(root, ...) fences, synchronises and copies to the host. Uploading a new mesh to any of
- * the contexts, or destroying the root, returns the contexts to their private output buffers. */
+ * frame; rz_read_gathered(root, ...) fences, synchronises and copies to the host. Uploading a new mesh to a
+ * contributor returns that context to its private output buffers; uploading one to the root, or destroying the
+ * root, returns all of them. */
 int rz_gather_direct(rz_ctx **ctxs, int n, uint32_t v_total, int root);
 int rz_gather_fence(rz_ctx *root);
 
