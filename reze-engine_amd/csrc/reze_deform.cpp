@@ -169,6 +169,7 @@ struct rz_ctx {
     size_t aabb_alloc_inst = 0;
     bool aabb_on = false;
     int aabb_slot = 0;                  // slot the NEXT frame accumulates into
+    bool aabb_rearm = false;            // both slots must be armed again before the next frame
 
     // pinned staging ring for rz_set_pose
     void *stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
@@ -240,15 +241,21 @@ int ensure_outputs(rz_ctx *c)
         HIP_TRY(hipMemsetAsync(c->out_hull, 0, need * sizeof(float), c->stream));
         c->hull_alloc_floats = need;
     }
-    if (c->aabb_on && c->I > c->aabb_alloc_inst) {
+    // Bounding-box keys: a frame accumulates into one slot and re-arms the other FOR THE INSTANCES IT LAUNCHES, so the
+    // buffer is armed from scratch whenever the reduction is switched on or the instance count changes (aabb_rearm) —
+    // otherwise an instance that sat out some frames would come back onto a slot still holding its old extents.
+    if (c->aabb_on && (c->I > c->aabb_alloc_inst || c->aabb_rearm)) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        dfree(c->aabb);
-        HIP_TRY(hipMalloc(&c->aabb, (size_t)c->I * 12 * sizeof(uint32_t)));
-        std::vector<uint32_t> init((size_t)c->I * 12);
+        if (c->I > c->aabb_alloc_inst) {
+            dfree(c->aabb);
+            HIP_TRY(hipMalloc(&c->aabb, (size_t)c->I * 12 * sizeof(uint32_t)));
+            c->aabb_alloc_inst = c->I;
+        }
+        std::vector<uint32_t> init((size_t)c->aabb_alloc_inst * 12);
         for (size_t i = 0; i < init.size(); ++i) init[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
         HIP_TRY(hipMemcpy(c->aabb, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        c->aabb_alloc_inst = c->I;
         c->aabb_slot = 0;
+        c->aabb_rearm = false;
     }
     return RZ_OK;
 }
@@ -819,7 +826,7 @@ int rz_set_instances(rz_ctx *c, uint32_t I)
     if (int r = use(c)) return r;
     if (I == 0 || I > 65535) return fail(RZ_ERR_INVALID, "instance count must be 1..65535");
     if (I > 1 && (c->comm || c->gather_root)) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive");
-    if (I != c->I) forget_search(c);
+    if (I != c->I) { forget_search(c); c->aabb_rearm = true; }
     c->I = I;
     if (int r = ensure_pose_buffers(c)) return r;
     return ensure_outputs(c);
@@ -1189,6 +1196,7 @@ int rz_enable_aabb(rz_ctx *c, int enable)
 {
     if (int r = use(c)) return r;
     c->aabb_on = enable != 0;
+    c->aabb_rearm = true;
     return ensure_outputs(c);
 }
 

@@ -1,0 +1,181 @@
+"""Randomised walk over the C ABI's state machine on the GPU: meshes, skeletons, morph sets, instance counts, tuning keys,
+pose kinds, fused consumers and the launch-shape search are changed in random order, and after every pose the deformed
+mesh of a random instance is compared with the CPU oracle fed with the state the walk believes the context is in.
+Catches stale plans, stale buffers and flags that outlive the data they described."""
+import numpy as np
+import pytest
+
+from helpers import assert_parity, fk_reference, sample_reference
+from reze_engine_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+class Walk:
+    def __init__(self, rz, oracle, seed):
+        self.rz, self.oracle, self.rng = rz, oracle, np.random.default_rng(seed)
+        self.c = rz.DeformContext(0)
+        self.mesh = None
+        self.kind = None            # morph kind: None / "dense" / "sparse"
+        self.I = 1
+        self.topology = False
+        self.edge = None
+        self.aabb = False
+        self.checked = 0
+        self.tuning = {}
+        self.log = []
+
+    # ---- state changes -------------------------------------------------------------------------------------------
+    def new_mesh(self):
+        V = int(self.rng.choice([1, 3, 257, 1023, 2048, 4099, 9001]))
+        B = int(self.rng.choice([1, 2, 7, 64, 300]))
+        self.mesh = synth.make_mesh(V, B, seed=int(self.rng.integers(1 << 30)))
+        self.c.upload_mesh(self.mesh["pos"], self.mesh["nrm"], self.mesh["joints"], self.mesh["weights"])
+        self.c.upload_skeleton(self.mesh["inv_bind"])
+        self.kind, self.topology, self.edge = None, False, None      # a new mesh drops morphs / edge scale; new skeleton: topology
+        self.anim = None                                               # ... and the motion was flattened for the old skeleton
+        self.M = 0
+
+    def new_morphs(self):
+        V = len(self.mesh["pos"])
+        which = self.rng.choice(["dense", "sparse", "none"])
+        if which == "none":
+            self.c.upload_morphs_dense(None)
+            self.kind, self.M = None, 0
+            self.anim = None
+            return
+        M = int(self.rng.choice([1, 3, 9, 40, 140]))
+        if which == "dense":
+            self.deltas, _ = synth.make_morphs_dense(V, M, seed=int(self.rng.integers(1 << 30)))
+            self.c.upload_morphs_dense(self.deltas)
+        else:
+            region = (0, max(1, V // 3)) if self.rng.random() < 0.5 else None
+            self.sp = synth.make_morphs_sparse(V, M, density=min(1.0, 40.0 / V + 0.02), seed=int(self.rng.integers(1 << 30)), region=region)[:3]
+            self.c.upload_morphs_sparse(*self.sp)
+        self.kind, self.M = which, M
+        self.anim = None            # its (empty) morph feeds were sized for the old morph set
+
+    def new_instances(self):
+        self.I = int(self.rng.choice([1, 1, 2, 5, 13]))
+        if self.I > 1 and (self.edge is not None or self.aabb):
+            pass                                            # allowed: the generic kernel carries the consumers
+        self.c.set_instances(self.I)
+
+    def new_tuning(self):
+        key = self.rng.choice(["morph_split", "unroll", "grid_cap", "geo_lds", "nontemporal", "nt_store", "fast", "out_cap", "inst_loop"])
+        val = {"morph_split": [0, 1, 2, 4, 8], "unroll": [0, 4, 8], "grid_cap": [0, 1, 7, 64, 2048], "geo_lds": [0, 1], "nontemporal": [0, 1],
+               "nt_store": [-1, 0, 1], "fast": [-1, 0, 1], "out_cap": [-1, 0, 64, 640], "inst_loop": [-1, 0, 2, 5, 8, 9]}[key]
+        v = int(self.rng.choice(val))
+        self.c.set_tuning(**{key: v})
+        self.tuning[key] = v
+
+    def toggle_consumers(self):
+        V = len(self.mesh["pos"])
+        if self.rng.random() < 0.5:
+            self.edge = None if self.edge is not None else self.rng.random(V).astype(np.float32)
+            self.c.upload_edge_scale(self.edge)
+        else:
+            self.aabb = not self.aabb
+            self.c.enable_aabb(self.aabb)
+
+    # ---- pose + check ----------------------------------------------------------------------------------------------
+    def pose_and_check(self):
+        m, B, I, rng = self.mesh, len(self.mesh["parents"]), self.I, self.rng
+        mw = None
+        if self.M:
+            mw = rng.random((I, self.M)).astype(np.float32)
+            mw[rng.random((I, self.M)) < 0.4] = 0
+            if rng.random() < 0.1:
+                mw[:] = 0
+        sampled = rng.random() < 0.2
+        local = sampled or rng.random() < 0.4
+        t = None
+        if sampled:
+            if not self.topology:
+                self.c.upload_skeleton_topology(m["parents"], m["bind"])
+                self.topology = True
+            if self.anim is None:
+                nk = int(rng.integers(1, 5))
+                kq = rng.normal(size=(B, nk, 4)).astype(np.float32)
+                kq /= np.linalg.norm(kq, axis=2, keepdims=True)
+                self.anim = dict(track_bone=np.arange(B, dtype=np.int32), key_off=(np.arange(B + 1) * nk).astype(np.uint32),
+                                 key_frame=np.tile(np.arange(nk, dtype=np.float32) * 7, B), key_rot=kq,
+                                 key_pos=(rng.random((B, nk, 3), dtype=np.float32) - 0.5), key_interp=rng.integers(0, 128, size=(B * nk, 16)).astype(np.uint8))
+                self.c.upload_animation(self.anim["track_bone"], self.anim["key_off"], self.anim["key_frame"], self.anim["key_rot"], self.anim["key_pos"], self.anim["key_interp"])
+            fr = (rng.random(I) * 30 - 3).astype(np.float32)
+            self.c.set_pose_sampled(fr)
+            mw = None
+        elif local:
+            if not self.topology:
+                self.c.upload_skeleton_topology(m["parents"], m["bind"])
+                self.topology = True
+            q = rng.normal(size=(I, B, 4)).astype(np.float32)
+            q /= np.linalg.norm(q, axis=2, keepdims=True)
+            t = (rng.random((I, B, 3), dtype=np.float32) - 0.5) if rng.random() < 0.5 else None
+            self.c.set_pose_local(q, mw, t)
+        else:
+            worlds = np.stack([synth.make_pose(m["parents"], m["bind"], B, seed=int(rng.integers(1 << 30))) for _ in range(I)])
+            self.c.set_pose(worlds if I > 1 else worlds[0], mw)
+        if rng.random() < 0.15:
+            self.c.autotune(3)
+            self.log.append('autotune')
+        self.c.deform()
+        if rng.random() < 0.3:
+            self.c.deform_n(2)
+            self.log.append('deform_n')
+        if rng.random() < 0.1:
+            self.c.time_frames(2)
+            self.log.append('time_frames')                              # replaying the frame must not change it
+        i = int(rng.integers(0, I))
+        world = self.c.read_world(i) if local else worlds[i]
+        if sampled:
+            qs, ts, _ = sample_reference(self.anim, float(fr[i]), B, 0)
+            ref = fk_reference(m["parents"], m["bind"], qs, ts)
+            assert np.abs(world - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+        elif local:
+            ref = fk_reference(m["parents"], m["bind"], q[i], None if t is None else t[i])
+            assert np.abs(world - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
+        w = np.zeros(self.M, dtype=np.float32) if mw is None else mw[i]     # no weights given (or a motion without morph tracks): all zero
+        if self.kind == "dense":
+            pm = self.oracle.morph_dense(self.deltas, w, m["pos"])
+        elif self.kind == "sparse":
+            pm = self.oracle.morph_sparse(len(m["pos"]), self.sp[0], self.sp[1], self.sp[2], w, m["pos"])
+        else:
+            pm = m["pos"]
+        pr, nr = self.oracle.skin(pm, m["nrm"], m["joints"], m["weights"], self.oracle.palette(world, m["inv_bind"]))
+        pg, ng = self.c.read(instance=i)
+        assert_parity(pg, ng, pr, nr, "walk step, V=%d B=%d M=%d(%s) I=%d local=%s" % (len(pr), B, self.M, self.kind, I, local))
+        if self.edge is not None:
+            assert np.abs(self.c.read_hull(instance=i) - self.oracle.hull(pr, nr, self.edge)).max() <= 1e-3
+        if self.aabb:
+            bb = self.c.read_aabb(i)
+            assert np.abs(bb[:3] - pg.min(axis=0)).max() <= 1e-5 and np.abs(bb[3:] - pg.max(axis=0)).max() <= 1e-5, \
+                "aabb V=%d B=%d M=%d(%s) I=%d inst=%d local=%s tuning=%s eff(split=%d grid=%d fast=%d) log=%s bb=%s want=%s %s" % (
+                    len(pr), B, self.M, self.kind, I, i, local, self.tuning, self.c.get_tuning("effective_split"), self.c.get_tuning("effective_grid"),
+                    self.c.get_tuning("effective_fast"), self.log[-6:], bb, pg.min(axis=0), pg.max(axis=0))
+        self.checked += 1
+
+
+@pytest.mark.parametrize("seed", list(range(1, 17)))
+def test_random_walk_over_the_abi_state_machine(rz, oracle, seed):
+    w = Walk(rz, oracle, seed)
+    w.new_mesh()
+    for step in range(110):
+        r = w.rng.random()
+        w.log.append(round(float(r), 2))
+        if r < 0.10:
+            w.new_mesh()
+            w.I = w.I       # the instance count survives a mesh upload
+        elif r < 0.25:
+            w.new_morphs()
+        elif r < 0.35:
+            w.new_instances()
+        elif r < 0.50:
+            w.new_tuning()
+        elif r < 0.58:
+            w.toggle_consumers()
+        else:
+            w.pose_and_check()
+    w.pose_and_check()
+    assert w.checked >= 20
+    w.c.close()
