@@ -179,3 +179,70 @@ def test_random_walk_over_the_abi_state_machine(rz, oracle, seed):
     w.pose_and_check()
     assert w.checked >= 20
     w.c.close()
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_random_walk_over_sharded_contexts(rz, oracle, seed):
+    """The same idea for the multi-context paths (several vertex shards on this one GPU): shard counts, morph kinds,
+    peer-direct gather on and off, roots, re-uploads and pose kinds change at random; after every frame the whole mesh —
+    read shard by shard, and through the root's gathered buffer when the gather is on — must match the oracle."""
+    rng = np.random.default_rng(seed)
+    checked = 0
+    for scene in range(4):
+        V = int(rng.choice([5, 1030, 4097, 20011]))
+        B = int(rng.choice([3, 40, 200]))
+        G = int(rng.choice([1, 2, 3, 4]))
+        mesh = synth.make_mesh(V, B, seed=int(rng.integers(1 << 30)))
+        kind = rng.choice(["none", "dense", "sparse"])
+        M = int(rng.choice([2, 17]))
+        if kind == "dense":
+            deltas, _ = synth.make_morphs_dense(V, M, seed=int(rng.integers(1 << 30)))
+        elif kind == "sparse":
+            sp = synth.make_morphs_sparse(V, M, density=min(1.0, 30.0 / V + 0.05), seed=int(rng.integers(1 << 30)))[:3]
+            deltas = synth.sparse_to_dense(V, *sp)
+        else:
+            deltas, M = None, 0
+        ctxs = []
+        for r in range(G):
+            b, n, _ = rz.shard.shard_of(V, G, r)
+            shard, d = rz.shard.cut_mesh(mesh, deltas, b, n)
+            c = rz.DeformContext(0)
+            if n > 0:
+                c.upload_mesh(shard["pos"], shard["nrm"], shard["joints"], shard["weights"])
+                c.upload_skeleton(mesh["inv_bind"])
+                if kind == "dense":
+                    c.upload_morphs_dense(d)
+                elif kind == "sparse":       # cut the PMX-order entry list to the shard, indices relative to it
+                    off, idx, d3 = sp
+                    keep = (idx >= b) & (idx < b + n)
+                    noff = np.concatenate([[0], np.cumsum([keep[off[m]:off[m + 1]].sum() for m in range(M)])]).astype(np.uint32)
+                    c.upload_morphs_sparse(noff, (idx[keep] - b).astype(np.uint32), d3[keep])
+            ctxs.append((c, b, n))
+        live = [(c, b, n) for c, b, n in ctxs if n > 0]
+        gather_root = None
+        for frame in range(6):
+            if len(live) == G and rng.random() < 0.5:
+                gather_root = int(rng.integers(0, G))
+                rz.capi.gather_direct([c for c, _, _ in ctxs], V, root=gather_root)
+            world = synth.make_pose(mesh["parents"], mesh["bind"], B, seed=int(rng.integers(1 << 30)))
+            mw = None
+            if M:
+                mw = rng.random(M).astype(np.float32)
+                mw[rng.random(M) < 0.3] = 0
+            for c, _, _ in live:
+                c.set_tuning(grid_cap=int(rng.choice([0, 3, 512])), morph_split=int(rng.choice([0, 1, 4])), out_cap=int(rng.choice([-1, 0])))
+                c.set_pose(world, mw)
+                c.deform()
+            pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], world, mesh["inv_bind"], deltas, mw)
+            for c, b, n in live:
+                pg, ng = c.read()
+                assert_parity(pg, ng, pr[b:b + n], nr[b:b + n], "scene %d frame %d shard at %d" % (scene, frame, b))
+            if gather_root is not None:
+                pg, ng = ctxs[gather_root][0].read_gathered()
+                assert_parity(pg, ng, pr, nr, "scene %d frame %d gathered on root %d" % (scene, frame, gather_root))
+            checked += 1
+        order = list(range(G))
+        rng.shuffle(order)                    # destroy in random order: the root may go first
+        for r in order:
+            ctxs[r][0].close()
+    assert checked == 24
