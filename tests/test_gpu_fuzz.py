@@ -246,3 +246,32 @@ def test_random_walk_over_sharded_contexts(rz, oracle, seed):
         for r in order:
             ctxs[r][0].close()
     assert checked == 24
+
+
+@pytest.mark.parametrize("seed", list(range(1, 11)))
+def test_random_walk_over_the_host_engine_api(tmp_path, seed):
+    """tests/js/engine_fuzz.js: random Engine options and random API calls through Node -> N-API -> GPU, every rendered
+    frame checked inside Node against the JS oracle."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    from pmx_synth import write_pmx, write_vmd
+    if shutil.which("node") is None:
+        pytest.skip("node is not installed on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(seed)
+    (tmp_path / "m.pmx").write_bytes(write_pmx(V=int(rng.choice([700, 3000, 5000])), B=int(rng.choice([12, 40])), seed=seed, max_depth=8))
+    keys = []
+    for b in rng.choice(12, size=6, replace=False):
+        for f in sorted(rng.choice(40, size=int(rng.integers(1, 4)), replace=False)):
+            q = rng.normal(size=4)
+            q /= np.linalg.norm(q)
+            curve = bytes(rng.integers(0, 128, size=16).astype(np.uint8)) + bytes(48)
+            keys.append(("bone%d" % b, int(f), tuple(q), tuple(rng.normal(size=3) * 0.3), curve))
+    (tmp_path / "a.vmd").write_bytes(write_vmd(keys, [("v1", 0, 0.8), ("v1", 20, 0.1), ("v2", 6, 0.4), ("grp", 0, 0.0), ("grp", 30, 1.0)]))
+    p = subprocess.run(["node", os.path.join(root, "tests", "js", "engine_fuzz.js"), str(tmp_path / "m.pmx"), str(tmp_path / "a.vmd"), str(seed)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    r = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert r["frames"] >= 5 and r["worst"] <= 1e-4
