@@ -422,3 +422,16 @@ def test_vmd_frame_sampler_bezier_translation_and_morph_keys(tmp_path):
         q, t, w = sample_reference(anim, smp["f"], 2, 3)
         assert np.allclose(q[0], smp["a"]["rotation"], atol=1e-9) and np.allclose(t[0], smp["a"]["position"], atol=1e-7), smp["f"]
         assert abs(w[0] - smp["m"]) < 1e-9 and w[1] == 0 and w[2] == 0 and np.allclose(q[1], [0, 0, 0, 1])
+
+
+def test_parsers_survive_corrupt_input(tmp_path):
+    """600 corrupted copies of a valid PMX / VMD (truncated, byte-flipped, wild counts): every parse ends cleanly or in a
+    thrown Error, quickly."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from pmx_synth import write_pmx, write_vmd
+    (tmp_path / "f.pmx").write_bytes(write_pmx(V=800, B=20))
+    (tmp_path / "f.vmd").write_bytes(write_vmd([("bone1", 0, (0, 0, 0, 1)), ("bone2", 10, (0, 0, 0.7071, 0.7071))], [("v1", 0, 0.5)]))
+    r = json.loads(subprocess.check_output(["node", os.path.join(ROOT, "tests", "js", "parser_fuzz.js"), str(tmp_path / "f.pmx"), str(tmp_path / "f.vmd")],
+                                           timeout=120).decode().strip().splitlines()[-1])
+    assert r["ok"] + r["thrown"] == 600 and r["slow"] == 0 and r["notError"] == 0 and r["ok"] > 100 and r["thrown"] > 100
