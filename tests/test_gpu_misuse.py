@@ -1,0 +1,101 @@
+"""Misuse of the C ABI must come back as a negative rz_status with a message — never a crash. Runs in a child process so
+that a segfault shows up as a test failure instead of taking pytest down."""
+import subprocess
+import sys
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import ctypes, sys
+sys.path.insert(0, %r)
+import numpy as np
+import reze_engine_amd as rz
+from reze_engine_amd import synth
+L = rz.capi.load()
+c = rz.DeformContext(0)
+h = c._h
+N = None
+bad = []
+def expect_fail(name, rc):
+    if rc >= 0:
+        bad.append(name + " returned %%d" %% rc)
+    elif not L.rz_last_error():
+        bad.append(name + " left no message")
+fp = ctypes.POINTER(ctypes.c_float)
+# null context everywhere
+for name in rz.capi.SYMBOLS:
+    if name in ("rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_shard_range", "rz_comm_unique_id",
+                "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_destroy"):      # rz_destroy(NULL) is a no-op, like free
+        continue
+    f = getattr(L, name)
+    args = [None] + [0 if t in (ctypes.c_uint32, ctypes.c_int, ctypes.c_uint) else None for t in f.argtypes[1:]]
+    expect_fail(name + "(NULL ctx)", f(*args))
+# null / inconsistent data on a live context
+expect_fail("upload_mesh(NULL)", L.rz_upload_mesh(h, 10, N, N, N))
+expect_fail("upload_mesh_soa(NULL)", L.rz_upload_mesh_soa(h, 10, N, N, N, N))
+expect_fail("upload_mesh(V=0)", L.rz_upload_mesh(h, 0, N, N, N))
+expect_fail("upload_skeleton(NULL)", L.rz_upload_skeleton(h, 4, N))
+expect_fail("upload_skeleton(B=0)", L.rz_upload_skeleton(h, 0, N))
+expect_fail("morphs before mesh", L.rz_upload_morphs_dense(h, 2, N))
+expect_fail("set_pose before skeleton", L.rz_set_pose(h, N, N))
+expect_fail("deform before anything", L.rz_deform(h))
+expect_fail("time_frames before anything", L.rz_time_frames(h, 3, N))
+expect_fail("autotune before anything", L.rz_autotune(h, 3))
+expect_fail("read before anything", L.rz_read(h, 0, 0, 1, N, N))
+expect_fail("create(NULL out)", L.rz_create(0, N))
+expect_fail("create(device 99)", L.rz_create(99, ctypes.byref(ctypes.c_void_p())))
+expect_fail("shard_range(NULL)", L.rz_shard_range(100, 2, 0, N, N))
+expect_fail("shard_range(rank >= n)", L.rz_shard_range(100, 2, 5, ctypes.byref(ctypes.c_uint32()), ctypes.byref(ctypes.c_uint32())))
+expect_fail("gather_direct(NULL list)", L.rz_gather_direct(N, 2, 100, 0))
+expect_fail("comm_init_all(NULL list)", L.rz_comm_init_all(N, 2, 100))
+expect_fail("allgather_all(NULL list)", L.rz_allgather_all(N, 2, 0))
+expect_fail("comm_unique_id(NULL)", L.rz_comm_unique_id(N))
+m = synth.make_mesh(300, 6, seed=1)
+c.upload_mesh(m["pos"], m["nrm"], m["joints"], m["weights"]); c.upload_skeleton(m["inv_bind"])
+expect_fail("set_pose(NULL world)", L.rz_set_pose(h, N, N))
+expect_fail("dense morphs NULL deltas", L.rz_upload_morphs_dense(h, 3, N))
+expect_fail("sparse morphs NULL offsets", L.rz_upload_morphs_sparse(h, 3, N, N, N))
+off = (ctypes.c_uint32 * 3)(0, 5, 2)
+expect_fail("sparse morphs decreasing offsets", L.rz_upload_morphs_sparse(h, 2, off, N, N))
+expect_fail("set_instances(0)", L.rz_set_instances(h, 0))
+expect_fail("set_instances(70000)", L.rz_set_instances(h, 70000))
+expect_fail("set_pose_local without topology", L.rz_set_pose_local(h, m["quats"].ctypes.data_as(fp), N, N))
+expect_fail("set_pose_sampled without motion", L.rz_set_pose_sampled(h, m["quats"].ctypes.data_as(fp)))
+expect_fail("upload_animation(NULL)", L.rz_upload_animation(h, N))
+expect_fail("topology NULL parents", L.rz_upload_skeleton_topology(h, 6, N, N, N, N, N))
+expect_fail("topology wrong B", L.rz_upload_skeleton_topology(h, 5, m["parents"].ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), m["bind"].ctypes.data_as(fp), N, N, N))
+cyc = np.array([1, 2, 0, 0, 0, 0], dtype=np.int32)
+expect_fail("topology with a cycle", L.rz_upload_skeleton_topology(h, 6, cyc.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), m["bind"].ctypes.data_as(fp), N, N, N))
+expect_fail("edge scale wrong V", L.rz_upload_edge_scale(h, 7, m["quats"].ctypes.data_as(fp)))
+expect_fail("read_palette before pose", L.rz_read_palette(h, 0, N))
+expect_fail("tuning unknown key", L.rz_set_tuning(h, b"nonsense", 1))
+expect_fail("tuning NULL key", L.rz_set_tuning(h, N, 1))
+expect_fail("get_tuning NULL out", L.rz_get_tuning(h, b"bones", N))
+c.set_pose(m["world"]); c.deform()
+expect_fail("read out of range", L.rz_read(h, 0, 290, 20, N, N))
+expect_fail("read instance out of range", L.rz_read(h, 3, 0, 1, N, N))
+expect_fail("read_hull without edge scale", L.rz_read_hull(h, 0, 0, 1, N))
+expect_fail("read_aabb while off", L.rz_read_aabb(h, 0, N))
+expect_fail("read_gathered without gather", L.rz_read_gathered(h, 0, 1, N, N))
+expect_fail("gather_fence on a non-root", L.rz_gather_fence(h))
+expect_fail("allgather without comm", L.rz_allgather(h, 0))
+expect_fail("comm_init bad rank", L.rz_comm_init(h, 2, 7, ctypes.create_string_buffer(128), 300))
+expect_fail("time_frames NULL out", L.rz_time_frames(h, 3, N))
+# and the context still works afterwards
+c.deform(); p, n = c.read()
+assert np.isfinite(p).all()
+c.close()
+expect_fail("use after destroy is caught for NULL only", L.rz_deform(None))
+print("MISUSE-OK" if not bad else "MISUSE-BAD: " + "; ".join(bad))
+'''
+
+
+@pytest.mark.gpu
+def test_c_abi_misuse_returns_errors_never_crashes():
+    p = subprocess.run([sys.executable, "-c", CHILD % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    out = p.stdout.decode()
+    assert p.returncode == 0, "child died with %d\n%s\n%s" % (p.returncode, out[-2000:], p.stderr.decode()[-3000:])
+    assert "MISUSE-OK" in out, out[-3000:]
