@@ -435,3 +435,11 @@ def test_parsers_survive_corrupt_input(tmp_path):
     r = json.loads(subprocess.check_output(["node", os.path.join(ROOT, "tests", "js", "parser_fuzz.js"), str(tmp_path / "f.pmx"), str(tmp_path / "f.vmd")],
                                            timeout=120).decode().strip().splitlines()[-1])
     assert r["ok"] + r["thrown"] == 600 and r["slow"] == 0 and r["notError"] == 0 and r["ok"] > 100 and r["thrown"] > 100
+
+
+def test_addon_misuse_throws_never_crashes():
+    """Every N-API export called with ten kinds of junk: JS exceptions, no crash (the child reaches its last line)."""
+    p = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "addon_misuse.js")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    r = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert r["alive"] is True and r["functions"] >= 38 and r["thrown"] >= 300
