@@ -201,7 +201,7 @@ int rz_set_tuning(rz_ctx *ctx, const char *key, int value);
 int rz_get_tuning(rz_ctx *ctx, const char *key, int *value);
 
 /* Setup-time search over launch shapes (like a GEMM library's "find" mode; no reference counterpart — WebGPU hides
- * the dispatch shape, engine.ts:2393-2402): times `frames` frames (0 = 30) of every distinct plan among morph split
+ * the dispatch shape, engine.ts:2393-2402): times `frames` frames (0 = 30, at most 1000) of every distinct plan among morph split
  * {1,2,4,8} x {1,2,4} workgroups per CU (instanced frames: {4,8} poses per workgroup x {2,4} workgroups per CU) with
  * the CURRENT mesh / morphs / pose on this GPU and keeps the fastest as the "morph_split" / "grid_cap" / "inst_loop"
  * tuning values. Needs a pose; costs a few hundred frames; results stay within the parity tolerance for every

@@ -67,8 +67,21 @@ static int get_ta(napi_env env, napi_value v, napi_typedarray_type want, int opt
     return tt == want;
 }
 
-static int get_u32(napi_env env, napi_value v, uint32_t *out) { return napi_get_value_uint32(env, v, out) == napi_ok; }
-static int get_i32(napi_env env, napi_value v, int32_t *out) { return napi_get_value_int32(env, v, out) == napi_ok; }
+/* numbers are validated, not wrapped: napi_get_value_uint32(-1) would quietly hand back 4294967295 (frames, vertices ...) */
+static int get_u32(napi_env env, napi_value v, uint32_t *out)
+{
+    double d;
+    if (napi_get_value_double(env, v, &d) != napi_ok || !(d >= 0.0) || d > 4294967295.0 || d != (double)(uint32_t)d) return 0;
+    *out = (uint32_t)d;
+    return 1;
+}
+static int get_i32(napi_env env, napi_value v, int32_t *out)
+{
+    double d;
+    if (napi_get_value_double(env, v, &d) != napi_ok || !(d >= -2147483648.0) || d > 2147483647.0 || d != (double)(int32_t)d) return 0;
+    *out = (int32_t)d;
+    return 1;
+}
 
 static napi_value undef(napi_env env)
 {
@@ -544,8 +557,9 @@ static napi_value fn_comm_init(napi_env env, napi_callback_info info)
     uint32_t vt;
     void *id = NULL;
     size_t idl = 0;
-    if (!get_i32(env, argv[1], &nr) || !get_i32(env, argv[2], &r) || napi_get_buffer_info(env, argv[3], &id, &idl) != napi_ok ||
-        idl != 128 || !get_u32(env, argv[4], &vt))
+    bool is_buf = false;        /* napi_get_buffer_info aborts the process on a non-Buffer in Node 12: ask first */
+    if (!get_i32(env, argv[1], &nr) || !get_i32(env, argv[2], &r) || napi_is_buffer(env, argv[3], &is_buf) != napi_ok || !is_buf ||
+        napi_get_buffer_info(env, argv[3], &id, &idl) != napi_ok || idl != 128 || !get_u32(env, argv[4], &vt))
         return throw_msg(env, "commInit(ctx, nranks, rank, Buffer id /* 128 B */, vTotal)");
     int rc = rz_comm_init(ctx, nr, r, (const char *)id, vt);
     return rc ? throw_rz(env, rc) : undef(env);

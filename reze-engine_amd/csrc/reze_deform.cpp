@@ -1267,6 +1267,7 @@ int rz_autotune(rz_ctx *c, uint32_t frames)
     if (int r = check_ready(c)) return r;
     if (int r = ensure_outputs(c)) return r;
     if (frames == 0) frames = 30;
+    frames = std::min<uint32_t>(frames, 1000);      // a search, not a benchmark
     // candidates: morph split x workgroups per CU (single mesh), poses per workgroup x workgroups per CU (instanced).
     // Every candidate is a legal plan; the search only picks among the variants the parity tests already cover.
     struct Cand { int split, cap, loop; };

@@ -12,4 +12,30 @@ for (const name of Object.keys(a).sort()) {
     try { a[name](...args); returned++ } catch (e) { if (!(e instanceof Error)) throw new Error(name + ' threw a non-Error'); thrown++ }
   }
 }
-console.log(JSON.stringify({ functions: Object.keys(a).length, thrown, returned, alive: true }))
+let live = 0
+if (process.argv[2] === '--live') { // on a GPU box: the same with a LIVE context in front, a mesh + skeleton + pose behind it
+  const ctx = a.create(0)
+  const V = 300, B = 5
+  const mesh = new Float32Array(V * 8).map((_, i) => Math.sin(i)), joints = new Uint16Array(V * 4), weights = new Uint8Array(V * 4).fill(64)
+  const ib = new Float32Array(B * 16); for (let b = 0; b < B; b++) for (let k = 0; k < 4; k++) ib[b * 16 + k * 5] = 1
+  a.uploadMesh(ctx, mesh, joints, weights); a.uploadSkeleton(ctx, ib); a.setPose(ctx, ib, null); a.deform(ctx)
+  const tails = [[], [undefined], [null, null], [1, 2, 3], ['x', {}], [new Float32Array(3)], [new Float32Array(3), new Float32Array(1e6)], [new Uint32Array(2), new Uint32Array(1), new Float32Array(2)],
+    [-1, -1, -1, -1], [70000, 70000, new Float32Array(3), new Float32Array(3)], [0, 0, 70000, new Float32Array(3), new Float32Array(3)], [{ trackBone: new Int32Array(2), keyOff: new Uint32Array([0, 5, 9]) }],
+    [[ctx, ctx], 300, 0], ['grid_cap', 'x'], [new Uint8Array(7)]]
+  for (const name of Object.keys(a).sort()) {
+    if (typeof a[name] !== 'function' || name === 'destroy' || name === 'create') continue
+    for (const args of tails) {
+      if ((name === 'deformN' || name === 'timeFrames' || name === 'autotune') && typeof args[0] === 'number' && args[0] > 1000) continue // a legal, just very long, request
+      const t0 = Date.now()
+      try { a[name](ctx, ...args); returned++ } catch (e) { if (!(e instanceof Error)) throw new Error(name + ' threw a non-Error'); thrown++ }
+      if (Date.now() - t0 > 300) console.error('SLOW ' + name + ' tail #' + tails.indexOf(args) + ' took ' + (Date.now() - t0) + ' ms')
+      live++
+    }
+  }
+  a.setPose(ctx, ib, null); a.deform(ctx)           // still usable
+  const pos = new Float32Array(V * 3), nrm = new Float32Array(V * 3)
+  a.read(ctx, 0, 0, V, pos, nrm)
+  if (!pos.every(Number.isFinite)) throw new Error('context damaged by the misuse')
+  a.destroy(ctx)
+}
+console.log(JSON.stringify({ functions: Object.keys(a).length, thrown, returned, live, alive: true }))

@@ -99,3 +99,17 @@ def test_c_abi_misuse_returns_errors_never_crashes():
     out = p.stdout.decode()
     assert p.returncode == 0, "child died with %d\n%s\n%s" % (p.returncode, out[-2000:], p.stderr.decode()[-3000:])
     assert "MISUSE-OK" in out, out[-3000:]
+
+
+@pytest.mark.gpu
+def test_napi_addon_misuse_with_a_live_context():
+    """tests/js/addon_misuse.js --live: every export called with a live context followed by junk (wrong types, wrong
+    lengths, huge ranges): exceptions or values, the context survives and still deforms."""
+    import json
+    import shutil
+    if shutil.which("node") is None:
+        pytest.skip("node is not installed on this box")
+    p = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "addon_misuse.js"), "--live"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode == 0, "node died with %d\n%s" % (p.returncode, p.stderr.decode()[-3000:])
+    r = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert r["alive"] is True and r["live"] >= 400
