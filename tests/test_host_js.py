@@ -443,3 +443,24 @@ def test_addon_misuse_throws_never_crashes():
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     r = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert r["alive"] is True and r["functions"] >= 38 and r["thrown"] >= 300
+
+
+@pytest.mark.skipif(not os.path.isdir(ASSETS), reason="reference sources / assets only exist in the build container")
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_host_model_tracks_the_reference_model_under_random_driving(tmp_path, seed):
+    """Differential fuzz against the reference's own code (types erased into a scratch directory, nothing stored): the
+    real 349-bone model, 120 random rotateBones / clock / evaluatePose steps, local rotations and world matrices
+    bit-identical after every evaluation."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_erased_run as rer
+    scratch = tmp_path / "erased"
+    scratch.mkdir()
+    for f in ("math", "model", "pmx-loader", "vmd-loader"):
+        (scratch / (f + ".js")).write_text(rer.erase(open(os.path.join(rer.REF, f + ".ts"), encoding="utf-8").read(), f), encoding="utf-8")
+    pmx = os.path.join(ASSETS, "models", "塞尔凯特2", "塞尔凯特2.pmx")
+    p = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "ref_diff_fuzz.js"), str(scratch), pmx, str(seed)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    r = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert r["evals"] >= 15 and r["bones"] == 349
