@@ -464,3 +464,17 @@ def test_host_model_tracks_the_reference_model_under_random_driving(tmp_path, se
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     r = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert r["evals"] >= 15 and r["bones"] == 349
+
+
+@pytest.mark.skipif(not os.path.isdir(ASSETS), reason="reference sources only exist in the build container")
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_host_math_is_bit_identical_to_the_reference_math(tmp_path, seed):
+    """Every public method of the reference's math.ts (types erased into a scratch directory) against host/math.js on 400
+    random inputs each, special values included; numbers and arrays must be identical bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_erased_run as rer
+    (tmp_path / "math.js").write_text(rer.erase(open(os.path.join(rer.REF, "math.ts"), encoding="utf-8").read(), "math"), encoding="utf-8")
+    p = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "ref_diff_math.js"), str(tmp_path), str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2500:]
+    assert json.loads(p.stdout.decode().strip().splitlines()[-1])["cases"] >= 14000
