@@ -478,3 +478,35 @@ def test_host_math_is_bit_identical_to_the_reference_math(tmp_path, seed):
     p = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "ref_diff_math.js"), str(tmp_path), str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-2500:]
     assert json.loads(p.stdout.decode().strip().splitlines()[-1])["cases"] >= 14000
+
+
+@pytest.mark.skipif(not os.path.isdir(ASSETS), reason="reference sources only exist in the build container")
+def test_host_parsers_agree_with_the_reference_parsers_on_synthetic_files(tmp_path):
+    """Beyond the three real PMX files (CRC fixtures above): a dozen synthetic PMX (all index widths, odd sizes, append
+    bones) and VMD files parsed by the reference's loaders (types erased into a scratch directory) and by host/*.js —
+    vertices, indices, joints, weights, inverse bind matrices, bone topology, materials and keys identical."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_erased_run as rer
+    from pmx_synth import write_pmx as synth_pmx, write_vmd
+    scratch = tmp_path / "erased"
+    scratch.mkdir()
+    for f in ("math", "model", "pmx-loader", "vmd-loader"):
+        (scratch / (f + ".js")).write_text(rer.erase(open(os.path.join(rer.REF, f + ".ts"), encoding="utf-8").read(), f), encoding="utf-8")
+    files = []
+    for k, (V, B, nm) in enumerate([(120, 3, 1), (257, 9, 2), (1000, 40, 6), (5000, 300, 12)]):
+        p = tmp_path / ("s%d.pmx" % k)
+        p.write_bytes(synth_pmx(V=V, B=B, n_vertex_morphs=nm, seed=100 + k, max_depth=6 if k % 2 else None))
+        files.append(str(p))
+    for bi, vi in ((1, 1), (2, 2), (4, 4), (1, 4), (4, 1)):
+        p = tmp_path / ("w%d%d.pmx" % (bi, vi))
+        p.write_bytes(write_pmx(bi, vi)[0])
+        files.append(str(p))
+    rng = np.random.default_rng(9)
+    keys = [("bone%d" % int(rng.integers(0, 40)), int(rng.integers(0, 90)), tuple(rng.normal(size=4)), tuple(rng.normal(size=3))) for _ in range(200)]
+    (tmp_path / "k.vmd").write_bytes(write_vmd(keys, [("v1", 3, 0.5)]))
+    files.append(str(tmp_path / "k.vmd"))
+    p = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "ref_diff_parse.js"), str(scratch)] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2500:]
+    assert json.loads(p.stdout.decode().strip().splitlines()[-1])["files"] == len(files)
