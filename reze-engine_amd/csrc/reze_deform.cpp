@@ -745,6 +745,7 @@ int rz_upload_skeleton(rz_ctx *c, uint32_t B, const float *inverse_bind16)
     c->B = B;
     c->pose_set = false;
     c->has_topology = false;            // belongs to the previous skeleton
+    free_animation(c);                  // ... and so does an uploaded motion (its tracks name bones of that skeleton)
     return ensure_pose_buffers(c);
 }
 
@@ -1177,7 +1178,8 @@ int rz_upload_edge_scale(rz_ctx *c, uint32_t V, const float *edge_size)
     if (V != c->V || V == 0) return fail(RZ_ERR_INVALID, "edge scale has %u entries but the mesh has %u vertices", V, c->V);
     dfree(c->edge);
     HIP_TRY(hipMalloc(&c->edge, (size_t)c->Vp * sizeof(float)));
-    HIP_TRY(hipMemset(c->edge, 0, (size_t)c->Vp * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(c->edge, 0, (size_t)c->Vp * sizeof(float), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(c->edge, edge_size, (size_t)V * sizeof(float), hipMemcpyHostToDevice));
     return ensure_outputs(c);
 }
@@ -1519,8 +1521,11 @@ int rz_gather_direct(rz_ctx **ctxs, int n, uint32_t v_total, int root)
     const size_t g = (size_t)n * chunk * 3 * sizeof(float);
     HIP_TRY(hipMalloc(&rt->g_pos, g));
     HIP_TRY(hipMalloc(&rt->g_nrm, g));
-    HIP_TRY(hipMemset(rt->g_pos, 0, g));
-    HIP_TRY(hipMemset(rt->g_nrm, 0, g));
+    // on the root's stream and drained: a plain hipMemset is asynchronous to the host and rides the NULL stream, which the
+    // contexts' non-blocking streams do not wait for — it could land on top of the first frame's output
+    HIP_TRY(hipMemsetAsync(rt->g_pos, 0, g, rt->stream));
+    HIP_TRY(hipMemsetAsync(rt->g_nrm, 0, g, rt->stream));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
     for (int r = 0; r < n; ++r) {
         rz_ctx *c = ctxs[r];
         HIP_TRY(hipSetDevice(c->device));

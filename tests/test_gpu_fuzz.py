@@ -229,17 +229,21 @@ def test_random_walk_over_sharded_contexts(rz, oracle, seed):
             if M:
                 mw = rng.random(M).astype(np.float32)
                 mw[rng.random(M) < 0.3] = 0
+            tun = []
             for c, _, _ in live:
-                c.set_tuning(grid_cap=int(rng.choice([0, 3, 512])), morph_split=int(rng.choice([0, 1, 4])), out_cap=int(rng.choice([-1, 0])))
+                t = dict(grid_cap=int(rng.choice([0, 3, 512])), morph_split=int(rng.choice([0, 1, 4])), out_cap=int(rng.choice([-1, 0])))
+                tun.append(t)
+                c.set_tuning(**t)
                 c.set_pose(world, mw)
                 c.deform()
+            ctxt = "seed %d V=%d B=%d G=%d %s M=%d gather_root=%s tuning=%s" % (seed, V, B, G, kind, M, gather_root, tun)
             pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], world, mesh["inv_bind"], deltas, mw)
             for c, b, n in live:
                 pg, ng = c.read()
-                assert_parity(pg, ng, pr[b:b + n], nr[b:b + n], "scene %d frame %d shard at %d" % (scene, frame, b))
+                assert_parity(pg, ng, pr[b:b + n], nr[b:b + n], "scene %d frame %d shard at %d; %s" % (scene, frame, b, ctxt))
             if gather_root is not None:
                 pg, ng = ctxs[gather_root][0].read_gathered()
-                assert_parity(pg, ng, pr, nr, "scene %d frame %d gathered on root %d" % (scene, frame, gather_root))
+                assert_parity(pg, ng, pr, nr, "scene %d frame %d gathered on root %d; %s" % (scene, frame, gather_root, ctxt))
             checked += 1
         order = list(range(G))
         rng.shuffle(order)                    # destroy in random order: the root may go first
