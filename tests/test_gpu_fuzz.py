@@ -101,7 +101,17 @@ class Walk:
                 self.anim = dict(track_bone=np.arange(B, dtype=np.int32), key_off=(np.arange(B + 1) * nk).astype(np.uint32),
                                  key_frame=np.tile(np.arange(nk, dtype=np.float32) * 7, B), key_rot=kq,
                                  key_pos=(rng.random((B, nk, 3), dtype=np.float32) - 0.5), key_interp=rng.integers(0, 128, size=(B * nk, 16)).astype(np.uint8))
-                self.c.upload_animation(self.anim["track_bone"], self.anim["key_off"], self.anim["key_frame"], self.anim["key_rot"], self.anim["key_pos"], self.anim["key_interp"])
+                if self.M:            # morph tracks: some vertex morphs keyed directly, some fed by "group" tracks, some both, some never
+                    mt = int(rng.integers(1, 5))
+                    mk = [np.sort(rng.choice(30, size=int(rng.integers(1, 4)), replace=False)).astype(np.float32) for _ in range(mt)]
+                    feeds = [[(int(rng.integers(0, mt)), float(rng.choice([1.0, 0.5, -0.25]))) for _ in range(int(rng.integers(0, 3)))] for _ in range(self.M)]
+                    self.anim.update(mkey_off=np.cumsum([0] + [len(k) for k in mk]).astype(np.uint32), mkey_frame=np.concatenate(mk),
+                                     mkey_weight=rng.random(sum(len(k) for k in mk)).astype(np.float32),
+                                     feed_off=np.cumsum([0] + [len(f) for f in feeds]).astype(np.uint32),
+                                     feed_track=np.array([t for f in feeds for t, _ in f], np.int32), feed_ratio=np.array([r for f in feeds for _, r in f], np.float32))
+                a = self.anim
+                self.c.upload_animation(a["track_bone"], a["key_off"], a["key_frame"], a["key_rot"], a["key_pos"], a["key_interp"],
+                                        a.get("mkey_off"), a.get("mkey_frame"), a.get("mkey_weight"), a.get("feed_off"), a.get("feed_track"), a.get("feed_ratio"))
             fr = (rng.random(I) * 30 - 3).astype(np.float32)
             self.c.set_pose_sampled(fr)
             mw = None
@@ -129,13 +139,15 @@ class Walk:
         i = int(rng.integers(0, I))
         world = self.c.read_world(i) if local else worlds[i]
         if sampled:
-            qs, ts, _ = sample_reference(self.anim, float(fr[i]), B, 0)
+            qs, ts, ws = sample_reference(self.anim, float(fr[i]), B, self.M if self.anim.get("mkey_off") is not None else 0)
             ref = fk_reference(m["parents"], m["bind"], qs, ts)
             assert np.abs(world - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
         elif local:
             ref = fk_reference(m["parents"], m["bind"], q[i], None if t is None else t[i])
             assert np.abs(world - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
-        w = np.zeros(self.M, dtype=np.float32) if mw is None else mw[i]     # no weights given (or a motion without morph tracks): all zero
+        w = np.zeros(self.M, dtype=np.float32) if mw is None else mw[i]     # no weights given: all zero
+        if sampled and self.M and self.anim.get("mkey_off") is not None:
+            w = ws.astype(np.float32)                                        # the motion's own morph tracks
         if self.kind == "dense":
             pm = self.oracle.morph_dense(self.deltas, w, m["pos"])
         elif self.kind == "sparse":
