@@ -58,7 +58,7 @@ function compare(got, want, what) {
   }
   const engine = new Engine(null, opt)
   await engine.init(); await engine.loadModel(pmx); await engine.loadAnimation(vmd)
-  const model = engine.currentModel
+  let model = engine.currentModel
   const names = model.getBoneNames(), morphNames = model.getMorphNames()
   // device-sampling engines are stateless per seek: their reference is a fresh host model posed by the host sampler
   const shadow = await PmxLoader.load(pmx)
@@ -68,7 +68,23 @@ function compare(got, want, what) {
   for (let stepNo = 0; stepNo < 40; stepNo++) {
     const r = rnd()
     let rendered = null
-    if (deviceSampling || r < 0.2) {
+    if (deviceSampling && nShards === 1 && !opt.outline && !opt.bounds && r < 0.25) {
+      // a crowd: n copies, each at its own frame; every instance against the shadow model at that frame
+      const n = 1 + Math.floor(rnd() * 4)
+      engine.setInstanceCount(n)
+      const fs2 = Array.from({ length: n }, () => rnd() * 40 - 2)
+      log.push('crowd ' + fs2.map((x) => x.toFixed(1)).join('/'))
+      engine.seekFrame(fs2)
+      for (let k = 0; k < n; k++) {
+        shadow.applySampledFrame(sampler, fs2[k]); shadow.evaluatePose()
+        worst = Math.max(worst, compare(engine.getDeformed(k), expected(shadow), JSON.stringify(opt) + ' crowd instance ' + k + ' after ' + log.slice(-6).join(' | ')))
+      }
+      engine.setInstanceCount(1)
+      frames++
+    } else if (rnd() < 0.04) {
+      log.push('reload'); await engine.loadModel(pmx)       // the same file again: fresh model, fresh device buffers
+      model = engine.currentModel
+    } else if (deviceSampling || r < 0.2) {
       const f = rnd() * 40 - 2
       log.push('seek ' + f.toFixed(2))
       engine.seekFrame(f)
