@@ -113,3 +113,64 @@ def test_napi_addon_misuse_with_a_live_context():
     assert p.returncode == 0, "node died with %d\n%s" % (p.returncode, p.stderr.decode()[-3000:])
     r = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert r["alive"] is True and r["live"] >= 400
+
+
+@pytest.mark.gpu
+def test_contexts_give_all_device_memory_back():
+    """Forty create / use-everything / destroy cycles: the free device memory reported by the runtime must come back to
+    where it started (a leak of even one 1 MB buffer per cycle would show as 40 MB)."""
+    child = r'''
+import sys
+sys.path.insert(0, %r)
+import ctypes
+import numpy as np
+import reze_engine_amd as rz
+from reze_engine_amd import synth
+hip = ctypes.CDLL("libamdhip64.so")
+def free_bytes():
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+    return f.value
+V, B, M, I = 60000, 120, 12, 6
+mesh = synth.make_mesh(V, B, seed=3)
+deltas, mw = synth.make_morphs_dense(V, M, seed=4)
+sp = synth.make_morphs_sparse(V, M, seed=5)[:3]
+q = np.tile(np.array([0, 0, 0, 1], np.float32), (I, B, 1))
+def cycle(k):
+    cs = []
+    for r in range(2):
+        b, n, _ = rz.shard.shard_of(V, 2, r)
+        shard, d = rz.shard.cut_mesh(mesh, deltas, b, n)
+        c = rz.DeformContext(0)
+        c.upload_mesh(shard["pos"], shard["nrm"], shard["joints"], shard["weights"]); c.upload_skeleton(mesh["inv_bind"])
+        c.upload_morphs_dense(d)
+        c.upload_edge_scale(np.ones(n, np.float32)); c.enable_aabb(True)
+        c.set_pose(mesh["world"], mw); c.deform(); c.autotune(2)
+        cs.append(c)
+    rz.capi.gather_direct(cs, V, root=k %% 2)
+    for c in cs:
+        c.set_pose(mesh["world"], mw); c.deform()
+    cs[k %% 2].read_gathered()
+    big = rz.DeformContext(0)
+    big.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); big.upload_skeleton(mesh["inv_bind"])
+    big.upload_morphs_sparse(*sp)
+    big.set_instances(I)
+    big.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+    big.set_pose_local(q, None, np.zeros((I, B, 3), np.float32)); big.deform()
+    big.upload_animation(np.arange(B), np.arange(B + 1) * 2, np.tile([0.0, 9.0], B), np.tile([0, 0, 0, 1], (2 * B, 1)), np.zeros((2 * B, 3)))
+    big.set_pose_sampled(np.arange(I, dtype=np.float32)); big.deform(); big.read(instance=I - 1)
+    big.upload_morphs_dense(None); big.set_pose(np.stack([mesh["world"]] * I)); big.deform_n(3); big.time_frames(2)
+    for c in cs + [big]:
+        c.close()
+cycle(0); cycle(1)
+base = free_bytes()
+for k in range(40):
+    cycle(k)
+leak = base - free_bytes()
+print("LEAK-BYTES", leak)
+'''
+    p = subprocess.run([sys.executable, "-c", child % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0, "child died with %d\n%s" % (p.returncode, p.stderr.decode()[-3000:])
+    leak = int(out.strip().splitlines()[-1].split()[-1])
+    assert leak < (8 << 20), "device memory not returned: %d bytes after 40 cycles" % leak
