@@ -56,7 +56,6 @@ export class Engine {
   setMorphWeights(namesOrIndices: Array<string | number>, weights: number[]): void
   render(): void
   step(timeMs: number): void
-  /** Pose the model at a (fractional) VMD frame with MMD interpolation and deform one frame. */
   /** MMD-interpolated pose at a (fractional, 30 fps) frame; with a crowd (setInstanceCount) one frame per instance. */
   seekFrame(frame: number | ArrayLike<number>): void
   /** n independently posed copies of the model (needs { deviceFK, deviceSampling }, one GPU). */
@@ -73,3 +72,12 @@ export class Engine {
 export class Model { [key: string]: any }
 export class PmxLoader { static load(path: string): Promise<Model>; static loadFromBuffer(buf: ArrayBuffer | Uint8Array): Model }
 export class VMDLoader { static load(path: string): Promise<any[]>; static loadFromBuffer(buf: ArrayBuffer | Uint8Array): any[] }
+/** Frame-indexed MMD sampling of a loaded motion (rotation / position / morph keys); flatten() feeds the device sampler. */
+export class VMDSampler {
+  constructor(keyFrames: any[])
+  lastFrame: number
+  sampleBone(name: string, frame: number): { rotation: number[]; position: number[] } | null
+  sampleMorph(name: string, frame: number): number | null
+  boneNames(): string[]; morphNames(): string[]
+  flatten(boneNameIndex: Record<string, number>, morphs: { names: string[]; types: ArrayLike<number>; groups: Array<Array<[number, number]> | null> } | null): Record<string, Int32Array | Uint32Array | Float32Array | Uint8Array>
+}
