@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for the barrier / max-reduce (gloo + --share-gpu lets a 1-GPU box rehearse N > 1)")
     ap.add_argument("--share-gpu", action="store_true", help="map every rank onto GPU (local_rank %% visible devices)")
+    ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs of 16 frames in the timed loop (rz_set_tuning graph=1): for launch-bound small frames")
     ap.add_argument("--tune", default="", help="comma list key=value passed to rz_set_tuning (disables the autotune pass)")
     ap.add_argument("--no-autotune", action="store_true", help="skip rz_autotune (setup-time search over launch shapes) and use the built-in heuristics")
     return ap.parse_args()
@@ -210,6 +211,9 @@ def main():
             sys.stderr.write("[bench] autotune failed, using the heuristics: %r\n" % (e,))
             ctx.set_tuning(morph_split=0, grid_cap=0, inst_loop=-1)
 
+    if args.graph:
+        ctx.set_tuning(graph=1)
+
     def barrier():
         ctx.sync()
         if torch.cuda.is_available():
@@ -315,6 +319,7 @@ def main():
                 "parallelism": "vertex-shard x%d" % world_size,
                 "bone_hierarchy_solve": ("device (motion sampling + hierarchy solve in rz_fk_kernel)" if args.device_sampling else "device (rz_fk_kernel)") if args.device_fk else "host",
                 "autotune": tuned is not None,
+                "graph_replay": bool(args.graph),
                 "morph_split": ctx.get_tuning("effective_split"),
                 "grid": ctx.get_tuning("effective_grid"),
                 "frame_ms_events": timing["frame_ms"],

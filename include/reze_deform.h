@@ -194,7 +194,8 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * morph-stream loads), "nt_store" (0/1, output stores), "fast" (-1 auto, 0 always run the
  * separate prep kernel, 1 one-launch frame when possible), "out_cap" (-1 auto, 0 off, else vertices a wave
  * parks in LDS before writing them out in one burst), "inst_loop" (-1 auto, 0 off, 2..8 poses
- * per workgroup in instanced morph-free frames, 9 = the register-resident form). rz_get_tuning also answers
+ * per workgroup in instanced morph-free frames, 9 = the register-resident form), "graph" (0/1: rz_deform_n replays
+ * hipGraphs of 16 captured frames instead of launching every kernel — for launch-bound replay of small frames). rz_get_tuning also answers
  * "effective_split" / "effective_unroll" / "effective_grid" / "effective_fast" / "effective_out_cap".
  * Unknown keys return RZ_ERR_INVALID. */
 int rz_set_tuning(rz_ctx *ctx, const char *key, int value);

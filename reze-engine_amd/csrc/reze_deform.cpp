@@ -184,6 +184,9 @@ struct rz_ctx {
 
     // tuning (0 / -1 = automatic)
     int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1;
+    int t_graph = 0;                    // "graph" tuning key: rz_deform_n replays captured hipGraphs of kGraphFrames frames
+    hipGraphExec_t graph_exec = nullptr;
+    uint64_t graph_sig = 0;             // signature of everything the captured launches depend on
     bool tuned_by_search = false;       // rz_autotune set morph_split / grid_cap / inst_loop for the CURRENT mesh, morphs and instance count
 
     // multi-GPU
@@ -361,6 +364,7 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
 Plan make_plan(const rz_ctx *c)
 {
     Plan pl;
+    memset(&pl, 0, sizeof pl);          // padding too: frame_signature() hashes the struct
     RzVariant &v = pl.v;
     v.mode = c->morph_mode;
     // Without dense targets S only sets the size of a wave step: S = 4 makes it 64 vertices instead of 256, so a small
@@ -656,6 +660,7 @@ int rz_destroy(rz_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
     drop_direct_gather(c);
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->inv_bind);
@@ -1127,13 +1132,66 @@ int rz_deform(rz_ctx *c)
     return launch_deform(c, pl);
 }
 
+// FNV-1a over the plain-data structs a frame's launches are built from: if none of them changed, a captured graph of
+// those launches is still the same work.
+static uint64_t fnv(uint64_t h, const void *p, size_t n)
+{
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+static uint64_t frame_signature(rz_ctx *c, const Plan &pl)
+{
+    uint64_t h = 1469598103934665603ull;
+    RzDeformParams dp = deform_params(c, pl);
+    dp.aabb_slot &= 1;
+    h = fnv(h, &dp, sizeof dp);
+    h = fnv(h, &c->ml, sizeof c->ml);
+    h = fnv(h, &pl, sizeof pl);
+    RzPrepParams pp = prep_params(c);
+    h = fnv(h, &pp, sizeof pp);
+    const uint64_t misc[8] = { c->I, c->pose_local, c->pose_local_t, c->pose_sampled, (uint64_t)c->morph_mode, (uint64_t)(uintptr_t)c->local_q,
+                               (uint64_t)(uintptr_t)c->an_frames, (uint64_t)c->fk_levels };
+    return fnv(h, misc, sizeof misc);
+}
+
+constexpr uint32_t kGraphFrames = 16;   // even: the bounding-box slot parity is the same after a replay as before it
+
 int rz_deform_n(rz_ctx *c, uint32_t frames)
 {
     if (int r = use(c)) return r;
     if (int r = check_ready(c)) return r;
     if (int r = ensure_outputs(c)) return r;
     const Plan pl = make_plan(c);
-    for (uint32_t f = 0; f < frames; ++f) {
+    uint32_t f = 0;
+    if (c->t_graph && frames >= 2 * kGraphFrames) {
+        // Launch-bound replay (a 30 k-vertex frame is 3-6 us of GPU time per ~3 us of launch work on the host): capture
+        // kGraphFrames whole frames once into a hipGraph and replay that; one launch call per 16 frames.
+        const uint64_t sig = frame_signature(c, pl);
+        if (!c->graph_exec || c->graph_sig != sig) {
+            if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+            if (int r = launch_front(c, pl)) return r;             // one plain frame first: attributes set, modules loaded
+            if (int r = launch_deform(c, pl)) return r;
+            ++f;
+            hipGraph_t g = nullptr;
+            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            int rc = RZ_OK;
+            for (uint32_t k = 0; k < kGraphFrames && rc == RZ_OK; ++k) {
+                rc = launch_front(c, pl);
+                if (rc == RZ_OK) rc = launch_deform(c, pl);
+            }
+            hipError_t ce = hipStreamEndCapture(c->stream, &g);
+            if (rc != RZ_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (ce != hipSuccess || !g) return fail(RZ_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+            hipError_t ie = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ie != hipSuccess) { c->graph_exec = nullptr; return fail(RZ_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
+            c->graph_sig = sig;
+        }
+        for (; f + kGraphFrames <= frames; f += kGraphFrames) HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+    }
+    for (; f < frames; ++f) {
         if (int r = launch_front(c, pl)) return r;
         if (int r = launch_deform(c, pl)) return r;
     }
@@ -1347,6 +1405,9 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
     } else if (!strcmp(key, "out_cap")) {
         if (value < -1 || value > 2048) return fail(RZ_ERR_INVALID, "out_cap must be -1 (auto), 0 (off) or 64..2048 vertices per wave");
         c->t_outcap = value;
+    } else if (!strcmp(key, "graph")) {
+        if (value < 0 || value > 1) return fail(RZ_ERR_INVALID, "graph must be 0 or 1");
+        c->t_graph = value;
     } else if (!strcmp(key, "dbg")) {
         c->t_dbg = value;
     } else if (!strcmp(key, "inst_loop")) {
@@ -1379,6 +1440,7 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "effective_fast")) *value = make_plan(c).v.fast ? 1 : 0;
     else if (!strcmp(key, "inst_loop")) *value = c->t_instloop;
     else if (!strcmp(key, "out_cap")) *value = c->t_outcap;
+    else if (!strcmp(key, "graph")) *value = c->t_graph;
     else if (!strcmp(key, "effective_out_cap")) *value = (int)make_plan(c).out_cap;
     else if (!strcmp(key, "effective_inst_group")) *value = make_plan(c).inst_group;
     else if (!strcmp(key, "effective_poses_per_wg")) *value = make_plan(c).poses_per_wg;

@@ -738,6 +738,56 @@ def test_autotune_keeps_parity_and_picks_a_listed_plan(rz, oracle):
     ctx.close()
 
 
+def test_graph_replay_is_the_same_frames(rz, oracle):
+    """"graph" tuning key: rz_deform_n replays hipGraphs of 16 captured frames. Same output bits as plain launches for a
+    one-launch frame, a crowd (prep + skin), a device-FK crowd and a frame with the fused consumers; the capture is redone
+    when the pose, the tuning or the mesh changes."""
+    V, B = 9000, 48
+    mesh = synth.make_mesh(V, B, seed=14)
+    deltas, mw = synth.make_morphs_dense(V, 10, seed=15)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    c.upload_morphs_dense(deltas)
+    c.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+
+    def both(setup, inst=0):
+        outs = []
+        for g in (0, 1):
+            c.set_tuning(graph=g)
+            setup()
+            c.deform_n(70)                         # 1 plain + 4 graphs + 5 plain frames when graph = 1
+            outs.append(c.read(instance=inst))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        return outs[1]
+
+    pg, ng = both(lambda: c.set_pose(mesh["world"], mw))
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"], deltas, mw)
+    assert_parity(pg, ng, pr, nr, "graph replay, one-launch frame")
+    world2 = synth.make_pose(mesh["parents"], mesh["bind"], B, seed=77)
+    pg, ng = both(lambda: c.set_pose(world2, mw))                       # a new pose: the captured kernel arguments are stale
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], world2, mesh["inv_bind"], deltas, mw)
+    assert_parity(pg, ng, pr, nr, "graph replay after a new pose")
+    c.enable_aabb(True); c.upload_edge_scale(np.full(V, 0.5, np.float32))
+    pg, ng = both(lambda: c.set_pose(world2, mw))
+    bb = c.read_aabb()
+    assert np.abs(bb[:3] - pg.min(axis=0)).max() <= 1e-5 and np.abs(bb[3:] - pg.max(axis=0)).max() <= 1e-5
+    assert np.abs(c.read_hull() - oracle.hull(pr, nr, np.full(V, 0.5, np.float32))).max() <= 1e-3
+    c.enable_aabb(False); c.upload_edge_scale(None); c.upload_morphs_dense(None)
+    I = 9
+    c.set_instances(I)
+    worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=200 + i) for i in range(I)])
+    pg, ng = both(lambda: c.set_pose(worlds), inst=I - 1)
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[I - 1], mesh["inv_bind"])
+    assert_parity(pg, ng, pr, nr, "graph replay, crowd")
+    q = np.random.default_rng(3).normal(size=(I, B, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=2, keepdims=True)
+    pg, ng = both(lambda: c.set_pose_local(q), inst=4)
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], c.read_world(4), mesh["inv_bind"])
+    assert_parity(pg, ng, pr, nr, "graph replay, device FK crowd")
+    c.close()
+
+
 def test_peer_direct_gather_three_shards(rz, oracle):
     """rz_gather_direct: three contexts (three vertex shards; one GPU here, so no peer mapping but the same
     pointers-into-the-root's-buffer mechanism) store their frames straight into the root's gathered arrays. The
