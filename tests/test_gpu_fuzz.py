@@ -62,9 +62,9 @@ class Walk:
         self.c.set_instances(self.I)
 
     def new_tuning(self):
-        key = self.rng.choice(["morph_split", "unroll", "grid_cap", "geo_lds", "nontemporal", "nt_store", "fast", "out_cap", "inst_loop"])
+        key = self.rng.choice(["morph_split", "unroll", "grid_cap", "geo_lds", "nontemporal", "nt_store", "fast", "out_cap", "inst_loop", "graph"])
         val = {"morph_split": [0, 1, 2, 4, 8], "unroll": [0, 4, 8], "grid_cap": [0, 1, 7, 64, 2048], "geo_lds": [0, 1], "nontemporal": [0, 1],
-               "nt_store": [-1, 0, 1], "fast": [-1, 0, 1], "out_cap": [-1, 0, 64, 640], "inst_loop": [-1, 0, 2, 5, 8, 9]}[key]
+               "nt_store": [-1, 0, 1], "fast": [-1, 0, 1], "out_cap": [-1, 0, 64, 640], "inst_loop": [-1, 0, 2, 5, 8, 9], "graph": [0, 1]}[key]
         v = int(self.rng.choice(val))
         self.c.set_tuning(**{key: v})
         self.tuning[key] = v
@@ -131,7 +131,7 @@ class Walk:
             self.log.append('autotune')
         self.c.deform()
         if rng.random() < 0.3:
-            self.c.deform_n(2)
+            self.c.deform_n(int(rng.choice([2, 40])))      # 40: long enough for the graph replay when that key is on
             self.log.append('deform_n')
         if rng.random() < 0.1:
             self.c.time_frames(2)
