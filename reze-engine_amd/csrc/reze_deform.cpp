@@ -1557,7 +1557,7 @@ int rz_allgather_all(rz_ctx **ctxs, int n, int with_normals)
     return RZ_OK;
 }
 
-int rz_gather_direct(rz_ctx **ctxs, int n, uint32_t v_total, int root)
+static int gather_direct_attach(rz_ctx **ctxs, int n, uint32_t v_total, int root, bool *started)
 {
     if (!ctxs || n < 1 || n > 64 || root < 0 || root >= n) return fail(RZ_ERR_INVALID, "bad context list / root");
     for (int r = 0; r < n; ++r) {
@@ -1571,6 +1571,7 @@ int rz_gather_direct(rz_ctx **ctxs, int n, uint32_t v_total, int root)
             if (ctxs[k] == c) return fail(RZ_ERR_INVALID, "context listed twice");
     }
     rz_ctx *rt = ctxs[root];
+    *started = true;                    // validation passed: from here on state changes
     for (int r = 0; r < n; ++r) drop_direct_gather(ctxs[r]);
     // the gathered buffer lives on the root's GPU (rz_read_gathered, or a renderer there, consumes it)
     rt->nranks = n; rt->rank = root; rt->v_total = v_total;
@@ -1609,6 +1610,21 @@ int rz_gather_direct(rz_ctx **ctxs, int n, uint32_t v_total, int root)
     }
     HIP_TRY(hipSetDevice(rt->device));
     return RZ_OK;
+}
+
+int rz_gather_direct(rz_ctx **ctxs, int n, uint32_t v_total, int root)
+{
+    bool started = false;
+    const int rc = gather_direct_attach(ctxs, n, v_total, root, &started);
+    if (rc != RZ_OK && started) {
+        // all or nothing: a failure half-way (no peer access from one of the GPUs, out of memory ...) must not leave some
+        // shards storing into the root's buffer and others not
+        const std::string msg = rz_last_error();
+        for (int r = 0; r < n; ++r)
+            if (ctxs[r]) drop_direct_gather(ctxs[r]);
+        return fail(rc, "%s", msg.c_str());
+    }
+    return rc;
 }
 
 int rz_gather_fence(rz_ctx *root)
