@@ -150,6 +150,17 @@ typedef struct rz_animation {
 } rz_animation;
 int rz_upload_animation(rz_ctx *ctx, const rz_animation *anim);
 int rz_set_pose_sampled(rz_ctx *ctx, const float *frames);
+/* ---- physics hand-off for device-solved poses ----
+ * updateModelPose()  engine/src/engine.ts:2375-2381: between evaluatePose() and the world-matrix upload the reference
+ * lets physics overwrite the world matrices of rigid-body-driven bones IN PLACE (physics.ts:715-751,
+ * boneWorldMatrices.set(values, boneIndex * 16)): children keep the matrices solved from the un-overridden parent.
+ * With rz_set_pose the host owns the world matrices and does exactly that before the call. When the hierarchy is
+ * solved on the GPU (rz_set_pose_local / rz_set_pose_sampled) this entry point is the same hook: `n` world matrices
+ * (column-major 4x4, affine) replace the solved ones of (instance[k], bone[k]) after the hierarchy solve and before
+ * the palette product, in every following frame until the next call; n = 0 clears. instance = NULL means instance 0.
+ * Several entries for one bone: the last wins (successive set() calls). Asynchronous H2D through pinned staging.
+ * Physics itself (Bullet via @fred3d/ammo) stays out of scope: this only carries its result. */
+int rz_override_world(rz_ctx *ctx, uint32_t n, const uint32_t *instance, const uint32_t *bone, const float *world16);
 /* Blocking readback of one instance's world matrices (B x 16, column-major) as the frame used them. */
 int rz_read_world(rz_ctx *ctx, uint32_t instance, float *world16);
 

@@ -21,11 +21,19 @@
  * PARITY STATUS. The reference has no tests and no golden vectors for this path, its skinning is
  * WGSL inside a vertex shader (engine.ts:245-276) whose outputs are never written to a buffer, and
  * the image has no WebGPU / WGSL executor and no tsc. Therefore:
- *   - rzo_palette / rzo_skin (rows a1-a3, a6): PARITY UNPINNED BY REFERENCE EXECUTION — nothing can
- *     run the shader here. They are pinned by analytic known-answer tests (identity pose => rest
- *     mesh, single-bone rigid motion about a pivot, hand-computed 2-bone blend, zero-weight and
- *     zero-normal branches; tests/test_oracle.py) and by bit-exact three-way agreement between this
- *     file, the NumPy twin (oracle/rz_oracle_np.py) and the JS Math.fround twin (oracle/js/skin_f32.js).
+ *   - rzo_palette (row a6): PINNED TO REFERENCE EXECUTION. engine.ts:926-928 is the column-major product
+ *     world * inverseBind, which the reference's own Mat4.multiply (math.ts:303-320) computes; tools/ref_erased_run.py
+ *     runs that method on the real 349-bone model for two poses and tests/test_oracle.py holds this file to the stored
+ *     result within the rounding the two evaluations can differ by (doubles + one f32 store there, four f32 roundings
+ *     here): |diff| <= 2^-22 * SUM_k |a_k * b_k| per element.
+ *   - rzo_skin (rows a1-a3): the WGSL of vs() itself cannot be executed here (no WebGPU / naga / tint), so the shader
+ *     stays UNPINNED BY SHADER EXECUTION; what IS pinned: the same fixture run evaluates vs()'s formula
+ *     (engine.ts:255-272) on 256 real vertices with the reference's Mat4 / Vec3 primitives (every M_i * vec4 is a
+ *     Mat4.multiply; for the 173 BDEF1 vertices of the slice the position is Mat4.multiply alone), and this file agrees
+ *     with it to 2e-7 relative (bar in the test: 1e-6). On top of that: analytic known-answer tests (identity pose =>
+ *     rest mesh, single-bone rigid motion about a pivot, hand-computed 2-bone blend, zero-weight and zero-normal
+ *     branches) and bit-exact three-way agreement between this file, the NumPy twin (oracle/rz_oracle_np.py) and the
+ *     JS Math.fround twin (oracle/js/skin_f32.js).
  *   - the inputs they consume (world matrices, inverse bind, joints, weights: rows a9-a12) ARE pinned
  *     to the reference's own code: tools/ref_erased_run.py runs math.ts/model.ts/pmx-loader.ts/
  *     vmd-loader.ts with their TypeScript types erased on the reference's assets and stores numeric

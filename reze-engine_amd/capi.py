@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libreze_deform.so")
 SYMBOLS = [
     "rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_destroy", "rz_shard_range",
     "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
-    "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_upload_animation", "rz_set_pose_sampled", "rz_read_world", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
+    "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_upload_animation", "rz_set_pose_sampled", "rz_override_world", "rz_read_world", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
     "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_autotune", "rz_output_ptrs",
     "rz_comm_unique_id", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_gather_fence", "rz_upload_edge_scale", "rz_read_hull", "rz_enable_aabb", "rz_read_aabb",
 ]
@@ -79,6 +79,7 @@ def load():
     L.rz_set_pose_local.argtypes = [vp, fp, fp, fp]
     L.rz_upload_animation.argtypes = [vp, ctypes.POINTER(RzAnimation)]
     L.rz_set_pose_sampled.argtypes = [vp, fp]
+    L.rz_override_world.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), fp]
     L.rz_read_world.argtypes = [vp, u32, fp]
     L.rz_deform.argtypes = [vp]
     L.rz_deform_n.argtypes = [vp, u32]
@@ -310,6 +311,23 @@ class DeformContext:
         f = _f32(np.atleast_1d(frames)).reshape(-1)
         assert f.size == self.I
         _chk(self._L.rz_set_pose_sampled(self._h, _fptr(f)))
+
+    def override_world(self, bones, world16, instances=None):
+        """Physics hand-off for device-solved poses (engine.ts:2379-2381): world matrices that replace the solved ones of
+        (instance, bone) after the hierarchy solve, until the next call; empty `bones` clears."""
+        b = np.ascontiguousarray(bones, dtype=np.uint32).reshape(-1)
+        if b.size == 0:
+            _chk(self._L.rz_override_world(self._h, 0, None, None, None))
+            return
+        w = _f32(world16).reshape(-1)
+        assert w.size == b.size * 16
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        ip = None
+        if instances is not None:
+            i = np.ascontiguousarray(instances, dtype=np.uint32).reshape(-1)
+            assert i.size == b.size
+            ip = i.ctypes.data_as(u32p)
+        _chk(self._L.rz_override_world(self._h, int(b.size), ip, b.ctypes.data_as(u32p), _fptr(w)))
 
     def read_world(self, instance=0):
         out = np.empty((self.B, 16), dtype=np.float32)

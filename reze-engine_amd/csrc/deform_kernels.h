@@ -55,6 +55,12 @@ struct RzFkParams {
     float4 *palette;            // [I][B][3] out
     int B;
     int n_levels;
+    // physics hand-off (engine.ts:2379-2381, physics.ts:715-751): world matrices that replace the solved ones AFTER the
+    // hierarchy solve — children keep the matrices solved from the un-overridden parent, exactly like the reference's
+    // in-place boneWorldMatrices.set(). Entries sorted by instance; ovr_off[i]..ovr_off[i+1] are instance i's.
+    const int *ovr_off;         // [I + 1] or nullptr
+    const int *ovr_bone;        // [n]
+    const float *ovr_world;     // [n][16] column-major
     RzSampleParams sample;      // sample.frames != nullptr: local_q / local_t are ignored, the pose is sampled in the kernel
 };
 
@@ -85,7 +91,9 @@ struct RzDeformParams {
     uint32_t n_quads;           // ceil(V / 4)
     uint32_t quads_per_wave;    // contiguous run owned by each wave of the grid (multiple of 8)
     uint32_t out_cap;           // vertices buffered in LDS per wave before a 16-B/lane flush (0 = store directly)
-    int dbg;                    // ablation switch for profiling experiments (0 in production)
+#ifdef RZ_ABLATE
+    int dbg;                    // ablation switch — tools-only build (see RZ_DBG in deform_kernels.hip); absent from the product
+#endif
     int dma;                    // FAST: stage raw matrices by LDS-DMA (else plain loads after the first morph phase)
     int B;
     int M;
@@ -124,7 +132,7 @@ size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v);
 hipError_t rz_launch_skin_instances_reg(const RzDeformParams &p, int n_inst, int poses_per_wg, uint32_t grid_x, bool nts,
                                         hipStream_t st);
 hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
-                                    bool nts, hipStream_t st);
+                                    int block, bool nts, hipStream_t st);
 uint32_t rz_quads_per_tile(int S);
 hipError_t rz_launch_deinterleave(const float *src, int stride, int offset, uint32_t n, float *px, float *py,
                                   float *pz, hipStream_t st);

@@ -35,6 +35,15 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// Ablation switches for profiling experiments exist only in the tools-only build (make ablate ->
+// tools/ablate/libreze_deform_ablate.so, -DRZ_ABLATE). In the shipped library RZ_DBG is the constant 0, the branches
+// fold away, and rz_set_tuning("dbg", ...) is rejected: no key can make rz_deform emit anything but the deformed mesh.
+#ifdef RZ_ABLATE
+#define RZ_DBG(p) ((p).dbg)
+#else
+#define RZ_DBG(p) 0
+#endif
+
 __device__ __forceinline__ float4 ld_stream(const float4 *p, bool nt)
 {
     // morph planes are read exactly once per frame: optionally bypass-hint the load
@@ -345,6 +354,18 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
         }
         __syncthreads();
     }
+    if (p.ovr_off) {
+        // physics-driven bones: the supplied world matrix replaces the solved one (rows 0..2 of the column-major 4x4)
+        for (int k = p.ovr_off[inst] + tid; k < p.ovr_off[inst + 1]; k += kBlock) {
+            const int b = p.ovr_bone[k];
+            const float4 *m = reinterpret_cast<const float4 *>(p.ovr_world + (size_t)k * 16);
+            const float4 c0 = m[0], c1 = m[1], c2 = m[2], c3 = m[3];
+            wl[b * 3] = make_float4(c0.x, c1.x, c2.x, c3.x);
+            wl[b * 3 + 1] = make_float4(c0.y, c1.y, c2.y, c3.y);
+            wl[b * 3 + 2] = make_float4(c0.z, c1.z, c2.z, c3.z);
+        }
+        __syncthreads();
+    }
     // all levels solved: one parallel pass writes the world matrices and the palette (the inverse-bind loads of
     // every bone are in flight together instead of once per level)
     for (int b = tid; b < p.B; b += kBlock) {
@@ -483,7 +504,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     // requested FIRST, as plain loads into registers, so they are the oldest entries of the vmcnt queue: the palette
     // math below only has to wait for them (a counted wait) while the morph loads issued after them stay in flight.
     float4 ew0, ew1, ew2, ew3, ei0, ei1, ei2, ei3;
-    const bool early = FAST && tid < p.B && p.dbg != 3;      // dbg 3: ablation — no palette staging (output is garbage)
+    const bool early = FAST && tid < p.B && RZ_DBG(p) != 3;      // dbg 3: ablation — no palette staging (output is garbage)
     if (early) {
         const float4 *gw = reinterpret_cast<const float4 *>(p.world) + tid * 4;
         const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + tid * 4;
@@ -518,7 +539,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     const uint32_t bmax = (uint32_t)(p.B - 1);
     float *opos = p.out_pos + (size_t)inst * Vp * 3;
     float *onrm = p.out_nrm + (size_t)inst * Vp * 3;
-    bool need_palette = FAST && p.dbg != 3;
+    bool need_palette = FAST && RZ_DBG(p) != 3;
     float bb[6] = { __builtin_inff(), __builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
 
     // palette rows 0..2 of world * inverseBind, out[c*4+r] = ((a0[r]*b0 + a1[r]*b1) + a2[r]*b2) + a3[r]*b3 (engine.ts:928)
@@ -550,7 +571,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         }
         need_palette = false;
     };
-    bool need_sync = FAST && p.dbg != 3;          // one workgroup barrier publishes the palette before the first phase 2
+    bool need_sync = FAST && RZ_DBG(p) != 3;          // one workgroup barrier publishes the palette before the first phase 2
 
     // persistent, evenly balanced partition: every wave of the grid owns one contiguous run of quads
     // (a multiple of 8 quads = 128 B per plane) and walks it QPW quads at a time; the last step is masked.
@@ -703,7 +724,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
 
         // ---- phase 2: one vertex per lane ----
         const size_t vw0 = qw * 4;     // first vertex of this wave's step
-        const int v_live = p.dbg == 4 ? 0 : (int)min((size_t)VW, (q_end - qw) * 4);   // dbg 4: ablation — morph phase only
+        const int v_live = RZ_DBG(p) == 4 ? 0 : (int)min((size_t)VW, (q_end - qw) * 4);   // dbg 4: ablation — morph phase only
 #pragma unroll 1
         for (int r = 0; r < ROUNDS; ++r) {
             const int vl = r * 64 + lane;
@@ -745,7 +766,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
                     const uint32_t li = (ob_fill + vl) * 3;
                     ob_pos[li] = o.px; ob_pos[li + 1] = o.py; ob_pos[li + 2] = o.pz;
                     ob_nrm[li] = o.nx; ob_nrm[li + 1] = o.ny; ob_nrm[li + 2] = o.nz;
-                } else if (p.dbg != 5 || o.px == 1234.5f) {   // dbg 5: ablation — skin phase without its output stream
+                } else if (RZ_DBG(p) != 5 || o.px == 1234.5f) {   // dbg 5: ablation — skin phase without its output stream
                     st3<NTS>(opos + v * 3, o.px, o.py, o.pz);
                     st3<NTS>(onrm + v * 3, o.nx, o.ny, o.nz);
                 }
@@ -814,9 +835,16 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
 // ------------------------------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <bool NTS>
-__global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDeformParams p, int G, int n_inst,
-                                                                   uint32_t verts_per_wg)
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
+
+// BLOCK threads per workgroup (256: two workgroups per CU; 512 / 1024: one, with 8 / 16 waves sharing one staged palette
+// group — half / a quarter of the palette traffic per CU). NB = how many influences the pose loop gathers: the host picks
+// nothing here, every wave decides per vertex step from a ballot over its lanes' weights (wave-uniform, so no divergence):
+// a step whose 64 vertices are all BDEF1 / BDEF2 (real PMX models cluster them by mesh part) reads 3 / 6 palette rows per
+// pose instead of 12. Skipped terms are w = 0, i.e. fma(0, row, m) = m: the result bits do not depend on the path taken.
+template <int BLOCK, bool NTS>
+__global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeformParams p, int G, int n_inst,
+                                                                  uint32_t verts_per_wg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *pal = reinterpret_cast<float4 *>(smem);
@@ -826,26 +854,15 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
     const int rows = p.B * 3;                       // float4 per palette in global memory
     const int rstride = p.dma ? 3 : 4;              // float4 per palette slot in LDS
     const int lrows = p.B * rstride;
-    if (p.dma) {
-        // prep-kernel path: the group's palettes are contiguous in global memory -> one linear LDS-DMA copy
-        const float4 *src = p.palette + (size_t)inst0 * rows;
-        const int n = ng * rows;
-        for (int c = wave * 64; c < n; c += kBlock) {
-            const int e = c + lane;
-            if (e < n) {
-                typedef const __attribute__((address_space(1))) void *gptr_t;
-                typedef __attribute__((address_space(3))) void *lptr_t;
-                __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(src + e), (lptr_t)(uint32_t)(uintptr_t)(pal + c), 16, 0, 0);
-            }
-        }
-    } else {
-        // one-launch frame: the group's WORLD matrices are staged instead, whole (64-byte slots, the same linear
+    {
+        // prep-kernel path (dma): the group's finished palettes are contiguous in global memory -> one linear LDS-DMA copy.
+        // one-launch frame (!dma): the group's WORLD matrices are staged instead, whole (64-byte slots, the same linear
         // 16-byte LDS-DMA); the conversion pass below multiplies by the inverse bind matrix in place and leaves the
         // palette rows in the first 48 bytes of each slot. (A compact 48-byte slot would need gfx950's 12-byte LDS-DMA
         // to pack its cells — measured: it keeps a 16-byte lane stride — or loads + ds_write, measured 3 us slower.)
-        const float4 *src = reinterpret_cast<const float4 *>(p.world) + (size_t)inst0 * p.B * 4;
-        const int n = ng * p.B * 4;
-        for (int c = wave * 64; c < n; c += kBlock) {
+        const float4 *src = p.dma ? p.palette + (size_t)inst0 * rows : reinterpret_cast<const float4 *>(p.world) + (size_t)inst0 * p.B * 4;
+        const int n = p.dma ? ng * rows : ng * p.B * 4;
+        for (int c = wave * 64; c < n; c += BLOCK) {
             const int e = c + lane;
             if (e < n) {
                 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -865,7 +882,7 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
     const uint32_t v_end = min(p.n_quads * 4u, v_begin + verts_per_wg);
     const uint32_t bmax = (uint32_t)(p.B - 1);
     // software-pipelined vertex loop: the next vertex's nine attribute loads are issued before the current
-    // vertex's pose loop, so their L2 latency hides behind 8 poses of LDS gathers + FMA
+    // vertex's pose loop, so their L2 latency hides behind the poses' LDS gathers + FMA
     uint32_t v = v_begin + tid;
     float x = 0, y = 0, z = 0, nx = 0, ny = 0, nz = 0;
     uint32_t j01 = 0, j23 = 0, wq = 0;
@@ -879,8 +896,9 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
     if (!p.dma) {
         // in-place conversion: slot (g, b) = rows 0..2 of world * inverseBind (engine.ts:926-928). Packed math: the
         // inverse bind matrix is held as column PAIRS (c0,c1),(c2,c3) per k, so each result row is two v_pk_fma
-        // chains; the next pose's cells are read before the current product is formed.
-        for (int b = tid; b < p.B; b += kBlock) {           // one trip unless the skeleton has > 256 bones
+        // chains (the same chain as rz_prep_kernel: ((a0*b0 + a1*b1) + a2*b2) + a3*b3); the next pose's cells are read
+        // before the current product is formed.
+        for (int b = tid; b < p.B; b += BLOCK) {            // one trip unless the skeleton has more bones than threads
             if (b != tid) {
                 const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + b * 4;
                 ib0 = gi[0]; ib1 = gi[1]; ib2 = gi[2]; ib3 = gi[3];
@@ -893,13 +911,12 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
                 float4 *nxt = slot + lrows;
                 float4 n0 = a0, n1 = a1, n2 = a2, n3 = a3;
                 if (g + 1 < ng) { n0 = nxt[0]; n1 = nxt[1]; n2 = nxt[2]; n3 = nxt[3]; }
-                // row r of the product = a3[r]*P_w + (a2[r]*P_z + (a1[r]*P_y + a0[r]*P_x))
-                const f2 r0a = a3.x * pw01 + (a2.x * pz01 + (a1.x * py01 + a0.x * px01));
-                const f2 r0b = a3.x * pw23 + (a2.x * pz23 + (a1.x * py23 + a0.x * px23));
-                const f2 r1a = a3.y * pw01 + (a2.y * pz01 + (a1.y * py01 + a0.y * px01));
-                const f2 r1b = a3.y * pw23 + (a2.y * pz23 + (a1.y * py23 + a0.y * px23));
-                const f2 r2a = a3.z * pw01 + (a2.z * pz01 + (a1.z * py01 + a0.z * px01));
-                const f2 r2b = a3.z * pw23 + (a2.z * pz23 + (a1.z * py23 + a0.z * px23));
+                auto row = [&](float e0, float e1, float e2, float e3, const f2 &bx, const f2 &by, const f2 &bz, const f2 &bw) {
+                    return pk_fma(f2{e3, e3}, bw, pk_fma(f2{e2, e2}, bz, pk_fma(f2{e1, e1}, by, f2{e0, e0} * bx)));
+                };
+                const f2 r0a = row(a0.x, a1.x, a2.x, a3.x, px01, py01, pz01, pw01), r0b = row(a0.x, a1.x, a2.x, a3.x, px23, py23, pz23, pw23);
+                const f2 r1a = row(a0.y, a1.y, a2.y, a3.y, px01, py01, pz01, pw01), r1b = row(a0.y, a1.y, a2.y, a3.y, px23, py23, pz23, pw23);
+                const f2 r2a = row(a0.z, a1.z, a2.z, a3.z, px01, py01, pz01, pw01), r2b = row(a0.z, a1.z, a2.z, a3.z, px23, py23, pz23, pw23);
                 slot[0] = make_float4(r0a.x, r0a.y, r0b.x, r0b.y);
                 slot[1] = make_float4(r1a.x, r1a.y, r1b.x, r1b.y);
                 slot[2] = make_float4(r2a.x, r2a.y, r2b.x, r2b.y);
@@ -913,11 +930,11 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
             const int n = ng * rows, per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
             const int lo = (int)blockIdx.x * per, hi = min(n, lo + per);
             float4 *gp = p.palette + (size_t)inst0 * rows;
-            for (int i = lo + tid; i < hi; i += kBlock) gp[i] = pal[(i / 3) * 4 + i % 3];
+            for (int i = lo + tid; i < hi; i += BLOCK) gp[i] = pal[(i / 3) * 4 + i % 3];
         }
     }
-    for (; v < v_end; v += kBlock) {
-        const uint32_t vn = v + kBlock;
+    for (uint32_t vb = v_begin; vb < v_end; vb += BLOCK, v += BLOCK) {   // workgroup-uniform trip count (the ballots below need whole waves)
+        const uint32_t vn = v + BLOCK;
         float xn = 0, yn = 0, zn = 0, nxn = 0, nyn = 0, nzn = 0;
         uint32_t j01n = 0, j23n = 0, wqn = 0;
         if (vn < v_end) {
@@ -925,6 +942,7 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
             nxn = p.geom[3 * Vp + vn]; nyn = p.geom[4 * Vp + vn]; nzn = p.geom[5 * Vp + vn];
             j01n = p.joints01[vn]; j23n = p.joints23[vn]; wqn = p.weights[vn];
         }
+        const bool live = v < v_end;
         // decode once per vertex (engine.ts:255-258)
         const uint32_t b0 = wq & 255u, b1 = (wq >> 8) & 255u, b2 = (wq >> 16) & 255u, b3 = wq >> 24;
         const uint32_t isum = b0 + b1 + b2 + b3;
@@ -935,46 +953,73 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_kernel(const RzDefor
                        o2 = min(j23 & 0xffffu, bmax) * rstride, o3 = min(j23 >> 16, bmax) * rstride;
         float *dp = p.out_pos + ((size_t)inst0 * Vp + v) * 3;
         float *dn = p.out_nrm + ((size_t)inst0 * Vp + v) * 3;
-        const float4 *pg = pal;
         // Packed-math form (v_pk_fma_f32 = two f32 FMAs per lane per instruction): palette rows are blended as
         // (xy),(zw) register pairs straight out of ds_read_b128, and position + normal are transformed together
-        // as the pairs (x,nx),(y,ny),(z,nz),(1,0), so one FMA chain yields (p_r, n_r) for row r.
-        const f2 vx = {x, nx}, vy = {y, ny}, vz = {z, nz}, vw = {1.0f, 0.0f};
+        // as the pairs (x,nx),(y,ny),(z,nz), so one FMA chain yields (p_r, n_r) for row r. Every chain is spelled out
+        // with explicit FMAs in the order of skin_vertex() above — bones ascending from w0 * row, then
+        // fma(m.z, z, fma(m.y, y, fma(m.x, x, m.w))) — so a pose of a crowd has the SAME BITS as that pose run alone
+        // through rz_deform_kernel (tests/test_gpu_round2.py checks it at full C4 size).
+        const f2 vx = {x, nx}, vy = {y, ny}, vz = {z, nz};
+        const f2 W0 = {w0, w0}, W1 = {w1, w1}, W2 = {w2, w2}, W3 = {w3, w3};
+#ifdef RZ_ABLATE
         if (p.dbg == 2) {                        // dbg 2: ablation — the output stream without gathers / math
-            for (int g = 0; g < ng; ++g) {
-                st3<NTS>(dp, x, y, z); st3<NTS>(dn, nx, ny, nz);
-                dp += Vp * 3; dn += Vp * 3;
-            }
+            if (live)
+                for (int g = 0; g < ng; ++g) {
+                    st3<NTS>(dp, x, y, z); st3<NTS>(dn, nx, ny, nz);
+                    dp += Vp * 3; dn += Vp * 3;
+                }
             x = xn; y = yn; z = zn; nx = nxn; ny = nyn; nz = nzn; j01 = j01n; j23 = j23n; wq = wqn;
             continue;
         }
+#endif
+        auto pose_loop = [&](auto nb_tag) {
+            constexpr int NB = decltype(nb_tag)::value;
+            const float4 *pg = pal;
 #pragma unroll 2
-        for (int g = 0; g < ng; ++g) {
-            f2 r[3][2];
+            for (int g = 0; g < ng; ++g) {
+                f2 r[3][2];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float4 a = pg[o0 + k], c = pg[o1 + k], d = pg[o2 + k], e = pg[o3 + k];
-                const f2 axy = {a.x, a.y}, azw = {a.z, a.w}, cxy = {c.x, c.y}, czw = {c.z, c.w};
-                const f2 dxy = {d.x, d.y}, dzw = {d.z, d.w}, exy = {e.x, e.y}, ezw = {e.z, e.w};
-                r[k][0] = w3 * exy + (w2 * dxy + (w1 * cxy + w0 * axy));
-                r[k][1] = w3 * ezw + (w2 * dzw + (w1 * czw + w0 * azw));
+                for (int k = 0; k < 3; ++k) {
+                    const float4 a = pg[o0 + k];
+                    r[k][0] = W0 * f2{a.x, a.y};
+                    r[k][1] = W0 * f2{a.z, a.w};
+                    if (NB >= 2) {
+                        const float4 c = pg[o1 + k];
+                        r[k][0] = pk_fma(W1, f2{c.x, c.y}, r[k][0]);
+                        r[k][1] = pk_fma(W1, f2{c.z, c.w}, r[k][1]);
+                    }
+                    if (NB >= 4) {
+                        const float4 d = pg[o2 + k], e = pg[o3 + k];
+                        r[k][0] = pk_fma(W3, f2{e.x, e.y}, pk_fma(W2, f2{d.x, d.y}, r[k][0]));
+                        r[k][1] = pk_fma(W3, f2{e.z, e.w}, pk_fma(W2, f2{d.z, d.w}, r[k][1]));
+                    }
+                }
+                // (p_r, t_r) = fma(m_r.z, (z,nz), fma(m_r.y, (y,ny), fma(m_r.x, (x,nx), (m_r.w, 0))))
+                f2 q[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const f2 m_xy = r[k][0], m_zw = r[k][1];
+                    q[k] = pk_fma(f2{m_zw.x, m_zw.x}, vz, pk_fma(f2{m_xy.y, m_xy.y}, vy, pk_fma(f2{m_xy.x, m_xy.x}, vx, f2{m_zw.y, 0.0f})));
+                }
+                const float tx = q[0].y, ty = q[1].y, tz = q[2].y;
+                const float l2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+                const bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
+                const float rl = __builtin_amdgcn_rsqf(good ? l2 : 1.0f);
+                if (live && (RZ_DBG(p) != 1 || l2 == 1234.5f)) {   // dbg 1 (tools-only build): compute without the output stream
+                    st3<NTS>(dp, q[0].x, q[1].x, q[2].x);
+                    st3<NTS>(dn, good ? tx * rl : nx, good ? ty * rl : ny, good ? tz * rl : nz);
+                }
+                pg += lrows;
+                dp += Vp * 3;
+                dn += Vp * 3;
             }
-            // (p_r, t_r) = m_r.x*(x,nx) + m_r.y*(y,ny) + m_r.z*(z,nz) + m_r.w*(1,0)
-            const f2 q0 = r[0][0].x * vx + (r[0][0].y * vy + (r[0][1].x * vz + r[0][1].y * vw));
-            const f2 q1 = r[1][0].x * vx + (r[1][0].y * vy + (r[1][1].x * vz + r[1][1].y * vw));
-            const f2 q2 = r[2][0].x * vx + (r[2][0].y * vy + (r[2][1].x * vz + r[2][1].y * vw));
-            const float tx = q0.y, ty = q1.y, tz = q2.y;
-            const float l2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
-            const bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
-            const float rl = __builtin_amdgcn_rsqf(good ? l2 : 1.0f);
-            if (p.dbg != 1 || l2 == 1234.5f) {   // dbg 1: ablation — compute without the output stream
-                st3<NTS>(dp, q0.x, q1.x, q2.x);
-                st3<NTS>(dn, good ? tx * rl : nx, good ? ty * rl : ny, good ? tz * rl : nz);
-            }
-            pg += lrows;
-            dp += Vp * 3;
-            dn += Vp * 3;
-        }
+        };
+        const bool any34 = __ballot((wq >> 16) != 0u) != 0ull;
+        const bool any2 = __ballot(((wq >> 8) & 255u) != 0u) != 0ull;
+        if (__ballot(live) == 0ull) {}                     // a wave past the end of the run (last step only)
+        else if (any34) pose_loop(std::integral_constant<int, 4>{});
+        else if (any2) pose_loop(std::integral_constant<int, 2>{});
+        else pose_loop(std::integral_constant<int, 1>{});
         x = xn; y = yn; z = zn; nx = nxn; ny = nyn; nz = nzn; j01 = j01n; j23 = j23n; wq = wqn;
     }
 }
@@ -1198,18 +1243,27 @@ hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, cons
     }
 }
 
-hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
-                                    bool nts, hipStream_t st)
+template <int BLOCK>
+static hipError_t launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
+                                        bool nts, hipStream_t st)
 {
     const size_t lds = (size_t)G * p.B * (p.dma ? 48 : 64);
-    auto k = nts ? rz_skin_instances_kernel<true> : rz_skin_instances_kernel<false>;
+    auto k = nts ? rz_skin_instances_kernel<BLOCK, true> : rz_skin_instances_kernel<BLOCK, false>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     dim3 grid(grid_x, (n_inst + G - 1) / G);
-    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p, G, n_inst, verts_per_wg);
+    hipLaunchKernelGGL(k, grid, dim3(BLOCK), lds, st, p, G, n_inst, verts_per_wg);
     return hipGetLastError();
+}
+
+hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
+                                    int block, bool nts, hipStream_t st)
+{
+    if (block == 1024) return launch_skin_instances<1024>(p, G, n_inst, verts_per_wg, grid_x, nts, st);
+    if (block == 512) return launch_skin_instances<512>(p, G, n_inst, verts_per_wg, grid_x, nts, st);
+    return launch_skin_instances<256>(p, G, n_inst, verts_per_wg, grid_x, nts, st);
 }
 
 hipError_t rz_launch_skin_instances_reg(const RzDeformParams &p, int n_inst, int poses_per_wg, uint32_t grid_x, bool nts,

@@ -215,7 +215,12 @@ static napi_value fn_upload_morphs_dense(napi_env env, napi_callback_info info)
     size_t n;
     if (!get_u32(env, argv[1], &M) || !get_ta(env, argv[2], napi_float32_array, 1, &d, &n))
         return throw_msg(env, "uploadMorphsDense(ctx, M, Float32Array deltas /* M*V*3 */)");
-    if (M && (!d || n % ((size_t)M * 3))) return throw_msg(env, "uploadMorphsDense: deltas length must be M*V*3");
+    // the C ABI copies M*V*3 floats out of `deltas`: the typed array must be exactly that long for THIS context's mesh
+    // (a shorter one — wrong shard, stale model — would be read past its end)
+    int V = 0;
+    if (rz_get_tuning(ctx, "verts", &V)) return throw_rz(env, RZ_ERR_INVALID);
+    if (M && (!d || n != (size_t)M * (size_t)V * 3))
+        return throw_msg(env, "uploadMorphsDense: deltas length must be M*V*3 for the uploaded mesh");
     int rc = rz_upload_morphs_dense(ctx, M, (const float *)d);
     return rc ? throw_rz(env, rc) : undef(env);
 }
@@ -361,6 +366,20 @@ static napi_value fn_set_pose_sampled(napi_env env, napi_callback_info info)
     if (!get_ta(env, argv[1], napi_float32_array, 0, &f, &nf)) return throw_msg(env, "setPoseSampled(ctx, Float32Array frames /* one per instance */)");
     if (rz_get_tuning(ctx, "instances", &I) || nf != (size_t)I) return throw_msg(env, "setPoseSampled: frames must hold one float per instance");
     int rc = rz_set_pose_sampled(ctx, (const float *)f);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_override_world(napi_env env, napi_callback_info info)
+{
+    ARGS(4);
+    CTX(0);
+    void *b = NULL, *w = NULL, *in = NULL;
+    size_t nb = 0, nw = 0, ni = 0;
+    if (!get_ta(env, argv[1], napi_uint32_array, 1, &b, &nb) || !get_ta(env, argv[2], napi_float32_array, 1, &w, &nw) ||
+        !get_ta(env, argv[3], napi_uint32_array, 1, &in, &ni))
+        return throw_msg(env, "overrideWorld(ctx, Uint32Array|null bones, Float32Array|null world16 /* n*16 */, Uint32Array|null instances)");
+    if (nw != nb * 16 || (in && ni != nb)) return throw_msg(env, "overrideWorld: array lengths disagree");
+    int rc = rz_override_world(ctx, (uint32_t)nb, (const uint32_t *)in, (const uint32_t *)b, (const float *)w);
     return rc ? throw_rz(env, rc) : undef(env);
 }
 
@@ -671,7 +690,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "timeFrames", fn_time_frames }, { "setTuning", fn_set_tuning }, { "getTuning", fn_get_tuning },
         { "commUniqueId", fn_comm_unique_id }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },
         { "readGathered", fn_read_gathered }, { "commInitAll", fn_comm_init_all }, { "allgatherAll", fn_allgather_all },
-        { "autotune", fn_autotune }, { "uploadAnimation", fn_upload_animation }, { "setPoseSampled", fn_set_pose_sampled }, { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
+        { "autotune", fn_autotune }, { "uploadAnimation", fn_upload_animation }, { "setPoseSampled", fn_set_pose_sampled }, { "overrideWorld", fn_override_world }, { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value f;

@@ -129,6 +129,11 @@ struct rz_ctx {
     float4 *local_q_buf[2] = {nullptr, nullptr};
     size_t local_q_alloc = 0;
     bool pose_local = false;            // the current pose came from rz_set_pose_local
+    // physics hand-off for device-solved frames (rz_override_world)
+    int *ovr_off = nullptr, *ovr_bone = nullptr;
+    float *ovr_world = nullptr;
+    uint32_t ovr_count = 0;
+    size_t ovr_alloc = 0, ovr_off_alloc = 0;
 
     // morphs
     int morph_mode = 0;                 // 0 none, 1 dense, 2 sparse
@@ -183,7 +188,7 @@ struct rz_ctx {
     RzMorphList ml;
 
     // tuning (0 / -1 = automatic)
-    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1;
+    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1, t_instblock = 0;
     int t_graph = 0;                    // "graph" tuning key: rz_deform_n replays captured hipGraphs of kGraphFrames frames
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_sig = 0;             // signature of everything the captured launches depend on
@@ -213,6 +218,14 @@ int use(rz_ctx *c)
 template <class T> void dfree(T *&p)
 {
     if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+// A captured hipGraph bakes device pointers and launch shapes in. The replay key (frame_signature) covers all of them; on
+// top of that every entry point that frees or re-shapes something a frame reads drops the graph outright.
+void drop_graph(rz_ctx *c)
+{
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    c->graph_sig = 0;
 }
 
 // upload-time scratch that is released on every exit path (HIP_TRY returns early on failure)
@@ -297,6 +310,7 @@ int ensure_pose_buffers(rz_ctx *c)
 
 void free_animation(rz_ctx *c)
 {
+    drop_graph(c);
     dfree(c->an_bone_track); dfree(c->an_feed_track); dfree(c->an_key_off); dfree(c->an_mkey_off); dfree(c->an_feed_off);
     dfree(c->an_key_frame); dfree(c->an_key_pos); dfree(c->an_mkey_frame); dfree(c->an_mkey_weight); dfree(c->an_feed_ratio);
     dfree(c->an_key_rot); dfree(c->an_key_interp);
@@ -323,6 +337,7 @@ void forget_search(rz_ctx *c)
 void free_morphs(rz_ctx *c)
 {
     forget_search(c);
+    drop_graph(c);
     dfree(c->dense); dfree(c->sp_ptr); dfree(c->sp_entries);
     c->morph_mode = 0; c->M = 0; c->Mpad = 12; c->sp_count = 0;
     c->pose_set = false;                  // morph weights belong to the old target set
@@ -341,7 +356,7 @@ int auto_split(const rz_ctx *c)
     return S;
 }
 
-struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; };
+struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; int inst_block; };
 
 RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
 {
@@ -356,7 +371,9 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     p.n_verts = c->V;
     p.Vp = c->Vp; p.n_quads = pl.n_quads; p.quads_per_wave = pl.quads_per_wave; p.dma = pl.dma ? 1 : 0;
     p.B = (int)c->B; p.M = (int)c->M; p.Mpad = (int)c->Mpad;
+#ifdef RZ_ABLATE
     p.dbg = c->t_dbg;
+#endif
     p.out_cap = pl.out_cap;
     return p;
 }
@@ -420,19 +437,24 @@ Plan make_plan(const rz_ctx *c)
     //       multiplies by the inverse bind matrices in place — one launch per frame, 39.6-40 us: the staging costs
     //       what the extra launch did, so it is opt-in.
     const bool epilogues = c->edge != nullptr || c->aabb_on;   // only the generic kernel carries the fused consumers
-    if (v.mode == 0 && c->I > 1 && c->t_instloop != 0 && !epilogues) {
+    if (v.mode == 0 && c->I > 1 && c->t_instloop != 0 && c->t_instloop != 9 && !epilogues) {
         const bool in_kernel = c->t_fast == 1 && !c->pose_local;
         const uint32_t slot = in_kernel ? 64u : 48u;           // LDS bytes per bone per pose (deform_kernels.hip)
-        const uint32_t g_lds = (80u * 1024u) / (c->B * slot);  // two workgroups per CU must fit
+        // workgroup size: 256 threads = two workgroups per CU (80 KB of palettes each); 512 / 1024 = one workgroup per CU
+        // whose 8 / 16 waves share one staged palette group (up to 156 KB)
+        const int blk = c->t_instblock == 512 || c->t_instblock == 1024 ? c->t_instblock : 256;
+        const uint32_t wg_per_cu = blk == 256 ? 2u : 1u;
+        const uint32_t g_lds = ((blk == 256 ? 80u : 156u) * 1024u) / (c->B * slot);
         int G = (int)std::min<uint32_t>(8, g_lds);
-        if (c->t_instloop > 0 && c->t_instloop <= 8) G = (int)std::min<uint32_t>(g_lds, (uint32_t)c->t_instloop);
+        if (c->t_instloop > 0) G = (int)std::min<uint32_t>(g_lds, (uint32_t)c->t_instloop);
         if (G >= 2) {
             G = (int)std::min<uint32_t>((uint32_t)G, c->I);
             const uint32_t groups = (c->I + G - 1) / G;
-            uint32_t total = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : 2u * (uint32_t)c->n_cu;
+            uint32_t total = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : wg_per_cu * (uint32_t)c->n_cu;
             uint32_t gxi = std::max<uint32_t>(1, total / groups);
             uint32_t per = round_up((c->V + gxi - 1) / gxi, 64);
             pl.inst_group = G;
+            pl.inst_block = blk;
             pl.verts_per_wg = per;
             pl.prep = !in_kernel;
             pl.dma = !in_kernel;
@@ -474,16 +496,17 @@ int check_ready(rz_ctx *c)
 
 int launch_prep(rz_ctx *c);
 
-int launch_fk(rz_ctx *c)
+RzFkParams fk_params(const rz_ctx *c)
 {
     RzFkParams p;
-    memset(&p, 0, sizeof p);
+    memset(&p, 0, sizeof p);            // padding too: frame_signature() hashes the struct
     p.local_q = c->local_q;
     p.local_t = c->pose_local_t ? reinterpret_cast<const float *>(c->local_q + (size_t)c->I * c->B) : nullptr;
     p.append_move = c->fk_append_move;
     p.parents = c->fk_parents; p.bind = c->fk_bind; p.append_parent = c->fk_append_parent;
     p.append_ratio = c->fk_append_ratio; p.order = c->fk_order; p.level_off = c->fk_level_off; p.inv_bind = c->inv_bind;
     p.world = c->world; p.palette = c->palette; p.B = (int)c->B; p.n_levels = c->fk_levels;
+    if (c->ovr_count) { p.ovr_off = c->ovr_off; p.ovr_bone = c->ovr_bone; p.ovr_world = c->ovr_world; }
     if (c->pose_sampled) {
         RzSampleParams &q = p.sample;
         q.frames = c->an_frames; q.bone_track = c->an_bone_track; q.key_off = c->an_key_off; q.key_frame = c->an_key_frame;
@@ -492,7 +515,12 @@ int launch_fk(rz_ctx *c)
         q.feed_off = c->an_feed_off; q.feed_track = c->an_feed_track; q.feed_ratio = c->an_feed_ratio;
         q.morph_w = c->morph_w; q.M = (int)c->M;
     }
-    HIP_TRY(rz_launch_fk(p, c->I, c->stream));
+    return p;
+}
+
+int launch_fk(rz_ctx *c)
+{
+    HIP_TRY(rz_launch_fk(fk_params(c), c->I, c->stream));
     return RZ_OK;
 }
 
@@ -524,7 +552,7 @@ int launch_deform(rz_ctx *c, const Plan &pl)
         return RZ_OK;
     }
     if (pl.inst_group > 0) {
-        HIP_TRY(rz_launch_skin_instances(p, pl.inst_group, (int)c->I, pl.verts_per_wg, pl.grid_x, pl.v.nts, c->stream));
+        HIP_TRY(rz_launch_skin_instances(p, pl.inst_group, (int)c->I, pl.verts_per_wg, pl.grid_x, pl.inst_block, pl.v.nts, c->stream));
         return RZ_OK;
     }
     size_t lds = rz_deform_lds_bytes(p, pl.v);
@@ -563,6 +591,8 @@ int upload_skinning(rz_ctx *c, uint32_t V, const uint16_t *joints4, const uint8_
 // the root's list.
 void drop_direct_gather(rz_ctx *c)
 {
+    drop_graph(c);
+    for (rz_ctx *k : c->contributors) drop_graph(k);
     for (rz_ctx *k : c->contributors) {
         if (k != c) { (void)hipSetDevice(k->device); if (k->stream) (void)hipStreamSynchronize(k->stream); }
         k->ext_pos = k->ext_nrm = nullptr;
@@ -660,13 +690,14 @@ int rz_destroy(rz_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
     drop_direct_gather(c);
-    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    drop_graph(c);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->inv_bind);
     dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind);
     free_animation(c); dfree(c->an_frames);
     dfree(c->fk_append_ratio); dfree(c->fk_append_move); dfree(c->local_q_buf[0]); dfree(c->local_q_buf[1]);
+    dfree(c->ovr_off); dfree(c->ovr_bone); dfree(c->ovr_world);
     free_morphs(c);
     for (int k = 0; k < 2; ++k) {
         dfree(c->world_buf[k]); dfree(c->morph_w_buf[k]);
@@ -744,6 +775,8 @@ int rz_upload_skeleton(rz_ctx *c, uint32_t B, const float *inverse_bind16)
     if (B == 0 || !inverse_bind16) return fail(RZ_ERR_INVALID, "rz_upload_skeleton: model has no bones");
     if ((size_t)B * 48 + 8192 > 160 * 1024) return fail(RZ_ERR_UNSUPPORTED, "more than %d bones do not fit the LDS palette", (160 * 1024 - 8192) / 48);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    c->ovr_count = 0;
     dfree(c->inv_bind);
     HIP_TRY(hipMalloc(&c->inv_bind, (size_t)B * 16 * sizeof(float)));
     HIP_TRY(hipMemcpy(c->inv_bind, inverse_bind16, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice));
@@ -832,7 +865,15 @@ int rz_set_instances(rz_ctx *c, uint32_t I)
     if (int r = use(c)) return r;
     if (I == 0 || I > 65535) return fail(RZ_ERR_INVALID, "instance count must be 1..65535");
     if (I > 1 && (c->comm || c->gather_root)) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive");
-    if (I != c->I) { forget_search(c); c->aabb_rearm = true; }
+    if (I != c->I) {
+        forget_search(c);
+        drop_graph(c);
+        c->aabb_rearm = true;
+        c->ovr_count = 0;                 // overrides name (instance, bone) pairs of the old crowd
+        // The host-compacted active-morph list is only maintained while I == 1 (upload_pose). Coming back to one instance
+        // from a crowd it is stale (zeroed): let the prep kernel compact instance 0's weights, which are still on the device.
+        if (c->M > 0 && c->morph_mode == 1) c->ml.count = -1;
+    }
     c->I = I;
     if (int r = ensure_pose_buffers(c)) return r;
     return ensure_outputs(c);
@@ -974,6 +1015,8 @@ int rz_upload_skeleton_topology(rz_ctx *c, uint32_t B, const int32_t *parents, c
         if (append_move) mv[b] = append_move[b] ? 1 : 0;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    c->ovr_count = 0;
     dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind); dfree(c->fk_append_ratio);
     dfree(c->fk_append_move);
     HIP_TRY(hipMalloc(&c->fk_append_move, B));
@@ -1033,14 +1076,16 @@ int rz_upload_animation(rz_ctx *c, const rz_animation *a)
         if (b < 0 || (uint32_t)b >= c->B) continue;                      // a motion may key bones this model lacks
         if (bone_track[b] >= 0) return fail(RZ_ERR_INVALID, "bone %d is driven by two tracks", b);
         for (uint32_t k = a->key_off[t] + 1; k < a->key_off[t + 1]; ++k)
-            if (!(a->key_frame[k] > a->key_frame[k - 1])) return fail(RZ_ERR_INVALID, "track %u: key frames must ascend", t);
+            // equal frames are legal (real VMD files carry duplicate keys; host/vmd-sampler.js keeps them too): the span search
+            // lands on the last key <= frame and the first key > frame, so a zero-length span is never divided by
+            if (!(a->key_frame[k] >= a->key_frame[k - 1])) return fail(RZ_ERR_INVALID, "track %u: key frames must not descend", t);
         bone_track[b] = (int)t;
     }
     const uint32_t Km = mt ? a->mkey_off[mt] : 0;
     for (uint32_t t = 0; t < mt; ++t) {
         if (a->mkey_off[t] > a->mkey_off[t + 1]) return fail(RZ_ERR_INVALID, "morph key offsets must be non-decreasing");
         for (uint32_t k = a->mkey_off[t] + 1; k < a->mkey_off[t + 1]; ++k)
-            if (!(a->mkey_frame[k] > a->mkey_frame[k - 1])) return fail(RZ_ERR_INVALID, "morph track %u: key frames must ascend", t);
+            if (!(a->mkey_frame[k] >= a->mkey_frame[k - 1])) return fail(RZ_ERR_INVALID, "morph track %u: key frames must not descend", t);
     }
     std::vector<uint32_t> feed_off(c->M + 1, 0);
     uint32_t F = 0;
@@ -1113,6 +1158,61 @@ int rz_set_pose_sampled(rz_ctx *c, const float *frames)
     return RZ_OK;
 }
 
+int rz_override_world(rz_ctx *c, uint32_t n, const uint32_t *instance, const uint32_t *bone, const float *world16)
+{
+    if (int r = use(c)) return r;
+    if (n == 0) { c->ovr_count = 0; return RZ_OK; }
+    if (!c->has_topology) return fail(RZ_ERR_INVALID, "rz_override_world applies to device-solved poses: call rz_upload_skeleton_topology first");
+    if (!bone || !world16) return fail(RZ_ERR_INVALID, "null override arrays");
+    // sort by (instance, bone); of several entries for one bone the LAST wins, like successive boneWorldMatrices.set() calls
+    std::vector<uint32_t> order(n);
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t i = instance ? instance[k] : 0;
+        if (i >= c->I || bone[k] >= c->B) return fail(RZ_ERR_INVALID, "override %u names instance %u bone %u (have %u x %u)", k, i, bone[k], c->I, c->B);
+        for (int e = 0; e < 16; ++e)
+            if (!(world16[(size_t)k * 16 + e] == world16[(size_t)k * 16 + e])) return fail(RZ_ERR_INVALID, "override %u holds a NaN", k);
+        order[k] = k;
+    }
+    auto key = [&](uint32_t k) { return (uint64_t)(instance ? instance[k] : 0) * c->B + bone[k]; };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+    std::vector<int> off(c->I + 1, 0), bones;
+    std::vector<float> mats;
+    for (uint32_t q = 0; q < n; ++q) {
+        if (q + 1 < n && key(order[q + 1]) == key(order[q])) continue;
+        const uint32_t k = order[q];
+        off[(instance ? instance[k] : 0) + 1]++;
+        bones.push_back((int)bone[k]);
+        mats.insert(mats.end(), world16 + (size_t)k * 16, world16 + (size_t)k * 16 + 16);
+    }
+    for (uint32_t i = 0; i < c->I; ++i) off[i + 1] += off[i];
+    const size_t m = bones.size();
+    if (m > c->ovr_alloc || off.size() > c->ovr_off_alloc) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        drop_graph(c);
+        dfree(c->ovr_off); dfree(c->ovr_bone); dfree(c->ovr_world);
+        c->ovr_alloc = std::max<size_t>(m, 64); c->ovr_off_alloc = off.size();
+        c->ovr_count = 0;
+        HIP_TRY(hipMalloc(&c->ovr_off, c->ovr_off_alloc * sizeof(int)));
+        HIP_TRY(hipMalloc(&c->ovr_bone, c->ovr_alloc * sizeof(int)));
+        HIP_TRY(hipMalloc(&c->ovr_world, c->ovr_alloc * 16 * sizeof(float)));
+    }
+    // one pinned ring slot carries offsets | bones | matrices down the compute stream, in order with the frames
+    const size_t b_off = off.size() * sizeof(int), b_bone = m * sizeof(int), b_mat = m * 16 * sizeof(float);
+    int slot = 0;
+    if (int r = stage_acquire(c, std::max<size_t>(b_off + b_bone + b_mat, 4096), &slot)) return r;
+    char *st = static_cast<char *>(c->stage[slot]);
+    memcpy(st, off.data(), b_off);
+    memcpy(st + b_off, bones.data(), b_bone);
+    memcpy(st + b_off + b_bone, mats.data(), b_mat);
+    HIP_TRY(hipMemcpyAsync(c->ovr_off, st, b_off, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ovr_bone, st + b_off, b_bone, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ovr_world, st + b_off + b_bone, b_mat, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->stage_ev[slot], c->stream));
+    c->stage_used[slot] = true;
+    c->ovr_count = (uint32_t)m;
+    return RZ_OK;
+}
+
 int rz_read_world(rz_ctx *c, uint32_t instance, float *world16)
 {
     if (int r = use(c)) return r;
@@ -1143,16 +1243,19 @@ static uint64_t fnv(uint64_t h, const void *p, size_t n)
 
 static uint64_t frame_signature(rz_ctx *c, const Plan &pl)
 {
+    // every parameter block a frame's launches are built from, whole: device pointers included, so a buffer that was
+    // freed and re-allocated (rz_upload_animation, rz_upload_skeleton_topology, a grown pose ring ...) changes the key,
+    // and the bounding-box slot parity as it is RIGHT NOW (the captured frames alternate from it)
     uint64_t h = 1469598103934665603ull;
-    RzDeformParams dp = deform_params(c, pl);
-    dp.aabb_slot &= 1;
+    const RzDeformParams dp = deform_params(c, pl);
     h = fnv(h, &dp, sizeof dp);
     h = fnv(h, &c->ml, sizeof c->ml);
     h = fnv(h, &pl, sizeof pl);
-    RzPrepParams pp = prep_params(c);
+    const RzPrepParams pp = prep_params(c);
     h = fnv(h, &pp, sizeof pp);
-    const uint64_t misc[8] = { c->I, c->pose_local, c->pose_local_t, c->pose_sampled, (uint64_t)c->morph_mode, (uint64_t)(uintptr_t)c->local_q,
-                               (uint64_t)(uintptr_t)c->an_frames, (uint64_t)c->fk_levels };
+    const RzFkParams fp = fk_params(c);
+    h = fnv(h, &fp, sizeof fp);
+    const uint64_t misc[6] = { c->I, c->pose_local, c->pose_local_t, c->pose_sampled, (uint64_t)c->morph_mode, (uint64_t)c->aabb_on };
     return fnv(h, misc, sizeof misc);
 }
 
@@ -1168,12 +1271,18 @@ int rz_deform_n(rz_ctx *c, uint32_t frames)
     if (c->t_graph && frames >= 2 * kGraphFrames) {
         // Launch-bound replay (a 30 k-vertex frame is 3-6 us of GPU time per ~3 us of launch work on the host): capture
         // kGraphFrames whole frames once into a hipGraph and replay that; one launch call per 16 frames.
-        const uint64_t sig = frame_signature(c, pl);
+        // The key is taken from the state the capture starts in. A cached graph whose key differs only in the bounding-box
+        // slot parity is brought back in phase by one plain frame (which the graph's first build needs anyway: it sets the
+        // kernel attributes and loads the modules); kGraphFrames is even, so a replay ends on the parity it began with.
+        uint64_t sig = frame_signature(c, pl);
         if (!c->graph_exec || c->graph_sig != sig) {
-            if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-            if (int r = launch_front(c, pl)) return r;             // one plain frame first: attributes set, modules loaded
+            if (int r = launch_front(c, pl)) return r;
             if (int r = launch_deform(c, pl)) return r;
             ++f;
+            sig = frame_signature(c, pl);
+        }
+        if (!c->graph_exec || c->graph_sig != sig) {
+            drop_graph(c);
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             int rc = RZ_OK;
@@ -1232,6 +1341,7 @@ int rz_upload_edge_scale(rz_ctx *c, uint32_t V, const float *edge_size)
 {
     if (int r = use(c)) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
     if (!edge_size) { dfree(c->edge); return RZ_OK; }
     if (V != c->V || V == 0) return fail(RZ_ERR_INVALID, "edge scale has %u entries but the mesh has %u vertices", V, c->V);
     dfree(c->edge);
@@ -1255,6 +1365,7 @@ int rz_read_hull(rz_ctx *c, uint32_t instance, uint32_t v0, uint32_t n, float *p
 int rz_enable_aabb(rz_ctx *c, int enable)
 {
     if (int r = use(c)) return r;
+    drop_graph(c);
     c->aabb_on = enable != 0;
     c->aabb_rearm = true;
     return ensure_outputs(c);
@@ -1409,10 +1520,19 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
         if (value < 0 || value > 1) return fail(RZ_ERR_INVALID, "graph must be 0 or 1");
         c->t_graph = value;
     } else if (!strcmp(key, "dbg")) {
+#ifdef RZ_ABLATE
         c->t_dbg = value;
+#else
+        // ablation modes (they make the kernels skip work, i.e. emit garbage) are compiled into the tools-only build only
+        return fail(RZ_ERR_INVALID, "tuning key 'dbg' does not exist in the product library (tools-only build: make -C reze-engine_amd/csrc ablate)");
+#endif
     } else if (!strcmp(key, "inst_loop")) {
-        if (value < -1 || value > 9) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off), 2..8 (poses per workgroup, LDS form) or 9 (register form)");
+        if (value < -1 || value == 1 || value > 16) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off), 2..8 / 10..16 (poses per workgroup, LDS form) or 9 (register form)");
         c->t_instloop = value;
+    } else if (!strcmp(key, "inst_block")) {
+        if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(RZ_ERR_INVALID, "inst_block must be 0 (auto), 256, 512 or 1024 threads per workgroup");
+        c->t_instblock = value;
+        c->tuned_by_search = false;
     } else if (!strcmp(key, "fast")) {
         c->t_fast = value;        // -1 auto, 0 never (always prep kernel), 1 when possible
     } else {
@@ -1439,6 +1559,8 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "effective_unroll")) *value = make_plan(c).v.U;
     else if (!strcmp(key, "effective_fast")) *value = make_plan(c).v.fast ? 1 : 0;
     else if (!strcmp(key, "inst_loop")) *value = c->t_instloop;
+    else if (!strcmp(key, "inst_block")) *value = c->t_instblock;
+    else if (!strcmp(key, "effective_inst_block")) *value = make_plan(c).inst_block;
     else if (!strcmp(key, "out_cap")) *value = c->t_outcap;
     else if (!strcmp(key, "graph")) *value = c->t_graph;
     else if (!strcmp(key, "effective_out_cap")) *value = (int)make_plan(c).out_cap;

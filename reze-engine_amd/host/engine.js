@@ -49,6 +49,11 @@ class Engine {
     this.gather = o.gather === 'direct' ? 'direct' : o.gather === true
     this.morphLayout = o.morphLayout || 'sparse'
     this.realtime = o.realtime !== false // false: time only advances through step()
+    // physics hand-off (engine.ts:2379-2381): an object with the reference Physics' step(dt, worldMats, inverseBind),
+    // called between evaluatePose() and the world-matrix upload; it may overwrite world matrices in place. Physics
+    // itself (Bullet via @fred3d/ammo) is out of scope — this is only the seam it plugs into.
+    this.physics = o.physics || null
+    this.lastPhysicsTime = null
     this.native = null
     // deviceSampling (needs deviceFK): seekFrame() sends one float — the frame — and the motion is sampled on the GPU
     this.deviceSampling = o.deviceSampling === true && o.deviceFK === true
@@ -343,6 +348,12 @@ class Engine {
     const tra = gpuFK && model.applyLocalTranslations ? model.runtimeSkeleton.localTranslations : null
     if (gpuFK) model.updateRotationTweens() // tweens stay on the host; the hierarchy solve moves to the GPU
     else model.evaluatePose()
+    if (this.physics && !gpuFK) { // updateModelPose(): physics.step(deltaTime, worldMats, inverseBind) mutates in place
+      const now = this.now()
+      const dt = this.lastPhysicsTime === null ? 0 : (now - this.lastPhysicsTime) / 1000
+      this.lastPhysicsTime = now
+      this.physics.step(dt, model.getBoneWorldMatrices(), model.getBoneInverseBindMatrices())
+    }
     const mw = model.getMorphCount() > 0 ? model.getEffectiveMorphWeights() : null
     // per-frame inputs are replicated to every shard (16-22 KB); launches are asynchronous, so the GPUs run concurrently
     for (const s of this.shards) {
@@ -397,6 +408,22 @@ class Engine {
     if (this.gather === 'direct' && this.shards.length > 1) this.native.gatherFence(this.ctx)
     else if (this.gather && this.shards.length > 1) this.native.allgatherAll(this.shards.map((s) => s.ctx), true)
     this.updateStats(wallClock() - t0)
+  }
+
+  /**
+   * Physics hand-off when the hierarchy is solved on the GPU ({ deviceFK }): the world matrices of physics-driven bones
+   * (what physics.ts:715-751 writes with boneWorldMatrices.set(values, boneIndex * 16)) replace the solved ones after
+   * the hierarchy solve in every following frame, until the next call; an empty list clears. Children keep the
+   * matrices solved from the un-overridden parent, as in the reference. `instances` (optional) names the crowd member
+   * of each entry. On the host-FK path use the { physics } option instead — there the host owns the world matrices.
+   */
+  setBoneWorldOverrides(boneIndices, worldMatrices, instances) {
+    if (!this.ctx) throw new Error('Engine.init() has not been called')
+    if (!this.deviceFK) throw new Error('setBoneWorldOverrides needs new Engine(canvas, { deviceFK: true }); with host FK pass { physics }')
+    const b = boneIndices && boneIndices.length ? Uint32Array.from(boneIndices) : null
+    const w = b ? (worldMatrices instanceof Float32Array ? worldMatrices : Float32Array.from(worldMatrices)) : null
+    const i = b && instances ? Uint32Array.from(instances) : null
+    for (const s of this.shards) if (s.count > 0) this.native.overrideWorld(s.ctx, b, w, i)
   }
 
   /** Deterministic stepping: move the clock to timeMs, fire the timers that came due, render one frame. */

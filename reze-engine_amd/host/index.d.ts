@@ -40,6 +40,8 @@ export interface EngineOptions {
    *  straight into the first GPU's gathered buffer over xGMI — no collective, GPUs may repeat in `devices`. */ gather?: boolean | 'direct'
   /** How PMX vertex morphs are laid out in HBM (default 'sparse'). */ morphLayout?: 'sparse' | 'dense'
   /** false: time only advances through step(timeMs). */ realtime?: boolean
+  /** Physics hand-off (engine.ts:2379-2381), host-FK frames: step() may overwrite world matrices in place before they are uploaded. */
+  physics?: { step(dt: number, boneWorldMatrices: Float32Array, boneInverseBindMatrices: Float32Array): void }
 }
 export interface EngineStats {
   fps: number; frameTime: number; gpuMemory: number
@@ -60,6 +62,8 @@ export class Engine {
   seekFrame(frame: number | ArrayLike<number>): void
   /** n independently posed copies of the model (needs { deviceFK, deviceSampling }, one GPU). */
   setInstanceCount(n: number): void
+  /** Physics hand-off with { deviceFK }: world matrices (column-major 4x4 each) that replace the GPU-solved ones of the listed bones until the next call. */
+  setBoneWorldOverrides(boneIndices: ArrayLike<number>, worldMatrices: ArrayLike<number>, instances?: ArrayLike<number>): void
   getDeformed(instance?: number): { positions: Float32Array; normals: Float32Array }
   getOutlineHull(): Float32Array
   getBounds(): { min: number[]; max: number[] }

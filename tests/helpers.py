@@ -23,6 +23,17 @@ def assert_parity(pos_g, nrm_g, pos_r, nrm_r, what=""):
     return float(ep.max()), float(en.max())
 
 
+def assert_hull(hull_g, hull_r, what=""):
+    """Outline hull P + N * edge * 0.01 (engine.ts:458-461): same per-vertex bar as positions —
+    |Hg - Hr|_2 <= POS_TOL * max(|Hr|_2, 1). (edge <= 1.5, so the hull error is the position error + 0.015 x the normal error.)"""
+    hull_g = np.asarray(hull_g, dtype=np.float64)
+    hull_r = np.asarray(hull_r, dtype=np.float64)
+    assert np.isfinite(hull_g).all(), "NaN/Inf in the hull " + what
+    e = np.linalg.norm(hull_g - hull_r, axis=1) / np.maximum(np.linalg.norm(hull_r, axis=1), 1.0)
+    assert e.max() <= POS_TOL, "%s hull error max %.3e" % (what, e.max())
+    return float(e.max())
+
+
 def fk_reference(parents, bind, quats, trans=None, append_parent=None, append_ratio=None, append_move=None):
     """Model.computeWorldMatrices with this build's local translations (engine/src/model.ts:330-420 restated in float64):
     R = fromQuat(q); with an append parent and |clamp(ratio)| > 1e-6: R = fromQuat(slerp(I, +-q_ap, |ratio|)) * R and,

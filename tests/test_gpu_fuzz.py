@@ -5,7 +5,7 @@ Catches stale plans, stale buffers and flags that outlive the data they describe
 import numpy as np
 import pytest
 
-from helpers import assert_parity, fk_reference, sample_reference
+from helpers import assert_hull, assert_parity, fk_reference, sample_reference
 from reze_engine_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -158,7 +158,7 @@ class Walk:
         pg, ng = self.c.read(instance=i)
         assert_parity(pg, ng, pr, nr, "walk step, V=%d B=%d M=%d(%s) I=%d local=%s" % (len(pr), B, self.M, self.kind, I, local))
         if self.edge is not None:
-            assert np.abs(self.c.read_hull(instance=i) - self.oracle.hull(pr, nr, self.edge)).max() <= 1e-3
+            assert_hull(self.c.read_hull(instance=i), self.oracle.hull(pr, nr, self.edge), "fuzz hull instance %d" % i)
         if self.aabb:
             bb = self.c.read_aabb(i)
             assert np.abs(bb[:3] - pg.min(axis=0)).max() <= 1e-5 and np.abs(bb[3:] - pg.max(axis=0)).max() <= 1e-5, \

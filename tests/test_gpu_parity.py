@@ -3,7 +3,7 @@ same seeded inputs (BASELINE.json configs C2-C5), plus size-independent properti
 import numpy as np
 import pytest
 
-from helpers import assert_parity
+from helpers import assert_hull, assert_parity
 from reze_engine_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -639,7 +639,7 @@ def test_fused_outline_hull_and_bounding_box(ctx, oracle):
         hg = ctx.read_hull()
         assert_parity(pg, ng, pr, nr, "with epilogues S=%d" % split)
         href = oracle.hull(pr, nr, edge)
-        assert np.abs(hg - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
+        assert_hull(hg, href, "hull S=%d" % split)
         assert np.array_equal(hg[::4], pg[::4])            # edge 0 => hull == position
         box = ctx.read_aabb()
         assert np.array_equal(box[:3], pg.min(axis=0)) and np.array_equal(box[3:], pg.max(axis=0))   # exact on the GPU's own output
@@ -657,7 +657,7 @@ def test_fused_outline_hull_and_bounding_box(ctx, oracle):
         box = ctx.read_aabb(i)
         assert np.array_equal(box[:3], pg.min(axis=0)) and np.array_equal(box[3:], pg.max(axis=0))
         p_i, n_i = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[i], mesh["inv_bind"])
-        assert np.abs(ctx.read_hull(i) - oracle.hull(p_i, n_i, edge)).max() <= 1e-3
+        assert_hull(ctx.read_hull(i), oracle.hull(p_i, n_i, edge), "hull instance %d" % i)
     ctx.upload_edge_scale(None)
     ctx.enable_aabb(False)
     ctx.set_instances(1)
@@ -772,7 +772,7 @@ def test_graph_replay_is_the_same_frames(rz, oracle):
     pg, ng = both(lambda: c.set_pose(world2, mw))
     bb = c.read_aabb()
     assert np.abs(bb[:3] - pg.min(axis=0)).max() <= 1e-5 and np.abs(bb[3:] - pg.max(axis=0)).max() <= 1e-5
-    assert np.abs(c.read_hull() - oracle.hull(pr, nr, np.full(V, 0.5, np.float32))).max() <= 1e-3
+    assert_hull(c.read_hull(), oracle.hull(pr, nr, np.full(V, 0.5, np.float32)), "hull under graph replay")
     c.enable_aabb(False); c.upload_edge_scale(None); c.upload_morphs_dense(None)
     I = 9
     c.set_instances(I)
@@ -925,7 +925,7 @@ def test_engine_through_napi_matches_oracle(tmp_path, oracle):
             edge = rd("edge.f32", np.float32)
             assert (edge > 0).sum() > 0
             hull = rd("hull_%d.f32" % step, np.float32).reshape(-1, 3)
-            assert np.abs(hull - oracle.hull(pr, nr, edge)).max() <= 1e-3
+            assert_hull(hull.reshape(-1, 3), oracle.hull(pr, nr, edge), "hull through N-API")
             box = rd("bounds_%d.f32" % step, np.float32)
             assert np.array_equal(box[:3], pg.min(axis=0)) and np.array_equal(box[3:], pg.max(axis=0))
             seen_morph = seen_morph or (mw != 0).sum() >= 3

@@ -1,0 +1,303 @@
+"""GPU tests added in round 2: BASELINE config 4 at FULL size, real model vertices under a reference-produced pose (pinned
+to reference execution), the physics hand-off for device-solved poses, and regression tests for the round-1 review
+(graph replay keys, instance-count changes, duplicate VMD keys, ablation keys absent from the product)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_parity, fk_reference, sample_reference
+from reze_engine_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_c1_pose0.npz")
+
+
+def _identity_world(mesh, B):
+    q = np.zeros((B, 4), dtype=np.float32)
+    q[:, 3] = 1
+    return synth.fk_world(mesh["parents"], mesh["bind"], q)
+
+
+def test_c4_full_size_256x30k_200b(rz, oracle):
+    """BASELINE config 4 at full size: 256 instances x 30 000 verts / 200 bones, per-instance palette in LDS
+    (rz_skin_instances_kernel), with the built-in plan AND the plan rz_autotune picks. vs() restatement engine.ts:253-272:
+      * oracle parity on instances 0, 127, 255 and one random instance;
+      * instance k is BIT-IDENTICAL to the same pose run alone as a single-instance frame (one-launch and prep-kernel
+        forms): the crowd kernel evaluates the same FMA chains in the same order as rz_deform_kernel;
+      * every instance under the identity pose is the rest mesh."""
+    V, B, I = 30000, 200, 256
+    mesh = synth.make_mesh(V, B)
+    worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=1000 + i) for i in range(I)])
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    rnd = int(np.random.default_rng(2).integers(1, I - 1))
+    picks = sorted({0, 127, 255, rnd})
+    singles = {}
+    for k in picks:                                        # the same poses as single-instance frames, both forms
+        for fast in (1, 0):
+            c.set_instances(1)
+            c.set_tuning(fast=fast)
+            c.set_pose(worlds[k])
+            c.deform()
+            singles[(k, fast)] = c.read()
+    assert np.array_equal(singles[(0, 1)][0], singles[(0, 0)][0])
+    c.set_tuning(fast=-1)
+    c.set_instances(I)
+    c.set_pose(worlds)
+    plans = []
+    for tuned in (False, True):
+        if tuned:
+            c.autotune(20)
+        c.deform()
+        assert c.get_tuning("effective_inst_group") >= 2, "C4 must run the instanced (palette-group-in-LDS) kernel"
+        plans.append((c.get_tuning("effective_inst_group"), c.get_tuning("effective_grid")))
+        for k in picks:
+            pg, ng = c.read(instance=k)
+            pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[k], mesh["inv_bind"], threads=4)
+            assert_parity(pg, ng, pr, nr, "C4 full size instance %d (autotuned=%s)" % (k, tuned))
+            for fast in (1, 0):
+                ps, ns = singles[(k, fast)]
+                assert np.array_equal(pg, ps) and np.array_equal(ng, ns), "instance %d differs from its single-instance frame (fast=%d)" % (k, fast)
+        # palettes of the crowd are observable too (engine.ts:926-928)
+        S = oracle.palette(worlds[rnd], mesh["inv_bind"]).reshape(-1, 4, 4)
+        np.testing.assert_allclose(c.read_palette(rnd), np.transpose(S, (0, 2, 1))[:, :3, :].reshape(-1, 12), rtol=1e-6, atol=1e-6)
+    # identity pose in EVERY instance == rest mesh, all 256 read back
+    ident = np.tile(_identity_world(mesh, B)[None], (I, 1, 1))
+    c.set_pose(ident)
+    c.deform()
+    for k in range(I):
+        pg, ng = c.read(instance=k)
+        assert np.abs(pg - mesh["pos"]).max() <= 2e-5 and np.abs(ng - mesh["nrm"]).max() <= 1e-6, "identity pose, instance %d" % k
+    c.close()
+
+
+@pytest.mark.parametrize("pose", ["pose0", "tween150"])
+def test_real_model_vertices_under_the_reference_pose(rz, oracle, pose):
+    """Real vertices of the demo model (256-vertex slices of its vertex / joints / weights buffers as the reference's
+    loader produced them) deformed on the GPU under world matrices the reference's own Model.evaluatePose produced.
+    Checked against (a) the oracle and (b) DIRECTLY against reference execution: the palette the reference's Mat4.multiply
+    computed (math.ts:303-320) and the slice skinned with the reference's Mat4 / Vec3 primitives composed as vs()
+    (engine.ts:255-272) — tests/golden/ref_c1_pose0.npz, tools/ref_erased_run.py. Tolerance 1e-4 (north_star)."""
+    g = np.load(GOLD)
+    v = g["slice_vertices"]
+    pos, nrm = np.ascontiguousarray(v[:, 0:3]), np.ascontiguousarray(v[:, 3:6])
+    c = rz.DeformContext(0)
+    for upload in ("soa", "interleaved"):
+        if upload == "soa":
+            c.upload_mesh(pos, nrm, g["slice_joints"], g["slice_weights"])
+        else:
+            c.upload_mesh_interleaved(v, g["slice_joints"], g["slice_weights"])      # the reference's own 8-float layout
+        c.upload_skeleton(g["inv_bind"])
+        for fast in (1, 0):
+            c.set_tuning(fast=fast)
+            c.set_pose(g["world_" + pose])
+            c.deform()
+            pg, ng = c.read()
+            pr, nr = oracle.deform(pos, nrm, g["slice_joints"], g["slice_weights"], g["world_" + pose], g["inv_bind"])
+            assert_parity(pg, ng, pr, nr, "real slice vs oracle (%s, fast=%d)" % (upload, fast))
+            ref = g["skinned_" + pose]
+            assert_parity(pg, ng, ref[:, :3], ref[:, 3:], "real slice vs REFERENCE EXECUTION (%s, fast=%d)" % (upload, fast))
+            pal = c.read_palette()                          # rows 0..2, row-major 3x4
+            ref_pal = np.transpose(g["palette_" + pose].reshape(-1, 4, 4), (0, 2, 1))[:, :3, :].reshape(-1, 12)
+            scale = np.maximum(1.0, np.abs(ref_pal).max(axis=1, keepdims=True))
+            assert (np.abs(pal - ref_pal) <= 1e-5 * scale).all(), "palette vs the reference's Mat4.multiply: %g" % np.abs(pal - ref_pal).max()
+    c.close()
+
+
+def test_override_world_is_the_physics_hand_off(rz, oracle):
+    """rz_override_world mirrors engine.ts:2379-2381 for device-solved poses: the supplied world matrices replace the
+    solved ones of the listed bones after the hierarchy solve; children keep the matrices solved from the un-overridden
+    parent. Equals the host path fed with the same in-place edit; last entry wins; n = 0 clears; per-instance entries."""
+    V, B, I = 5000, 60, 3
+    mesh = synth.make_mesh(V, B, seed=91)
+    rng = np.random.default_rng(92)
+    q = rng.normal(size=(I, B, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=2, keepdims=True)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    c.set_instances(I)
+    with pytest.raises(Exception):
+        c.override_world([1], np.eye(4, dtype=np.float32).reshape(1, 16))           # no topology yet
+    c.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+    c.set_pose_local(q)
+    c.deform()
+    solved = np.stack([c.read_world(i) for i in range(I)])
+    bones = np.array([5, 17, 17, 40, 3], dtype=np.uint32)
+    insts = np.array([0, 0, 0, 2, 1], dtype=np.uint32)
+    mats = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=300 + k)[int(b)] for k, b in enumerate(bones)])
+    c.override_world(bones, mats, insts)
+    for _ in range(2):                                      # persists across frames until replaced
+        c.deform()
+    want = solved.copy()
+    for k in range(len(bones)):                             # in order: the later entry for (0, 17) wins
+        want[insts[k], bones[k]] = mats[k]
+    for i in range(I):
+        got = c.read_world(i)
+        assert np.array_equal(got, want[i]), "world matrices of instance %d" % i
+        pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], want[i], mesh["inv_bind"])
+        pg, ng = c.read(instance=i)
+        assert_parity(pg, ng, pr, nr, "override, instance %d" % i)
+    # the host path given the same in-place edit produces the same frame bit for bit
+    dev = [c.read(instance=i) for i in range(I)]
+    c.set_pose(want)
+    c.deform()
+    for i in range(I):
+        ph, nh = c.read(instance=i)
+        assert np.array_equal(ph, dev[i][0]) and np.array_equal(nh, dev[i][1])
+    # invalid entries are rejected, the context keeps working
+    with pytest.raises(Exception):
+        c.override_world([B], mats[:1], [0])
+    with pytest.raises(Exception):
+        c.override_world([1], mats[:1], [I])
+    bad = mats[:1].copy(); bad[0, 3] = np.nan
+    with pytest.raises(Exception):
+        c.override_world([1], bad, [0])
+    c.set_pose_local(q)
+    c.override_world([], None)                              # clear
+    c.deform()
+    for i in range(I):
+        assert np.array_equal(c.read_world(i), solved[i])
+    # an instance-count change drops the overrides (they name members of the old crowd)
+    c.override_world(bones, mats, insts)
+    c.set_instances(1)
+    c.set_pose_local(q[0])
+    c.deform()
+    assert np.array_equal(c.read_world(0), solved[0])
+    c.close()
+
+
+def test_graph_replay_keys_cover_slot_parity_and_reallocated_buffers(rz, oracle):
+    """Round-1 review: (1) aabb on + graph on + deform_n(32) twice — the second call replays two graphs with no plain frame
+    behind them, the bounding box read back must be the last frame's; (2) an animation (and a topology) re-uploaded
+    between two replays frees and re-allocates buffers the captured FK launches point at: the graph must be rebuilt."""
+    V, B = 7000, 40
+    mesh = synth.make_mesh(V, B, seed=31)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    c.enable_aabb(True)
+    c.set_tuning(graph=1)
+    c.set_pose(mesh["world"])
+    for n in (32, 32, 33, 32, 47, 32):
+        c.deform_n(n)
+        pg, _ = c.read()
+        box = c.read_aabb()
+        assert np.isfinite(box).all(), "re-armed (empty) slot read back after deform_n(%d)" % n
+        assert np.array_equal(box[:3], pg.min(axis=0)) and np.array_equal(box[3:], pg.max(axis=0))
+    c.deform()                                               # and a plain frame after a replay accumulates into a clean slot
+    box = c.read_aabb()
+    assert np.array_equal(box[:3], pg.min(axis=0)) and np.array_equal(box[3:], pg.max(axis=0))
+    c.enable_aabb(False)
+    # (2) sampled poses: replay, re-upload a DIFFERENT motion (buffers freed + re-allocated), replay again
+    c.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+    rng = np.random.default_rng(8)
+    nk = 5
+
+    def motion(seed):
+        r = np.random.default_rng(seed)
+        kq = r.normal(size=(B, nk, 4)).astype(np.float32)
+        kq /= np.linalg.norm(kq, axis=2, keepdims=True)
+        return dict(track_bone=np.arange(B), key_off=np.arange(B + 1) * nk, key_frame=np.tile(np.arange(nk) * 10.0, B),
+                    key_rot=kq, key_pos=(r.random((B, nk, 3), dtype=np.float32) - 0.5) * 0.3, key_interp=None)
+    outs = []
+    for seed in (100, 101, 100):
+        a = motion(seed)
+        # churn the allocator so the re-uploaded tracks do not land on the old addresses by luck
+        junk = [rz.DeformContext(0) for _ in range(2)]
+        c.upload_animation(a["track_bone"], a["key_off"], a["key_frame"], a["key_rot"], a["key_pos"])
+        for j in junk:
+            j.close()
+        c.set_pose_sampled(np.array([17.25], np.float32))
+        c.deform_n(40)
+        q, t, _ = sample_reference(a, 17.25, B, 0)
+        ref = fk_reference(mesh["parents"], mesh["bind"], q, t)
+        got = c.read_world(0)
+        assert np.abs(got - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), "motion %d under graph replay" % seed
+        pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], got, mesh["inv_bind"])
+        pg, ng = c.read()
+        assert_parity(pg, ng, pr, nr, "sampled pose under graph replay (motion %d)" % seed)
+        outs.append(pg)
+    assert np.array_equal(outs[0], outs[2]) and not np.array_equal(outs[0], outs[1])
+    c.upload_skeleton_topology(mesh["parents"], mesh["bind"])           # frees the fk_* arrays a captured graph would name
+    c.set_pose_local(np.tile(np.array([0, 0, 0, 1], np.float32), (B, 1)))
+    c.deform_n(40)
+    np.testing.assert_allclose(c.read()[0], mesh["pos"], rtol=1e-6, atol=2e-5)
+    c.close()
+
+
+def test_crowd_back_to_one_instance_keeps_dense_morph_weights(rz, oracle):
+    """Round-1 review: set_instances(I > 1) -> set_pose -> set_instances(1) -> deform without a new pose. The host-side
+    active-morph list is only maintained for one instance, so the frame must compact instance 0's weights on the device."""
+    V, B, M = 4000, 30, 7
+    mesh = synth.make_mesh(V, B, seed=51)
+    deltas, mw = synth.make_morphs_dense(V, M, seed=52)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    c.upload_morphs_dense(deltas)
+    c.set_instances(3)
+    worlds = np.stack([mesh["world"]] * 3)
+    mws = np.stack([mw, mw * 0.5, mw * 0.0]).astype(np.float32)
+    c.set_pose(worlds, mws)
+    c.deform()
+    c.set_instances(1)
+    c.deform()
+    pg, ng = c.read()
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"], deltas, mw)
+    assert_parity(pg, ng, pr, nr, "instance 0 after the crowd shrank to one")
+    p0, _ = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"])
+    assert np.abs(pr - p0).max() > 1e-3                      # the morphs matter in this frame
+    c.close()
+
+
+def test_device_sampler_accepts_duplicate_key_frames(rz):
+    """Round-1 review: real VMD files carry duplicate-frame keys; host/vmd-sampler.js keeps them (stable sort) and its span
+    search never divides by a zero span. The device sampler takes the same tracks and lands on the same keys."""
+    B = 12
+    mesh = synth.make_mesh(500, B, seed=61)
+    rng = np.random.default_rng(62)
+    frames_per = np.array([0, 10, 10, 20, 20, 20, 35], dtype=np.float32)      # duplicates inside, not at the ends only
+    nk = len(frames_per)
+    kq = rng.normal(size=(B, nk, 4)).astype(np.float32)
+    kq /= np.linalg.norm(kq, axis=2, keepdims=True)
+    a = dict(track_bone=np.arange(B), key_off=np.arange(B + 1) * nk, key_frame=np.tile(frames_per, B), key_rot=kq,
+             key_pos=(rng.random((B, nk, 3), dtype=np.float32) - 0.5), key_interp=None)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    c.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+    c.upload_animation(a["track_bone"], a["key_off"], a["key_frame"], a["key_rot"], a["key_pos"])
+    for f in (0.0, 5.0, 10.0, 12.5, 20.0, 27.0, 35.0, 50.0):
+        c.set_pose_sampled(np.array([f], np.float32))
+        c.deform()
+        q, t, _ = sample_reference(a, f, B, 0)
+        ref = fk_reference(mesh["parents"], mesh["bind"], q, t)
+        got = c.read_world(0)
+        assert np.isfinite(got).all() and np.abs(got - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), "frame %g" % f
+    bad = a["key_frame"].copy(); bad[3] = 5.0                  # descending is still an error
+    with pytest.raises(Exception):
+        c.upload_animation(a["track_bone"], a["key_off"], bad, a["key_rot"], a["key_pos"])
+    c.close()
+
+
+def test_ablation_key_is_not_part_of_the_product(rz):
+    """The ablation switches ("dbg": kernels skip work, output is garbage) exist only in the tools-only build. The shipped
+    library rejects the key and keeps producing the deformed mesh."""
+    mesh = synth.make_mesh(2000, 16, seed=5)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    c.set_pose(mesh["world"])
+    c.deform()
+    before = c.read()
+    for v in (1, 2, 3, 4, 5):
+        with pytest.raises(rz.capi.RzError):
+            c.set_tuning(dbg=v)
+    c.deform()
+    after = c.read()
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    c.close()

@@ -157,3 +157,43 @@ def test_outline_hull_twins_agree(oracle):
     a = oracle.hull(p, n, e)
     assert np.array_equal(a, oracle.np_twin.hull(p, n, e))
     np.testing.assert_allclose(a, p + n * e[:, None] * 0.01, rtol=1e-6, atol=1e-6)
+
+
+# ---- pins to REFERENCE EXECUTION (tests/golden/ref_c1_pose0.npz, written by tools/ref_erased_run.py) ----
+def _golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_c1_pose0.npz"))
+
+
+@pytest.mark.parametrize("pose", ["pose0", "tween150"])
+def test_palette_pinned_to_the_reference_mat4_multiply(oracle, pose):
+    """engine.ts:926-928 (skin = world * inverseBind) as computed by the reference's own Mat4.multiply (math.ts:303-320) on
+    the real 349-bone model. The reference sums in doubles and stores f32 (<= 0.5 ulp of the result); the oracle (like the
+    WGSL) rounds after each of the 4 products-and-adds. Bound per element: 4 * 2^-24 * SUM_k |a_k b_k| (+ one denormal)."""
+    g = _golden()
+    W, IB, ref = g["world_" + pose], g["inv_bind"], g["palette_" + pose]
+    S = oracle.palette(W, IB).reshape(-1, 16)
+    A = np.abs(W.astype(np.float64)).reshape(-1, 4, 4)           # [b, k, r]  column k of world
+    Bm = np.abs(IB.astype(np.float64)).reshape(-1, 4, 4)         # [b, c, k]  column c of inverse bind
+    bound = np.einsum("bkr,bck->bcr", A, Bm).reshape(-1, 16) * 2.0 ** -22 + 1e-30
+    diff = np.abs(S.astype(np.float64) - ref.astype(np.float64))
+    assert (diff <= bound).all(), "worst excess %.3e" % (diff - bound).max()
+    assert (S == ref).mean() > 0.8                               # most elements are bit-identical
+    assert np.array_equal(S, oracle.np_twin.palette(W, IB))      # and the twins still agree with each other
+
+
+@pytest.mark.parametrize("pose", ["pose0", "tween150"])
+def test_skin_pinned_to_reference_primitives_on_real_vertices(oracle, pose):
+    """vs() (engine.ts:255-272) of 256 real vertices of the demo model, evaluated in the reference run with math.ts'
+    Mat4.multiply / Vec3.scale / add / normalize (doubles); 173 of them are BDEF1, where the position is a single
+    Mat4.multiply. Bar: 1e-6 relative (f32 rounding of a handful of operations; the GPU tolerance is 1e-4)."""
+    g = _golden()
+    v = g["slice_vertices"]
+    S = oracle.palette(g["world_" + pose], g["inv_bind"])
+    p, n = oracle.skin(np.ascontiguousarray(v[:, 0:3]), np.ascontiguousarray(v[:, 3:6]), g["slice_joints"], g["slice_weights"], S)
+    ref = g["skinned_" + pose]
+    ep = np.linalg.norm(p - ref[:, :3], axis=1) / np.maximum(np.linalg.norm(ref[:, :3], axis=1), 1.0)
+    en = np.linalg.norm(n - ref[:, 3:], axis=1)
+    assert ep.max() <= 1e-6 and en.max() <= 1e-6, (ep.max(), en.max())
+    assert (g["slice_weights"][:, 0] == 255).sum() >= 100        # the BDEF1 share the docstring promises
+    assert np.abs(p - v[:, 0:3]).max() > 1e-3 or pose == "pose0"  # tween150 really moves the slice

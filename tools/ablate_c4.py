@@ -5,6 +5,8 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import reze_engine_amd as rz
+# the ablation switches only exist in the tools-only build (make -C reze-engine_amd/csrc ablate)
+rz.capi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ablate", "libreze_deform_ablate.so")
 from reze_engine_amd import synth
 ctx = rz.DeformContext(0)
 mesh = synth.make_mesh(30000, 200)

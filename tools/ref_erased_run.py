@@ -11,7 +11,10 @@ tests/golden/:
 
   ref_c1_pose0.npz   real demo model (web/public/models/塞尔凯特2/塞尔凯特2.pmx) + pool.vmd frame 0,
                      applied the way Engine.playAnimation does (engine.ts:1474-1505): world matrices
-                     [349,16], inverse bind, CRC32s of every parsed array, 256-vertex slices.
+                     [349,16], inverse bind, CRC32s of every parsed array, 256-vertex slices; plus the HOT-PATH
+                     pins: the palette world x inverseBind through the reference's Mat4.multiply (math.ts:303-320)
+                     and the slice vertices skinned with the reference's Mat4 / Vec3 primitives composed as vs()
+                     (engine.ts:255-272), for pose0 and the mid-tween pose.
   ref_models.json    per-asset counts + CRC32s of joints / weights / vertex buffer / inverse bind
                      for the three PMX files and key counts of the two VMD files.
 
@@ -164,10 +167,53 @@ DRIVER = r"""
 const fs = require('fs'), path = require('path'), zlib = require('zlib')
 global.performance = require('perf_hooks').performance
 global.fetch = (p) => Promise.resolve({ arrayBuffer: () => { const b = fs.readFileSync(p); return Promise.resolve(b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength)) } })
-const { PmxLoader } = require('./pmx-loader'), { VMDLoader } = require('./vmd-loader'), { Quat } = require('./math')
+const { PmxLoader } = require('./pmx-loader'), { VMDLoader } = require('./vmd-loader'), { Quat, Vec3, Mat4 } = require('./math')
 const ASSETS = process.argv[2], OUT = process.argv[3]
 const crc = (ta) => zlib.crc32 ? zlib.crc32(Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength)) : null
 const dump = (name, ta) => fs.writeFileSync(path.join(OUT, name), Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength))
+// Hot-path pins executed by the REFERENCE's own math.ts primitives on the reference's own model + pose:
+//   palette   skinMatrices[b] = worldMatrices[b] * inverseBindMatrices[b]  (engine.ts:926-928) through Mat4.multiply
+//             (math.ts:303-320) — doubles with an f32 store, the WGSL does the same sum in f32
+//   skinned   vs() (engine.ts:255-272) of the 256 slice vertices: every M_i * vec4(p, 1) and M_i * vec4(n, 0) is a
+//             Mat4.multiply against a matrix whose last column holds the vector; the weighted sum uses Vec3.scale / add and
+//             the normal Vec3.normalize. For a BDEF1 vertex (weights 255,0,0,0) the result is Mat4.multiply alone.
+function pinHotPath(m, tag) {
+  const world = m.getBoneWorldMatrices(), ib = m.getSkeleton().inverseBindMatrices
+  const B = m.getSkeleton().bones.length
+  const pal = new Float32Array(B * 16), mats = []
+  for (let b = 0; b < B; b++) {
+    const S = new Mat4(world.slice(b * 16, b * 16 + 16)).multiply(new Mat4(ib.slice(b * 16, b * 16 + 16)))
+    pal.set(S.values, b * 16)
+    mats.push(S)
+  }
+  dump('m2_palette_' + tag + '.f32', pal)
+  const v = m.getVertices(), sk = m.getSkinning(), V = m.getVertexCount()
+  const idx = []
+  for (let i = 0; i < 128; i++) idx.push(i)
+  for (let i = 14000; i < 14064; i++) idx.push(i)
+  for (let i = V - 64; i < V; i++) idx.push(i)
+  const out = new Float64Array(idx.length * 6)
+  idx.forEach((vi, k) => {
+    const w = [0, 1, 2, 3].map((i) => sk.weights[vi * 4 + i] / 255)
+    const sum = w[0] + w[1] + w[2] + w[3]
+    const inv = sum > 0.0001 ? 1 / sum : 1                       // engine.ts:255-257
+    const nw = sum > 0.0001 ? w.map((x) => x * inv) : [1, 0, 0, 0]
+    let P = new Vec3(0, 0, 0), N = new Vec3(0, 0, 0)
+    for (let i = 0; i < 4; i++) {
+      const S = mats[sk.joints[vi * 4 + i]]
+      const col = new Float32Array(16)
+      col[0] = 1; col[5] = 1; col[10] = 1
+      col[12] = v[vi * 8]; col[13] = v[vi * 8 + 1]; col[14] = v[vi * 8 + 2]; col[15] = 1
+      P = P.add(S.multiply(new Mat4(col)).getPosition().scale(nw[i]))
+      const ncol = new Float32Array(16)
+      ncol[12] = v[vi * 8 + 3]; ncol[13] = v[vi * 8 + 4]; ncol[14] = v[vi * 8 + 5]; ncol[15] = 0
+      N = N.add(S.multiply(new Mat4(ncol)).getPosition().scale(nw[i]))
+    }
+    N = N.normalize()
+    out.set([P.x, P.y, P.z, N.x, N.y, N.z], k * 6)
+  })
+  dump('m2_skinned_' + tag + '.f64', out)
+}
 ;(async () => {
   const silent = console.warn; console.warn = () => {}
   const models = { 'models/塞尔凯特2/塞尔凯特2.pmx': 'm2', 'models/塞尔凯特/塞尔凯特.pmx': 'm1', 'models/塞尔凯特/武器.pmx': 'w' }
@@ -199,6 +245,7 @@ const dump = (name, ta) => fs.writeFileSync(path.join(OUT, name), Buffer.from(ta
       m.evaluatePose()
       dump('m2_world_pose0.f32', m.getBoneWorldMatrices())
       dump('m2_localrot_pose0.f32', m.runtimeSkeleton.localRotations)
+      pinHotPath(m, 'pose0')
       info.pool = { keyTimes: frames.map((f) => [Math.round(f.time * 30), f.boneFrames.length]), bones0: names0 }
       // a second pose exercising tweens: a 400 ms tween sampled at +150 ms through the reference's own clock
       let now = 1000
@@ -208,6 +255,7 @@ const dump = (name, ta) => fs.writeFileSync(path.join(OUT, name), Buffer.from(ta
       m.evaluatePose()
       dump('m2_world_tween150.f32', m.getBoneWorldMatrices())
       dump('m2_localrot_tween150.f32', m.runtimeSkeleton.localRotations)
+      pinHotPath(m, 'tween150')
       now = 1500
       m.evaluatePose()
       dump('m2_world_tween500.f32', m.getBoneWorldMatrices())
@@ -267,6 +315,10 @@ def main():
         parents=np.array(d["parents"], dtype=np.int32), bind=np.array(d["bind"], dtype=np.float64),
         append_parent=np.array(d["appendParent"], dtype=np.int32), append_ratio=np.array(d["appendRatio"], dtype=np.float64),
         append_rotate=np.array(d["appendRotate"]), append_move=np.array(d["appendMove"]),
+        palette_pose0=rd("m2_palette_pose0.f32", np.float32).reshape(-1, 16),
+        palette_tween150=rd("m2_palette_tween150.f32", np.float32).reshape(-1, 16),
+        skinned_pose0=rd("m2_skinned_pose0.f64", np.float64).reshape(-1, 6),
+        skinned_tween150=rd("m2_skinned_tween150.f64", np.float64).reshape(-1, 6),
         slice_index=sl.astype(np.int32), slice_vertices=v[sl],
         slice_joints=rd("m2_joints.u16", np.uint16).reshape(-1, 4)[sl],
         slice_weights=rd("m2_weights.u8", np.uint8).reshape(-1, 4)[sl])
