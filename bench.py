@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--share-gpu", action="store_true", help="map every rank onto GPU (local_rank %% visible devices)")
     ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs of 16 frames in the timed loop (rz_set_tuning graph=1): for launch-bound small frames")
     ap.add_argument("--tune", default="", help="comma list key=value passed to rz_set_tuning (disables the autotune pass)")
+    ap.add_argument("--no-sampled-loop", action="store_true", help="skip the secondary per-frame loop with the motion sampled on the GPU")
     ap.add_argument("--no-autotune", action="store_true", help="skip rz_autotune (setup-time search over launch shapes) and use the built-in heuristics")
     return ap.parse_args()
 
@@ -64,7 +65,7 @@ def cpu_baseline(args, mesh, deltas, mw):
     Preferred: the all-core JavaScript f32 skin (oracle/js/cpu_baseline.js, worker_threads).
     Fallback: the threaded C oracle, labelled as a stand-in."""
     import oracle
-    n = min(args.cpu_sample_verts, len(mesh["pos"]))
+    n = min(args.cpu_sample_verts, len(mesh["pos"]))     # rank 0's shard = the head of the mesh
     sub = {k: np.ascontiguousarray(mesh[k][:n]) for k in ("pos", "nrm", "joints", "weights")}
     d = None if deltas is None else np.ascontiguousarray(deltas[:, :n])
     cores = os.cpu_count() or 1
@@ -151,13 +152,11 @@ def main():
     B, M, I = args.bones, args.morphs, args.instances
     b, n, _chunk = rz.shard.shard_of(V_total, world_size, rank)
 
-    # every rank generates the same full mesh deterministically and keeps its shard
-    mesh = synth.make_mesh(V_total, B)
-    if M > 0:
-        deltas_full, mw = synth.make_morphs_dense(V_total, M)
-    else:
-        deltas_full, mw = None, None
-    shard, deltas = rz.shard.cut_mesh(mesh, deltas_full, b, n)
+    # every rank generates ITS OWN shard of the same block-seeded mesh (synth.make_mesh_range): an 8-rank node never
+    # builds eight copies of the 1 M-vertex mesh + 768 MB of morph targets on the host, and N = 1 ... 8 deform the same mesh
+    shard = synth.make_mesh_range(V_total, B, b, n)
+    deltas, mw = synth.make_morphs_dense_range(V_total, M, b, n) if M > 0 else (None, None)
+    mesh = shard                         # skeleton / pose fields are the same on every rank
 
     ctx = rz.DeformContext(local_rank)
     ctx.upload_mesh(shard["pos"], shard["nrm"], shard["joints"], shard["weights"])
@@ -181,18 +180,22 @@ def main():
         quats /= np.linalg.norm(quats, axis=2, keepdims=True)
         ctx.upload_skeleton_topology(mesh["parents"], mesh["bind"])
 
-    frames = None
-    if args.device_sampling:
-        if not args.device_fk:
-            raise SystemExit("--device-sampling needs --device-fk")
+    def upload_motion():
+        """A synthetic motion (8 keys per bone, every 10 frames, default curves) for the device sampler."""
         rng = np.random.default_rng(777)
-        nk = 8                                              # keys per bone, every 10 frames, default (identity) curves
+        nk = 8
         kq = rng.normal(size=(B, nk, 4)).astype(np.float32)
         kq /= np.linalg.norm(kq, axis=2, keepdims=True)
         ctx.upload_animation(np.arange(B), np.arange(B + 1) * nk, np.tile(np.arange(nk) * 10.0, B), kq,
                              (rng.random((B, nk, 3), dtype=np.float32) - 0.5) * 0.2, np.tile(np.array([20] * 8 + [107] * 8, np.uint8), B * nk))
-        frames = rng.random(I).astype(np.float32) * 70.0
-        tick = [0]
+        return rng.random(I).astype(np.float32) * 70.0
+
+    frames = None
+    tick = [0]
+    if args.device_sampling:
+        if not args.device_fk:
+            raise SystemExit("--device-sampling needs --device-fk")
+        frames = upload_motion()
 
     def put_pose():
         if frames is not None:
@@ -221,6 +224,15 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def rank_max(x):
+        """max over ranks of a host-side scalar (None stays None when every rank has None)."""
+        if dist is None:
+            return x
+        vals = [None] * world_size
+        dist.all_gather_object(vals, x)
+        vals = [v for v in vals if v is not None]
+        return max(vals) if vals else None
+
     # ---- warmup, then EXACTLY K timed steps between barrier + synchronize on both sides ----
     # Each rank stamps t1 when ITS K steps have drained (stream sync + torch.cuda.synchronize()), the closing
     # barrier follows, and the reported time is the MAX over ranks: the wall time until the slowest GPU finished,
@@ -243,7 +255,10 @@ def main():
     timing = ctx.time_frames(max(20, min(args.steps, 200)))
     kern_s = timing["deform_kernel_ms"] * 1e-3
     achieved = timing["algorithmic_bytes_per_frame"] / kern_s / 1e9
-    traffic = None
+    kernel_name = ctx.kernel_name()
+    # HBM bytes per launch from the PMC counters are collected OFFLINE (rocprofv3 cannot run inside this process):
+    # tools/gpu_profile.sh + tools/parse_prof.py store them per workload shape; this line only looks the shape up.
+    traffic, traffic_source = None, None
     tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tj):
         try:
@@ -251,34 +266,71 @@ def main():
             key = "V%d_B%d_M%d_I%d" % (n, B, M, I)
             if key in rec:
                 traffic = rec[key]["hbm_bytes_per_launch"]
+                traffic_source = "stored: profiles/pmc_traffic.json[%s] (%s)" % (key, rec[key].get("command", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"))
         except Exception:
             traffic = None
+    if traffic is None:
+        traffic_source = "none stored for this workload shape (profiles/pmc_traffic.json)"
+    # the streaming ceiling measured on this kind of box (tools/membench): reads for the morph-stream frames, writes for crowds
+    ceiling, ceiling_what = None, None
+    cj = os.path.join(ROOT, "profiles", "ceilings.json")
+    if os.path.exists(cj):
+        try:
+            cz = json.load(open(cj))
+            which = "write_GBps" if (M == 0 and I > 1) else "nt_read_GBps"
+            ceiling, ceiling_what = cz[which], "%s (%s)" % (which, cz.get("source", "tools/membench"))
+        except Exception:
+            ceiling = None
 
     # per-frame pose upload included (PCIe-inclusive rate; never `value`)
     # (secondary numbers never take the line down with them: a failure here is reported as null)
     n_up = min(args.steps, 200)
-    with_upload_ms = None
-    try:
-        for _ in range(400):            # the upload path's own warm-up: pinned ring, upload stream (the HIP runtime
-                                        # stalls ~25 ms once, somewhere in the first few hundred two-stream frames)
-            put_pose()
-            ctx.deform()
-        ctx.sync()
-        tp0 = time.perf_counter()
-        for _ in range(n_up):
-            put_pose()
-            ctx.deform()
-        ctx.sync()
-        with_upload_ms = (time.perf_counter() - tp0) * 1e3 / n_up
-    except Exception as e:              # noqa: BLE001
-        sys.stderr.write("[bench] per-frame upload timing failed: %r\n" % (e,))
 
-    ag_ms = None
+    def per_frame_loop(put):
+        try:
+            for _ in range(400):        # the upload path's own warm-up: pinned ring, upload stream (the HIP runtime
+                                        # stalls ~25 ms once, somewhere in the first few hundred two-stream frames)
+                put()
+                ctx.deform()
+            barrier()
+            tp0 = time.perf_counter()
+            for _ in range(n_up):
+                put()
+                ctx.deform()
+            ctx.sync()
+            return rank_max((time.perf_counter() - tp0) * 1e3 / n_up)
+        except Exception as e:          # noqa: BLE001
+            sys.stderr.write("[bench] per-frame upload timing failed: %r\n" % (e,))
+            return rank_max(None)
+    with_upload_ms = per_frame_loop(put_pose)
+    # ... and the same loop when the motion lives on the GPU (rz_set_pose_sampled: ONE float per instance per frame, bones
+    # sampled + hierarchy solved by rz_fk_kernel): the per-frame loop that does not pay for the pose upload at any N
+    sampled_ms = None
+    if not args.no_sampled_loop:
+        try:
+            if frames is None:
+                if not args.device_fk:
+                    ctx.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+                fr2 = upload_motion()
+            else:
+                fr2 = frames
+
+            def put_sampled():
+                tick[0] += 1
+                ctx.set_pose_sampled((fr2 + 0.5 * tick[0]) % 70.0)
+            sampled_ms = per_frame_loop(put_sampled)
+        except Exception as e:          # noqa: BLE001
+            sys.stderr.write("[bench] device-sampling loop failed: %r\n" % (e,))
+            sampled_ms = rank_max(None)
+        put_pose()                      # back to the primary pose kind
+
+    ag_ms, rccl = None, None
     if args.allgather and I == 1:
         uid = [rz.capi.comm_unique_id() if rank == 0 else None]
         if dist is not None:
             dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(world_size, rank, uid[0], V_total)
+        rccl = rz.capi.rccl_info()
         for _ in range(5):
             ctx.allgather()
         barrier()
@@ -288,15 +340,25 @@ def main():
         barrier()
         ag_ms = (time.perf_counter() - ta) * 1e3 / 50
 
+    # one record per rank, so a slow or oddly planned GPU is visible in the scaling file
+    mine = {"rank": rank, "device": local_rank, "verts": n, "kernel_ms": timing["deform_kernel_ms"], "frame_ms": timing["frame_ms"],
+            "kernel": kernel_name, "grid": ctx.get_tuning("effective_grid"), "morph_split": ctx.get_tuning("effective_split"),
+            "autotuned": tuned is not None, "rccl": rccl}
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world_size
+        dist.all_gather_object(per_rank, mine)
+
     cpu = None
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(args, mesh, deltas_full, mw)
+            cpu = cpu_baseline(args, mesh, deltas, mw)
         except Exception as e:          # noqa: BLE001
             sys.stderr.write("[bench] cpu baseline failed: %r\n" % (e,))
 
     if rank == 0:
         verts = V_total * I * args.steps
+        kms = [r["kernel_ms"] for r in per_rank]
         out = {
             "metric": "deformed verts/sec at 1/2/4/8 GPU; achieved HBM GB/s vs ~8 TB/s roofline",
             "value": verts / elapsed,
@@ -325,18 +387,28 @@ def main():
                 "frame_ms_events": timing["frame_ms"],
                 "prep_kernel_ms": timing["prep_kernel_ms"],
                 "frame_ms_with_pose_upload": with_upload_ms,
+                "frame_ms_device_sampled_pose": sampled_ms,
+                "per_frame_loops": "max over ranks; with_pose_upload = rz_set_pose%s + rz_deform per frame, device_sampled_pose = rz_set_pose_sampled (1 float / instance) + rz_deform"
+                                   % ("_local" if args.device_fk else ""),
                 "allgather_ms": ag_ms,
+                "kernel_ms_min_over_ranks": min(kms), "kernel_ms_max_over_ranks": max(kms),
+                "ranks": per_rank,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "rz_deform_kernel (fused morph+skin)",
+                "kernel": kernel_name,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
+                "measured_ceiling": ceiling,
+                "measured_ceiling_what": ceiling_what,
+                "frac_of_measured_ceiling": (achieved / ceiling) if ceiling else None,
                 "algorithmic_bytes_per_launch": timing["algorithmic_bytes_per_frame"],
                 "kernel_ms": timing["deform_kernel_ms"],
+                "frame_frac": timing["algorithmic_bytes_per_frame"] / (timing["frame_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             },
             "cpu_baseline": cpu,
         }

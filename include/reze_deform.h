@@ -233,6 +233,10 @@ int rz_output_ptrs(rz_ctx *ctx, void **pos, void **nrm, uint32_t *v_padded);
  * context's stream: every rank ends up with the full [v_total_padded][3] position (and, when
  * with_normals != 0, normal) arrays of instance 0. */
 int rz_comm_unique_id(char id[128]);
+/* Which RCCL this library is bound to (lazily, on the first multi-GPU call): the file it came from, ncclGetVersion(),
+ * and whether it is a copy the process had ALREADY loaded (PyTorch ships its own librccl.so with the same soname): the
+ * library looks for one with RTLD_NOLOAD first, so that a process never runs two RCCL runtimes side by side. */
+int rz_rccl_info(char *path, size_t path_bytes, int *version, int *reused);
 int rz_comm_init(rz_ctx *ctx, int nranks, int rank, const char id[128], uint32_t v_total);
 int rz_allgather(rz_ctx *ctx, int with_normals);
 int rz_read_gathered(rz_ctx *ctx, uint32_t v0, uint32_t n, float *pos3, float *nrm3);

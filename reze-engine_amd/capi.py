@@ -18,7 +18,7 @@ SYMBOLS = [
     "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
     "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_upload_animation", "rz_set_pose_sampled", "rz_override_world", "rz_read_world", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
     "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_autotune", "rz_output_ptrs",
-    "rz_comm_unique_id", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_gather_fence", "rz_upload_edge_scale", "rz_read_hull", "rz_enable_aabb", "rz_read_aabb",
+    "rz_comm_unique_id", "rz_rccl_info", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_gather_fence", "rz_upload_edge_scale", "rz_read_hull", "rz_enable_aabb", "rz_read_aabb",
 ]
 
 
@@ -92,6 +92,7 @@ def load():
     L.rz_get_tuning.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     L.rz_output_ptrs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u32)]
     L.rz_comm_unique_id.argtypes = [ctypes.c_char_p]
+    L.rz_rccl_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.rz_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, u32]
     L.rz_allgather.argtypes = [vp, ctypes.c_int]
     L.rz_read_gathered.argtypes = [vp, u32, u32, fp, fp]
@@ -141,6 +142,14 @@ def comm_unique_id():
     buf = ctypes.create_string_buffer(128)
     _chk(load().rz_comm_unique_id(buf))
     return buf.raw
+
+
+def rccl_info():
+    """{path, version, reused}: the RCCL the library bound (reused = a copy the process had already loaded, e.g. PyTorch's)."""
+    buf = ctypes.create_string_buffer(512)
+    ver, reused = ctypes.c_int(0), ctypes.c_int(0)
+    _chk(load().rz_rccl_info(buf, 512, ctypes.byref(ver), ctypes.byref(reused)))
+    return {"path": buf.value.decode("utf-8", "replace"), "version": ver.value, "reused": bool(reused.value)}
 
 
 def comm_init_all(contexts, v_total):
@@ -380,6 +389,21 @@ class DeformContext:
         """Setup-time search over launch shapes with the current mesh / morphs / pose (rz_autotune)."""
         _chk(self._L.rz_autotune(self._h, int(frames)))
         return {k: self.get_tuning(k) for k in ("effective_split", "effective_grid", "effective_inst_group")}
+
+    def kernel_name(self):
+        """The dominant kernel the CURRENT plan launches, spelled like rocprofv3's kernel trace spells it."""
+        g = self.get_tuning
+        tf = lambda k: "true" if g(k) else "false"  # noqa: E731
+        if g("effective_poses_per_wg") > 0:
+            return "rz_skin_instances_reg_kernel<8, %s>" % tf("effective_nt_store")
+        if g("effective_inst_group") > 0:
+            return "rz_skin_instances_kernel<%d, %s>" % (g("effective_inst_block"), tf("effective_nt_store"))
+        mode = g("morph_mode")
+        s_, u = g("effective_split"), (g("effective_unroll") if mode == 1 else 1)
+        if mode != 1:
+            s_ = 4 if s_ >= 4 else 1
+        return "rz_deform_kernel<%d, %d, %d, %s, %s, %s, %s>" % (s_, 8 if (mode == 1 and u >= 8) else (4 if mode == 1 else 1), mode,
+                                                                 tf("effective_nt"), tf("effective_nt_store"), tf("effective_geo"), tf("effective_fast"))
 
     def time_frames(self, frames):
         t = RzTiming()

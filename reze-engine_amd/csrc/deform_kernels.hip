@@ -861,7 +861,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         // palette rows in the first 48 bytes of each slot. (A compact 48-byte slot would need gfx950's 12-byte LDS-DMA
         // to pack its cells — measured: it keeps a 16-byte lane stride — or loads + ds_write, measured 3 us slower.)
         const float4 *src = p.dma ? p.palette + (size_t)inst0 * rows : reinterpret_cast<const float4 *>(p.world) + (size_t)inst0 * p.B * 4;
-        const int n = p.dma ? ng * rows : ng * p.B * 4;
+        const int n = (RZ_DBG(p) == 6 || RZ_DBG(p) == 7) ? 0 : (p.dma ? ng * rows : ng * p.B * 4);   // dbg 6 / 7 (tools-only build): no palette staging
         for (int c = wave * 64; c < n; c += BLOCK) {
             const int e = c + lane;
             if (e < n) {
@@ -962,7 +962,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         const f2 vx = {x, nx}, vy = {y, ny}, vz = {z, nz};
         const f2 W0 = {w0, w0}, W1 = {w1, w1}, W2 = {w2, w2}, W3 = {w3, w3};
 #ifdef RZ_ABLATE
-        if (p.dbg == 2) {                        // dbg 2: ablation — the output stream without gathers / math
+        if (p.dbg == 2 || p.dbg == 7) {          // dbg 2 / 7: ablation — the output stream without gathers / math
             if (live)
                 for (int g = 0; g < ng; ++g) {
                     st3<NTS>(dp, x, y, z); st3<NTS>(dn, nx, ny, nz);

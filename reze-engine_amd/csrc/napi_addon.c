@@ -568,6 +568,21 @@ static napi_value fn_comm_unique_id(napi_env env, napi_callback_info info)
     return buf;
 }
 
+static napi_value fn_rccl_info(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    char path[512];
+    int ver = 0, reused = 0;
+    int rc = rz_rccl_info(path, sizeof path, &ver, &reused);
+    if (rc) return throw_rz(env, rc);
+    napi_value o, v;
+    if (napi_create_object(env, &o) != napi_ok) return throw_msg(env, "object alloc failed");
+    napi_create_string_utf8(env, path, NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, o, "path", v);
+    napi_create_int32(env, ver, &v); napi_set_named_property(env, o, "version", v);
+    napi_get_boolean(env, reused != 0, &v); napi_set_named_property(env, o, "reused", v);
+    return o;
+}
+
 static napi_value fn_comm_init(napi_env env, napi_callback_info info)
 {
     ARGS(5);
@@ -688,7 +703,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "readHull", fn_read_hull }, { "enableAabb", fn_enable_aabb }, { "readAabb", fn_read_aabb }, { "deform", fn_deform },
         { "deformN", fn_deform_n }, { "sync", fn_sync }, { "read", fn_read }, { "readPalette", fn_read_palette },
         { "timeFrames", fn_time_frames }, { "setTuning", fn_set_tuning }, { "getTuning", fn_get_tuning },
-        { "commUniqueId", fn_comm_unique_id }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },
+        { "commUniqueId", fn_comm_unique_id }, { "rcclInfo", fn_rccl_info }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },
         { "readGathered", fn_read_gathered }, { "commInitAll", fn_comm_init_all }, { "allgatherAll", fn_allgather_all },
         { "autotune", fn_autotune }, { "uploadAnimation", fn_upload_animation }, { "setPoseSampled", fn_set_pose_sampled }, { "overrideWorld", fn_override_world }, { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
     };

@@ -59,17 +59,28 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    bool reused = false;                // bound to a copy the process had already loaded (e.g. PyTorch's)
 };
 Rccl g_rccl;
 
 int rccl_bind()
 {
     if (g_rccl.h) return RZ_OK;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // ONE RCCL per process. A host that already carries a copy (PyTorch bundles its own librccl.so, soname librccl.so.1,
+    // and loads it with libtorch_hip) must not get a second one next to it — two RCCL runtimes in one process each
+    // start their own proxy threads and IPC state. RTLD_NOLOAD returns the already-mapped object with that soname, if
+    // there is one; only a process without RCCL loads ROCm's.
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    bool reused = h != nullptr;
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD), reused = h != nullptr;
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return fail(RZ_ERR_UNSUPPORTED, "RCCL not available: %s", dlerror());
     Rccl r;
     r.h = h;
+    r.reused = reused;
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(h, "ncclGetVersion"));
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
@@ -1555,6 +1566,11 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "verts")) *value = (int)c->V;
     else if (!strcmp(key, "nt_store")) *value = c->t_nts;
     else if (!strcmp(key, "fast")) *value = c->t_fast;
+    else if (!strcmp(key, "morph_mode")) *value = c->morph_mode;
+    else if (!strcmp(key, "effective_nt")) *value = make_plan(c).v.nt && c->morph_mode == 1 ? 1 : 0;
+    else if (!strcmp(key, "effective_nt_store")) *value = make_plan(c).v.nts ? 1 : 0;
+    else if (!strcmp(key, "effective_geo")) *value = make_plan(c).v.geo ? 1 : 0;
+    else if (!strcmp(key, "effective_prep")) *value = (make_plan(c).prep || c->pose_local) ? 1 : 0;
     else if (!strcmp(key, "effective_split")) *value = make_plan(c).v.S;
     else if (!strcmp(key, "effective_unroll")) *value = make_plan(c).v.U;
     else if (!strcmp(key, "effective_fast")) *value = make_plan(c).v.fast ? 1 : 0;
@@ -1591,6 +1607,20 @@ int rz_comm_unique_id(char id[128])
     ncclUniqueId u;
     NCCL_TRY(g_rccl.GetUniqueId(&u));
     memcpy(id, &u, 128);
+    return RZ_OK;
+}
+
+int rz_rccl_info(char *path, size_t path_bytes, int *version, int *reused)
+{
+    if (int r = rccl_bind()) return r;
+    if (path && path_bytes) {
+        Dl_info di;
+        memset(&di, 0, sizeof di);
+        path[0] = 0;
+        if (dladdr(reinterpret_cast<void *>(g_rccl.AllGather), &di) && di.dli_fname) snprintf(path, path_bytes, "%s", di.dli_fname);
+    }
+    if (version) { *version = 0; if (g_rccl.GetVersion) (void)g_rccl.GetVersion(version); }
+    if (reused) *reused = g_rccl.reused ? 1 : 0;
     return RZ_OK;
 }
 

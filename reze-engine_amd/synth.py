@@ -215,3 +215,55 @@ def sparse_to_dense(n_verts, morph_off, vert_idx, delta3):
         lo, hi = int(morph_off[m]), int(morph_off[m + 1])
         np.add.at(d[m], vert_idx[lo:hi].astype(np.int64), delta3[lo:hi])
     return d
+
+
+# ---- range generators: any rank can produce ITS shard of a large mesh without building the whole mesh ----
+# Per-vertex data is generated in fixed blocks of RANGE_BLOCK vertices, every block from its own seed
+# (SeedSequence [seed, block]), so [begin, begin + count) of an n_total-vertex mesh is the same numbers no matter
+# which ranges the other ranks ask for; the skeleton (and its pose) only depends on (n_bones, seed). bench.py uses these
+# at every N, so the N = 1 and N = 8 runs deform the same mesh while an 8-rank node never holds 8 copies of it.
+RANGE_BLOCK = 16384
+
+
+def make_mesh_range(n_total, n_bones, begin, count, seed=SEED):
+    """Shard [begin, begin + count) of the n_total-vertex block-seeded synthetic mesh (same distributions as make_mesh).
+    Returns dict(pos, nrm, joints, weights, parents, bind, quats, inv_bind, world); per-vertex arrays have `count` rows."""
+    pos, nrm, joints, weights = [], [], [], []
+    for blk in range(begin // RANGE_BLOCK, (begin + count + RANGE_BLOCK - 1) // RANGE_BLOCK if count else begin // RANGE_BLOCK):
+        v0 = blk * RANGE_BLOCK
+        n = min(RANGE_BLOCK, n_total - v0)
+        rng = np.random.default_rng([seed, 1, blk])
+        p = (BBOX_LO + rng.random((n, 3), dtype=np.float32) * (BBOX_HI - BBOX_LO)).astype(np.float32)
+        nn = rng.standard_normal((n, 3), dtype=np.float32)
+        nn /= np.maximum(np.linalg.norm(nn, axis=1, keepdims=True), 1e-12)
+        j, w = make_skinning(n, n_bones, rng)
+        # bone locality follows the GLOBAL vertex index: re-centre the block's joints around floor(v * B / V)
+        centre_local = (np.arange(n, dtype=np.int64) * n_bones) // max(n, 1)
+        centre_global = ((v0 + np.arange(n, dtype=np.int64)) * n_bones) // max(n_total, 1)
+        used = w > 0
+        j = np.where(used, np.clip(j.astype(np.int64) - centre_local[:, None] + centre_global[:, None], 0, n_bones - 1), 0).astype(np.uint16)
+        lo, hi = max(begin, v0) - v0, min(begin + count, v0 + n) - v0
+        pos.append(p[lo:hi]); nrm.append(nn[lo:hi].astype(np.float32)); joints.append(j[lo:hi]); weights.append(w[lo:hi])
+    cat = lambda xs, shape, dt: np.ascontiguousarray(np.concatenate(xs)) if xs else np.zeros(shape, dtype=dt)  # noqa: E731
+    rng = np.random.default_rng([seed, 0])
+    parents, bind, quats = make_skeleton(n_bones, rng)
+    return dict(pos=cat(pos, (0, 3), np.float32), nrm=cat(nrm, (0, 3), np.float32), joints=cat(joints, (0, 4), np.uint16),
+                weights=cat(weights, (0, 4), np.uint8), parents=parents, bind=bind, quats=quats,
+                inv_bind=inverse_bind_translation_only(parents, bind), world=fk_world(parents, bind, quats))
+
+
+def make_morphs_dense_range(n_total, n_morphs, begin, count, seed=SEED + 1):
+    """deltas [M, count, 3] of vertices [begin, begin + count) (uniform [-0.05, 0.05], block-seeded) and weights [M]."""
+    parts = []
+    for blk in range(begin // RANGE_BLOCK, (begin + count + RANGE_BLOCK - 1) // RANGE_BLOCK if count else begin // RANGE_BLOCK):
+        v0 = blk * RANGE_BLOCK
+        n = min(RANGE_BLOCK, n_total - v0)
+        rng = np.random.default_rng([seed, 1, blk])
+        d = rng.random((n_morphs, n, 3), dtype=np.float32)
+        d -= np.float32(0.5)
+        d *= np.float32(0.1)
+        lo, hi = max(begin, v0) - v0, min(begin + count, v0 + n) - v0
+        parts.append(d[:, lo:hi])
+    deltas = np.ascontiguousarray(np.concatenate(parts, axis=1)) if parts else np.zeros((n_morphs, 0, 3), dtype=np.float32)
+    w = np.random.default_rng([seed, 0]).random(n_morphs, dtype=np.float32)
+    return deltas, w

@@ -32,6 +32,17 @@ if (process.argv[2] === '--live') { // on a GPU box: the same with a LIVE contex
       live++
     }
   }
+  // uploadMorphsDense must hold exactly M*V*3 floats for THIS context's mesh: a shorter array (wrong shard, stale model)
+  // would be read past its end by the C ABI's copy (round-1 review)
+  for (const [M, len] of [[2, 6], [2, 2 * (V - 1) * 3], [3, 2 * V * 3]]) {
+    let threw = false
+    try { a.uploadMorphsDense(ctx, M, new Float32Array(len)) } catch (e) { threw = e instanceof Error }
+    if (!threw) throw new Error('uploadMorphsDense accepted ' + len + ' floats for M=' + M + ' V=' + V)
+  }
+  a.uploadMorphsDense(ctx, 2, new Float32Array(2 * V * 3)); a.uploadMorphsDense(ctx, 0, null)
+  let threwOv = false
+  try { a.overrideWorld(ctx, new Uint32Array([1]), new Float32Array(15), null) } catch (e) { threwOv = e instanceof Error }
+  if (!threwOv) throw new Error('overrideWorld accepted a short matrix array')
   a.setPose(ctx, ib, null); a.deform(ctx)           // still usable
   const pos = new Float32Array(V * 3), nrm = new Float32Array(V * 3)
   a.read(ctx, 0, 0, V, pos, nrm)

@@ -39,6 +39,12 @@ def _check(d, n_gpus, steps, verts):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0
+    assert r["kernel"].startswith("rz_") and "traffic_source" in r and r["frac_of_measured_ceiling"] > 0
+    ranks = d["config"]["ranks"]
+    assert len(ranks) == n_gpus and sorted(x["rank"] for x in ranks) == list(range(n_gpus))
+    assert sum(x["verts"] for x in ranks) == verts and all(x["kernel_ms"] > 0 and x["kernel"].startswith("rz_") for x in ranks)
+    assert d["config"]["kernel_ms_max_over_ranks"] >= d["config"]["kernel_ms_min_over_ranks"] > 0
+    assert d["config"]["frame_ms_with_pose_upload"] > 0 and d["config"]["frame_ms_device_sampled_pose"] > 0
 
 
 @pytest.mark.gpu

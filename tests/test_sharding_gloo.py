@@ -1,6 +1,9 @@
-"""N > 1 host path on CPU: two processes over gloo shard the mesh exactly as bench.py does, deform their
-shard (CPU oracle standing in for the GPU kernel — this test is about partition + gather layout, not
-arithmetic), all-gather padded chunks, and must reproduce the unsharded result bit for bit."""
+"""N > 1 host path: two processes over gloo shard the mesh exactly as bench.py does — every rank GENERATES only its own
+range of the block-seeded synthetic mesh (synth.make_mesh_range) — deform their shard, all-gather padded chunks, and must
+reproduce the unsharded result bit for bit.
+  * CPU variant (runs everywhere): the CPU oracle stands in for the kernel — partition, per-rank generation and gather layout.
+  * GPU variant (-m gpu): every rank drives the REAL HIP kernel through the C ABI on the box's GPU (two ranks share it),
+    and the gathered mesh must equal a single context's whole-mesh frame bit for bit."""
 import os
 import socket
 import sys
@@ -11,10 +14,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, v_total, q):
+def _worker(rank, world, port, v_total, q, on_gpu=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import oracle
@@ -23,21 +27,44 @@ def _worker(rank, world, port, v_total, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         B, M = 24, 5
-        mesh = synth.make_mesh(v_total, B, seed=77)
-        deltas, mw = synth.make_morphs_dense(v_total, M, seed=78)
         b, n, chunk = rz.shard.shard_of(v_total, world, rank)
-        part, d = rz.shard.cut_mesh(mesh, deltas, b, n)
-        if n:
-            pos, nrm = oracle.deform(part["pos"], part["nrm"], part["joints"], part["weights"], part["world"],
-                                     part["inv_bind"], d, mw)
+        part = synth.make_mesh_range(v_total, B, b, n, seed=77)          # this rank's range only
+        d, mw = synth.make_morphs_dense_range(v_total, M, b, n, seed=78)
+        if n == 0:
+            pos = np.zeros((0, 3), dtype=np.float32)
+        elif on_gpu:
+            c = rz.DeformContext(0)                                      # both ranks share GPU 0 of the box
+            c.upload_mesh(part["pos"], part["nrm"], part["joints"], part["weights"])
+            c.upload_skeleton(part["inv_bind"])
+            c.upload_morphs_dense(d)
+            c.set_pose(part["world"], mw)
+            c.deform()
+            pos, _ = c.read()
+            c.close()
         else:
-            pos = nrm = np.zeros((0, 3), dtype=np.float32)
+            pos, _ = oracle.deform(part["pos"], part["nrm"], part["joints"], part["weights"], part["world"], part["inv_bind"], d, mw)
         send = torch.from_numpy(rz.shard.pad_to_chunk(pos, chunk))
         recv = torch.empty((world * chunk, 3), dtype=torch.float32)
-        dist.all_gather_into_tensor(recv, send) if hasattr(dist, "all_gather_into_tensor") else None
+        dist.all_gather_into_tensor(recv, send)
         full = rz.shard.gathered_to_mesh(recv.numpy(), v_total)
-        ref, _ = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"],
-                               deltas, mw)
+        # the unsharded result, from the whole mesh generated in one piece
+        mesh = synth.make_mesh_range(v_total, B, 0, v_total, seed=77)
+        deltas, mw_all = synth.make_morphs_dense_range(v_total, M, 0, v_total, seed=78)
+        assert np.array_equal(mw, mw_all) and np.array_equal(mesh["pos"][b:b + n], part["pos"]) and np.array_equal(mesh["joints"][b:b + n], part["joints"])
+        if on_gpu:
+            c = rz.DeformContext(0)
+            c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+            c.upload_skeleton(mesh["inv_bind"])
+            c.upload_morphs_dense(deltas)
+            c.set_pose(mesh["world"], mw)
+            c.deform()
+            ref, _ = c.read()
+            c.close()
+            pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"], deltas, mw)
+            err = np.linalg.norm(ref.astype(np.float64) - pr, axis=1) / np.maximum(np.linalg.norm(pr, axis=1), 1.0)
+            assert err.max() <= 1e-4, err.max()
+        else:
+            ref, _ = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"], deltas, mw)
         ranges = [None] * world
         dist.all_gather_object(ranges, (b, n))
         q.put((rank, bool(np.array_equal(full, ref)), ranges, chunk))
@@ -45,8 +72,7 @@ def _worker(rank, world, port, v_total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("v_total", [5000, 1024, 2049])
-def test_two_rank_shard_and_gather_equals_single_rank(v_total):
+def _run_two_ranks(v_total, on_gpu):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -54,10 +80,10 @@ def test_two_rank_shard_and_gather_equals_single_rank(v_total):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, v_total, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, v_total, q, on_gpu)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -65,3 +91,14 @@ def test_two_rank_shard_and_gather_equals_single_rank(v_total):
         assert ok, "rank %d: gathered mesh differs from the unsharded result" % rank
         assert ranges[0][0] == 0 and ranges[0][1] + ranges[1][1] == v_total and ranges[1][0] == ranges[0][1] or ranges[1][1] == 0
         assert chunk % 1024 == 0
+
+
+@pytest.mark.parametrize("v_total", [5000, 1024, 2049, 40000])
+def test_two_rank_shard_and_gather_equals_single_rank(v_total):
+    _run_two_ranks(v_total, on_gpu=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("v_total", [40000, 2049])
+def test_two_ranks_real_kernel_per_rank_sharing_the_gpu(v_total):
+    _run_two_ranks(v_total, on_gpu=True)

@@ -1,6 +1,6 @@
-"""Ablation of the instanced (C4) skin kernel on one MI355X: dbg 0 = full kernel, 1 = gathers + math without the
-output stream, 2 = output stream without gathers / math; pose-group size G, grid and palette source swept
-(fast = 1: palettes formed inside the skin kernel, one launch per frame; otherwise rz_prep_kernel + LDS-DMA)."""
+"""Ablation of the instanced (C4) skin kernel on one MI355X (tools-only build with the dbg switches, make ablate):
+dbg 0 = full kernel, 1 = gathers + math without the output stream, 2 = output stream without gathers / math,
+6 = full kernel without the palette staging at its start (garbage palettes), 7 = 2 + 6 (nothing but the mesh loads and the stores)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,9 +14,8 @@ ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); ctx.
 ctx.set_instances(256)
 worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], 200, seed=1000 + i) for i in range(256)])
 ctx.set_pose(worlds)
-for fast in (-1, 1):
-    for il, cap in ((8, 512), (4, 1024), (8, 1024)):
-        for dbg in (0, 1, 2):
-            ctx.set_tuning(inst_loop=il, fast=fast, grid_cap=cap, dbg=dbg)
-            t = min((ctx.time_frames(200) for _ in range(3)), key=lambda t: t["frame_ms"])
-            print("fast=%d G=%d cap=%d dbg=%d kernel %.4f ms frame %.4f ms" % (fast, il, cap, dbg, t["deform_kernel_ms"], t["frame_ms"]))
+for blk, il, cap in ((256, 8, 512), (1024, 8, 256)):
+    for dbg in (0, 1, 2, 6, 7):
+        ctx.set_tuning(inst_block=blk, inst_loop=il, grid_cap=cap, dbg=dbg)
+        t = min((ctx.time_frames(200) for _ in range(3)), key=lambda t: t["deform_kernel_ms"])
+        print("block=%d G=%d cap=%d dbg=%d kernel %.2f us frame %.2f us" % (blk, il, cap, dbg, t["deform_kernel_ms"] * 1e3, t["frame_ms"] * 1e3), flush=True)

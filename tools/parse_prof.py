@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof/ (rocprofv3 CSVs written by tools/gpu_profile.sh) into the tracked
-summaries under profiles/: kernel-trace stats tables and the PMC-derived HBM traffic
-(profiles/pmc_traffic.json, read back by bench.py for `roofline.traffic`).
+"""Condense gpurun_out/prof/ (rocprofv3 CSVs written by tools/gpu_profile.sh) into the tracked summaries under profiles/:
+kernel-trace stats tables per workload and the PMC-derived HBM traffic per launch (profiles/pmc_traffic.json, which
+bench.py looks `roofline.traffic` up in — it says so in `roofline.traffic_source`).
 
-HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are
-collected in separate passes, are in KiB, and on gfx950 FETCH_SIZE counts exactly half of a wide
-coalesced read stream — the factor is re-derived here from membench's known-byte kernels run
-under the same counters (calibration pass) instead of being assumed."""
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are collected in separate passes, are
+in KiB, and on gfx950 FETCH_SIZE counts exactly half of a wide coalesced read stream — the factor is re-derived here from
+membench's known-byte kernels run under the same counters (calibration pass) instead of being assumed. The dominant
+kernel of a workload = the rz_* deform / skin kernel with the most launches in that run (the variant rz_autotune kept)."""
 import collections
 import csv
 import json
@@ -15,20 +15,37 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+
+WORK = {   # name -> (title, V per GPU, B, M, I)
+    "c5": ("python bench.py --steps 40 --warmup 5 (C5: 1M verts / 256 bones / 64 morphs, 1 GPU)", 1000000, 256, 64, 1),
+    "shard": ("python bench.py --verts 125952 (one 1/8 shard of C5)", 125952, 256, 64, 1),
+    "c4": ("python bench.py --config c4 (256 x 30000 verts / 200 bones, instanced)", 30000, 200, 0, 256),
+    "c3": ("python bench.py --config c3 (30000 verts / 200 bones / 64 morphs)", 30000, 200, 64, 1),
+}
 
 
 def counters(path):
-    agg = collections.defaultdict(list)
+    """{kernel name: {counter: (mean, launches)}}"""
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in agg.items()}
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in agg.items()}
+
+
+def dominant(agg, counter):
+    best = None
+    for k, d in agg.items():
+        if ("rz_deform_kernel" in k or "rz_skin_instances" in k) and counter in d:
+            if best is None or d[counter][1] > agg[best][counter][1]:
+                best = k
+    return best
 
 
 def find(agg, name_part, counter):
-    for (k, c), v in agg.items():
-        if name_part in k and c == counter:
-            return v
+    for k, d in agg.items():
+        if name_part in k and counter in d:
+            return d[counter][0]
     return None
 
 
@@ -45,42 +62,52 @@ def stats_table(path, title, out):
 
 
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-stats_table(os.path.join(P, "trace", "bench_kernel_stats.csv"), "python bench.py --steps 40 --warmup 5 (C5: 1M verts / 256 bones / 64 morphs, 1 GPU)",
-            os.path.join(ROOT, "profiles", "%s_kernel_stats_c5.txt" % tag))
-for name, title in (("trace_shard", "python bench.py --verts 125952 (one 1/8 shard of C5)"),
-                    ("trace_c4", "python bench.py --verts 30000 --bones 200 --morphs 0 --instances 256 (C4)")):
-    p = os.path.join(P, name, "bench_kernel_stats.csv")
-    if os.path.exists(p):
-        stats_table(p, title, os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.txt" % (tag, name.split("_")[1])))
-
 cal_f = counters(os.path.join(P, "cal_fetch", "mb_counter_collection.csv"))
 cal_w = counters(os.path.join(P, "cal_write", "mb_counter_collection.csv"))
 known_kib = 828 * 1024.0
 f_read = known_kib / find(cal_f, "k_read<true, 4>", "FETCH_SIZE")         # nontemporal 16 B/lane stream
 f_read_plain = known_kib / find(cal_f, "k_read<false, 4>", "FETCH_SIZE")
 f_write3 = (known_kib * 1024 // 12 * 12 / 1024.0) / find(cal_w, "k_fill3<true>", "WRITE_SIZE")   # NT 12 B/lane stores
+f_write3_plain = (known_kib * 1024 // 12 * 12 / 1024.0) / find(cal_w, "k_fill3<false>", "WRITE_SIZE")
 f_write4 = known_kib / find(cal_w, "k_fill<false>", "WRITE_SIZE")
-fe = counters(os.path.join(P, "fetch", "bench_counter_collection.csv"))
-wr = counters(os.path.join(P, "write", "bench_counter_collection.csv"))
-fetch_kib = find(fe, "rz_deform_kernel", "FETCH_SIZE")
-write_kib = find(wr, "rz_deform_kernel", "WRITE_SIZE")
-read_b = fetch_kib * 1024 * f_read
-write_b = write_kib * 1024 * f_write3
-V, B, M, I = 1000000, 256, 64, 1
-alg_read = V * (36 + 12 * M) + B * 128 + M * 4
-alg_write = V * 24
-rec = {
-    "V%d_B%d_M%d_I%d" % (V, B, M, I): {
+rec = {}
+for name, (title, V, B, M, I) in WORK.items():
+    st = os.path.join(P, "trace_" + name, "bench_kernel_stats.csv")
+    if os.path.exists(st):
+        stats_table(st, title, os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.txt" % (tag, name)))
+    line = os.path.join(P, "line_%s.json" % name)
+    if os.path.exists(line) and os.path.getsize(line) > 2:
+        open(os.path.join(ROOT, "profiles", "%s_bench_under_rocprof_%s.json" % (tag, name)), "w").write(open(line).read())
+    fp, wp = os.path.join(P, "fetch_" + name, "bench_counter_collection.csv"), os.path.join(P, "write_" + name, "bench_counter_collection.csv")
+    if not (os.path.exists(fp) and os.path.exists(wp)):
+        print("no PMC passes for", name)
+        continue
+    fe, wr = counters(fp), counters(wp)
+    kf, kw = dominant(fe, "FETCH_SIZE"), dominant(wr, "WRITE_SIZE")
+    fetch_kib, write_kib = fe[kf]["FETCH_SIZE"][0], wr[kw]["WRITE_SIZE"][0]
+    nts = "true" in kf.split("<")[1].split(",")[4] if "rz_deform_kernel" in kf else False
+    read_b = fetch_kib * 1024 * f_read
+    write_b = write_kib * 1024 * (f_write3 if nts else f_write3_plain)
+    if I > 1:
+        alg_read = V * 36 + I * B * 48          # the skin kernel reads the mesh once and the finished palettes
+        alg_write = I * V * 24
+    else:
+        alg_read = V * (36 + 12 * M) + B * 128 + M * 4
+        alg_write = V * 24
+    rec["V%d_B%d_M%d_I%d" % (V, B, M, I)] = {
+        "kernel": kf.split("(")[0] if "(anonymous namespace)::" not in kf else kf.replace("void (anonymous namespace)::", "").split("(")[0],
+        "launches_counted": fe[kf]["FETCH_SIZE"][1],
         "hbm_bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_bytes": write_b,
         "raw_FETCH_SIZE_KiB": fetch_kib, "raw_WRITE_SIZE_KiB": write_kib,
-        "calibration": {"FETCH_SIZE_factor_nt_16B_reads": f_read, "FETCH_SIZE_factor_plain_16B_reads": f_read_plain,
-                        "WRITE_SIZE_factor_nt_12B_stores": f_write3, "WRITE_SIZE_factor_16B_stores": f_write4,
-                        "known_bytes": "tools/membench quick: 828 MiB read / filled per launch"},
         "algorithmic_read_bytes": alg_read, "algorithmic_write_bytes": alg_write,
         "traffic_over_algorithmic": (read_b + write_b) / (alg_read + alg_write),
-        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --steps 40 --warmup 5",
+        "note": ("reads of this kernel are 4-byte loads + LDS-DMA served mostly from L2 / Infinity Cache (whose hits FETCH_SIZE counts); the x2 "
+                 "factor calibrated on 16 B/lane streams is applied as an upper bound") if I > 1 else "",
+        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- " + title.split(" (")[0] + " --no-cpu-baseline --no-sampled-loop",
     }
-}
+rec["_calibration"] = {"FETCH_SIZE_factor_nt_16B_reads": f_read, "FETCH_SIZE_factor_plain_16B_reads": f_read_plain,
+                       "WRITE_SIZE_factor_nt_12B_stores": f_write3, "WRITE_SIZE_factor_plain_12B_stores": f_write3_plain,
+                       "WRITE_SIZE_factor_16B_stores": f_write4, "known_bytes": "tools/membench quick: 828 MiB read / filled per launch"}
 json.dump(rec, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 with open(os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.txt" % tag), "w") as f:
     f.write(json.dumps(rec, indent=1) + "\n")
