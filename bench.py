@@ -186,8 +186,12 @@ def main():
         nk = 8
         kq = rng.normal(size=(B, nk, 4)).astype(np.float32)
         kq /= np.linalg.norm(kq, axis=2, keepdims=True)
+        extra = {}
+        if M > 0:                           # every vertex morph keyed at its bench weight: the sampled frame streams the same 64 targets
+            extra = dict(mkey_off=np.arange(M + 1) * 2, mkey_frame=np.tile(np.array([0.0, 70.0], np.float32), M), mkey_weight=np.repeat(mw, 2),
+                         feed_off=np.arange(M + 1), feed_track=np.arange(M), feed_ratio=np.ones(M, np.float32))
         ctx.upload_animation(np.arange(B), np.arange(B + 1) * nk, np.tile(np.arange(nk) * 10.0, B), kq,
-                             (rng.random((B, nk, 3), dtype=np.float32) - 0.5) * 0.2, np.tile(np.array([20] * 8 + [107] * 8, np.uint8), B * nk))
+                             (rng.random((B, nk, 3), dtype=np.float32) - 0.5) * 0.2, np.tile(np.array([20] * 8 + [107] * 8, np.uint8), B * nk), **extra)
         return rng.random(I).astype(np.float32) * 70.0
 
     frames = None

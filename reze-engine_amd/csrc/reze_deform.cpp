@@ -166,11 +166,23 @@ struct rz_ctx {
     hipStream_t up_stream = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     bool free_recorded[2] = {false, false};
-    float4 *palette = nullptr;          // I x B x 3
+    float4 *palette = nullptr;          // I x B x 3   (current ring slot)
     float *morph_w = nullptr;           // I x M   (current pose slot)
-    uint32_t *act_idx = nullptr;        // I x Mpad
-    float *act_w = nullptr;             // I x Mpad
-    int *act_count = nullptr;           // I
+    uint32_t *act_idx = nullptr;        // I x Mpad    (current ring slot)
+    float *act_w = nullptr;             // I x Mpad    (current ring slot)
+    int *act_count = nullptr;           // I           (current ring slot)
+    // Everything the FRONT kernels (rz_prep_kernel / rz_fk_kernel) hand to the skin kernel lives in a 2-slot ring, so the
+    // front kernels of frame f+1 can run on the upload stream while the skin kernel of frame f is still reading slot f:
+    // ev_front[s] = slot s is ready (compute stream waits), ev_skin[s] = the skin kernel that read slot s has been enqueued
+    // up to here (the front stream waits before overwriting the slot, two frames later). Used by crowds (overlap_on).
+    float4 *palette_ring[2] = {nullptr, nullptr};
+    uint32_t *act_idx_ring[2] = {nullptr, nullptr};
+    float *act_w_ring[2] = {nullptr, nullptr};
+    int *act_count_ring[2] = {nullptr, nullptr};
+    int ring_slot = 0;
+    hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_skin[2] = {nullptr, nullptr};
+    bool skin_recorded[2] = {false, false};
+    bool overlap_on = false;            // the two streams currently follow the overlapped-front protocol
     bool pose_set = false;
     size_t pose_alloc_I = 0, pose_alloc_B = 0, pose_alloc_M = 0;
 
@@ -199,7 +211,7 @@ struct rz_ctx {
     RzMorphList ml;
 
     // tuning (0 / -1 = automatic)
-    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1, t_instblock = 0;
+    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1, t_instblock = 0, t_overlap = -1;
     int t_graph = 0;                    // "graph" tuning key: rz_deform_n replays captured hipGraphs of kGraphFrames frames
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_sig = 0;             // signature of everything the captured launches depend on
@@ -287,6 +299,12 @@ int ensure_outputs(rz_ctx *c)
     return RZ_OK;
 }
 
+void set_ring(rz_ctx *c, int slot)
+{
+    c->ring_slot = slot;
+    c->palette = c->palette_ring[slot]; c->act_idx = c->act_idx_ring[slot]; c->act_w = c->act_w_ring[slot]; c->act_count = c->act_count_ring[slot];
+}
+
 int ensure_pose_buffers(rz_ctx *c)
 {
     if (c->B == 0) return RZ_OK;
@@ -296,7 +314,8 @@ int ensure_pose_buffers(rz_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->up_stream));
     for (int k = 0; k < 2; ++k) { dfree(c->world_buf[k]); dfree(c->morph_w_buf[k]); c->free_recorded[k] = false; }
     c->world = nullptr; c->morph_w = nullptr;
-    dfree(c->palette); dfree(c->act_idx); dfree(c->act_w); dfree(c->act_count);
+    for (int k = 0; k < 2; ++k) { dfree(c->palette_ring[k]); dfree(c->act_idx_ring[k]); dfree(c->act_w_ring[k]); dfree(c->act_count_ring[k]); c->skin_recorded[k] = false; }
+    c->palette = nullptr; c->act_idx = nullptr; c->act_w = nullptr; c->act_count = nullptr;
     const size_t I = c->I, B = c->B;
     const size_t Mpad = round_up(Mq + 8, 4);
     for (int k = 0; k < 2; ++k) {
@@ -306,13 +325,17 @@ int ensure_pose_buffers(rz_ctx *c)
     }
     c->pose_slot = 0;
     c->world = c->world_buf[0]; c->morph_w = c->morph_w_buf[0];
-    HIP_TRY(hipMalloc(&c->palette, I * B * 3 * sizeof(float4)));
-    HIP_TRY(hipMalloc(&c->act_idx, I * Mpad * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&c->act_w, I * Mpad * sizeof(float)));
-    HIP_TRY(hipMalloc(&c->act_count, I * sizeof(int)));
-    HIP_TRY(hipMemsetAsync(c->act_idx, 0, I * Mpad * sizeof(uint32_t), c->stream));
-    HIP_TRY(hipMemsetAsync(c->act_w, 0, I * Mpad * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->act_count, 0, I * sizeof(int), c->stream));
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipMalloc(&c->palette_ring[k], I * B * 3 * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->act_idx_ring[k], I * Mpad * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->act_w_ring[k], I * Mpad * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->act_count_ring[k], I * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(c->palette_ring[k], 0, I * B * 3 * sizeof(float4), c->stream));
+        HIP_TRY(hipMemsetAsync(c->act_idx_ring[k], 0, I * Mpad * sizeof(uint32_t), c->stream));
+        HIP_TRY(hipMemsetAsync(c->act_w_ring[k], 0, I * Mpad * sizeof(float), c->stream));
+        HIP_TRY(hipMemsetAsync(c->act_count_ring[k], 0, I * sizeof(int), c->stream));
+    }
+    set_ring(c, 0);
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->pose_alloc_I = I; c->pose_alloc_B = B; c->pose_alloc_M = Mq;
     c->pose_set = false;
@@ -505,8 +528,6 @@ int check_ready(rz_ctx *c)
     return RZ_OK;
 }
 
-int launch_prep(rz_ctx *c);
-
 RzFkParams fk_params(const rz_ctx *c)
 {
     RzFkParams p;
@@ -529,29 +550,29 @@ RzFkParams fk_params(const rz_ctx *c)
     return p;
 }
 
-int launch_fk(rz_ctx *c)
+int launch_fk(rz_ctx *c, hipStream_t st)
 {
-    HIP_TRY(rz_launch_fk(fk_params(c), c->I, c->stream));
+    HIP_TRY(rz_launch_fk(fk_params(c), c->I, st));
+    return RZ_OK;
+}
+
+int launch_prep(rz_ctx *c, hipStream_t st)
+{
+    HIP_TRY(rz_launch_prep(prep_params(c), c->I, st));
     return RZ_OK;
 }
 
 // Everything a frame launches in front of the deform kernel: on-device FK (local-rotation poses) and/or the prep
 // kernel. The FK kernel already writes the palette, so prep is only still needed for its morph compaction.
-int launch_front(rz_ctx *c, const Plan &pl)
+int launch_front(rz_ctx *c, const Plan &pl, hipStream_t st)
 {
     if (c->pose_local) {
-        if (int r = launch_fk(c)) return r;
+        if (int r = launch_fk(c, st)) return r;
         if (pl.prep && c->morph_mode == 1)
-            if (int r = launch_prep(c)) return r;
+            if (int r = launch_prep(c, st)) return r;
         return RZ_OK;
     }
-    if (pl.prep) return launch_prep(c);
-    return RZ_OK;
-}
-
-int launch_prep(rz_ctx *c)
-{
-    HIP_TRY(rz_launch_prep(prep_params(c), c->I, c->stream));
+    if (pl.prep) return launch_prep(c, st);
     return RZ_OK;
 }
 
@@ -572,6 +593,49 @@ int launch_deform(rz_ctx *c, const Plan &pl)
     if (c->aabb_on) c->aabb_slot ^= 1;     // this launch re-armed the other slot for the next frame
     return RZ_OK;
 }
+
+// Crowds overlap the front kernels of a frame with the skin kernel of the frame before it. The protocol
+// needs a frame that HAS front kernels and a skin kernel that reads nothing of the pose slots themselves (sparse morph
+// frames read the uploaded weights directly), and plain stream capture (the graph key) stays single-stream.
+bool want_overlap(const rz_ctx *c, const Plan &pl)
+{
+    return c->t_overlap != 0 && c->I > 1 && c->morph_mode != 2 && !c->t_graph && (pl.prep || c->pose_local);
+}
+
+// Switching protocols is rare (instance count, tuning keys): drain both streams so that nothing enqueued under the old
+// rules is still running when the first frame under the new ones starts.
+int set_overlap(rz_ctx *c, bool on)
+{
+    if (c->overlap_on == on) return RZ_OK;
+    HIP_TRY(hipStreamSynchronize(c->up_stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->overlap_on = on;
+    c->skin_recorded[0] = c->skin_recorded[1] = false;
+    c->free_recorded[0] = c->free_recorded[1] = false;
+    return RZ_OK;
+}
+
+// One whole frame: front kernels (if the plan has any) + the deform / skin kernel.
+int run_frame(rz_ctx *c, const Plan &pl)
+{
+    if (c->overlap_on) {
+        const int s = c->ring_slot ^ 1;                       // the slot the skin kernel of two frames ago read
+        if (c->skin_recorded[s]) HIP_TRY(hipStreamWaitEvent(c->up_stream, c->ev_skin[s], 0));
+        set_ring(c, s);
+        if (int r = launch_front(c, pl, c->up_stream)) return r;
+        HIP_TRY(hipEventRecord(c->ev_front[s], c->up_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_front[s], 0));
+        if (int r = launch_deform(c, pl)) return r;
+        HIP_TRY(hipEventRecord(c->ev_skin[s], c->stream));
+        c->skin_recorded[s] = true;
+        return RZ_OK;
+    }
+    if (int r = launch_front(c, pl, c->stream)) return r;
+    return launch_deform(c, pl);
+}
+
+// the stream per-frame inputs travel on and front kernels run on
+hipStream_t front_stream(const rz_ctx *c) { return c->overlap_on ? c->up_stream : c->stream; }
 
 uint64_t algorithmic_bytes(const rz_ctx *c)
 {
@@ -681,6 +745,8 @@ int rz_create(int device, rz_ctx **out)
     for (int k = 0; k < 2 && se == hipSuccess; ++k) {
         se = hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_free[k], hipEventDisableTiming);
+        if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_front[k], hipEventDisableTiming);
+        if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_skin[k], hipEventDisableTiming);
     }
     if (se == hipSuccess) se = hipEventCreate(&c->ev0);
     if (se == hipSuccess) se = hipEventCreate(&c->ev1);
@@ -715,7 +781,11 @@ int rz_destroy(rz_ctx *c)
         if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]);
         if (c->ev_free[k]) (void)hipEventDestroy(c->ev_free[k]);
     }
-    dfree(c->palette); dfree(c->act_idx); dfree(c->act_w); dfree(c->act_count);
+    for (int k = 0; k < 2; ++k) {
+        dfree(c->palette_ring[k]); dfree(c->act_idx_ring[k]); dfree(c->act_w_ring[k]); dfree(c->act_count_ring[k]);
+        if (c->ev_front[k]) (void)hipEventDestroy(c->ev_front[k]);
+        if (c->ev_skin[k]) (void)hipEventDestroy(c->ev_skin[k]);
+    }
     dfree(c->out_pos); dfree(c->out_nrm); dfree(c->g_pos); dfree(c->g_nrm);
     dfree(c->edge); dfree(c->out_hull); dfree(c->aabb);
     for (int i = 0; i < kStageSlots; ++i) {
@@ -916,6 +986,11 @@ static int stage_acquire(rz_ctx *c, size_t need, int *slot_out)
 static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void *secondary, size_t sbytes, bool local,
                        const float *morph_weights)
 {
+    // the pose kind decides the plan, the plan decides which stream protocol the frame (and therefore this upload) follows
+    c->pose_set = false;
+    c->pose_local = local;
+    c->pose_sampled = false;
+    if (int r = set_overlap(c, want_overlap(c, make_plan(c)))) return r;
     const size_t p1 = pbytes;           // `secondary` (local translations) rides right behind `primary` in the slot
     pbytes += sbytes;
     const size_t mb = (size_t)c->I * c->M * sizeof(float);
@@ -926,9 +1001,13 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
     // Large ones (instanced crowds: MBs) take the upload stream: everything enqueued so far reads the current device
     // slot, so mark it, fill the other slot once ITS last readers are done, and make the compute stream wait for it.
     const int cur = c->pose_slot, k = cur ^ 1;
-    const bool piped = pbytes + mb > (256u << 10);
-    hipStream_t us = piped ? c->up_stream : c->stream;
-    if (piped) {
+    // Overlapped-front protocol (crowds): EVERY per-frame input travels on the upload stream and is consumed there, by the
+    // front kernels — stream order is the only ordering needed, no event at all.
+    const bool piped = !c->overlap_on && pbytes + mb > (256u << 10);
+    hipStream_t us = (piped || c->overlap_on) ? c->up_stream : c->stream;
+    if (c->overlap_on) {
+        c->free_recorded[0] = c->free_recorded[1] = false;
+    } else if (piped) {
         HIP_TRY(hipEventRecord(c->ev_free[cur], c->stream));
         c->free_recorded[cur] = true;
         // Slot k was last current two uploads ago; its readers (and the FK kernel that WRITES its world matrices) were
@@ -976,8 +1055,6 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
         }
         c->ml.count = n <= kKargMorphs ? n : -1;
     }
-    c->pose_local = local;
-    c->pose_sampled = false;
     c->pose_set = true;
     return RZ_OK;
 }
@@ -1153,16 +1230,19 @@ int rz_set_pose_sampled(rz_ctx *c, const float *frames)
         HIP_TRY(hipMalloc(&c->an_frames, (size_t)c->I * sizeof(float)));
         c->an_frames_alloc = c->I;
     }
-    int slot = 0;
-    if (int r = stage_acquire(c, std::max<size_t>((size_t)c->I * sizeof(float), 4096), &slot)) return r;
-    memcpy(c->stage[slot], frames, (size_t)c->I * sizeof(float));
-    HIP_TRY(hipMemcpyAsync(c->an_frames, c->stage[slot], (size_t)c->I * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->stage_ev[slot], c->stream));
-    c->stage_used[slot] = true;
-    c->local_q = c->local_q_buf[c->pose_slot];
+    c->pose_set = false;
     c->pose_sampled = true;
     c->pose_local = true;
     c->pose_local_t = true;
+    if (int r = set_overlap(c, want_overlap(c, make_plan(c)))) return r;
+    int slot = 0;
+    if (int r = stage_acquire(c, std::max<size_t>((size_t)c->I * sizeof(float), 4096), &slot)) return r;
+    memcpy(c->stage[slot], frames, (size_t)c->I * sizeof(float));
+    hipStream_t us = front_stream(c);       // consumed by rz_fk_kernel, which runs on this stream
+    HIP_TRY(hipMemcpyAsync(c->an_frames, c->stage[slot], (size_t)c->I * sizeof(float), hipMemcpyHostToDevice, us));
+    HIP_TRY(hipEventRecord(c->stage_ev[slot], us));
+    c->stage_used[slot] = true;
+    c->local_q = c->local_q_buf[c->pose_slot];
     memset(&c->ml, 0, sizeof c->ml);
     if (c->M > 0) c->ml.count = -1;          // the weights only exist on the device: the prep kernel compacts them
     c->pose_set = true;
@@ -1198,6 +1278,7 @@ int rz_override_world(rz_ctx *c, uint32_t n, const uint32_t *instance, const uin
     for (uint32_t i = 0; i < c->I; ++i) off[i + 1] += off[i];
     const size_t m = bones.size();
     if (m > c->ovr_alloc || off.size() > c->ovr_off_alloc) {
+        HIP_TRY(hipStreamSynchronize(c->up_stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         drop_graph(c);
         dfree(c->ovr_off); dfree(c->ovr_bone); dfree(c->ovr_world);
@@ -1215,10 +1296,11 @@ int rz_override_world(rz_ctx *c, uint32_t n, const uint32_t *instance, const uin
     memcpy(st, off.data(), b_off);
     memcpy(st + b_off, bones.data(), b_bone);
     memcpy(st + b_off + b_bone, mats.data(), b_mat);
-    HIP_TRY(hipMemcpyAsync(c->ovr_off, st, b_off, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->ovr_bone, st + b_off, b_bone, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->ovr_world, st + b_off + b_bone, b_mat, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->stage_ev[slot], c->stream));
+    hipStream_t us = front_stream(c);       // consumed by rz_fk_kernel, which runs on this stream
+    HIP_TRY(hipMemcpyAsync(c->ovr_off, st, b_off, hipMemcpyHostToDevice, us));
+    HIP_TRY(hipMemcpyAsync(c->ovr_bone, st + b_off, b_bone, hipMemcpyHostToDevice, us));
+    HIP_TRY(hipMemcpyAsync(c->ovr_world, st + b_off + b_bone, b_mat, hipMemcpyHostToDevice, us));
+    HIP_TRY(hipEventRecord(c->stage_ev[slot], us));
     c->stage_used[slot] = true;
     c->ovr_count = (uint32_t)m;
     return RZ_OK;
@@ -1228,6 +1310,7 @@ int rz_read_world(rz_ctx *c, uint32_t instance, float *world16)
 {
     if (int r = use(c)) return r;
     if (instance >= c->I || !world16 || !c->world) return fail(RZ_ERR_INVALID, "bad world read");
+    HIP_TRY(hipStreamSynchronize(c->up_stream));        // rz_fk_kernel may have written them on the front stream
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(world16, c->world + (size_t)instance * c->B * 16, (size_t)c->B * 16 * sizeof(float), hipMemcpyDeviceToHost));
     return RZ_OK;
@@ -1239,8 +1322,8 @@ int rz_deform(rz_ctx *c)
     if (int r = check_ready(c)) return r;
     if (int r = ensure_outputs(c)) return r;
     const Plan pl = make_plan(c);
-    if (int r = launch_front(c, pl)) return r;
-    return launch_deform(c, pl);
+    if (int r = set_overlap(c, want_overlap(c, pl))) return r;
+    return run_frame(c, pl);
 }
 
 // FNV-1a over the plain-data structs a frame's launches are built from: if none of them changed, a captured graph of
@@ -1278,6 +1361,7 @@ int rz_deform_n(rz_ctx *c, uint32_t frames)
     if (int r = check_ready(c)) return r;
     if (int r = ensure_outputs(c)) return r;
     const Plan pl = make_plan(c);
+    if (int r = set_overlap(c, want_overlap(c, pl))) return r;      // never on while the graph key is set
     uint32_t f = 0;
     if (c->t_graph && frames >= 2 * kGraphFrames) {
         // Launch-bound replay (a 30 k-vertex frame is 3-6 us of GPU time per ~3 us of launch work on the host): capture
@@ -1287,8 +1371,7 @@ int rz_deform_n(rz_ctx *c, uint32_t frames)
         // kernel attributes and loads the modules); kGraphFrames is even, so a replay ends on the parity it began with.
         uint64_t sig = frame_signature(c, pl);
         if (!c->graph_exec || c->graph_sig != sig) {
-            if (int r = launch_front(c, pl)) return r;
-            if (int r = launch_deform(c, pl)) return r;
+            if (int r = run_frame(c, pl)) return r;
             ++f;
             sig = frame_signature(c, pl);
         }
@@ -1298,7 +1381,7 @@ int rz_deform_n(rz_ctx *c, uint32_t frames)
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             int rc = RZ_OK;
             for (uint32_t k = 0; k < kGraphFrames && rc == RZ_OK; ++k) {
-                rc = launch_front(c, pl);
+                rc = launch_front(c, pl, c->stream);
                 if (rc == RZ_OK) rc = launch_deform(c, pl);
             }
             hipError_t ce = hipStreamEndCapture(c->stream, &g);
@@ -1311,16 +1394,15 @@ int rz_deform_n(rz_ctx *c, uint32_t frames)
         }
         for (; f + kGraphFrames <= frames; f += kGraphFrames) HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
     }
-    for (; f < frames; ++f) {
-        if (int r = launch_front(c, pl)) return r;
-        if (int r = launch_deform(c, pl)) return r;
-    }
+    for (; f < frames; ++f)
+        if (int r = run_frame(c, pl)) return r;
     return RZ_OK;
 }
 
 int rz_sync(rz_ctx *c)
 {
     if (int r = use(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->up_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RZ_OK;
 }
@@ -1405,21 +1487,23 @@ int rz_time_frames(rz_ctx *c, uint32_t frames, rz_timing *out)
     if (int r = check_ready(c)) return r;
     if (int r = ensure_outputs(c)) return r;
     const Plan pl = make_plan(c);
+    if (int r = set_overlap(c, want_overlap(c, pl))) return r;
     memset(out, 0, sizeof *out);
     float ms = 0.f;
-    // whole frames (prep kernel when the plan needs one + fused kernel), back to back on the context's stream
-    if (int r = launch_front(c, pl)) return r;    // the deform-only loop below needs a palette
+    // whole frames (front kernels when the plan has any + the deform / skin kernel), back to back exactly as rz_deform
+    // issues them — for crowds that is the overlapped protocol: fronts on the upload stream, skin kernels on the
+    // context's stream (the events below sit on the context's stream; the last skin kernel waits for the last front)
+    if (int r = run_frame(c, pl)) return r;       // the deform-only loop below needs a palette
+    HIP_TRY(hipStreamSynchronize(c->up_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    for (uint32_t f = 0; f < frames; ++f) {
-        if (int r = launch_front(c, pl)) return r;
-        if (int r = launch_deform(c, pl)) return r;
-    }
+    for (uint32_t f = 0; f < frames; ++f)
+        if (int r = run_frame(c, pl)) return r;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     out->frame_ms = ms / frames;
-    // the fused morph+skin kernel alone
+    // the deform / skin kernel alone (reads the ring slot the last frame left current)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     for (uint32_t f = 0; f < frames; ++f)
         if (int r = launch_deform(c, pl)) return r;
@@ -1427,16 +1511,19 @@ int rz_time_frames(rz_ctx *c, uint32_t frames, rz_timing *out)
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     out->deform_kernel_ms = ms / frames;
-    // the prep kernel alone (only part of the frame when the plan is not the one-launch FAST form)
+    // the front kernels alone (only part of the frame when the plan is not the one-launch FAST form); everything has
+    // drained at this point, so they may run on the context's stream whatever the protocol
     if (pl.prep || c->pose_local) {
+        HIP_TRY(hipStreamSynchronize(c->up_stream));
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
         for (uint32_t f = 0; f < frames; ++f)
-            if (int r = launch_front(c, pl)) return r;
+            if (int r = launch_front(c, pl, c->stream)) return r;
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
         HIP_TRY(hipEventSynchronize(c->ev1));
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         out->prep_kernel_ms = ms / frames;
     }
+    c->skin_recorded[0] = c->skin_recorded[1] = false;      // both streams are idle: no slot has a reader in flight
     out->verts_per_frame = (uint64_t)c->V * c->I;
     out->algorithmic_bytes_per_frame = algorithmic_bytes(c);
     out->frames = frames;
@@ -1473,6 +1560,7 @@ int rz_autotune(rz_ctx *c, uint32_t frames)
         c->t_split = cands[i].split; c->t_grid_cap = cands[i].cap;
         if (instanced) c->t_instloop = cands[i].loop;
         const Plan pl = make_plan(c);
+        if (int r = set_overlap(c, want_overlap(c, pl))) return r;
         bool dup = false;              // different requests often resolve to the same launch
         for (int k = 0; k < n_seen; ++k)
             dup |= seen_grid[k] == pl.grid_x && seen_qpw[k] == pl.quads_per_wave && seen_s[k] == pl.v.S && seen_g[k] == pl.inst_group;
@@ -1480,15 +1568,11 @@ int rz_autotune(rz_ctx *c, uint32_t frames)
         if (n_seen < 32) { seen_grid[n_seen] = pl.grid_x; seen_qpw[n_seen] = pl.quads_per_wave; seen_s[n_seen] = pl.v.S; seen_g[n_seen++] = pl.inst_group; }
         float cand_ms = 0.f;
         for (int rep = 0; rep < 2; ++rep) {        // best of two, the first pass also warms the variant up
-            for (uint32_t f = 0; f < 5; ++f) {
-                if (int r = launch_front(c, pl)) return r;
-                if (int r = launch_deform(c, pl)) return r;
-            }
+            for (uint32_t f = 0; f < 5; ++f)
+                if (int r = run_frame(c, pl)) return r;
             HIP_TRY(hipEventRecord(c->ev0, c->stream));
-            for (uint32_t f = 0; f < frames; ++f) {
-                if (int r = launch_front(c, pl)) return r;
-                if (int r = launch_deform(c, pl)) return r;
-            }
+            for (uint32_t f = 0; f < frames; ++f)
+                if (int r = run_frame(c, pl)) return r;
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
             HIP_TRY(hipEventSynchronize(c->ev1));
             float ms = 0.f;
@@ -1540,6 +1624,9 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
     } else if (!strcmp(key, "inst_loop")) {
         if (value < -1 || value == 1 || value > 16) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off), 2..8 / 10..16 (poses per workgroup, LDS form) or 9 (register form)");
         c->t_instloop = value;
+    } else if (!strcmp(key, "overlap")) {
+        if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "overlap must be -1 (auto: crowds), 0 (off) or 1");
+        c->t_overlap = value;
     } else if (!strcmp(key, "inst_block")) {
         if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(RZ_ERR_INVALID, "inst_block must be 0 (auto), 256, 512 or 1024 threads per workgroup");
         c->t_instblock = value;
@@ -1576,6 +1663,8 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "effective_fast")) *value = make_plan(c).v.fast ? 1 : 0;
     else if (!strcmp(key, "inst_loop")) *value = c->t_instloop;
     else if (!strcmp(key, "inst_block")) *value = c->t_instblock;
+    else if (!strcmp(key, "overlap")) *value = c->t_overlap;
+    else if (!strcmp(key, "effective_overlap")) *value = want_overlap(c, make_plan(c)) ? 1 : 0;
     else if (!strcmp(key, "effective_inst_block")) *value = make_plan(c).inst_block;
     else if (!strcmp(key, "out_cap")) *value = c->t_outcap;
     else if (!strcmp(key, "graph")) *value = c->t_graph;

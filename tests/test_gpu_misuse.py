@@ -28,10 +28,10 @@ fp = ctypes.POINTER(ctypes.c_float)
 # null context everywhere
 for name in rz.capi.SYMBOLS:
     if name in ("rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_shard_range", "rz_comm_unique_id",
-                "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_destroy"):      # rz_destroy(NULL) is a no-op, like free
+                "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_destroy", "rz_rccl_info"):      # rz_destroy(NULL) is a no-op, like free
         continue
     f = getattr(L, name)
-    args = [None] + [0 if t in (ctypes.c_uint32, ctypes.c_int, ctypes.c_uint) else None for t in f.argtypes[1:]]
+    args = [None] + [0 if t in (ctypes.c_uint32, ctypes.c_int, ctypes.c_uint, ctypes.c_size_t) else None for t in f.argtypes[1:]]
     expect_fail(name + "(NULL ctx)", f(*args))
 # null / inconsistent data on a live context
 expect_fail("upload_mesh(NULL)", L.rz_upload_mesh(h, 10, N, N, N))
@@ -72,6 +72,11 @@ expect_fail("topology with a cycle", L.rz_upload_skeleton_topology(h, 6, cyc.cty
 expect_fail("edge scale wrong V", L.rz_upload_edge_scale(h, 7, m["quats"].ctypes.data_as(fp)))
 expect_fail("read_palette before pose", L.rz_read_palette(h, 0, N))
 expect_fail("tuning unknown key", L.rz_set_tuning(h, b"nonsense", 1))
+expect_fail("ablation key absent from the product", L.rz_set_tuning(h, b"dbg", 3))
+expect_fail("inst_block 300", L.rz_set_tuning(h, b"inst_block", 300))
+expect_fail("overlap 7", L.rz_set_tuning(h, b"overlap", 7))
+expect_fail("override_world without topology", L.rz_override_world(h, 1, N, (ctypes.c_uint32 * 1)(0), m["world"].ctypes.data_as(fp)))
+if L.rz_rccl_info(N, 0, N, N) not in (0, -6): bad.append("rccl_info(NULLs) must be OK or UNSUPPORTED")
 expect_fail("tuning NULL key", L.rz_set_tuning(h, N, 1))
 expect_fail("get_tuning NULL out", L.rz_get_tuning(h, b"bones", N))
 c.set_pose(m["world"]); c.deform()
