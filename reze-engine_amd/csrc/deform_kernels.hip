@@ -871,10 +871,15 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
             }
         }
     }
-    // the inverse bind matrix of the bone this thread converts (one bone per thread across the group's poses)
+    // One-launch frame: which (bone, pose stripe) this thread converts. With B <= BLOCK / 2 the spare threads take a second,
+    // third ... stripe of the group's poses (stripe s converts poses s, s + stripes, ...): 200 bones on 512 threads = 2 stripes.
+    const int stripes = (!p.dma && p.B <= BLOCK) ? max(1, min(ng, BLOCK / p.B)) : 1;
+    const int cv_b0 = stripes > 1 ? tid % p.B : tid;
+    const int cv_g0 = stripes > 1 ? tid / p.B : 0;
+    const bool cv_on = !p.dma && cv_g0 < stripes && cv_b0 < p.B;
     float4 ib0 = {0, 0, 0, 0}, ib1 = ib0, ib2 = ib0, ib3 = ib0;
-    if (!p.dma && tid < p.B) {
-        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + tid * 4;
+    if (cv_on) {                                    // requested first: lands while the staging copy is in flight
+        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + cv_b0 * 4;
         ib0 = gi[0]; ib1 = gi[1]; ib2 = gi[2]; ib3 = gi[3];
     }
     const size_t Vp = p.Vp;
@@ -898,19 +903,20 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         // inverse bind matrix is held as column PAIRS (c0,c1),(c2,c3) per k, so each result row is two v_pk_fma
         // chains (the same chain as rz_prep_kernel: ((a0*b0 + a1*b1) + a2*b2) + a3*b3); the next pose's cells are read
         // before the current product is formed.
-        for (int b = tid; b < p.B; b += BLOCK) {            // one trip unless the skeleton has more bones than threads
-            if (b != tid) {
+        for (int b = cv_b0; cv_on && b < p.B; b += BLOCK) {  // one trip unless the skeleton has more bones than threads
+            if (b != cv_b0) {
                 const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + b * 4;
                 ib0 = gi[0]; ib1 = gi[1]; ib2 = gi[2]; ib3 = gi[3];
             }
             const f2 px01 = {ib0.x, ib1.x}, px23 = {ib2.x, ib3.x}, py01 = {ib0.y, ib1.y}, py23 = {ib2.y, ib3.y};
             const f2 pz01 = {ib0.z, ib1.z}, pz23 = {ib2.z, ib3.z}, pw01 = {ib0.w, ib1.w}, pw23 = {ib2.w, ib3.w};
-            float4 *slot = pal + (size_t)b * 4;
+            const int gstep = stripes * lrows;
+            float4 *slot = pal + (size_t)cv_g0 * lrows + (size_t)b * 4;
             float4 a0 = slot[0], a1 = slot[1], a2 = slot[2], a3 = slot[3];       // the world matrix's columns
-            for (int g = 0; g < ng; ++g) {
-                float4 *nxt = slot + lrows;
+            for (int g = cv_g0; g < ng; g += stripes) {
+                float4 *nxt = slot + gstep;
                 float4 n0 = a0, n1 = a1, n2 = a2, n3 = a3;
-                if (g + 1 < ng) { n0 = nxt[0]; n1 = nxt[1]; n2 = nxt[2]; n3 = nxt[3]; }
+                if (g + stripes < ng) { n0 = nxt[0]; n1 = nxt[1]; n2 = nxt[2]; n3 = nxt[3]; }
                 auto row = [&](float e0, float e1, float e2, float e3, const f2 &bx, const f2 &by, const f2 &bz, const f2 &bw) {
                     return pk_fma(f2{e3, e3}, bw, pk_fma(f2{e2, e2}, bz, pk_fma(f2{e1, e1}, by, f2{e0, e0} * bx)));
                 };

@@ -472,11 +472,17 @@ Plan make_plan(const rz_ctx *c)
     //       what the extra launch did, so it is opt-in.
     const bool epilogues = c->edge != nullptr || c->aabb_on;   // only the generic kernel carries the fused consumers
     if (v.mode == 0 && c->I > 1 && c->t_instloop != 0 && c->t_instloop != 9 && !epilogues) {
-        const bool in_kernel = c->t_fast == 1 && !c->pose_local;
+        // Where the palettes come from. World-matrix poses (rz_set_pose): the skin kernel forms them itself — ONE launch
+        // per frame, measured 35.5 us on C4 against 39.0 us for rz_prep_kernel + launch boundary + skin kernel; it stages
+        // the group's world matrices in 64-byte slots, so the default shape for it is one 512-thread workgroup per CU
+        // (8 poses x 200 bones = 102 KB; two 256-thread workgroups of 6 poses each measured 39.5 us). Device-solved poses:
+        // rz_fk_kernel has written the palettes already, the skin kernel copies them in (48-byte slots, LDS-DMA).
+        // fast = 0 forces the prep-kernel form, fast = 1 / -1 (auto) the one-launch form.
+        const bool in_kernel = c->t_fast != 0 && !c->pose_local;
         const uint32_t slot = in_kernel ? 64u : 48u;           // LDS bytes per bone per pose (deform_kernels.hip)
         // workgroup size: 256 threads = two workgroups per CU (80 KB of palettes each); 512 / 1024 = one workgroup per CU
         // whose 8 / 16 waves share one staged palette group (up to 156 KB)
-        const int blk = c->t_instblock == 512 || c->t_instblock == 1024 ? c->t_instblock : 256;
+        const int blk = c->t_instblock == 256 || c->t_instblock == 512 || c->t_instblock == 1024 ? c->t_instblock : (in_kernel ? 512 : 256);
         const uint32_t wg_per_cu = blk == 256 ? 2u : 1u;
         const uint32_t g_lds = ((blk == 256 ? 80u : 156u) * 1024u) / (c->B * slot);
         int G = (int)std::min<uint32_t>(8, g_lds);
@@ -599,7 +605,9 @@ int launch_deform(rz_ctx *c, const Plan &pl)
 // frames read the uploaded weights directly), and plain stream capture (the graph key) stays single-stream.
 bool want_overlap(const rz_ctx *c, const Plan &pl)
 {
-    return c->t_overlap != 0 && c->I > 1 && c->morph_mode != 2 && !c->t_graph && (pl.prep || c->pose_local);
+    // OPT-IN (overlap = 1): measured on MI355X / ROCm 7.2 the two cross-stream hand-offs per frame cost more than the front
+    // kernels they hide — C4 39.0 -> 44.8 us with rz_prep_kernel in front, 43.4 -> 62.1 us with rz_fk_kernel
+    return c->t_overlap == 1 && c->I > 1 && c->morph_mode != 2 && !c->t_graph && (pl.prep || c->pose_local);
 }
 
 // Switching protocols is rare (instance count, tuning keys): drain both streams so that nothing enqueued under the old
@@ -1544,8 +1552,10 @@ int rz_autotune(rz_ctx *c, uint32_t frames)
     const int ncu = c->n_cu;
     const bool instanced = c->morph_mode == 0 && c->I > 1 && c->t_instloop != 0 && c->t_instloop != 9 && !(c->edge || c->aabb_on);
     if (instanced) {
+        // total workgroups: one or two rounds of what the CUs hold at once (two 256-thread workgroups or one larger one)
+        const int base = (make_plan(c).inst_block > 256 ? 1 : 2) * ncu;
         for (int loop : {8, 4})
-            for (int cap : {2 * ncu, 4 * ncu}) cands.push_back({0, cap, loop});
+            for (int cap : {base, 2 * base}) cands.push_back({0, cap, loop});
     } else {
         const int smax = c->morph_mode == 1 ? (int)std::min<uint32_t>(8, std::max<uint32_t>(1, c->M)) : 4;
         for (int sp = 1; sp <= smax; sp <<= 1)
@@ -1625,7 +1635,7 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
         if (value < -1 || value == 1 || value > 16) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off), 2..8 / 10..16 (poses per workgroup, LDS form) or 9 (register form)");
         c->t_instloop = value;
     } else if (!strcmp(key, "overlap")) {
-        if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "overlap must be -1 (auto: crowds), 0 (off) or 1");
+        if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "overlap must be -1 (auto = off), 0 (off) or 1 (crowds: front kernels on the upload stream)");
         c->t_overlap = value;
     } else if (!strcmp(key, "inst_block")) {
         if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(RZ_ERR_INVALID, "inst_block must be 0 (auto), 256, 512 or 1024 threads per workgroup");

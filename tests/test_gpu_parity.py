@@ -351,7 +351,8 @@ def test_c5_full_size_parity_and_properties(ctx, oracle, rz):
     np.testing.assert_allclose(pi, mesh["pos"], rtol=1e-6, atol=2e-5)
 
 
-def test_pose_upload_pipeline_never_serves_a_stale_or_torn_pose(rz, oracle):
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_pose_upload_pipeline_never_serves_a_stale_or_torn_pose(rz, oracle, overlap):
     """Per-frame inputs are double-buffered and large uploads ride a second stream (pinned 4-slot ring, ev_up / ev_free
     hand-off). Hammer it: 400 frames cycling through four crowd poses — world matrices, local rotations, back and forth,
     and poses sampled on the device, with and without a deform between two uploads — and check, whenever a frame is read back, that it is exactly the
@@ -363,6 +364,10 @@ def test_pose_upload_pipeline_never_serves_a_stale_or_torn_pose(rz, oracle):
     c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
     c.upload_skeleton(mesh["inv_bind"])
     c.set_instances(I)
+    # overlap = 1: the opt-in protocol where the front kernels (prep / FK / sampling) of a frame run on the upload stream,
+    # into the other slot of a 2-slot ring, while the skin kernel of the frame before is still reading its slot
+    c.set_tuning(overlap=overlap, fast=0 if overlap else -1)
+    assert c.get_tuning("effective_overlap") == overlap
     c.upload_skeleton_topology(mesh["parents"], mesh["bind"])
     poses = []
     for k in range(4):

@@ -67,17 +67,49 @@ def _worker(rank, world, port, v_total, q, on_gpu=False):
             ref, _ = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"], deltas, mw)
         ranges = [None] * world
         dist.all_gather_object(ranges, (b, n))
-        q.put((rank, bool(np.array_equal(full, ref)), ranges, chunk))
+        res = (rank, bool(np.array_equal(full, ref)), ranges, chunk)
+        if q is not None:
+            q.put(res)
+        return res
     finally:
         dist.destroy_process_group()
 
 
-def _run_two_ranks(v_total, on_gpu):
-    import torch.multiprocessing as mp
+def _check(res, v_total):
+    for rank, ok, ranges, chunk in res:
+        assert ok, "rank %d: gathered mesh differs from the unsharded result" % rank
+        assert ranges[0][0] == 0 and ranges[0][1] + ranges[1][1] == v_total and (ranges[1][0] == ranges[0][1] or ranges[1][1] == 0)
+        assert chunk % 1024 == 0
+
+
+def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+def _run_two_ranks(v_total, on_gpu):
+    port = _free_port()
+    if on_gpu:
+        # Separate interpreters that import torch BEFORE the HIP library, like bench.py: PyTorch bundles its own ROCm
+        # runtime libraries, and pulling them into a process that already runs on /opt/rocm's (the pytest process, after
+        # the other GPU tests) ends in a double free at exit.
+        import json
+        import subprocess
+        code = ("import sys, json; sys.path.insert(0, %r); import test_sharding_gloo as t; "
+                "r = t._worker(int(sys.argv[1]), 2, int(sys.argv[2]), int(sys.argv[3]), None, True); print('RESULT ' + json.dumps(r))" % os.path.dirname(os.path.abspath(__file__)))
+        procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(port), str(v_total)], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+        res = []
+        for p in procs:
+            out, err = p.communicate(timeout=600)
+            assert p.returncode == 0, "rank process died with %d\n%s" % (p.returncode, err.decode()[-3000:])
+            line = [ln for ln in out.decode().splitlines() if ln.startswith("RESULT ")][-1]
+            res.append(json.loads(line[7:]))
+        _check(res, v_total)
+        return
+    import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, v_total, q, on_gpu)) for r in range(2)]
@@ -87,10 +119,7 @@ def _run_two_ranks(v_total, on_gpu):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok, ranges, chunk in res:
-        assert ok, "rank %d: gathered mesh differs from the unsharded result" % rank
-        assert ranges[0][0] == 0 and ranges[0][1] + ranges[1][1] == v_total and ranges[1][0] == ranges[0][1] or ranges[1][1] == 0
-        assert chunk % 1024 == 0
+    _check(res, v_total)
 
 
 @pytest.mark.parametrize("v_total", [5000, 1024, 2049, 40000])

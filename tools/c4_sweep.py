@@ -22,6 +22,14 @@ for blk, loops, caps in ((256, (8, 4), (512, 1024)), (512, (8, 16), (256, 512)),
                 print("block=%4d G=%2d(eff %2d) cap=%4d grid=%3d nts=%d : kernel %.2f us frame %.2f us prep %.2f us" % (
                     blk, il, ctx.get_tuning("effective_inst_group"), cap, ctx.get_tuning("effective_grid"), nts,
                     t["deform_kernel_ms"] * 1e3, t["frame_ms"] * 1e3, t["prep_kernel_ms"] * 1e3), flush=True)
+# one-launch frames: palettes formed inside the skin kernel (fast = 1), no prep kernel, no launch boundary
+for blk, il, cap in ((256, 8, 512), (256, 6, 512), (256, 4, 1024), (512, 8, 256), (512, 8, 512), (1024, 8, 256), (1024, 12, 256)):
+    ctx.set_tuning(inst_block=blk, inst_loop=il, grid_cap=cap, nt_store=0, fast=1)
+    t = min((ctx.time_frames(200) for _ in range(3)), key=lambda t: t["frame_ms"])
+    rows.append((t["frame_ms"], blk, il, cap, 0, t["deform_kernel_ms"], t["prep_kernel_ms"]))
+    print("ONE-LAUNCH block=%4d G=%2d(eff %2d) cap=%4d grid=%3d : kernel %.2f us frame %.2f us" % (
+        blk, il, ctx.get_tuning("effective_inst_group"), cap, ctx.get_tuning("effective_grid"), t["deform_kernel_ms"] * 1e3, t["frame_ms"] * 1e3), flush=True)
+ctx.set_tuning(fast=-1)
 best = min(rows)
 print("best frame: %.2f us at block=%d G=%d cap=%d nts=%d (kernel %.2f us); compulsory 188.69 MB -> %.1f %% of 8 TB/s (frame), %.1f %% (kernel)" % (
     best[0] * 1e3, best[1], best[2], best[3], best[4], best[5] * 1e3, 188.69e6 / (best[0] * 1e-3) / 8e12 * 100, 188.69e6 / (best[5] * 1e-3) / 8e12 * 100))
