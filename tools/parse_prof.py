@@ -89,7 +89,7 @@ for name, (title, V, B, M, I) in WORK.items():
     read_b = fetch_kib * 1024 * f_read
     write_b = write_kib * 1024 * (f_write3 if nts else f_write3_plain)
     if I > 1:
-        alg_read = V * 36 + I * B * 48          # the skin kernel reads the mesh once and the finished palettes
+        alg_read = V * 36 + I * B * 64 + B * 64  # mesh once, world matrices per instance, inverse bind
         alg_write = I * V * 24
     else:
         alg_read = V * (36 + 12 * M) + B * 128 + M * 4
