@@ -137,8 +137,7 @@ struct rz_ctx {
     float *fk_bind = nullptr, *fk_append_ratio = nullptr;
     int fk_levels = 0;
     float4 *local_q = nullptr;          // I x B   (current pose slot)
-    float4 *local_q_buf[2] = {nullptr, nullptr};
-    size_t local_q_alloc = 0;
+    float4 *local_q_buf[2] = {nullptr, nullptr};    // = pose_blk[k] + I*B*16 + mw_pad (rotations, then translations)
     bool pose_local = false;            // the current pose came from rz_set_pose_local
     // physics hand-off for device-solved frames (rz_override_world)
     int *ovr_off = nullptr, *ovr_bone = nullptr;
@@ -160,8 +159,14 @@ struct rz_ctx {
     // Per-frame INPUTS are double-buffered and uploaded on their own stream, so the upload of pose f+1 overlaps the
     // kernels of pose f: ev_up[k] = slot k has landed (the compute stream waits for it), ev_free[k] = everything
     // that reads slot k has been enqueued up to here (the upload stream waits for it before overwriting the slot).
-    float *world_buf[2] = {nullptr, nullptr};
-    float *morph_w_buf[2] = {nullptr, nullptr};
+    // One device block per pose slot: [world I*B*16 | morph weights pad4(I*max(M,1)) | local rotations I*B*4 | local
+    // translations I*B*3] floats. A world-matrix pose fills [world | weights], a local pose [weights | rotations (|
+    // translations)] — each a CONTIGUOUS range, so every upload is one copy (measured: a small H2D copy is a 4.5 us blit
+    // kernel on this runtime, and a second one for 256 bytes of morph weights cost as much as the first).
+    float *pose_blk[2] = {nullptr, nullptr};
+    float *world_buf[2] = {nullptr, nullptr};       // = pose_blk[k]
+    float *morph_w_buf[2] = {nullptr, nullptr};     // = pose_blk[k] + I*B*16
+    size_t mw_pad = 0;                              // floats reserved for the morph weights (multiple of 4)
     int pose_slot = 0;
     hipStream_t up_stream = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
@@ -312,19 +317,23 @@ int ensure_pose_buffers(rz_ctx *c)
     if (c->I <= c->pose_alloc_I && c->B <= c->pose_alloc_B && Mq <= c->pose_alloc_M && c->world) return RZ_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->up_stream));
-    for (int k = 0; k < 2; ++k) { dfree(c->world_buf[k]); dfree(c->morph_w_buf[k]); c->free_recorded[k] = false; }
-    c->world = nullptr; c->morph_w = nullptr;
+    for (int k = 0; k < 2; ++k) { dfree(c->pose_blk[k]); c->world_buf[k] = nullptr; c->morph_w_buf[k] = nullptr; c->local_q_buf[k] = nullptr; c->free_recorded[k] = false; }
+    c->world = nullptr; c->morph_w = nullptr; c->local_q = nullptr;
     for (int k = 0; k < 2; ++k) { dfree(c->palette_ring[k]); dfree(c->act_idx_ring[k]); dfree(c->act_w_ring[k]); dfree(c->act_count_ring[k]); c->skin_recorded[k] = false; }
     c->palette = nullptr; c->act_idx = nullptr; c->act_w = nullptr; c->act_count = nullptr;
     const size_t I = c->I, B = c->B;
     const size_t Mpad = round_up(Mq + 8, 4);
+    c->mw_pad = (I * Mq + 3) / 4 * 4;
+    const size_t blk_floats = I * B * 16 + c->mw_pad + I * B * 7;
     for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipMalloc(&c->world_buf[k], I * B * 16 * sizeof(float)));
-        HIP_TRY(hipMalloc(&c->morph_w_buf[k], I * Mq * sizeof(float)));
-        HIP_TRY(hipMemsetAsync(c->morph_w_buf[k], 0, I * Mq * sizeof(float), c->stream));
+        HIP_TRY(hipMalloc(&c->pose_blk[k], blk_floats * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(c->pose_blk[k], 0, blk_floats * sizeof(float), c->stream));
+        c->world_buf[k] = c->pose_blk[k];
+        c->morph_w_buf[k] = c->pose_blk[k] + I * B * 16;
+        c->local_q_buf[k] = reinterpret_cast<float4 *>(c->pose_blk[k] + I * B * 16 + c->mw_pad);
     }
     c->pose_slot = 0;
-    c->world = c->world_buf[0]; c->morph_w = c->morph_w_buf[0];
+    c->world = c->world_buf[0]; c->morph_w = c->morph_w_buf[0]; c->local_q = c->local_q_buf[0];
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipMalloc(&c->palette_ring[k], I * B * 3 * sizeof(float4)));
         HIP_TRY(hipMalloc(&c->act_idx_ring[k], I * Mpad * sizeof(uint32_t)));
@@ -781,11 +790,10 @@ int rz_destroy(rz_ctx *c)
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->inv_bind);
     dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind);
     free_animation(c); dfree(c->an_frames);
-    dfree(c->fk_append_ratio); dfree(c->fk_append_move); dfree(c->local_q_buf[0]); dfree(c->local_q_buf[1]);
+    dfree(c->fk_append_ratio); dfree(c->fk_append_move); dfree(c->pose_blk[0]); dfree(c->pose_blk[1]);
     dfree(c->ovr_off); dfree(c->ovr_bone); dfree(c->ovr_world);
     free_morphs(c);
     for (int k = 0; k < 2; ++k) {
-        dfree(c->world_buf[k]); dfree(c->morph_w_buf[k]);
         if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]);
         if (c->ev_free[k]) (void)hipEventDestroy(c->ev_free[k]);
     }
@@ -988,9 +996,10 @@ static int stage_acquire(rz_ctx *c, size_t need, int *slot_out)
     return RZ_OK;
 }
 
-// Shared tail of rz_set_pose / rz_set_pose_local. `primary` (world matrices or local rotations, `pbytes` long) and the
-// morph weights go through a pinned ring slot into the OTHER device slot on the upload stream, so this upload overlaps
-// whatever the compute stream is still running on the current slot; the compute stream then waits for the new slot.
+// Shared tail of rz_set_pose / rz_set_pose_local. `primary` (world matrices or local rotations, `pbytes` long), optional
+// `secondary` (local translations) and the morph weights are laid out in a pinned ring slot exactly as they sit in the
+// device pose block, and go down as ONE copy into the OTHER device slot — on the upload stream for big poses, so the
+// upload overlaps whatever the compute stream is still running on the current slot; the compute stream then waits for it.
 static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void *secondary, size_t sbytes, bool local,
                        const float *morph_weights)
 {
@@ -999,19 +1008,20 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
     c->pose_local = local;
     c->pose_sampled = false;
     if (int r = set_overlap(c, want_overlap(c, make_plan(c)))) return r;
-    const size_t p1 = pbytes;           // `secondary` (local translations) rides right behind `primary` in the slot
-    pbytes += sbytes;
-    const size_t mb = (size_t)c->I * c->M * sizeof(float);
+    const size_t mb = (size_t)c->I * c->M * sizeof(float);          // weights the caller handed over
+    const size_t mwb = c->mw_pad * sizeof(float);                    // their padded place in the block
+    // world pose: [world | weights]           local pose: [weights | rotations | translations]
+    const size_t total = local ? mwb + pbytes + sbytes : pbytes + (c->M > 0 ? mwb : 0);
     int slot = 0;
-    if (int r = stage_acquire(c, std::max(pbytes, (size_t)c->I * c->B * 64) + mb, &slot)) return r;
+    if (int r = stage_acquire(c, std::max<size_t>((size_t)c->I * c->B * 64 + mwb, mwb + (size_t)c->I * c->B * 28), &slot)) return r;
     // Small poses (one character: 16-22 KB) go down the compute stream itself — measured on C5, the two extra
     // packets of the cross-stream hand-off (marker + barrier) cost 3 us more per frame than the copy they hide.
     // Large ones (instanced crowds: MBs) take the upload stream: everything enqueued so far reads the current device
     // slot, so mark it, fill the other slot once ITS last readers are done, and make the compute stream wait for it.
     const int cur = c->pose_slot, k = cur ^ 1;
-    // Overlapped-front protocol (crowds): EVERY per-frame input travels on the upload stream and is consumed there, by the
-    // front kernels — stream order is the only ordering needed, no event at all.
-    const bool piped = !c->overlap_on && pbytes + mb > (256u << 10);
+    // Overlapped-front protocol (crowds, opt-in): EVERY per-frame input travels on the upload stream and is consumed there,
+    // by the front kernels — stream order is the only ordering needed, no event at all.
+    const bool piped = !c->overlap_on && total > (256u << 10);
     hipStream_t us = (piped || c->overlap_on) ? c->up_stream : c->stream;
     if (c->overlap_on) {
         c->free_recorded[0] = c->free_recorded[1] = false;
@@ -1028,18 +1038,16 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
         c->free_recorded[cur] = false;      // the slot's readers are about to be enqueued and nothing will mark their end
     }
     char *st = static_cast<char *>(c->stage[slot]);
-    memcpy(st, primary, p1);
-    if (sbytes) memcpy(st + p1, secondary, sbytes);
-    void *dst = local ? static_cast<void *>(c->local_q_buf[k]) : static_cast<void *>(c->world_buf[k]);
-    HIP_TRY(hipMemcpyAsync(dst, st, pbytes, hipMemcpyHostToDevice, us));
-    if (c->M > 0) {
-        if (morph_weights) {
-            memcpy(st + pbytes, morph_weights, mb);
-            HIP_TRY(hipMemcpyAsync(c->morph_w_buf[k], st + pbytes, mb, hipMemcpyHostToDevice, us));
-        } else {
-            HIP_TRY(hipMemsetAsync(c->morph_w_buf[k], 0, mb, us));
-        }
+    char *st_mw = local ? st : st + pbytes;
+    char *st_pr = local ? st + mwb : st;
+    memcpy(st_pr, primary, pbytes);
+    if (sbytes) memcpy(st_pr + pbytes, secondary, sbytes);
+    if (local || c->M > 0) {
+        if (morph_weights && mb) memcpy(st_mw, morph_weights, mb); else memset(st_mw, 0, mb);
+        if (mwb > mb) memset(st_mw + mb, 0, mwb - mb);
     }
+    void *dst = local ? static_cast<void *>(c->morph_w_buf[k]) : static_cast<void *>(c->world_buf[k]);
+    HIP_TRY(hipMemcpyAsync(dst, st, total, hipMemcpyHostToDevice, us));
     HIP_TRY(hipEventRecord(c->stage_ev[slot], us));
     c->stage_used[slot] = true;
     if (piped) {
@@ -1141,15 +1149,6 @@ int rz_set_pose_local(rz_ctx *c, const float *local_rotations4, const float *loc
     if (!local_rotations4) return fail(RZ_ERR_INVALID, "null local rotations");
     if (int r = ensure_pose_buffers(c)) return r;
     const size_t nq = (size_t)c->I * c->B;
-    if (nq > c->local_q_alloc) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipStreamSynchronize(c->up_stream));
-        for (int k = 0; k < 2; ++k) {
-            dfree(c->local_q_buf[k]);
-            HIP_TRY(hipMalloc(&c->local_q_buf[k], nq * (sizeof(float4) + 3 * sizeof(float))));   // rotations, then translations
-        }
-        c->local_q_alloc = nq;
-    }
     c->pose_local_t = local_translations3 != nullptr;
     return upload_pose(c, local_rotations4, nq * sizeof(float4), local_translations3, local_translations3 ? nq * 3 * sizeof(float) : 0, true,
                        morph_weights);
@@ -1222,16 +1221,6 @@ int rz_set_pose_sampled(rz_ctx *c, const float *frames)
     if (c->an_M != c->M) return fail(RZ_ERR_INVALID, "the motion's morph feeds were built for %u vertex morphs, the context holds %u", c->an_M, c->M);
     if (!frames) return fail(RZ_ERR_INVALID, "null frames");
     if (int r = ensure_pose_buffers(c)) return r;
-    const size_t nq = (size_t)c->I * c->B;
-    if (nq > c->local_q_alloc) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipStreamSynchronize(c->up_stream));
-        for (int k = 0; k < 2; ++k) {
-            dfree(c->local_q_buf[k]);
-            HIP_TRY(hipMalloc(&c->local_q_buf[k], nq * (sizeof(float4) + 3 * sizeof(float))));
-        }
-        c->local_q_alloc = nq;
-    }
     if (c->I > c->an_frames_alloc) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         dfree(c->an_frames);
