@@ -38,6 +38,8 @@ struct RzSampleParams {
     const float *feed_ratio;
     float *morph_w;               // [I][M] out
     int M;
+    int frames_inline;            // 1: every instance is posed at `frame0` (one character: the frame rides in the kernel arguments)
+    float frame0;
 };
 
 struct RzFkParams {
@@ -78,6 +80,11 @@ struct RzDeformParams {
     const float *act_w;         // [I][Mpad]
     const int *act_count;       // [I]
     const float *morph_w;       // [I][M]   (MODE 2)
+    // Zero-copy first frame (single character): `world` / `morph_w` point into PINNED HOST memory (the staging slot the
+    // host has just written) and workgroup 0 of the FAST kernel leaves a copy in device memory for the frames that replay
+    // this pose. null = the pose is already resident and `world` / `morph_w` are device pointers.
+    float *world_copy;          // [B][16] device destination, or null
+    float *morph_w_copy;        // [M]     device destination (MODE 2), or null
     const uint32_t *sp_ptr;     // [Vp+1]   (MODE 2) per-vertex CSR row pointers
     const float4 *sp_entries;   // [E]      (dx,dy,dz,bits(morph))
     float *out_pos;             // [I][Vp][3]

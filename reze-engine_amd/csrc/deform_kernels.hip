@@ -246,10 +246,10 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
     const int inst = blockIdx.x, tid = threadIdx.x;
     const float4 *lq = p.local_q + (size_t)inst * p.B;
     const float *glt = p.local_t ? p.local_t + (size_t)inst * p.B * 3 : nullptr;
-    const bool sampled = p.sample.frames != nullptr;      // rz_set_pose_sampled: the pose is evaluated right here
+    const bool sampled = p.sample.frames != nullptr || p.sample.frames_inline;      // rz_set_pose_sampled: the pose is evaluated right here
     const bool has_t = sampled || glt != nullptr;
     const float *lt = has_t ? s_lt : nullptr;
-    const float frame = sampled ? p.sample.frames[inst] : 0.0f;
+    const float frame = sampled ? (p.sample.frames_inline ? p.sample.frame0 : p.sample.frames[inst]) : 0.0f;
     float *world = p.world + (size_t)inst * p.B * 16;
     float4 *pal = p.palette + (size_t)inst * p.B * 3;
     // this thread's inverse bind matrix (consumed after the level loop) is requested first, so its latency hides
@@ -526,7 +526,12 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     }
 
     if (FAST && MODE == 2) {
-        for (int i = tid; i < p.M; i += kBlock) s_w[i] = p.morph_w[i];
+        const bool keep_w = blockIdx.x == 0 && p.morph_w_copy != nullptr;     // zero-copy first frame, as for `world`
+        for (int i = tid; i < p.M; i += kBlock) {
+            const float w = p.morph_w[i];
+            s_w[i] = w;
+            if (keep_w) p.morph_w_copy[i] = w;
+        }
         __syncthreads();
     }
 
@@ -562,12 +567,19 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         }
     };
     // executed once per wave, wherever the first step has its loads in flight; no barrier here
+    // zero-copy first frame: `world` is pinned host memory; workgroup 0 leaves the matrices in device memory for the replays
+    const bool keep_world = FAST && blockIdx.x == 0 && p.world_copy != nullptr;
     auto form_palette = [&]() {
-        if (early) palette_rows(tid, ew0, ew1, ew2, ew3, ei0, ei1, ei2, ei3);
+        if (early) {
+            palette_rows(tid, ew0, ew1, ew2, ew3, ei0, ei1, ei2, ei3);
+            if (keep_world) { float4 *d = reinterpret_cast<float4 *>(p.world_copy) + tid * 4; d[0] = ew0; d[1] = ew1; d[2] = ew2; d[3] = ew3; }
+        }
         for (int b = tid + kBlock; b < p.B; b += kBlock) {      // skeletons beyond 256 bones: plain loads, late
             const float4 *gw = reinterpret_cast<const float4 *>(p.world) + b * 4;
             const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + b * 4;
-            palette_rows(b, gw[0], gw[1], gw[2], gw[3], gi[0], gi[1], gi[2], gi[3]);
+            const float4 w0 = gw[0], w1 = gw[1], w2 = gw[2], w3 = gw[3];
+            palette_rows(b, w0, w1, w2, w3, gi[0], gi[1], gi[2], gi[3]);
+            if (keep_world) { float4 *d = reinterpret_cast<float4 *>(p.world_copy) + b * 4; d[0] = w0; d[1] = w1; d[2] = w2; d[3] = w3; }
         }
         need_palette = false;
     };

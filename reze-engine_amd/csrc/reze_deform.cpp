@@ -46,7 +46,7 @@ int fail(int code, const char *fmt, ...)
 uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
 constexpr uint32_t kVertPad = 1024;   // planes are padded to a whole S=1 tile (256 quads)
-constexpr int kStageSlots = 4;
+constexpr int kStageSlots = 8;
 
 // ---- lazily bound RCCL (librccl.so.1 is only needed by the multi-GPU entry points) ----
 struct Rccl {
@@ -133,11 +133,13 @@ struct rz_ctx {
     uint4 *an_key_interp = nullptr;
     uint32_t an_M = 0;                  // vertex-morph count the feeds were built for
     float *an_frames = nullptr;         // [I]
+    bool frames_inline = false;         // one character: the frame rides in the kernel arguments (frame0), nothing is uploaded
+    float frame0 = 0.0f;
     size_t an_frames_alloc = 0;          // the current local pose carries translations (behind the rotations in its slot)
     float *fk_bind = nullptr, *fk_append_ratio = nullptr;
     int fk_levels = 0;
     float4 *local_q = nullptr;          // I x B   (current pose slot)
-    float4 *local_q_buf[2] = {nullptr, nullptr};    // = pose_blk[k] + I*B*16 + mw_pad (rotations, then translations)
+
     bool pose_local = false;            // the current pose came from rz_set_pose_local
     // physics hand-off for device-solved frames (rz_override_world)
     int *ovr_off = nullptr, *ovr_bone = nullptr;
@@ -163,10 +165,10 @@ struct rz_ctx {
     // translations I*B*3] floats. A world-matrix pose fills [world | weights], a local pose [weights | rotations (|
     // translations)] — each a CONTIGUOUS range, so every upload is one copy (measured: a small H2D copy is a 4.5 us blit
     // kernel on this runtime, and a second one for 256 bytes of morph weights cost as much as the first).
+    // The offsets are those of the instance / bone / morph counts AT UPLOAD TIME (point_pose_slot): shrinking the crowd
+    // afterwards leaves the resident pose where it is.
     float *pose_blk[2] = {nullptr, nullptr};
-    float *world_buf[2] = {nullptr, nullptr};       // = pose_blk[k]
-    float *morph_w_buf[2] = {nullptr, nullptr};     // = pose_blk[k] + I*B*16
-    size_t mw_pad = 0;                              // floats reserved for the morph weights (multiple of 4)
+    size_t mw_pad = 0;                              // floats reserved for the morph weights in the current layout (multiple of 4)
     int pose_slot = 0;
     hipStream_t up_stream = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
@@ -205,18 +207,38 @@ struct rz_ctx {
     bool aabb_rearm = false;            // both slots must be armed again before the next frame
 
     // pinned staging ring for rz_set_pose
-    void *stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+    void *stage[kStageSlots] = {};
     size_t stage_bytes = 0;
-    hipEvent_t stage_ev[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
-    bool stage_used[kStageSlots] = {false, false, false, false};
+    hipEvent_t stage_ev[kStageSlots] = {};
+    bool stage_used[kStageSlots] = {};
     int stage_next = 0;
+
+    // Zero-copy poses (one character, <= 256 KB): rz_set_pose* only writes the pose into a slot of this pinned,
+    // device-mapped ring — no copy is enqueued at all. The first frame's kernels read it over the host link (rz_fk_kernel
+    // the local pose; the one-launch deform kernel the world matrices, whose workgroup 0 also leaves them in the device
+    // pose block for the frames that replay the pose); anything that needs a device-resident pose first (rz_prep_kernel)
+    // gets it through make_resident(). Measured on MI355X (tools/uploadbench): a 16.6 KB hipMemcpyAsync in front of a
+    // frame costs 18 us, two of <= 16 KB 9.5 us, reading the pinned slot from the kernel 7 us with the loads fully exposed.
+    // A slot is reused 8 uploads later; one event per FOUR uploads (recorded on the compute stream at upload time) proves
+    // its readers are done, so there is no per-frame marker either.
+    static constexpr int kZcSlots = 8;
+    void *zc_host[kZcSlots] = {};
+    void *zc_dev[kZcSlots] = {};
+    size_t zc_bytes = 0;
+    uint64_t zc_uploads = 0;
+    hipEvent_t zc_ev[2] = {nullptr, nullptr};
+    uint64_t zc_ev_seq[2] = {~0ull, ~0ull};
+    int zc_cur = -1;                    // slot of the current pose, -1 = the current pose came down as a copy
+    bool zc_local = false;              // layout of that slot: [weights | rotations | translations] or [world | weights]
+    size_t zc_total = 0, zc_mw_off = 0, zc_lq_off = 0;     // bytes in the slot, and where the weights / rotations sit in it
+    bool world_resident = true, mw_resident = true, local_resident = true;   // which parts the device pose block holds
 
     // host-compacted active-morph list of the current pose (single-instance FAST path);
     // count < 0 means "more than kKargMorphs active: use the prep kernel"
     RzMorphList ml;
 
     // tuning (0 / -1 = automatic)
-    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1, t_instblock = 0, t_overlap = -1;
+    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1, t_instblock = 0, t_overlap = -1, t_zerocopy = -1;
     int t_graph = 0;                    // "graph" tuning key: rz_deform_n replays captured hipGraphs of kGraphFrames frames
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_sig = 0;             // signature of everything the captured launches depend on
@@ -310,6 +332,17 @@ void set_ring(rz_ctx *c, int slot)
     c->palette = c->palette_ring[slot]; c->act_idx = c->act_idx_ring[slot]; c->act_w = c->act_w_ring[slot]; c->act_count = c->act_count_ring[slot];
 }
 
+// Lay the CURRENT instance / bone / morph counts out over pose slot k and make it the current slot.
+void point_pose_slot(rz_ctx *c, int k)
+{
+    const size_t I = c->I, B = c->B, Mq = std::max<uint32_t>(c->M, 1);
+    c->mw_pad = (I * Mq + 3) / 4 * 4;
+    c->pose_slot = k;
+    c->world = c->pose_blk[k];
+    c->morph_w = c->pose_blk[k] + I * B * 16;
+    c->local_q = reinterpret_cast<float4 *>(c->pose_blk[k] + I * B * 16 + c->mw_pad);
+}
+
 int ensure_pose_buffers(rz_ctx *c)
 {
     if (c->B == 0) return RZ_OK;
@@ -317,23 +350,18 @@ int ensure_pose_buffers(rz_ctx *c)
     if (c->I <= c->pose_alloc_I && c->B <= c->pose_alloc_B && Mq <= c->pose_alloc_M && c->world) return RZ_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->up_stream));
-    for (int k = 0; k < 2; ++k) { dfree(c->pose_blk[k]); c->world_buf[k] = nullptr; c->morph_w_buf[k] = nullptr; c->local_q_buf[k] = nullptr; c->free_recorded[k] = false; }
+    for (int k = 0; k < 2; ++k) { dfree(c->pose_blk[k]); c->free_recorded[k] = false; }
     c->world = nullptr; c->morph_w = nullptr; c->local_q = nullptr;
     for (int k = 0; k < 2; ++k) { dfree(c->palette_ring[k]); dfree(c->act_idx_ring[k]); dfree(c->act_w_ring[k]); dfree(c->act_count_ring[k]); c->skin_recorded[k] = false; }
     c->palette = nullptr; c->act_idx = nullptr; c->act_w = nullptr; c->act_count = nullptr;
     const size_t I = c->I, B = c->B;
     const size_t Mpad = round_up(Mq + 8, 4);
-    c->mw_pad = (I * Mq + 3) / 4 * 4;
-    const size_t blk_floats = I * B * 16 + c->mw_pad + I * B * 7;
+    const size_t blk_floats = I * B * 16 + ((I * Mq + 3) / 4 * 4) + I * B * 7;
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipMalloc(&c->pose_blk[k], blk_floats * sizeof(float)));
         HIP_TRY(hipMemsetAsync(c->pose_blk[k], 0, blk_floats * sizeof(float), c->stream));
-        c->world_buf[k] = c->pose_blk[k];
-        c->morph_w_buf[k] = c->pose_blk[k] + I * B * 16;
-        c->local_q_buf[k] = reinterpret_cast<float4 *>(c->pose_blk[k] + I * B * 16 + c->mw_pad);
     }
-    c->pose_slot = 0;
-    c->world = c->world_buf[0]; c->morph_w = c->morph_w_buf[0]; c->local_q = c->local_q_buf[0];
+    point_pose_slot(c, 0);
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipMalloc(&c->palette_ring[k], I * B * 3 * sizeof(float4)));
         HIP_TRY(hipMalloc(&c->act_idx_ring[k], I * Mpad * sizeof(uint32_t)));
@@ -401,13 +429,44 @@ int auto_split(const rz_ctx *c)
 
 struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; int inst_block; };
 
+// Where the kernels read the current pose from: the device pose block, or (zero-copy, not yet resident) the pinned slot.
+const float *src_world(const rz_ctx *c)
+{
+    return (c->zc_cur >= 0 && !c->world_resident && !c->zc_local) ? static_cast<const float *>(c->zc_dev[c->zc_cur]) : c->world;
+}
+const float *src_morph_w(const rz_ctx *c)
+{
+    if (c->zc_cur < 0 || c->mw_resident) return c->morph_w;
+    const char *base = static_cast<const char *>(c->zc_dev[c->zc_cur]);
+    return reinterpret_cast<const float *>(base + c->zc_mw_off);
+}
+const float4 *src_local_q(const rz_ctx *c)
+{
+    if (c->zc_cur < 0 || c->local_resident || !c->zc_local) return c->local_q;
+    return reinterpret_cast<const float4 *>(static_cast<const char *>(c->zc_dev[c->zc_cur]) + c->zc_lq_off);
+}
+
+// Bring every part of a zero-copy pose into the device pose block (one copy out of the pinned slot, stream-ordered).
+int make_resident(rz_ctx *c)
+{
+    if (c->zc_cur < 0 || (c->world_resident && c->mw_resident && c->local_resident)) return RZ_OK;
+    void *dst = c->zc_local ? static_cast<void *>(c->morph_w) : static_cast<void *>(c->world);
+    HIP_TRY(hipMemcpyAsync(dst, c->zc_host[c->zc_cur], c->zc_total, hipMemcpyHostToDevice, c->stream));
+    c->world_resident = c->mw_resident = c->local_resident = true;
+    return RZ_OK;
+}
+
 RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
 {
     RzDeformParams p;
     memset(&p, 0, sizeof p);
     p.geom = c->geom; p.joints01 = c->j01; p.joints23 = c->j23; p.weights = c->wq;
-    p.palette = c->palette; p.world = c->world; p.inv_bind = c->inv_bind; p.dense = c->dense;
-    p.act_idx = c->act_idx; p.act_w = c->act_w; p.act_count = c->act_count; p.morph_w = c->morph_w;
+    p.palette = c->palette; p.world = src_world(c); p.inv_bind = c->inv_bind; p.dense = c->dense;
+    p.act_idx = c->act_idx; p.act_w = c->act_w; p.act_count = c->act_count; p.morph_w = src_morph_w(c);
+    if (pl.v.fast && c->zc_cur >= 0) {            // the one-launch kernel's workgroup 0 makes the pose resident
+        if (!c->world_resident && !c->zc_local) p.world_copy = c->world;
+        if (!c->mw_resident && pl.v.mode == 2) p.morph_w_copy = c->morph_w;
+    }
     p.sp_ptr = c->sp_ptr; p.sp_entries = c->sp_entries;
     p.out_pos = c->ext_pos ? c->ext_pos : c->out_pos; p.out_nrm = c->ext_nrm ? c->ext_nrm : c->out_nrm;
     p.edge = c->edge; p.out_hull = c->out_hull; p.aabb = c->aabb_on ? c->aabb : nullptr; p.aabb_slot = c->aabb_slot;
@@ -547,8 +606,8 @@ RzFkParams fk_params(const rz_ctx *c)
 {
     RzFkParams p;
     memset(&p, 0, sizeof p);            // padding too: frame_signature() hashes the struct
-    p.local_q = c->local_q;
-    p.local_t = c->pose_local_t ? reinterpret_cast<const float *>(c->local_q + (size_t)c->I * c->B) : nullptr;
+    p.local_q = src_local_q(c);
+    p.local_t = c->pose_local_t ? reinterpret_cast<const float *>(p.local_q + (size_t)c->I * c->B) : nullptr;
     p.append_move = c->fk_append_move;
     p.parents = c->fk_parents; p.bind = c->fk_bind; p.append_parent = c->fk_append_parent;
     p.append_ratio = c->fk_append_ratio; p.order = c->fk_order; p.level_off = c->fk_level_off; p.inv_bind = c->inv_bind;
@@ -556,7 +615,8 @@ RzFkParams fk_params(const rz_ctx *c)
     if (c->ovr_count) { p.ovr_off = c->ovr_off; p.ovr_bone = c->ovr_bone; p.ovr_world = c->ovr_world; }
     if (c->pose_sampled) {
         RzSampleParams &q = p.sample;
-        q.frames = c->an_frames; q.bone_track = c->an_bone_track; q.key_off = c->an_key_off; q.key_frame = c->an_key_frame;
+        q.frames = c->frames_inline ? nullptr : c->an_frames; q.frames_inline = c->frames_inline ? 1 : 0; q.frame0 = c->frame0;
+        q.bone_track = c->an_bone_track; q.key_off = c->an_key_off; q.key_frame = c->an_key_frame;
         q.key_rot = c->an_key_rot; q.key_pos = c->an_key_pos; q.key_interp = c->an_key_interp;
         q.mkey_off = c->an_mkey_off; q.mkey_frame = c->an_mkey_frame; q.mkey_weight = c->an_mkey_weight;
         q.feed_off = c->an_feed_off; q.feed_track = c->an_feed_track; q.feed_ratio = c->an_feed_ratio;
@@ -605,6 +665,8 @@ int launch_deform(rz_ctx *c, const Plan &pl)
     size_t lds = rz_deform_lds_bytes(p, pl.v);
     if (lds > 160 * 1024) return fail(RZ_ERR_UNSUPPORTED, "skeleton too large for the LDS palette (%zu B)", lds);
     HIP_TRY(rz_launch_deform(p, c->ml, pl.v, pl.grid_x, c->I, c->stream));
+    if (p.world_copy) c->world_resident = true;        // workgroup 0 of that launch left the pose in the device block
+    if (p.morph_w_copy) c->mw_resident = true;
     if (c->aabb_on) c->aabb_slot ^= 1;     // this launch re-armed the other slot for the next frame
     return RZ_OK;
 }
@@ -635,6 +697,9 @@ int set_overlap(rz_ctx *c, bool on)
 // One whole frame: front kernels (if the plan has any) + the deform / skin kernel.
 int run_frame(rz_ctx *c, const Plan &pl)
 {
+    // rz_prep_kernel (and a skin kernel that is not the one-launch form) reads a device-resident pose
+    if (c->zc_cur >= 0 && (pl.prep || (!pl.v.fast && !c->pose_local)))
+        if (int r = make_resident(c)) return r;
     if (c->overlap_on) {
         const int s = c->ring_slot ^ 1;                       // the slot the skin kernel of two frames ago read
         if (c->skin_recorded[s]) HIP_TRY(hipStreamWaitEvent(c->up_stream, c->ev_skin[s], 0));
@@ -808,6 +873,10 @@ int rz_destroy(rz_ctx *c)
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
         if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
     }
+    for (int i = 0; i < rz_ctx::kZcSlots; ++i)
+        if (c->zc_host[i]) (void)hipHostFree(c->zc_host[i]);
+    for (int e = 0; e < 2; ++e)
+        if (c->zc_ev[e]) (void)hipEventDestroy(c->zc_ev[e]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
@@ -991,8 +1060,54 @@ static int stage_acquire(rz_ctx *c, size_t need, int *slot_out)
     }
     const int slot = c->stage_next;
     c->stage_next = (slot + 1) % kStageSlots;
-    if (c->stage_used[slot]) HIP_TRY(hipEventSynchronize(c->stage_ev[slot]));
+    if (c->stage_used[slot]) {
+        // the copy that read this slot kStageSlots uploads ago: normally long done. Polled, not slept on — a blocking wait
+        // wakes tens of microseconds late, which starves a GPU whose frames are 16 us long (measured: 36 us per frame).
+        hipError_t q;
+        while ((q = hipEventQuery(c->stage_ev[slot])) == hipErrorNotReady) {}
+        if (q != hipSuccess) return fail(RZ_ERR_HIP, "pinned staging slot: %s", hipGetErrorString(q));
+    }
     *slot_out = slot;
+    return RZ_OK;
+}
+
+// A slot of the zero-copy ring for the next upload: (re)allocate the ring when the pose outgrew it, record the 1-in-4 event,
+// and make sure the readers of the slot's previous tenant (8 uploads ago) are done.
+static int zc_acquire(rz_ctx *c, size_t need, int *slot_out)
+{
+    if (need > c->zc_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->up_stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        drop_graph(c);
+        for (int i = 0; i < rz_ctx::kZcSlots; ++i) {
+            if (c->zc_host[i]) { (void)hipHostFree(c->zc_host[i]); c->zc_host[i] = nullptr; c->zc_dev[i] = nullptr; }
+            HIP_TRY(hipHostMalloc(&c->zc_host[i], need, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer(&c->zc_dev[i], c->zc_host[i], 0));
+        }
+        c->zc_bytes = need;
+        c->zc_uploads = 0;
+        c->zc_ev_seq[0] = c->zc_ev_seq[1] = ~0ull;
+        c->zc_cur = -1;
+    }
+    const uint64_t u = c->zc_uploads;
+    if (u % 4 == 0) {
+        const int e = (int)((u / 4) & 1);
+        if (!c->zc_ev[e]) HIP_TRY(hipEventCreateWithFlags(&c->zc_ev[e], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->zc_ev[e], c->stream));      // everything launched before upload u, i.e. every reader of uploads < u
+        c->zc_ev_seq[e] = u;
+    }
+    if (u >= (uint64_t)rz_ctx::kZcSlots) {
+        // previous tenant = upload u - 8, read by frames launched before upload u - 7: covered by the event of the first
+        // multiple of 4 that is >= u - 7 (it is <= u - 4, so it was recorded at least four uploads ago)
+        const uint64_t cand = (u - 7 + 3) / 4 * 4;
+        const int e = (int)((cand / 4) & 1);
+        if (c->zc_ev_seq[e] != cand) return fail(RZ_ERR_HIP, "zero-copy ring bookkeeping is inconsistent (upload %llu)", (unsigned long long)u);
+        hipError_t q;
+        while ((q = hipEventQuery(c->zc_ev[e])) == hipErrorNotReady) {}
+        if (q != hipSuccess) return fail(RZ_ERR_HIP, "zero-copy ring: %s", hipGetErrorString(q));
+    }
+    *slot_out = (int)(u % rz_ctx::kZcSlots);
+    c->zc_uploads = u + 1;
     return RZ_OK;
 }
 
@@ -1009,9 +1124,34 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
     c->pose_sampled = false;
     if (int r = set_overlap(c, want_overlap(c, make_plan(c)))) return r;
     const size_t mb = (size_t)c->I * c->M * sizeof(float);          // weights the caller handed over
-    const size_t mwb = c->mw_pad * sizeof(float);                    // their padded place in the block
+    const size_t mwb = ((size_t)c->I * std::max<uint32_t>(c->M, 1) + 3) / 4 * 4 * sizeof(float);   // their padded place in the block
     // world pose: [world | weights]           local pose: [weights | rotations | translations]
     const size_t total = local ? mwb + pbytes + sbytes : pbytes + (c->M > 0 ? mwb : 0);
+    if (!c->overlap_on && c->I == 1 && total <= (256u << 10) && c->t_zerocopy != 0) {
+        // One character: no copy at all. The pose is laid out in a pinned, device-mapped slot; the frame's own kernels read it.
+        int zs = 0;
+        if (int r = zc_acquire(c, std::max<size_t>(std::max<size_t>((size_t)c->B * 64 + mwb, mwb + (size_t)c->B * 28), 4096), &zs)) return r;
+        char *st = static_cast<char *>(c->zc_host[zs]);
+        char *st_mw = local ? st : st + pbytes;
+        char *st_pr = local ? st + mwb : st;
+        memcpy(st_pr, primary, pbytes);
+        if (sbytes) memcpy(st_pr + pbytes, secondary, sbytes);
+        if (local || c->M > 0) {
+            if (morph_weights && mb) memcpy(st_mw, morph_weights, mb); else memset(st_mw, 0, mb);
+            if (mwb > mb) memset(st_mw + mb, 0, mwb - mb);
+        }
+        point_pose_slot(c, c->pose_slot ^ 1);   // where the pose will live once something makes it resident
+        c->free_recorded[c->pose_slot] = false;
+        c->zc_cur = zs; c->zc_local = local; c->zc_total = total;
+        c->zc_mw_off = local ? 0 : pbytes; c->zc_lq_off = mwb;
+        c->world_resident = local;              // a local pose has no world matrices to bring over: rz_fk_kernel writes them
+        c->mw_resident = false;
+        c->local_resident = !local;
+        goto pose_uploaded;
+    }
+    {
+    c->zc_cur = -1;
+    c->world_resident = c->mw_resident = c->local_resident = true;
     int slot = 0;
     if (int r = stage_acquire(c, std::max<size_t>((size_t)c->I * c->B * 64 + mwb, mwb + (size_t)c->I * c->B * 28), &slot)) return r;
     // Small poses (one character: 16-22 KB) go down the compute stream itself — measured on C5, the two extra
@@ -1046,7 +1186,8 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
         if (morph_weights && mb) memcpy(st_mw, morph_weights, mb); else memset(st_mw, 0, mb);
         if (mwb > mb) memset(st_mw + mb, 0, mwb - mb);
     }
-    void *dst = local ? static_cast<void *>(c->morph_w_buf[k]) : static_cast<void *>(c->world_buf[k]);
+    point_pose_slot(c, k);                  // c->world / c->morph_w / c->local_q now name slot k under the current counts
+    void *dst = local ? static_cast<void *>(c->morph_w) : static_cast<void *>(c->world);
     HIP_TRY(hipMemcpyAsync(dst, st, total, hipMemcpyHostToDevice, us));
     HIP_TRY(hipEventRecord(c->stage_ev[slot], us));
     c->stage_used[slot] = true;
@@ -1054,11 +1195,9 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
         HIP_TRY(hipEventRecord(c->ev_up[k], c->up_stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_up[k], 0));
     }
-    c->pose_slot = k;
     c->free_recorded[k] = false;            // slot k gets new readers from here on: its old end-of-readers mark is void
-    c->world = c->world_buf[k];
-    c->morph_w = c->morph_w_buf[k];
-    c->local_q = c->local_q_buf[k];
+    }
+pose_uploaded:
     // ordered compaction of the non-zero weights for the one-launch path (instance 0)
     memset(&c->ml, 0, sizeof c->ml);
     if (c->M > 0 && morph_weights && c->I == 1) {
@@ -1232,14 +1371,21 @@ int rz_set_pose_sampled(rz_ctx *c, const float *frames)
     c->pose_local = true;
     c->pose_local_t = true;
     if (int r = set_overlap(c, want_overlap(c, make_plan(c)))) return r;
-    int slot = 0;
-    if (int r = stage_acquire(c, std::max<size_t>((size_t)c->I * sizeof(float), 4096), &slot)) return r;
-    memcpy(c->stage[slot], frames, (size_t)c->I * sizeof(float));
-    hipStream_t us = front_stream(c);       // consumed by rz_fk_kernel, which runs on this stream
-    HIP_TRY(hipMemcpyAsync(c->an_frames, c->stage[slot], (size_t)c->I * sizeof(float), hipMemcpyHostToDevice, us));
-    HIP_TRY(hipEventRecord(c->stage_ev[slot], us));
-    c->stage_used[slot] = true;
-    c->local_q = c->local_q_buf[c->pose_slot];
+    c->zc_cur = -1;                         // the pose is produced on the device: nothing of it sits in a pinned slot
+    c->world_resident = c->mw_resident = c->local_resident = true;
+    c->frames_inline = c->I == 1 && !c->overlap_on && c->t_zerocopy != 0;
+    if (c->frames_inline) {
+        c->frame0 = frames[0];              // one character: the frame number rides in rz_fk_kernel's arguments
+    } else {
+        int slot = 0;
+        if (int r = stage_acquire(c, std::max<size_t>((size_t)c->I * sizeof(float), 4096), &slot)) return r;
+        memcpy(c->stage[slot], frames, (size_t)c->I * sizeof(float));
+        hipStream_t us = front_stream(c);   // consumed by rz_fk_kernel, which runs on this stream
+        HIP_TRY(hipMemcpyAsync(c->an_frames, c->stage[slot], (size_t)c->I * sizeof(float), hipMemcpyHostToDevice, us));
+        HIP_TRY(hipEventRecord(c->stage_ev[slot], us));
+        c->stage_used[slot] = true;
+    }
+    point_pose_slot(c, c->pose_slot);       // the sampled pose is written by rz_fk_kernel under the current counts
     memset(&c->ml, 0, sizeof c->ml);
     if (c->M > 0) c->ml.count = -1;          // the weights only exist on the device: the prep kernel compacts them
     c->pose_set = true;
@@ -1307,6 +1453,10 @@ int rz_read_world(rz_ctx *c, uint32_t instance, float *world16)
 {
     if (int r = use(c)) return r;
     if (instance >= c->I || !world16 || !c->world) return fail(RZ_ERR_INVALID, "bad world read");
+    if (c->zc_cur >= 0 && !c->zc_local && !c->world_resident) {     // a zero-copy pose no frame has consumed yet: still in its pinned slot
+        memcpy(world16, c->zc_host[c->zc_cur], (size_t)c->B * 16 * sizeof(float));
+        return RZ_OK;
+    }
     HIP_TRY(hipStreamSynchronize(c->up_stream));        // rz_fk_kernel may have written them on the front stream
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(world16, c->world + (size_t)instance * c->B * 16, (size_t)c->B * 16 * sizeof(float), hipMemcpyDeviceToHost));
@@ -1623,6 +1773,9 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
     } else if (!strcmp(key, "inst_loop")) {
         if (value < -1 || value == 1 || value > 16) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off), 2..8 / 10..16 (poses per workgroup, LDS form) or 9 (register form)");
         c->t_instloop = value;
+    } else if (!strcmp(key, "zero_copy")) {
+        if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "zero_copy must be -1 (auto = on for one character), 0 (every pose is copied to the device) or 1");
+        c->t_zerocopy = value;
     } else if (!strcmp(key, "overlap")) {
         if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "overlap must be -1 (auto = off), 0 (off) or 1 (crowds: front kernels on the upload stream)");
         c->t_overlap = value;
@@ -1663,6 +1816,8 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "inst_loop")) *value = c->t_instloop;
     else if (!strcmp(key, "inst_block")) *value = c->t_instblock;
     else if (!strcmp(key, "overlap")) *value = c->t_overlap;
+    else if (!strcmp(key, "zero_copy")) *value = c->t_zerocopy;
+    else if (!strcmp(key, "pose_resident")) *value = (c->zc_cur < 0 || (c->world_resident && c->mw_resident && c->local_resident)) ? 1 : 0;
     else if (!strcmp(key, "effective_overlap")) *value = want_overlap(c, make_plan(c)) ? 1 : 0;
     else if (!strcmp(key, "effective_inst_block")) *value = make_plan(c).inst_block;
     else if (!strcmp(key, "out_cap")) *value = c->t_outcap;

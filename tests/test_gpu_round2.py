@@ -301,3 +301,86 @@ def test_ablation_key_is_not_part_of_the_product(rz):
     after = c.read()
     assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
     c.close()
+
+
+@pytest.mark.parametrize("morphs", ["none", "dense", "sparse", "dense>128"])
+def test_zero_copy_pose_ring_never_serves_a_stale_or_torn_pose(rz, oracle, morphs):
+    """One character: rz_set_pose* enqueues NO copy — the pose sits in a slot of a pinned, device-mapped ring, the first
+    frame's kernels read it from there (workgroup 0 of the one-launch kernel leaves it in device memory for replays), a slot
+    is reused eight uploads later and only one event per four uploads guards the reuse. Hammer it: 600 frames cycling through
+    five poses of three kinds (world matrices, local rotations, sampled), replays in between, uploads that no frame consumes,
+    plans that need a resident pose (prep kernel) mixed in — every checked frame bit-identical to that pose in isolation."""
+    V, B = 12000, 150
+    mesh = synth.make_mesh(V, B, seed=15)
+    rng = np.random.default_rng(16)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    M = {"none": 0, "dense": 12, "sparse": 20, "dense>128": 140}[morphs]
+    deltas = None
+    if morphs.startswith("dense"):
+        deltas, _ = synth.make_morphs_dense(V, M, seed=17)
+        c.upload_morphs_dense(deltas)
+    elif morphs == "sparse":
+        off, vi, d3, _ = synth.make_morphs_sparse(V, M, seed=17)
+        c.upload_morphs_sparse(off, vi, d3)
+        deltas = synth.sparse_to_dense(V, off, vi, d3)
+    c.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+    nk = 4
+    kq = rng.normal(size=(B, nk, 4)).astype(np.float32)
+    kq /= np.linalg.norm(kq, axis=2, keepdims=True)
+    extra = {}
+    if M:
+        extra = dict(mkey_off=np.arange(M + 1) * 2, mkey_frame=np.tile(np.array([0.0, 30.0], np.float32), M), mkey_weight=rng.random(2 * M).astype(np.float32),
+                     feed_off=np.arange(M + 1), feed_track=np.arange(M), feed_ratio=np.ones(M, np.float32))
+    c.upload_animation(np.arange(B), np.arange(B + 1) * nk, np.tile(np.arange(nk) * 10.0, B), kq, (rng.random((B, nk, 3), dtype=np.float32) - 0.5) * 0.3, **extra)
+    P = 5
+    worlds = [synth.make_pose(mesh["parents"], mesh["bind"], B, seed=500 + k) for k in range(P)]
+    quats = rng.normal(size=(P, B, 4)).astype(np.float32)
+    quats /= np.linalg.norm(quats, axis=2, keepdims=True)
+    mws = [(rng.random(M).astype(np.float32) * (rng.random(M) < 0.7)).astype(np.float32) if M else None for _ in range(P)]
+    frames = [np.array([rng.random() * 30], np.float32) for _ in range(P)]
+
+    def put(kind, k):
+        if kind == "w":
+            c.set_pose(worlds[k], mws[k])
+        elif kind == "l":
+            c.set_pose_local(quats[k], mws[k])
+        else:
+            c.set_pose_sampled(frames[k])
+    iso = {}
+    for kind in "wls":
+        for k in range(P):
+            put(kind, k); c.deform(); iso[(kind, k)] = c.read()
+    assert c.get_tuning("zero_copy") == -1
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[3], mesh["inv_bind"], deltas, mws[3])
+    assert_parity(iso[("w", 3)][0], iso[("w", 3)][1], pr, nr, "isolated zero-copy world pose (%s)" % morphs)
+    # ... and the same frames when every pose is copied to the device instead: identical bits
+    c.set_tuning(zero_copy=0)
+    for kind, k in (("w", 1), ("l", 2), ("s", 4)):
+        put(kind, k); c.deform(); p2, n2 = c.read()
+        assert np.array_equal(p2, iso[(kind, k)][0]) and np.array_equal(n2, iso[(kind, k)][1]), "zero_copy=0 differs (%s%d)" % (kind, k)
+    c.set_tuning(zero_copy=-1)
+    checks = 0
+    for f in range(600):
+        kind = "wls"[int(rng.integers(0, 3))]
+        k = int(rng.integers(0, P))
+        r = rng.random()
+        if r < 0.15:                                       # an upload that is overwritten before any frame consumes it
+            put("wl"[int(rng.integers(0, 2))], (k + 1) % P)
+        if r > 0.9:                                        # a plan that wants the pose resident (prep kernel) for this frame only
+            c.set_tuning(fast=0)
+        put(kind, k)
+        if kind == "w" and f % 50 == 0:                    # readable before any frame has consumed it
+            assert np.array_equal(c.read_world(0), worlds[k])
+        c.deform()
+        if r > 0.9:
+            c.set_tuning(fast=-1)
+        if 0.4 < r < 0.5:
+            c.deform_n(int(rng.integers(1, 5)))            # replays of the resident pose
+        if f % 5 == 0 or f > 590:
+            got = c.read()
+            assert np.array_equal(got[0], iso[(kind, k)][0]) and np.array_equal(got[1], iso[(kind, k)][1]), "frame %d (%s%d, %s)" % (f, kind, k, morphs)
+            checks += 1
+    assert checks > 100
+    c.close()

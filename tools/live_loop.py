@@ -15,13 +15,18 @@ for V in (1000000, 125952):
     while time.time() - t0 < 2.5: ctx.deform_n(500); ctx.sync()
     n = 2000
     res = []
+    import ctypes
+    L, h = rz.capi.load(), ctx._h
+    fp = ctypes.POINTER(ctypes.c_float)
+    w32, m32 = np.ascontiguousarray(mesh["world"], np.float32), np.ascontiguousarray(mw, np.float32)
+    wp, mp = w32.ctypes.data_as(fp), m32.ctypes.data_as(fp)
     for rep in range(3):
         ctx.sync(); t0 = time.perf_counter(); ctx.deform_n(n); ctx.sync(); replay = (time.perf_counter() - t0) / n
         t0 = time.perf_counter()
-        for _ in range(n): ctx.set_pose(mesh["world"], mw); ctx.deform()
+        for _ in range(n): L.rz_set_pose(h, wp, mp); L.rz_deform(h)        # raw C ABI calls: no numpy conversions in the loop
         ctx.sync(); live = (time.perf_counter() - t0) / n
         t0 = time.perf_counter()
-        for _ in range(n): ctx.set_pose(mesh["world"], mw)
+        for _ in range(n): L.rz_set_pose(h, wp, mp)
         ctx.sync(); up_only = (time.perf_counter() - t0) / n
         res.append((replay, live, up_only))
     r = min(res)
