@@ -678,7 +678,10 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
                     dy[u] = ld_stream(d + plane4, NT);
                     dz[u] = ld_stream(d + 2 * plane4, NT);
                 }
-                if (FAST && FIRST && need_palette) form_palette();    // first group of the first step: overlaps the 3*U loads just issued
+                // first group of the first step: the palette math overlaps the 3*U loads just issued. On a zero-copy frame the
+                // matrices come over the host link (a few microseconds): there the palette waits until the LAST group has
+                // issued its loads, so the whole morph stream of the step is in flight under that latency.
+                if (FAST && FIRST && need_palette && (!p.world_copy || a0 + 2 * U * S > count)) form_palette();
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     ax.x = fmaf(w[u], dx[u].x, ax.x); ax.y = fmaf(w[u], dx[u].y, ax.y);

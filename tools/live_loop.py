@@ -28,6 +28,13 @@ for V in (1000000, 125952):
         t0 = time.perf_counter()
         for _ in range(n): L.rz_set_pose(h, wp, mp)
         ctx.sync(); up_only = (time.perf_counter() - t0) / n
-        res.append((replay, live, up_only))
+        ctx.sync(); t0 = time.perf_counter()
+        for _ in range(n): L.rz_deform(h)
+        ctx.sync(); single = (time.perf_counter() - t0) / n
+        t0 = time.perf_counter()
+        for _ in range(n): L.rz_deform(h)
+        host_only = (time.perf_counter() - t0) / n; ctx.sync()
+        res.append((replay, live, up_only, single, host_only))
     r = min(res)
-    print("V=%7d: replay %.2f us/frame | set_pose + deform %.2f us/frame (+%.2f) | set_pose alone %.2f us" % (V, r[0] * 1e6, r[1] * 1e6, (r[1] - r[0]) * 1e6, r[2] * 1e6), flush=True)
+    print("V=%7d: replay (deform_n) %.2f us/frame | rz_deform per frame %.2f us (host side of the call %.2f us) | set_pose + deform %.2f us/frame (+%.2f over replay, +%.2f over per-frame deform) | set_pose alone %.2f us"
+          % (V, r[0] * 1e6, r[3] * 1e6, r[4] * 1e6, r[1] * 1e6, (r[1] - r[0]) * 1e6, (r[1] - r[3]) * 1e6, r[2] * 1e6), flush=True)
