@@ -426,10 +426,21 @@ def main():
             },
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+    else:
+        out = None
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if out is not None:
+        # The JSON line must be the LAST thing on stdout: RCCL writes its version banner through C stdio, which sits in a
+        # buffer until exit when stdout is a pipe — flush that first, then print.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:       # noqa: BLE001
+            pass
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -1,13 +1,36 @@
 #!/bin/bash
-# Full confirmation run: GPU tests, smoke, default bench + C4 bench, profiles.
-mkdir -p gpurun_out
+# Full confirmation run of a round: GPU tests, smoke, the tracked bench lines (C5 default + C4 / C3 / C2 / one 1/8 shard /
+# device-animated C4), shard scaling, the Node frame loop, the per-frame upload loop, the C4 sweeps. Output: gpurun_out/full/.
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
+O=gpurun_out/full; rm -rf $O; mkdir -p $O
 echo "== pytest gpu"
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee gpurun_out/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee $O/pytest_gpu.txt; echo "pytest rc=${PIPESTATUS[0]}" | tee -a $O/pytest_gpu.txt
 echo "== smoke"
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/smoke.txt
 echo "== bench"
-timeout 600 python bench.py 2>gpurun_out/bench.err | tail -1 | tee gpurun_out/bench.json
-for c in c4 c3 c2; do
-  timeout 600 python bench.py --config $c --no-cpu-baseline 2>>gpurun_out/bench.err | tail -1 | tee gpurun_out/bench_$c.json
-done
-bash tools/gpu_profile.sh 2>&1 | tail -5
+timeout 600 python bench.py 2>$O/bench.err | tail -1 > $O/bench_c5.json
+for c in c4 c3 c2; do timeout 600 python bench.py --config $c --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_$c.json; done
+timeout 600 python bench.py --verts 125952 --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_shard8.json
+timeout 600 python bench.py --config c4 --device-fk --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c4_devicefk.json
+timeout 600 python bench.py --config c4 --device-fk --device-sampling --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c4_sampled.json
+REZE_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --allgather --steps 100 --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c5_allgather1.json
+python - <<'P'
+import json, glob
+for f in sorted(glob.glob('gpurun_out/full/bench_*.json')):
+    try:
+        d = json.load(open(f)); c = d['config']; r = d['roofline']
+        print('%-26s value %.4g verts/s  ms/step %.5f  kernel %s %.5f ms frac %.3f frame_frac %.3f | upload loop %s sampled loop %s' % (
+            f.split('/')[-1], d['value'], d['ms_per_step'], r['kernel'], r['kernel_ms'], r['frac'], r['frame_frac'], c['frame_ms_with_pose_upload'], c['frame_ms_device_sampled_pose']))
+    except Exception as e:
+        print(f, 'unreadable', e)
+P
+echo "== shard scaling"
+timeout 600 python tools/shard_scaling.py 2>&1 | tee $O/shard_scaling.txt
+echo "== live loop"
+timeout 300 python tools/live_loop.py 2>&1 | tee $O/live_loop.txt
+echo "== node frame loop"
+timeout 300 python tools/node_frame_bench.py 2>&1 | tail -8 | tee $O/node_frame_bench.txt
+echo "== c4 sweep / overlap"
+timeout 400 python tools/c4_sweep.py 2>&1 | tee $O/c4_sweep.txt | tail -4
+timeout 300 python tools/c4_overlap.py 2>&1 | tee $O/c4_overlap.txt
+tail -3 $O/bench.err
