@@ -93,7 +93,8 @@ int rz_upload_morphs_dense(rz_ctx *ctx, uint32_t M, const float *deltas);
 int rz_upload_morphs_sparse(rz_ctx *ctx, uint32_t M, const uint32_t *morph_off,
                             const uint32_t *vert_idx, const float *delta3);
 
-/* Instancing — NEW (the reference draws one model): I poses of the same static mesh. */
+/* Instancing — NEW (the reference draws one model): I poses of the same static mesh. Shrinking the crowd keeps the
+ * resident pose (instances 0 .. I-1 of it); growing it beyond the count the pose was set for needs a new rz_set_pose*. */
 int rz_set_instances(rz_ctx *ctx, uint32_t I);
 
 /* updateModelPose()  engine/src/engine.ts:2383-2389: queue.writeBuffer(worldMatrixBuffer).

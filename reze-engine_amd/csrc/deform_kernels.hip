@@ -505,10 +505,19 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     // math below only has to wait for them (a counted wait) while the morph loads issued after them stay in flight.
     float4 ew0, ew1, ew2, ew3, ei0, ei1, ei2, ei3;
     const bool early = FAST && tid < p.B && RZ_DBG(p) != 3;      // dbg 3: ablation — no palette staging (output is garbage)
-    if (early) {
+    // Zero-copy frame (world_copy != null: `world` is pinned HOST memory, a few microseconds away) with a dense morph stream:
+    // vmcnt retires in order, so host loads at the head of the queue would hold back the first morph FMAs; there the world
+    // matrices are requested BEHIND the first morph group instead, and the palette is formed after the last group.
+    const bool late_world = FAST && MODE == 1 && p.world_copy != nullptr;
+    bool world_pending = early && late_world;
+    auto load_world = [&]() {
         const float4 *gw = reinterpret_cast<const float4 *>(p.world) + tid * 4;
-        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + tid * 4;
         ew0 = gw[0]; ew1 = gw[1]; ew2 = gw[2]; ew3 = gw[3];
+        world_pending = false;
+    };
+    if (early) {
+        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + tid * 4;
+        if (!late_world) load_world();
         ei0 = gi[0]; ei1 = gi[1]; ei2 = gi[2]; ei3 = gi[3];
     }
     if (!FAST) {
@@ -570,6 +579,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     // zero-copy first frame: `world` is pinned host memory; workgroup 0 leaves the matrices in device memory for the replays
     const bool keep_world = FAST && blockIdx.x == 0 && p.world_copy != nullptr;
     auto form_palette = [&]() {
+        if (world_pending) load_world();          // no morph group ran in front of us
         if (early) {
             palette_rows(tid, ew0, ew1, ew2, ew3, ei0, ei1, ei2, ei3);
             if (keep_world) { float4 *d = reinterpret_cast<float4 *>(p.world_copy) + tid * 4; d[0] = ew0; d[1] = ew1; d[2] = ew2; d[3] = ew3; }
@@ -678,6 +688,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
                     dy[u] = ld_stream(d + plane4, NT);
                     dz[u] = ld_stream(d + 2 * plane4, NT);
                 }
+                if (FAST && FIRST && world_pending) load_world();     // zero-copy frame: behind the first group's loads
                 // first group of the first step: the palette math overlaps the 3*U loads just issued. On a zero-copy frame the
                 // matrices come over the host link (a few microseconds): there the palette waits until the LAST group has
                 // issued its loads, so the whole morph stream of the step is in flight under that latency.

@@ -191,6 +191,7 @@ struct rz_ctx {
     bool skin_recorded[2] = {false, false};
     bool overlap_on = false;            // the two streams currently follow the overlapped-front protocol
     bool pose_set = false;
+    uint32_t pose_I = 0;                // instance count the current pose was uploaded for
     size_t pose_alloc_I = 0, pose_alloc_B = 0, pose_alloc_M = 0;
 
     // outputs
@@ -1039,6 +1040,9 @@ int rz_set_instances(rz_ctx *c, uint32_t I)
         // The host-compacted active-morph list is only maintained while I == 1 (upload_pose). Coming back to one instance
         // from a crowd it is stale (zeroed): let the prep kernel compact instance 0's weights, which are still on the device.
         if (c->M > 0 && c->morph_mode == 1) c->ml.count = -1;
+        // A crowd larger than the one the resident pose was uploaded for has no pose for its new members (and a
+        // single-character pose may still sit in its pinned slot, which holds exactly one instance): ask for a new one.
+        if (I > c->pose_I) c->pose_set = false;
     }
     c->I = I;
     if (int r = ensure_pose_buffers(c)) return r;
@@ -1198,6 +1202,7 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
     c->free_recorded[k] = false;            // slot k gets new readers from here on: its old end-of-readers mark is void
     }
 pose_uploaded:
+    c->pose_I = c->I;
     // ordered compaction of the non-zero weights for the one-launch path (instance 0)
     memset(&c->ml, 0, sizeof c->ml);
     if (c->M > 0 && morph_weights && c->I == 1) {
@@ -1388,6 +1393,7 @@ int rz_set_pose_sampled(rz_ctx *c, const float *frames)
     point_pose_slot(c, c->pose_slot);       // the sampled pose is written by rz_fk_kernel under the current counts
     memset(&c->ml, 0, sizeof c->ml);
     if (c->M > 0) c->ml.count = -1;          // the weights only exist on the device: the prep kernel compacts them
+    c->pose_I = c->I;
     c->pose_set = true;
     return RZ_OK;
 }

@@ -384,3 +384,29 @@ def test_zero_copy_pose_ring_never_serves_a_stale_or_torn_pose(rz, oracle, morph
             checks += 1
     assert checks > 100
     c.close()
+
+
+def test_growing_the_crowd_needs_a_new_pose(rz, oracle):
+    """A single-character pose may still sit in its pinned slot (which holds exactly one instance): a crowd larger than
+    the one the resident pose was set for must be given a pose before it can be deformed; shrinking keeps the pose."""
+    V, B = 3000, 20
+    mesh = synth.make_mesh(V, B, seed=7)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    c.set_instances(4)                      # allocate for four up front
+    c.set_instances(1)
+    c.set_pose(mesh["world"])
+    c.set_instances(4)                      # no frame has consumed the pose yet, and it is one instance wide
+    with pytest.raises(rz.capi.RzError):
+        c.deform()
+    worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=70 + i) for i in range(4)])
+    c.set_pose(worlds)
+    c.deform()
+    c.set_instances(2)                      # shrinking keeps instances 0..1 of the resident pose
+    c.deform()
+    for i in range(2):
+        pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[i], mesh["inv_bind"])
+        pg, ng = c.read(instance=i)
+        assert_parity(pg, ng, pr, nr, "after shrinking the crowd, instance %d" % i)
+    c.close()
