@@ -1085,8 +1085,15 @@ static int zc_acquire(rz_ctx *c, size_t need, int *slot_out)
         drop_graph(c);
         for (int i = 0; i < rz_ctx::kZcSlots; ++i) {
             if (c->zc_host[i]) { (void)hipHostFree(c->zc_host[i]); c->zc_host[i] = nullptr; c->zc_dev[i] = nullptr; }
-            HIP_TRY(hipHostMalloc(&c->zc_host[i], need, hipHostMallocMapped));
-            HIP_TRY(hipHostGetDevicePointer(&c->zc_dev[i], c->zc_host[i], 0));
+            // no pinned, device-mapped memory to be had (locked-memory limits ...): not an error, the caller copies instead
+            if (hipHostMalloc(&c->zc_host[i], need, hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer(&c->zc_dev[i], c->zc_host[i], 0) != hipSuccess) {
+                (void)hipGetLastError();
+                for (int j = 0; j <= i; ++j)
+                    if (c->zc_host[j]) { (void)hipHostFree(c->zc_host[j]); c->zc_host[j] = nullptr; c->zc_dev[j] = nullptr; }
+                c->zc_bytes = 0; c->zc_cur = -1;
+                return RZ_ERR_UNSUPPORTED;
+            }
         }
         c->zc_bytes = need;
         c->zc_uploads = 0;
@@ -1134,7 +1141,9 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
     if (!c->overlap_on && c->I == 1 && total <= (256u << 10) && c->t_zerocopy != 0) {
         // One character: no copy at all. The pose is laid out in a pinned, device-mapped slot; the frame's own kernels read it.
         int zs = 0;
-        if (int r = zc_acquire(c, std::max<size_t>(std::max<size_t>((size_t)c->B * 64 + mwb, mwb + (size_t)c->B * 28), 4096), &zs)) return r;
+        const int zr = zc_acquire(c, std::max<size_t>(std::max<size_t>((size_t)c->B * 64 + mwb, mwb + (size_t)c->B * 28), 4096), &zs);
+        if (zr == RZ_ERR_UNSUPPORTED) { c->t_zerocopy = 0; goto copy_path; }      // from now on every pose is copied
+        if (zr) return zr;
         char *st = static_cast<char *>(c->zc_host[zs]);
         char *st_mw = local ? st : st + pbytes;
         char *st_pr = local ? st + mwb : st;
@@ -1153,6 +1162,7 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
         c->local_resident = !local;
         goto pose_uploaded;
     }
+copy_path:
     {
     c->zc_cur = -1;
     c->world_resident = c->mw_resident = c->local_resident = true;
