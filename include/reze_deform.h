@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 2
+#define RZ_ABI_VERSION 3
 
 typedef struct rz_ctx rz_ctx;
 

@@ -325,6 +325,21 @@ def test_engine_animation_scheduler_on_a_manual_clock():
     assert r["realtimeStepThrows"] is True
 
 
+def test_engine_physics_hand_off_seam():
+    """engine.ts:2375-2391: physics.step(dt, worldMats, inverseBind) sits between evaluatePose() and the world-matrix upload
+    and edits the matrices in place. Host FK: the { physics } option is called at that point, with the engine clock's dt, and
+    its edit is what setPose receives. Device FK: setBoneWorldOverrides reaches overrideWorld on every shard (the GPU side is
+    tests/test_gpu_round2.py::test_override_world_is_the_physics_hand_off); a host-FK engine refuses it."""
+    out = subprocess.check_output(["node", os.path.join(ROOT, "tests", "js", "engine_physics_mock.js")], timeout=60)
+    r = json.loads(out.decode().strip().splitlines()[-1])
+    assert [s["dt"] for s in r["seen"]] == [0, 0.05] and all(s["n"] == 48 and s["ib0"] == 5 and s["before"] == 2 for s in r["seen"])
+    assert r["poses"] == [[9, 9, 9, 1], [9, 9, 9, 1]] and r["order"] == ["setPose", "deform"] * 2
+    assert r["hostRefusesOverrides"] is True and r["physicsCallsOnDeviceFK"] == 0
+    assert len(r["device"]) == 4 and r["device"][0][1] == [2, 0] and len(r["device"][0][2]) == 32 and r["device"][0][3] == [0, 0]
+    assert r["device"][2] == ["overrideWorld", None, None, None]
+    assert r["deviceOrder"].index("overrideWorld") < r["deviceOrder"].index("setPoseLocal")
+
+
 def test_addon_exports_and_loud_failure_without_gpu():
     """The N-API shim binds every data-path entry point of the C ABI and refuses to run without a device."""
     js = ("const a=require('%s/reze-engine_amd/host/addon.js').requireAddon();"
@@ -334,7 +349,8 @@ def test_addon_exports_and_loud_failure_without_gpu():
     r = json.loads(subprocess.check_output(["node", "-e", js], timeout=60).decode().strip().splitlines()[-1])
     for k in ("create", "destroy", "uploadMesh", "uploadSkeleton", "uploadMorphsDense", "uploadMorphsSparse", "setInstances",
               "setPose", "deform", "sync", "read", "timeFrames", "commUniqueId", "commInit", "allgather", "shardRange",
-              "uploadSkeletonTopology", "setPoseLocal", "readWorld", "autotune", "gatherDirect", "gatherFence", "readGathered"):
+              "uploadSkeletonTopology", "setPoseLocal", "readWorld", "autotune", "gatherDirect", "gatherFence", "readGathered",
+              "overrideWorld", "rcclInfo", "uploadAnimation", "setPoseSampled"):
         assert k in r["keys"], k
     import re
     header = open(os.path.join(ROOT, "include", "reze_deform.h")).read()
