@@ -210,6 +210,10 @@ def main():
             ctx.set_pose_local(quats, mws)
         else:
             ctx.set_pose(worlds, mws)
+
+    def frame_table(fr):
+        """64 rows of per-instance frame numbers marching through the 70-frame motion (cycled by the per-frame loop)."""
+        return np.stack([(fr + 0.5 * k) % 70.0 for k in range(64)]).astype(np.float32)
     put_pose()
     tuned = None
     if not args.no_autotune and not args.tune:
@@ -300,23 +304,31 @@ def main():
     # (secondary numbers never take the line down with them: a failure here is reported as null)
     n_up = min(args.steps, 200)
 
-    def per_frame_loop(put):
+    def per_frame_loop(frame, check):
+        """frame() = one pose upload + rz_deform through the raw C ABI (DeformContext.frame_call: arrays and pointers are
+        prepared up front, so the loop times the library and the GPU, not numpy conversions)."""
         try:
             for _ in range(400):        # the upload path's own warm-up: pinned ring, upload stream (the HIP runtime
                                         # stalls ~25 ms once, somewhere in the first few hundred two-stream frames)
-                put()
-                ctx.deform()
+                frame()
             barrier()
             tp0 = time.perf_counter()
             for _ in range(n_up):
-                put()
-                ctx.deform()
+                frame()
             ctx.sync()
-            return rank_max((time.perf_counter() - tp0) * 1e3 / n_up)
+            dt = (time.perf_counter() - tp0) * 1e3 / n_up
+            check()
+            return rank_max(dt)
         except Exception as e:          # noqa: BLE001
             sys.stderr.write("[bench] per-frame upload timing failed: %r\n" % (e,))
             return rank_max(None)
-    with_upload_ms = per_frame_loop(put_pose)
+    if frames is not None:
+        primary_call = ctx.frame_call("sampled", frame_table(frames))
+    elif quats is not None:
+        primary_call = ctx.frame_call("local", quats, mws)
+    else:
+        primary_call = ctx.frame_call("world", worlds, mws)
+    with_upload_ms = per_frame_loop(*primary_call)
     # ... and the same loop when the motion lives on the GPU (rz_set_pose_sampled: ONE float per instance per frame, bones
     # sampled + hierarchy solved by rz_fk_kernel): the per-frame loop that does not pay for the pose upload at any N
     sampled_ms = None
@@ -329,10 +341,7 @@ def main():
             else:
                 fr2 = frames
 
-            def put_sampled():
-                tick[0] += 1
-                ctx.set_pose_sampled((fr2 + 0.5 * tick[0]) % 70.0)
-            sampled_ms = per_frame_loop(put_sampled)
+            sampled_ms = per_frame_loop(*ctx.frame_call("sampled", frame_table(fr2)))
         except Exception as e:          # noqa: BLE001
             sys.stderr.write("[bench] device-sampling loop failed: %r\n" % (e,))
             sampled_ms = rank_max(None)
@@ -402,7 +411,7 @@ def main():
                 "prep_kernel_ms": timing["prep_kernel_ms"],
                 "frame_ms_with_pose_upload": with_upload_ms,
                 "frame_ms_device_sampled_pose": sampled_ms,
-                "per_frame_loops": "max over ranks; with_pose_upload = rz_set_pose%s + rz_deform per frame, device_sampled_pose = rz_set_pose_sampled (1 float / instance) + rz_deform"
+                "per_frame_loops": "max over ranks, raw C ABI calls; with_pose_upload = rz_set_pose%s + rz_deform per frame, device_sampled_pose = rz_set_pose_sampled (1 float / instance) + rz_deform"
                                    % ("_local" if args.device_fk else ""),
                 "allgather_ms": ag_ms,
                 "kernel_ms_min_over_ranks": min(kms), "kernel_ms_max_over_ranks": max(kms),

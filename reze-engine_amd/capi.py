@@ -364,6 +364,48 @@ class DeformContext:
         _chk(self._L.rz_read_aabb(self._h, int(instance), _fptr(out)))
         return out
 
+    def frame_call(self, kind, primary, morph_weights=None, translations=None):
+        """A zero-argument callable that does ONE per-frame upload + rz_deform through the raw C ABI with every array
+        converted and every pointer built up front — for timing per-frame loops without numpy conversions in them
+        (bench.py, tools/live_loop.py). kind: 'world' (rz_set_pose), 'local' (rz_set_pose_local), 'sampled'
+        (rz_set_pose_sampled; `primary` = a [T, I] table of frame numbers that is cycled through). Returns (call, check)."""
+        L, h = self._L, self._h
+        keep = []
+
+        def ptr(a):
+            if a is None:
+                return None
+            a = _f32(a).reshape(-1)
+            keep.append(a)
+            return _fptr(a)
+        bad = []
+        if kind == "world":
+            wp, mp = ptr(primary), ptr(morph_weights if self.M > 0 else None)
+
+            def call():
+                if L.rz_set_pose(h, wp, mp) or L.rz_deform(h):
+                    bad.append(1)
+        elif kind == "local":
+            qp, tp, mp = ptr(primary), ptr(translations), ptr(morph_weights if self.M > 0 else None)
+
+            def call():
+                if L.rz_set_pose_local(h, qp, tp, mp) or L.rz_deform(h):
+                    bad.append(1)
+        else:
+            table = [ptr(row) for row in np.atleast_2d(primary)]
+            tick = [0]
+
+            def call():
+                tick[0] += 1
+                if L.rz_set_pose_sampled(h, table[tick[0] % len(table)]) or L.rz_deform(h):
+                    bad.append(1)
+
+        def check():
+            if bad:
+                raise RzError(-1, "a frame call failed: " + L.rz_last_error().decode("utf-8", "replace"))
+        call.keep = keep
+        return call, check
+
     def deform(self):
         _chk(self._L.rz_deform(self._h))
 
