@@ -410,3 +410,41 @@ def test_growing_the_crowd_needs_a_new_pose(rz, oracle):
         pg, ng = c.read(instance=i)
         assert_parity(pg, ng, pr, nr, "after shrinking the crowd, instance %d" % i)
     c.close()
+
+
+@pytest.mark.parametrize("pose", ["pose0", "tween150", "tween500"])
+def test_wide_sample_of_the_real_model_against_reference_execution(rz, oracle, pose):
+    """4 121 real vertices (every 7th of the demo model: all body parts, 234 bones, the model's own 40 / 52 / 8 % influence mix)
+    under three reference-produced poses, deformed on the GPU and compared DIRECTLY with vs() as the reference run evaluated
+    it with math.ts primitives (tests/golden, tools/ref_erased_run.py), then replicated as a small crowd: the instanced kernel
+    on real skinning data (its wave-uniform influence skipping takes all three paths here) must give the same bits."""
+    g = np.load(GOLD)
+    v = g["wide_vertices"]
+    pos, nrm = np.ascontiguousarray(v[:, 0:3]), np.ascontiguousarray(v[:, 3:6])
+    ref = g["skinnedwide_" + pose].astype(np.float64)
+    c = rz.DeformContext(0)
+    c.upload_mesh_interleaved(v, g["wide_joints"], g["wide_weights"])
+    c.upload_skeleton(g["inv_bind"])
+    c.set_pose(g["world_" + pose])
+    c.deform()
+    pg, ng = c.read()
+    assert_parity(pg, ng, ref[:, :3], ref[:, 3:], "wide real sample vs REFERENCE EXECUTION (%s)" % pose)
+    pr, nr = oracle.deform(pos, nrm, g["wide_joints"], g["wide_weights"], g["world_" + pose], g["inv_bind"])
+    assert_parity(pg, ng, pr, nr, "wide real sample vs oracle (%s)" % pose)
+    # the same vertices sorted by influence count (real models cluster them by mesh part), as a crowd of 5 poses
+    order = np.argsort((g["wide_weights"] > 0).sum(axis=1), kind="stable")
+    c.upload_mesh_interleaved(v[order], g["wide_joints"][order], g["wide_weights"][order])
+    c.upload_skeleton(g["inv_bind"])
+    c.set_pose(g["world_" + pose]); c.deform()
+    single = c.read()
+    assert np.array_equal(single[0], pg[order]) and np.array_equal(single[1], ng[order])
+    c.set_instances(5)
+    worlds = np.stack([g["world_pose0"], g["world_" + pose], g["world_tween150"], g["world_" + pose], g["world_tween500"]])
+    for fast in (-1, 0):
+        c.set_tuning(fast=fast)
+        c.set_pose(worlds); c.deform()
+        assert c.get_tuning("effective_inst_group") >= 2
+        for k in (1, 3):
+            pk, nk = c.read(instance=k)
+            assert np.array_equal(pk, single[0]) and np.array_equal(nk, single[1]), "crowd instance %d (fast=%d) vs the pose alone" % (k, fast)
+    c.close()

@@ -165,7 +165,7 @@ def _golden():
     return np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_c1_pose0.npz"))
 
 
-@pytest.mark.parametrize("pose", ["pose0", "tween150"])
+@pytest.mark.parametrize("pose", ["pose0", "tween150", "tween500"])
 def test_palette_pinned_to_the_reference_mat4_multiply(oracle, pose):
     """engine.ts:926-928 (skin = world * inverseBind) as computed by the reference's own Mat4.multiply (math.ts:303-320) on
     the real 349-bone model. The reference sums in doubles and stores f32 (<= 0.5 ulp of the result); the oracle (like the
@@ -197,3 +197,23 @@ def test_skin_pinned_to_reference_primitives_on_real_vertices(oracle, pose):
     assert ep.max() <= 1e-6 and en.max() <= 1e-6, (ep.max(), en.max())
     assert (g["slice_weights"][:, 0] == 255).sum() >= 100        # the BDEF1 share the docstring promises
     assert np.abs(p - v[:, 0:3]).max() > 1e-3 or pose == "pose0"  # tween150 really moves the slice
+
+
+@pytest.mark.parametrize("pose", ["pose0", "tween150", "tween500"])
+def test_skin_pinned_on_a_wide_sample_of_the_real_model(oracle, pose):
+    """Every 7th vertex of the demo model (4 121 vertices, 234 of its 349 bones, 1 652 BDEF1 / 2 159 BDEF2 / 310 BDEF4) under
+    three reference-produced poses, vs() evaluated by the reference run with math.ts primitives (stored as f32). Bar 1e-6."""
+    g = _golden()
+    v = g["wide_vertices"]
+    S = oracle.palette(g["world_" + pose], g["inv_bind"])
+    p, n = oracle.skin(np.ascontiguousarray(v[:, 0:3]), np.ascontiguousarray(v[:, 3:6]), g["wide_joints"], g["wide_weights"], S)
+    ref = g["skinnedwide_" + pose].astype(np.float64)
+    ep = np.linalg.norm(p - ref[:, :3], axis=1) / np.maximum(np.linalg.norm(ref[:, :3], axis=1), 1.0)
+    en = np.linalg.norm(n - ref[:, 3:], axis=1)
+    assert ep.max() <= 1e-6 and en.max() <= 1e-6, (ep.max(), en.max())
+    cnt = (g["wide_weights"] > 0).sum(axis=1)
+    assert len(v) > 4000 and (cnt == 1).sum() > 1000 and (cnt == 2).sum() > 1000 and (cnt >= 3).sum() > 100
+    assert np.abs(p - v[:, 0:3]).max() > 1.0                  # the poses really move the mesh
+    # the numpy twin lands on the same bits as the C oracle here too
+    p2, n2 = oracle.np_twin.skin(np.ascontiguousarray(v[:, 0:3]), np.ascontiguousarray(v[:, 3:6]), g["wide_joints"], g["wide_weights"], S)
+    assert np.array_equal(p, p2) and np.array_equal(n, n2)

@@ -213,6 +213,30 @@ function pinHotPath(m, tag) {
     out.set([P.x, P.y, P.z, N.x, N.y, N.z], k * 6)
   })
   dump('m2_skinned_' + tag + '.f64', out)
+  // a WIDE sample: every 7th vertex of the model (4 121 vertices over every body part, all three influence types)
+  const wide = []
+  for (let i = 0; i < V; i += 7) wide.push(i)
+  const wout = new Float64Array(wide.length * 6)
+  wide.forEach((vi, k) => {
+    const w = [0, 1, 2, 3].map((i) => sk.weights[vi * 4 + i] / 255)
+    const sum = w[0] + w[1] + w[2] + w[3]
+    const inv = sum > 0.0001 ? 1 / sum : 1
+    const nw = sum > 0.0001 ? w.map((x) => x * inv) : [1, 0, 0, 0]
+    let P = new Vec3(0, 0, 0), N = new Vec3(0, 0, 0)
+    for (let i = 0; i < 4; i++) {
+      const S = mats[sk.joints[vi * 4 + i]]
+      const col = new Float32Array(16)
+      col[0] = 1; col[5] = 1; col[10] = 1
+      col[12] = v[vi * 8]; col[13] = v[vi * 8 + 1]; col[14] = v[vi * 8 + 2]; col[15] = 1
+      P = P.add(S.multiply(new Mat4(col)).getPosition().scale(nw[i]))
+      const ncol = new Float32Array(16)
+      ncol[12] = v[vi * 8 + 3]; ncol[13] = v[vi * 8 + 4]; ncol[14] = v[vi * 8 + 5]; ncol[15] = 0
+      N = N.add(S.multiply(new Mat4(ncol)).getPosition().scale(nw[i]))
+    }
+    N = N.normalize()
+    wout.set([P.x, P.y, P.z, N.x, N.y, N.z], k * 6)
+  })
+  dump('m2_skinnedwide_' + tag + '.f64', wout)
 }
 ;(async () => {
   const silent = console.warn; console.warn = () => {}
@@ -259,6 +283,7 @@ function pinHotPath(m, tag) {
       now = 1500
       m.evaluatePose()
       dump('m2_world_tween500.f32', m.getBoneWorldMatrices())
+      pinHotPath(m, 'tween500')
       global.performance = require('perf_hooks').performance
     }
   }
@@ -303,6 +328,7 @@ def main():
     d = info["m2"]
     v = rd("m2_vertices.f32", np.float32).reshape(-1, 8)
     sl = np.r_[0:128, 14000:14064, len(v) - 64:len(v)]       # 256-vertex slices (numbers, not the model)
+    wide = np.arange(0, len(v), 7)                           # every 7th vertex: a thin sample of every body part
     np.savez_compressed(
         os.path.join(gold, "ref_c1_pose0.npz"),
         world_pose0=rd("m2_world_pose0.f32", np.float32).reshape(-1, 16),
@@ -319,6 +345,13 @@ def main():
         palette_tween150=rd("m2_palette_tween150.f32", np.float32).reshape(-1, 16),
         skinned_pose0=rd("m2_skinned_pose0.f64", np.float64).reshape(-1, 6),
         skinned_tween150=rd("m2_skinned_tween150.f64", np.float64).reshape(-1, 6),
+        palette_tween500=rd("m2_palette_tween500.f32", np.float32).reshape(-1, 16),
+        skinned_tween500=rd("m2_skinned_tween500.f64", np.float64).reshape(-1, 6),
+        wide_index=wide.astype(np.int32), wide_vertices=v[wide],
+        wide_joints=rd("m2_joints.u16", np.uint16).reshape(-1, 4)[wide], wide_weights=rd("m2_weights.u8", np.uint8).reshape(-1, 4)[wide],
+        skinnedwide_pose0=rd("m2_skinnedwide_pose0.f64", np.float64).reshape(-1, 6).astype(np.float32),
+        skinnedwide_tween150=rd("m2_skinnedwide_tween150.f64", np.float64).reshape(-1, 6).astype(np.float32),
+        skinnedwide_tween500=rd("m2_skinnedwide_tween500.f64", np.float64).reshape(-1, 6).astype(np.float32),
         slice_index=sl.astype(np.int32), slice_vertices=v[sl],
         slice_joints=rd("m2_joints.u16", np.uint16).reshape(-1, 4)[sl],
         slice_weights=rd("m2_weights.u8", np.uint8).reshape(-1, 4)[sl])
