@@ -30,7 +30,8 @@
  *     stays UNPINNED BY SHADER EXECUTION; what IS pinned: the same fixture run evaluates vs()'s formula
  *     (engine.ts:255-272) on 256 real vertices with the reference's Mat4 / Vec3 primitives (every M_i * vec4 is a
  *     Mat4.multiply; for the 173 BDEF1 vertices of the slice the position is Mat4.multiply alone), and this file agrees
- *     with it to 2e-7 relative (bar in the test: 1e-6). On top of that: analytic known-answer tests (identity pose =>
+ *     with it to 2e-7 relative (bar in the test: 1e-6); the same on every 7th vertex of the model (4 121 vertices, 234
+ *     bones, three poses): 3.2e-7. On top of that: analytic known-answer tests (identity pose =>
  *     rest mesh, single-bone rigid motion about a pivot, hand-computed 2-bone blend, zero-weight and zero-normal
  *     branches) and bit-exact three-way agreement between this file, the NumPy twin (oracle/rz_oracle_np.py) and the
  *     JS Math.fround twin (oracle/js/skin_f32.js).
