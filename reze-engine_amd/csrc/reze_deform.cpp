@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -269,6 +270,20 @@ int use(rz_ctx *c)
 template <class T> void dfree(T *&p)
 {
     if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+// Poll an event (no sleep: a blocking wait wakes tens of microseconds late, which starves a GPU whose frames are 16 us long
+// — measured: 36 us per frame). Bounded: a GPU that stops making progress turns into an error after 10 s, not a hang.
+int poll_event(hipEvent_t ev, const char *what)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return RZ_OK;
+        if (q != hipErrorNotReady) return fail(RZ_ERR_HIP, "%s: %s", what, hipGetErrorString(q));
+        if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
+            return fail(RZ_ERR_HIP, "%s: the GPU made no progress for 10 s", what);
+    }
 }
 
 // A captured hipGraph bakes device pointers and launch shapes in. The replay key (frame_signature) covers all of them; on
@@ -1065,11 +1080,8 @@ static int stage_acquire(rz_ctx *c, size_t need, int *slot_out)
     const int slot = c->stage_next;
     c->stage_next = (slot + 1) % kStageSlots;
     if (c->stage_used[slot]) {
-        // the copy that read this slot kStageSlots uploads ago: normally long done. Polled, not slept on — a blocking wait
-        // wakes tens of microseconds late, which starves a GPU whose frames are 16 us long (measured: 36 us per frame).
-        hipError_t q;
-        while ((q = hipEventQuery(c->stage_ev[slot])) == hipErrorNotReady) {}
-        if (q != hipSuccess) return fail(RZ_ERR_HIP, "pinned staging slot: %s", hipGetErrorString(q));
+        // the copy that read this slot kStageSlots uploads ago: normally long done
+        if (int r = poll_event(c->stage_ev[slot], "pinned staging slot")) return r;
     }
     *slot_out = slot;
     return RZ_OK;
@@ -1113,69 +1125,68 @@ static int zc_acquire(rz_ctx *c, size_t need, int *slot_out)
         const uint64_t cand = (u - 7 + 3) / 4 * 4;
         const int e = (int)((cand / 4) & 1);
         if (c->zc_ev_seq[e] != cand) return fail(RZ_ERR_HIP, "zero-copy ring bookkeeping is inconsistent (upload %llu)", (unsigned long long)u);
-        hipError_t q;
-        while ((q = hipEventQuery(c->zc_ev[e])) == hipErrorNotReady) {}
-        if (q != hipSuccess) return fail(RZ_ERR_HIP, "zero-copy ring: %s", hipGetErrorString(q));
+        if (int r = poll_event(c->zc_ev[e], "zero-copy pose ring")) return r;
     }
     *slot_out = (int)(u % rz_ctx::kZcSlots);
     c->zc_uploads = u + 1;
     return RZ_OK;
 }
 
-// Shared tail of rz_set_pose / rz_set_pose_local. `primary` (world matrices or local rotations, `pbytes` long), optional
-// `secondary` (local translations) and the morph weights are laid out in a pinned ring slot exactly as they sit in the
-// device pose block, and go down as ONE copy into the OTHER device slot — on the upload stream for big poses, so the
-// upload overlaps whatever the compute stream is still running on the current slot; the compute stream then waits for it.
-static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void *secondary, size_t sbytes, bool local,
-                       const float *morph_weights)
+// One per-frame pose as the host handed it over, and where its parts go inside a slot (pinned slot and device pose block share
+// the layout):   world pose [world | weights]     local pose [weights | rotations | translations]
+struct PoseParts {
+    const void *primary; size_t pbytes;       // world matrices or local rotations
+    const void *secondary; size_t sbytes;     // local translations (local poses only, may be absent)
+    const float *morph_weights;               // may be null (= all zero)
+    bool local;
+    size_t mb, mwb, total;                    // weight bytes handed over / their padded place / bytes of the whole range
+};
+
+static void lay_out_pose(const rz_ctx *c, const PoseParts &pp, char *st)
 {
-    // the pose kind decides the plan, the plan decides which stream protocol the frame (and therefore this upload) follows
-    c->pose_set = false;
-    c->pose_local = local;
-    c->pose_sampled = false;
-    if (int r = set_overlap(c, want_overlap(c, make_plan(c)))) return r;
-    const size_t mb = (size_t)c->I * c->M * sizeof(float);          // weights the caller handed over
-    const size_t mwb = ((size_t)c->I * std::max<uint32_t>(c->M, 1) + 3) / 4 * 4 * sizeof(float);   // their padded place in the block
-    // world pose: [world | weights]           local pose: [weights | rotations | translations]
-    const size_t total = local ? mwb + pbytes + sbytes : pbytes + (c->M > 0 ? mwb : 0);
-    if (!c->overlap_on && c->I == 1 && total <= (256u << 10) && c->t_zerocopy != 0) {
-        // One character: no copy at all. The pose is laid out in a pinned, device-mapped slot; the frame's own kernels read it.
-        int zs = 0;
-        const int zr = zc_acquire(c, std::max<size_t>(std::max<size_t>((size_t)c->B * 64 + mwb, mwb + (size_t)c->B * 28), 4096), &zs);
-        if (zr == RZ_ERR_UNSUPPORTED) { c->t_zerocopy = 0; goto copy_path; }      // from now on every pose is copied
-        if (zr) return zr;
-        char *st = static_cast<char *>(c->zc_host[zs]);
-        char *st_mw = local ? st : st + pbytes;
-        char *st_pr = local ? st + mwb : st;
-        memcpy(st_pr, primary, pbytes);
-        if (sbytes) memcpy(st_pr + pbytes, secondary, sbytes);
-        if (local || c->M > 0) {
-            if (morph_weights && mb) memcpy(st_mw, morph_weights, mb); else memset(st_mw, 0, mb);
-            if (mwb > mb) memset(st_mw + mb, 0, mwb - mb);
-        }
-        point_pose_slot(c, c->pose_slot ^ 1);   // where the pose will live once something makes it resident
-        c->free_recorded[c->pose_slot] = false;
-        c->zc_cur = zs; c->zc_local = local; c->zc_total = total;
-        c->zc_mw_off = local ? 0 : pbytes; c->zc_lq_off = mwb;
-        c->world_resident = local;              // a local pose has no world matrices to bring over: rz_fk_kernel writes them
-        c->mw_resident = false;
-        c->local_resident = !local;
-        goto pose_uploaded;
+    char *st_mw = pp.local ? st : st + pp.pbytes;
+    char *st_pr = pp.local ? st + pp.mwb : st;
+    memcpy(st_pr, pp.primary, pp.pbytes);
+    if (pp.sbytes) memcpy(st_pr + pp.pbytes, pp.secondary, pp.sbytes);
+    if (pp.local || c->M > 0) {
+        if (pp.morph_weights && pp.mb) memcpy(st_mw, pp.morph_weights, pp.mb); else memset(st_mw, 0, pp.mb);
+        if (pp.mwb > pp.mb) memset(st_mw + pp.mb, 0, pp.mwb - pp.mb);
     }
-copy_path:
-    {
+}
+
+// One character: no copy at all. The pose is laid out in a pinned, device-mapped slot; the frame's own kernels read it.
+// Returns RZ_ERR_UNSUPPORTED when no such memory can be had (the caller copies instead).
+static int upload_pose_zero_copy(rz_ctx *c, const PoseParts &pp)
+{
+    int zs = 0;
+    if (int r = zc_acquire(c, std::max<size_t>(std::max<size_t>((size_t)c->B * 64 + pp.mwb, pp.mwb + (size_t)c->B * 28), 4096), &zs)) return r;
+    lay_out_pose(c, pp, static_cast<char *>(c->zc_host[zs]));
+    point_pose_slot(c, c->pose_slot ^ 1);   // where the pose will live once something makes it resident
+    c->free_recorded[c->pose_slot] = false;
+    c->zc_cur = zs; c->zc_local = pp.local; c->zc_total = pp.total;
+    c->zc_mw_off = pp.local ? 0 : pp.pbytes; c->zc_lq_off = pp.mwb;
+    c->world_resident = pp.local;           // a local pose has no world matrices to bring over: rz_fk_kernel writes them
+    c->mw_resident = false;
+    c->local_resident = !pp.local;
+    return RZ_OK;
+}
+
+// The pose goes through a pinned ring slot into the OTHER device slot as ONE copy — on the upload stream for big poses, so
+// the upload overlaps whatever the compute stream is still running on the current slot; the compute stream then waits for it.
+static int upload_pose_copy(rz_ctx *c, const PoseParts &pp)
+{
     c->zc_cur = -1;
     c->world_resident = c->mw_resident = c->local_resident = true;
     int slot = 0;
-    if (int r = stage_acquire(c, std::max<size_t>((size_t)c->I * c->B * 64 + mwb, mwb + (size_t)c->I * c->B * 28), &slot)) return r;
-    // Small poses (one character: 16-22 KB) go down the compute stream itself — measured on C5, the two extra
-    // packets of the cross-stream hand-off (marker + barrier) cost 3 us more per frame than the copy they hide.
-    // Large ones (instanced crowds: MBs) take the upload stream: everything enqueued so far reads the current device
+    if (int r = stage_acquire(c, std::max<size_t>((size_t)c->I * c->B * 64 + pp.mwb, pp.mwb + (size_t)c->I * c->B * 28), &slot)) return r;
+    // Large poses (instanced crowds: MBs) take the upload stream: everything enqueued so far reads the current device
     // slot, so mark it, fill the other slot once ITS last readers are done, and make the compute stream wait for it.
+    // Small ones that are copied at all (zero_copy = 0, small crowds) go down the compute stream itself — measured on C5,
+    // the two extra packets of the cross-stream hand-off (marker + barrier) cost 3 us more per frame than the copy they hide.
     const int cur = c->pose_slot, k = cur ^ 1;
     // Overlapped-front protocol (crowds, opt-in): EVERY per-frame input travels on the upload stream and is consumed there,
     // by the front kernels — stream order is the only ordering needed, no event at all.
-    const bool piped = !c->overlap_on && total > (256u << 10);
+    const bool piped = !c->overlap_on && pp.total > (256u << 10);
     hipStream_t us = (piped || c->overlap_on) ? c->up_stream : c->stream;
     if (c->overlap_on) {
         c->free_recorded[0] = c->free_recorded[1] = false;
@@ -1192,17 +1203,10 @@ copy_path:
         c->free_recorded[cur] = false;      // the slot's readers are about to be enqueued and nothing will mark their end
     }
     char *st = static_cast<char *>(c->stage[slot]);
-    char *st_mw = local ? st : st + pbytes;
-    char *st_pr = local ? st + mwb : st;
-    memcpy(st_pr, primary, pbytes);
-    if (sbytes) memcpy(st_pr + pbytes, secondary, sbytes);
-    if (local || c->M > 0) {
-        if (morph_weights && mb) memcpy(st_mw, morph_weights, mb); else memset(st_mw, 0, mb);
-        if (mwb > mb) memset(st_mw + mb, 0, mwb - mb);
-    }
+    lay_out_pose(c, pp, st);
     point_pose_slot(c, k);                  // c->world / c->morph_w / c->local_q now name slot k under the current counts
-    void *dst = local ? static_cast<void *>(c->morph_w) : static_cast<void *>(c->world);
-    HIP_TRY(hipMemcpyAsync(dst, st, total, hipMemcpyHostToDevice, us));
+    void *dst = pp.local ? static_cast<void *>(c->morph_w) : static_cast<void *>(c->world);
+    HIP_TRY(hipMemcpyAsync(dst, st, pp.total, hipMemcpyHostToDevice, us));
     HIP_TRY(hipEventRecord(c->stage_ev[slot], us));
     c->stage_used[slot] = true;
     if (piped) {
@@ -1210,8 +1214,30 @@ copy_path:
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_up[k], 0));
     }
     c->free_recorded[k] = false;            // slot k gets new readers from here on: its old end-of-readers mark is void
+    return RZ_OK;
+}
+
+// Shared tail of rz_set_pose / rz_set_pose_local.
+static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void *secondary, size_t sbytes, bool local,
+                       const float *morph_weights)
+{
+    // the pose kind decides the plan, the plan decides which stream protocol the frame (and therefore this upload) follows
+    c->pose_set = false;
+    c->pose_local = local;
+    c->pose_sampled = false;
+    if (int r = set_overlap(c, want_overlap(c, make_plan(c)))) return r;
+    PoseParts pp;
+    pp.primary = primary; pp.pbytes = pbytes; pp.secondary = secondary; pp.sbytes = sbytes; pp.morph_weights = morph_weights; pp.local = local;
+    pp.mb = (size_t)c->I * c->M * sizeof(float);
+    pp.mwb = ((size_t)c->I * std::max<uint32_t>(c->M, 1) + 3) / 4 * 4 * sizeof(float);
+    pp.total = local ? pp.mwb + pbytes + sbytes : pbytes + (c->M > 0 ? pp.mwb : 0);
+    int rc = RZ_ERR_UNSUPPORTED;
+    if (!c->overlap_on && c->I == 1 && pp.total <= (256u << 10) && c->t_zerocopy != 0) {
+        rc = upload_pose_zero_copy(c, pp);
+        if (rc == RZ_ERR_UNSUPPORTED) c->t_zerocopy = 0;      // no pinned device-mapped memory: from now on every pose is copied
     }
-pose_uploaded:
+    if (rc == RZ_ERR_UNSUPPORTED) rc = upload_pose_copy(c, pp);
+    if (rc) return rc;
     c->pose_I = c->I;
     // ordered compaction of the non-zero weights for the one-launch path (instance 0)
     memset(&c->ml, 0, sizeof c->ml);
