@@ -877,15 +877,15 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int inst0 = blockIdx.y * G;
     const int ng = min(G, n_inst - inst0);
-    const int rows = p.B * 3;                       // float4 per palette in global memory
-    const int rstride = p.dma ? 3 : 4;              // float4 per palette slot in LDS
-    const int lrows = p.B * rstride;
+    const int rows = p.B * 3;                       // float4 per palette, in global memory and (finished) in LDS
+    constexpr int rstride = 3;                      // float4 per bone of a finished palette
+    const int lrows = rows;
     {
         // prep-kernel path (dma): the group's finished palettes are contiguous in global memory -> one linear LDS-DMA copy.
         // one-launch frame (!dma): the group's WORLD matrices are staged instead, whole (64-byte slots, the same linear
-        // 16-byte LDS-DMA); the conversion pass below multiplies by the inverse bind matrix in place and leaves the
-        // palette rows in the first 48 bytes of each slot. (A compact 48-byte slot would need gfx950's 12-byte LDS-DMA
-        // to pack its cells — measured: it keeps a 16-byte lane stride — or loads + ds_write, measured 3 us slower.)
+        // 16-byte LDS-DMA); the conversion pass below multiplies by the inverse bind matrix and re-packs the rows to the
+        // same 48-byte stride. (Leaving them in the 64-byte slots made every fourth bone share its LDS banks: 52 % of the
+        // skin loop's LDS cycles were bank conflicts, against 11 % at 48 bytes — profiles/r2_sq_counters_c4.txt.)
         const float4 *src = p.dma ? p.palette + (size_t)inst0 * rows : reinterpret_cast<const float4 *>(p.world) + (size_t)inst0 * p.B * 4;
         const int n = (RZ_DBG(p) == 6 || RZ_DBG(p) == 7) ? 0 : (p.dma ? ng * rows : ng * p.B * 4);   // dbg 6 / 7 (tools-only build): no palette staging
         for (int c = wave * 64; c < n; c += BLOCK) {
@@ -897,12 +897,13 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
             }
         }
     }
-    // One-launch frame: which (bone, pose stripe) this thread converts. With B <= BLOCK / 2 the spare threads take a second,
-    // third ... stripe of the group's poses (stripe s converts poses s, s + stripes, ...): 200 bones on 512 threads = 2 stripes.
-    const int stripes = (!p.dma && p.B <= BLOCK) ? max(1, min(ng, BLOCK / p.B)) : 1;
-    const int cv_b0 = stripes > 1 ? tid % p.B : tid;
-    const int cv_g0 = stripes > 1 ? tid / p.B : 0;
-    const bool cv_on = !p.dma && cv_g0 < stripes && cv_b0 < p.B;
+    // One-launch frame (the host only plans it for B <= BLOCK): which (bone, pose stripe) this thread converts. With
+    // B <= BLOCK / 2 the spare threads take a second, third ... stripe of the group's poses (stripe s converts poses s,
+    // s + stripes, ...): 200 bones on 512 threads = 2 stripes.
+    const int stripes = !p.dma ? max(1, min(ng, BLOCK / p.B)) : 1;
+    const int cv_b0 = tid % p.B;
+    const int cv_g0 = tid / p.B;
+    const bool cv_on = !p.dma && cv_g0 < stripes;
     float4 ib0 = {0, 0, 0, 0}, ib1 = ib0, ib2 = ib0, ib3 = ib0;
     if (cv_on) {                                    // requested first: lands while the staging copy is in flight
         const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + cv_b0 * 4;
@@ -929,30 +930,39 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         // inverse bind matrix is held as column PAIRS (c0,c1),(c2,c3) per k, so each result row is two v_pk_fma
         // chains (the same chain as rz_prep_kernel: ((a0*b0 + a1*b1) + a2*b2) + a3*b3); the next pose's cells are read
         // before the current product is formed.
-        for (int b = cv_b0; cv_on && b < p.B; b += BLOCK) {  // one trip unless the skeleton has more bones than threads
-            if (b != cv_b0) {
-                const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + b * 4;
-                ib0 = gi[0]; ib1 = gi[1]; ib2 = gi[2]; ib3 = gi[3];
+        // Rounds of up to four poses per thread: read the staged world matrices (64-byte slots) and form the palette rows
+        // in registers (engine.ts:926-928, packed math, the same FMA chain as rz_prep_kernel: ((a0*b0 + a1*b1) + a2*b2) +
+        // a3*b3) -> barrier -> write them back at the 48-byte stride. Poses ascend, and the compact rows of pose g only
+        // ever land on staged matrices of poses <= g, which every thread has read by then.
+        const f2 px01 = {ib0.x, ib1.x}, px23 = {ib2.x, ib3.x}, py01 = {ib0.y, ib1.y}, py23 = {ib2.y, ib3.y};
+        const f2 pz01 = {ib0.z, ib1.z}, pz23 = {ib2.z, ib3.z}, pw01 = {ib0.w, ib1.w}, pw23 = {ib2.w, ib3.w};
+        auto row = [&](float e0, float e1, float e2, float e3, const f2 &bx, const f2 &by, const f2 &bz, const f2 &bw) {
+            return pk_fma(f2{e3, e3}, bw, pk_fma(f2{e2, e2}, bz, pk_fma(f2{e1, e1}, by, f2{e0, e0} * bx)));
+        };
+        constexpr int PR = 4;                               // poses per thread per round
+        for (int g_base = 0; g_base < ng; g_base += PR * stripes) {       // workgroup-uniform trip count
+            f2 res[PR][6];
+#pragma unroll
+            for (int i = 0; i < PR; ++i) {
+                const int g = g_base + cv_g0 + i * stripes;
+                if (cv_on && g < ng) {
+                    const float4 *slot = pal + ((size_t)g * p.B + cv_b0) * 4;
+                    const float4 a0 = slot[0], a1 = slot[1], a2 = slot[2], a3 = slot[3];      // the world matrix's columns
+                    res[i][0] = row(a0.x, a1.x, a2.x, a3.x, px01, py01, pz01, pw01); res[i][1] = row(a0.x, a1.x, a2.x, a3.x, px23, py23, pz23, pw23);
+                    res[i][2] = row(a0.y, a1.y, a2.y, a3.y, px01, py01, pz01, pw01); res[i][3] = row(a0.y, a1.y, a2.y, a3.y, px23, py23, pz23, pw23);
+                    res[i][4] = row(a0.z, a1.z, a2.z, a3.z, px01, py01, pz01, pw01); res[i][5] = row(a0.z, a1.z, a2.z, a3.z, px23, py23, pz23, pw23);
+                }
             }
-            const f2 px01 = {ib0.x, ib1.x}, px23 = {ib2.x, ib3.x}, py01 = {ib0.y, ib1.y}, py23 = {ib2.y, ib3.y};
-            const f2 pz01 = {ib0.z, ib1.z}, pz23 = {ib2.z, ib3.z}, pw01 = {ib0.w, ib1.w}, pw23 = {ib2.w, ib3.w};
-            const int gstep = stripes * lrows;
-            float4 *slot = pal + (size_t)cv_g0 * lrows + (size_t)b * 4;
-            float4 a0 = slot[0], a1 = slot[1], a2 = slot[2], a3 = slot[3];       // the world matrix's columns
-            for (int g = cv_g0; g < ng; g += stripes) {
-                float4 *nxt = slot + gstep;
-                float4 n0 = a0, n1 = a1, n2 = a2, n3 = a3;
-                if (g + stripes < ng) { n0 = nxt[0]; n1 = nxt[1]; n2 = nxt[2]; n3 = nxt[3]; }
-                auto row = [&](float e0, float e1, float e2, float e3, const f2 &bx, const f2 &by, const f2 &bz, const f2 &bw) {
-                    return pk_fma(f2{e3, e3}, bw, pk_fma(f2{e2, e2}, bz, pk_fma(f2{e1, e1}, by, f2{e0, e0} * bx)));
-                };
-                const f2 r0a = row(a0.x, a1.x, a2.x, a3.x, px01, py01, pz01, pw01), r0b = row(a0.x, a1.x, a2.x, a3.x, px23, py23, pz23, pw23);
-                const f2 r1a = row(a0.y, a1.y, a2.y, a3.y, px01, py01, pz01, pw01), r1b = row(a0.y, a1.y, a2.y, a3.y, px23, py23, pz23, pw23);
-                const f2 r2a = row(a0.z, a1.z, a2.z, a3.z, px01, py01, pz01, pw01), r2b = row(a0.z, a1.z, a2.z, a3.z, px23, py23, pz23, pw23);
-                slot[0] = make_float4(r0a.x, r0a.y, r0b.x, r0b.y);
-                slot[1] = make_float4(r1a.x, r1a.y, r1b.x, r1b.y);
-                slot[2] = make_float4(r2a.x, r2a.y, r2b.x, r2b.y);
-                slot = nxt; a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < PR; ++i) {
+                const int g = g_base + cv_g0 + i * stripes;
+                if (cv_on && g < ng) {
+                    float4 *dst = pal + ((size_t)g * p.B + cv_b0) * 3;
+                    dst[0] = make_float4(res[i][0].x, res[i][0].y, res[i][1].x, res[i][1].y);
+                    dst[1] = make_float4(res[i][2].x, res[i][2].y, res[i][3].x, res[i][3].y);
+                    dst[2] = make_float4(res[i][4].x, res[i][4].y, res[i][5].x, res[i][5].y);
+                }
             }
         }
         __syncthreads();
@@ -962,7 +972,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
             const int n = ng * rows, per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
             const int lo = (int)blockIdx.x * per, hi = min(n, lo + per);
             float4 *gp = p.palette + (size_t)inst0 * rows;
-            for (int i = lo + tid; i < hi; i += BLOCK) gp[i] = pal[(i / 3) * 4 + i % 3];
+            for (int i = lo + tid; i < hi; i += BLOCK) gp[i] = pal[i];
         }
     }
     for (uint32_t vb = v_begin; vb < v_end; vb += BLOCK, v += BLOCK) {   // workgroup-uniform trip count (the ballots below need whole waves)

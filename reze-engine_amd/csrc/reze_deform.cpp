@@ -562,11 +562,12 @@ Plan make_plan(const rz_ctx *c)
         // (8 poses x 200 bones = 102 KB; two 256-thread workgroups of 6 poses each measured 39.5 us). Device-solved poses:
         // rz_fk_kernel has written the palettes already, the skin kernel copies them in (48-byte slots, LDS-DMA).
         // fast = 0 forces the prep-kernel form, fast = 1 / -1 (auto) the one-launch form.
-        const bool in_kernel = c->t_fast != 0 && !c->pose_local;
-        const uint32_t slot = in_kernel ? 64u : 48u;           // LDS bytes per bone per pose (deform_kernels.hip)
+        const bool want_in_kernel = c->t_fast != 0 && !c->pose_local;
         // workgroup size: 256 threads = two workgroups per CU (80 KB of palettes each); 512 / 1024 = one workgroup per CU
         // whose 8 / 16 waves share one staged palette group (up to 156 KB)
-        const int blk = c->t_instblock == 256 || c->t_instblock == 512 || c->t_instblock == 1024 ? c->t_instblock : (in_kernel ? 512 : 256);
+        const int blk = c->t_instblock == 256 || c->t_instblock == 512 || c->t_instblock == 1024 ? c->t_instblock : (want_in_kernel ? 512 : 256);
+        const bool in_kernel = want_in_kernel && c->B <= (uint32_t)blk;     // the conversion pass gives every bone its own thread
+        const uint32_t slot = in_kernel ? 64u : 48u;           // LDS bytes per bone per pose while staging (deform_kernels.hip)
         const uint32_t wg_per_cu = blk == 256 ? 2u : 1u;
         const uint32_t g_lds = ((blk == 256 ? 80u : 156u) * 1024u) / (c->B * slot);
         int G = (int)std::min<uint32_t>(8, g_lds);
