@@ -28,6 +28,16 @@ template <int MODE> __global__ void __launch_bounds__(256) k(float *pos, float *
                     const int v = vb + k4 * 64 + lane;
                     if (v < v1) { st3(pos + (inst0 + g) * S + (size_t)v * 3, 1.f); st3(nrm + (inst0 + g) * S + (size_t)v * 3, 2.f); }
                 }
+    } else if (MODE == 3) {
+        // vertex-major like A, but a wave writes its 64 vertices x 12 B = 768 B per array as 48 lanes x 16 B (hipMemset's shape)
+        const int lane = tid & 63;
+        for (int vb = v0 + (tid & ~63); vb < v1; vb += 256)
+            for (int g = 0; g < G; ++g)
+                if (lane < 48 && vb + 64 <= v1 + 63) {
+                    float4 *dp = reinterpret_cast<float4 *>(pos + (inst0 + g) * S + (size_t)vb * 3) + lane;
+                    float4 *dn = reinterpret_cast<float4 *>(nrm + (inst0 + g) * S + (size_t)vb * 3) + lane;
+                    *dp = make_float4(1.f, 1.f, 1.f, 1.f); *dn = make_float4(2.f, 2.f, 2.f, 2.f);
+                }
     } else {
         for (int g = 0; g < G; ++g)
             for (int v = v0 + tid; v < v1; v += 256) { st3(pos + (inst0 + g) * S + (size_t)v * 3, 1.f); st3(nrm + (inst0 + g) * S + (size_t)v * 3, 2.f); }
@@ -61,16 +71,18 @@ int main()
     CK(hipFuncSetAttribute((const void *)k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CK(hipFuncSetAttribute((const void *)k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CK(hipFuncSetAttribute((const void *)k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    CK(hipFuncSetAttribute((const void *)k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     const double mb = 2.0 * I * V * 12 / 1e6;
     for (int lds : {0, 77 * 1024})
-        for (int G : {8, 4, 2, 1})
-            for (int runs : {16, 32, 64}) {
+        for (int G : {8, 4})
+            for (int runs : {8, 16, 32}) {
                 const int per = ((V + runs - 1) / runs + 63) / 64 * 64;
                 dim3 grid((V + per - 1) / per, I / G);
                 double a = timeit([&] { k<0><<<grid, 256, lds>>>(pos, nrm, V, Vp, G, per); });
                 double b = timeit([&] { k<1><<<grid, 256, lds>>>(pos, nrm, V, Vp, G, per); });
                 double c = timeit([&] { k<2><<<grid, 256, lds>>>(pos, nrm, V, Vp, G, per); });
-                printf("lds=%dK G=%d runs=%d wgs=%d : A %.1f us (%.0f GB/s)  B %.1f us  C %.1f us\n", lds >> 10, G, runs, grid.x * grid.y, a, mb / a * 1e3, b, c);
+                double f = timeit([&] { k<3><<<grid, 256, lds>>>(pos, nrm, V, Vp, G, per); });
+                printf("lds=%dK G=%d runs=%d wgs=%d : A %.1f us (%.0f GB/s)  B %.1f us  C %.1f us  F(48 lanes x 16 B) %.1f us (%.0f GB/s)\n", lds >> 10, G, runs, grid.x * grid.y, a, mb / a * 1e3, b, c, f, mb / f * 1e3);
             }
     for (int grid : {512, 1024, 4096, 8192}) {
         double e = timeit([&] { k_lin<<<grid, 256>>>(pos, (size_t)I * Vp); k_lin<<<grid, 256>>>(nrm, (size_t)I * Vp); });
