@@ -2,6 +2,8 @@
 pose kinds, fused consumers and the launch-shape search are changed in random order, and after every pose the deformed
 mesh of a random instance is compared with the CPU oracle fed with the state the walk believes the context is in.
 Catches stale plans, stale buffers and flags that outlive the data they described."""
+import os
+
 import numpy as np
 import pytest
 
@@ -62,9 +64,11 @@ class Walk:
         self.c.set_instances(self.I)
 
     def new_tuning(self):
-        key = self.rng.choice(["morph_split", "unroll", "grid_cap", "geo_lds", "nontemporal", "nt_store", "fast", "out_cap", "inst_loop", "graph"])
+        key = self.rng.choice(["morph_split", "unroll", "grid_cap", "geo_lds", "nontemporal", "nt_store", "fast", "out_cap", "inst_loop", "graph",
+                               "inst_block", "overlap", "zero_copy"])
         val = {"morph_split": [0, 1, 2, 4, 8], "unroll": [0, 4, 8], "grid_cap": [0, 1, 7, 64, 2048], "geo_lds": [0, 1], "nontemporal": [0, 1],
-               "nt_store": [-1, 0, 1], "fast": [-1, 0, 1], "out_cap": [-1, 0, 64, 640], "inst_loop": [-1, 0, 2, 5, 8, 9], "graph": [0, 1]}[key]
+               "nt_store": [-1, 0, 1], "fast": [-1, 0, 1], "out_cap": [-1, 0, 64, 640], "inst_loop": [-1, 0, 2, 5, 8, 9, 12, 16], "graph": [0, 1],
+               "inst_block": [0, 256, 512, 1024], "overlap": [-1, 0, 1], "zero_copy": [-1, 0, 1]}[key]
         v = int(self.rng.choice(val))
         self.c.set_tuning(**{key: v})
         self.tuning[key] = v
@@ -168,7 +172,8 @@ class Walk:
         self.checked += 1
 
 
-@pytest.mark.parametrize("seed", list(range(1, 17)))
+# REZE_FUZZ_SEEDS=200 widens the walk for a soak run; the default keeps the suite short
+@pytest.mark.parametrize("seed", list(range(1, 1 + int(os.environ.get("REZE_FUZZ_SEEDS", "16")))))
 def test_random_walk_over_the_abi_state_machine(rz, oracle, seed):
     w = Walk(rz, oracle, seed)
     w.new_mesh()
