@@ -85,6 +85,12 @@ struct RzDeformParams {
     // this pose. null = the pose is already resident and `world` / `morph_w` are device pointers.
     float *world_copy;          // [B][16] device destination, or null
     float *morph_w_copy;        // [M]     device destination (MODE 2), or null
+    // FUSED single-character frame (fk_on): every workgroup of the (!FAST) kernel first solves the bone hierarchy itself —
+    // motion sampling included when the pose is sampled — straight into its LDS palette, and compacts the morph weights
+    // into its LDS list: no rz_fk_kernel, no rz_prep_kernel, ONE launch per device-animated frame. Workgroup 0 also
+    // leaves world matrices, palette and sampled weights in memory (rz_read_world / rz_read_palette).
+    RzFkParams fk;
+    int fk_on;
     const uint32_t *sp_ptr;     // [Vp+1]   (MODE 2) per-vertex CSR row pointers
     const float4 *sp_entries;   // [E]      (dx,dy,dz,bits(morph))
     float *out_pos;             // [I][Vp][3]

@@ -58,6 +58,39 @@ __device__ __forceinline__ float4 ld_stream(const float4 *p, bool nt)
 // ------------------------------------------------------------------------------------------------
 // prep: palette rows + ordered compaction of the non-zero morph weights. One workgroup per instance.
 // ------------------------------------------------------------------------------------------------
+// Ordered compaction of the non-zero morph weights of one pose (whole workgroup of kBlock threads; `mw` may be LDS or global,
+// `aidx` / `aw` likewise): entries keep ascending morph order = the oracle's accumulation order; the tail up to Mpad is
+// zero-padded so unrolled readers may over-read harmlessly. Returns the number of active morphs (workgroup-uniform).
+__device__ __forceinline__ int compact_active(const float *mw, const int M, const int Mpad, uint32_t *aidx, float *aw, int *wave_cnt)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int base = 0;
+    for (int m0 = 0; m0 < M; m0 += kBlock) {
+        const int m = m0 + tid;
+        const float w = (m < M) ? mw[m] : 0.0f;
+        const bool on = (w != 0.0f);
+        const unsigned long long bal = __ballot(on);
+        const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < kBlock / 64; ++k) {
+            const int c = wave_cnt[k];
+            before += (k < wave) ? c : 0;
+            total += c;
+        }
+        if (on) {
+            aidx[base + before + rank] = (uint32_t)m;
+            aw[base + before + rank] = w;
+        }
+        base += total;
+        __syncthreads();
+    }
+    for (int k = base + tid; k < Mpad; k += kBlock) { aidx[k] = 0; aw[k] = 0.0f; }
+    return base;
+}
+
 __global__ void __launch_bounds__(kBlock) rz_prep_kernel(RzPrepParams p)
 {
     const int inst = blockIdx.x;
@@ -86,36 +119,8 @@ __global__ void __launch_bounds__(kBlock) rz_prep_kernel(RzPrepParams p)
 
     if (p.M > 0) {
         __shared__ int wave_cnt[kBlock / 64];
-        const float *mw = p.morph_w + (size_t)inst * p.M;
-        uint32_t *aidx = p.act_idx + (size_t)inst * p.Mpad;
-        float *aw = p.act_w + (size_t)inst * p.Mpad;
-        const int lane = tid & 63, wave = tid >> 6;
-        int base = 0;
-        for (int m0 = 0; m0 < p.M; m0 += kBlock) {
-            int m = m0 + tid;
-            float w = (m < p.M) ? mw[m] : 0.0f;
-            bool on = (w != 0.0f);
-            unsigned long long bal = __ballot(on);
-            int rank = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) wave_cnt[wave] = __popcll(bal);
-            __syncthreads();
-            int before = 0, total = 0;
-#pragma unroll
-            for (int k = 0; k < kBlock / 64; ++k) {
-                int c = wave_cnt[k];
-                before += (k < wave) ? c : 0;
-                total += c;
-            }
-            if (on) {
-                aidx[base + before + rank] = (uint32_t)m;
-                aw[base + before + rank] = w;
-            }
-            base += total;
-            __syncthreads();
-        }
-        // pad the tail so unrolled readers may over-read harmlessly (weight 0, morph 0)
-        for (int k = base + tid; k < p.Mpad; k += kBlock) { aidx[k] = 0; aw[k] = 0.0f; }
-        if (tid == 0) p.act_count[inst] = base;
+        const int n = compact_active(p.morph_w + (size_t)inst * p.M, p.M, p.Mpad, p.act_idx + (size_t)inst * p.Mpad, p.act_w + (size_t)inst * p.Mpad, wave_cnt);
+        if (tid == 0) p.act_count[inst] = n;
     }
 }
 
@@ -232,18 +237,22 @@ __device__ __forceinline__ float sample_morph(const RzSampleParams &p, float fra
     return w;
 }
 
-__global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
+// The body of the hierarchy solve, shared by rz_fk_kernel (one workgroup per pose, results to global memory) and by the
+// FUSED single-character frame, where every workgroup of rz_deform_kernel runs it as its prologue: `wl` is then the deform
+// kernel's LDS palette (it ends up holding rows 0..2 of W * inverseBind), `scr` aliases its wave scratch, the sampled morph
+// weights go to `lds_mw`, and only workgroup 0 (`to_global`) also leaves world matrices / palette / weights in memory.
+// LDS behind `scr`: B x (16 + 3*4 + 4 + 12 + 12) = 56 bytes per bone. Ends with a barrier.
+template <bool FUSED>
+__device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, float4 *wl, unsigned char *scr, float *lds_mw, const bool to_global)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4 *wl = reinterpret_cast<float4 *>(smem);       // B x 3 rows of the world matrices of this pose
-    float4 *sq = wl + (size_t)p.B * 3;                   // local rotations of this pose
+    float4 *sq = reinterpret_cast<float4 *>(scr);        // local rotations of this pose
     int *s_par = reinterpret_cast<int *>(sq + p.B);
     int *s_ap = s_par + p.B;
     int *s_order = s_ap + p.B;
     float *s_ratio = reinterpret_cast<float *>(s_order + p.B);
     float *s_bind = s_ratio + p.B;
     float *s_lt = s_bind + (size_t)p.B * 3;               // local translations of this pose
-    const int inst = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const float4 *lq = p.local_q + (size_t)inst * p.B;
     const float *glt = p.local_t ? p.local_t + (size_t)inst * p.B * 3 : nullptr;
     const bool sampled = p.sample.frames != nullptr || p.sample.frames_inline;      // rz_set_pose_sampled: the pose is evaluated right here
@@ -274,8 +283,12 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
             if (glt) { s_lt[i * 3] = glt[i * 3]; s_lt[i * 3 + 1] = glt[i * 3 + 1]; s_lt[i * 3 + 2] = glt[i * 3 + 2]; }
         }
     }
-    if (sampled)        // vertex-morph weights of this pose: consumed by the prep / deform kernels that follow
-        for (int m = tid; m < p.sample.M; m += kBlock) p.sample.morph_w[(size_t)inst * p.sample.M + m] = sample_morph(p.sample, frame, m);
+    if (sampled)        // vertex-morph weights of this pose: consumed by the prep / deform kernels that follow (FUSED: by this very workgroup)
+        for (int m = tid; m < p.sample.M; m += kBlock) {
+            const float w = sample_morph(p.sample, frame, m);
+            if (FUSED) lds_mw[m] = w;
+            if (to_global) p.sample.morph_w[(size_t)inst * p.sample.M + m] = w;
+        }
     __syncthreads();
     // Pass A, every bone in parallel: its LOCAL matrix L = T(bind + t) * R * T(add) (rows 0..2), parked in the slot that
     // will hold its world matrix. The level loop below is then only W = W_parent * L — the quaternion / append / slerp
@@ -372,11 +385,13 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
         const float4 w0 = wl[b * 3], w1 = wl[b * 3 + 1], w2 = wl[b * 3 + 2];
         const float W[12] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w };
         // world, column-major 4x4 (what queue.writeBuffer(worldMatrixBuffer) would have carried)
-        float4 *wo = reinterpret_cast<float4 *>(world + (size_t)b * 16);
-        wo[0] = make_float4(W[0], W[4], W[8], 0.0f);
-        wo[1] = make_float4(W[1], W[5], W[9], 0.0f);
-        wo[2] = make_float4(W[2], W[6], W[10], 0.0f);
-        wo[3] = make_float4(W[3], W[7], W[11], 1.0f);
+        if (to_global) {
+            float4 *wo = reinterpret_cast<float4 *>(world + (size_t)b * 16);
+            wo[0] = make_float4(W[0], W[4], W[8], 0.0f);
+            wo[1] = make_float4(W[1], W[5], W[9], 0.0f);
+            wo[2] = make_float4(W[2], W[6], W[10], 0.0f);
+            wo[3] = make_float4(W[3], W[7], W[11], 1.0f);
+        }
         // palette rows 0..2 of W * IB (IB general 4x4, column-major)
         const float4 *Im = reinterpret_cast<const float4 *>(p.inv_bind + (size_t)b * 16);
         const bool mine = b == tid;
@@ -389,11 +404,20 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
             for (int i = 0; i < 3; ++i)
                 r[i][c] = fmaf(W[i * 4 + 3], bc.w, fmaf(W[i * 4 + 2], bc.z, fmaf(W[i * 4 + 1], bc.y, W[i * 4] * bc.x)));
         }
-        pal[b * 3] = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]);
-        pal[b * 3 + 1] = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]);
-        pal[b * 3 + 2] = make_float4(r[2][0], r[2][1], r[2][2], r[2][3]);
+        const float4 q0 = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]), q1 = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]),
+                     q2 = make_float4(r[2][0], r[2][1], r[2][2], r[2][3]);
+        if (to_global) { pal[b * 3] = q0; pal[b * 3 + 1] = q1; pal[b * 3 + 2] = q2; }
+        if (FUSED) { wl[b * 3] = q0; wl[b * 3 + 1] = q1; wl[b * 3 + 2] = q2; }     // in place: bone b's rows are only ever read by this thread in this pass
     }
+    if (FUSED) __syncthreads();
 }
+
+__global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fk_solve<false>(p, (int)blockIdx.x, reinterpret_cast<float4 *>(smem), smem + (size_t)p.B * 48, nullptr, true);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // helpers for the skin phase
@@ -520,7 +544,23 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         if (!late_world) load_world();
         ei0 = gi[0]; ei1 = gi[1]; ei2 = gi[2]; ei3 = gi[3];
     }
-    if (!FAST) {
+    int fused_count = 0;
+    if (!FAST && p.fk_on) {
+        // FUSED single-character frame: hierarchy solve (and motion sampling) as this workgroup's prologue, palette straight
+        // into `pal`; the solve's scratch and the pose's morph weights alias the wave scratch, which nothing uses yet.
+        __shared__ int fz_cnt[kBlock / 64];
+        unsigned char *fscr = reinterpret_cast<unsigned char *>(scratch_all);
+        float *lds_mw = reinterpret_cast<float *>(fscr + (((size_t)p.B * 56 + 15) & ~(size_t)15));
+        const bool sampled = p.fk.sample.frames != nullptr || p.fk.sample.frames_inline;
+        if (MODE != 0 && !sampled) {
+            for (int i = tid; i < p.M; i += kBlock) lds_mw[i] = p.morph_w[i];       // uploaded weights (pinned slot or device block)
+        }
+        fk_solve<true>(p.fk, 0, pal, fscr, lds_mw, blockIdx.x == 0);             // ends with a barrier: pal and lds_mw are complete
+        if (MODE == 1) fused_count = compact_active(lds_mw, p.M, p.Mpad, s_idx, s_w, fz_cnt);
+        if (MODE == 2)
+            for (int i = tid; i < p.M; i += kBlock) s_w[i] = lds_mw[i];
+        __syncthreads();
+    } else if (!FAST) {
         const float4 *gpal = p.palette + (size_t)inst * p.B * 3;
         for (int i = tid; i < p.B * 3; i += kBlock) pal[i] = gpal[i];
         if (MODE == 1) {
@@ -546,7 +586,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
 
     const int s = lane / QPW;                // morph slice of this lane
     const int qi = lane % QPW;
-    const int count = (MODE == 1) ? (FAST ? ml.count : p.act_count[inst]) : 0;
+    const int count = (MODE == 1) ? (FAST ? ml.count : (p.fk_on ? fused_count : p.act_count[inst])) : 0;
     const size_t Vp = p.Vp;
     const size_t plane4 = Vp / 4;            // float4 per plane
     float *scr = scratch_all + (size_t)wave * NPL * VW;
@@ -1222,7 +1262,9 @@ size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v)
     const size_t vw = 256 / v.S;   // vertices per wave per tile
     size_t scratch = (size_t)(kBlock / 64) * (v.geo ? 9 : 3) * vw * 4;
     const size_t list = (v.mode == 2 || (!v.fast && v.mode == 1)) ? (size_t)p.Mpad * 8 : 0;
-    return (size_t)p.B * 48 + list + scratch + (size_t)(kBlock / 64) * p.out_cap * 24;
+    size_t work = scratch + (size_t)(kBlock / 64) * p.out_cap * 24;
+    if (p.fk_on) work = std::max(work, (((size_t)p.B * 56 + 15) & ~(size_t)15) + (size_t)std::max(p.M, 1) * 4 + 16);   // the fused solve's scratch aliases it
+    return (size_t)p.B * 48 + list + work;
 }
 
 uint32_t rz_quads_per_tile(int S) { return (kBlock / 64) * (64 / S); }

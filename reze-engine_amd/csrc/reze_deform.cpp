@@ -240,7 +240,7 @@ struct rz_ctx {
     RzMorphList ml;
 
     // tuning (0 / -1 = automatic)
-    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1, t_instblock = 0, t_overlap = -1, t_zerocopy = -1;
+    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1, t_instblock = 0, t_overlap = -1, t_zerocopy = -1, t_fusefk = -1;
     int t_graph = 0;                    // "graph" tuning key: rz_deform_n replays captured hipGraphs of kGraphFrames frames
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_sig = 0;             // signature of everything the captured launches depend on
@@ -443,7 +443,7 @@ int auto_split(const rz_ctx *c)
     return S;
 }
 
-struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; int inst_block; };
+struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; int inst_block; bool fuse_fk; };
 
 // Where the kernels read the current pose from: the device pose block, or (zero-copy, not yet resident) the pinned slot.
 const float *src_world(const rz_ctx *c)
@@ -472,6 +472,8 @@ int make_resident(rz_ctx *c)
     return RZ_OK;
 }
 
+RzFkParams fk_params(const rz_ctx *c);
+
 RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
 {
     RzDeformParams p;
@@ -493,6 +495,7 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     p.dbg = c->t_dbg;
 #endif
     p.out_cap = pl.out_cap;
+    if (pl.fuse_fk) { p.fk = fk_params(c); p.fk_on = 1; }
     return p;
 }
 
@@ -516,7 +519,13 @@ Plan make_plan(const rz_ctx *c)
     v.nts = c->t_nts < 0 ? (v.mode == 1 && (uint64_t)c->V * c->I * 24 >= (16u << 20)) : c->t_nts != 0;
     v.geo = c->t_geo != 0;
     // one-launch frame: single instance, and (dense) the active list fits the kernel arguments
-    const bool can_fast = c->I == 1 && (v.mode != 1 || c->ml.count >= 0);
+    // Device-animated single character: the hierarchy solve (and the motion sampling) runs as the prologue of every
+    // workgroup of the deform kernel — one launch per frame, no rz_fk_kernel / rz_prep_kernel in front of it. Sampled
+    // poses by default (nothing of the pose has to be fetched: the frame number rides in the kernel arguments); local
+    // poses on request ("fuse_fk" = 1), since there every workgroup reads the rotations from the pose slot.
+    pl.fuse_fk = c->I == 1 && c->pose_local && c->has_topology && (c->t_fusefk == 1 || (c->t_fusefk < 0 && c->pose_sampled)) &&
+                 (size_t)c->B * 104 + 4096 <= 160 * 1024;
+    const bool can_fast = c->I == 1 && !pl.fuse_fk && (v.mode != 1 || c->ml.count >= 0);
     v.fast = can_fast && c->t_fast != 0;
     pl.dma = false;
     pl.inst_group = 0;
@@ -526,7 +535,7 @@ Plan make_plan(const rz_ctx *c)
     pl.n_quads = (c->V + 3) / 4;
     pl.quads_per_wave = 8;
     pl.grid_x = 1;
-    pl.prep = !v.fast;
+    pl.prep = !v.fast && !pl.fuse_fk;
     // persistent, balanced grid: `cap` workgroups in total, every wave owns an equal contiguous run of quads
     const uint32_t waves_per_wg = 4, qpw_step = 64 / (uint32_t)v.S;
     // measured (profiles/r1_*sweep*): 2 workgroups per CU for one big mesh, 8 per instance when instanced
@@ -658,6 +667,7 @@ int launch_prep(rz_ctx *c, hipStream_t st)
 // kernel. The FK kernel already writes the palette, so prep is only still needed for its morph compaction.
 int launch_front(rz_ctx *c, const Plan &pl, hipStream_t st)
 {
+    if (pl.fuse_fk) return RZ_OK;       // the deform kernel solves the hierarchy itself
     if (c->pose_local) {
         if (int r = launch_fk(c, st)) return r;
         if (pl.prep && c->morph_mode == 1)
@@ -1816,6 +1826,9 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
     } else if (!strcmp(key, "inst_loop")) {
         if (value < -1 || value == 1 || value > 16) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off), 2..8 / 10..16 (poses per workgroup, LDS form) or 9 (register form)");
         c->t_instloop = value;
+    } else if (!strcmp(key, "fuse_fk")) {
+        if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "fuse_fk must be -1 (auto: sampled single poses), 0 (always rz_fk_kernel) or 1 (local poses too)");
+        c->t_fusefk = value;
     } else if (!strcmp(key, "zero_copy")) {
         if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "zero_copy must be -1 (auto = on for one character), 0 (every pose is copied to the device) or 1");
         c->t_zerocopy = value;
@@ -1860,6 +1873,8 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "inst_block")) *value = c->t_instblock;
     else if (!strcmp(key, "overlap")) *value = c->t_overlap;
     else if (!strcmp(key, "zero_copy")) *value = c->t_zerocopy;
+    else if (!strcmp(key, "fuse_fk")) *value = c->t_fusefk;
+    else if (!strcmp(key, "effective_fuse_fk")) *value = make_plan(c).fuse_fk ? 1 : 0;
     else if (!strcmp(key, "pose_resident")) *value = (c->zc_cur < 0 || (c->world_resident && c->mw_resident && c->local_resident)) ? 1 : 0;
     else if (!strcmp(key, "effective_overlap")) *value = want_overlap(c, make_plan(c)) ? 1 : 0;
     else if (!strcmp(key, "effective_inst_block")) *value = make_plan(c).inst_block;

@@ -448,3 +448,87 @@ def test_wide_sample_of_the_real_model_against_reference_execution(rz, oracle, p
             pk, nk = c.read(instance=k)
             assert np.array_equal(pk, single[0]) and np.array_equal(nk, single[1]), "crowd instance %d (fast=%d) vs the pose alone" % (k, fast)
     c.close()
+
+
+@pytest.mark.parametrize("morphs", ["none", "dense", "sparse"])
+def test_fused_hierarchy_solve_is_the_same_frame(rz, oracle, morphs):
+    """One launch per device-animated frame: with a single character whose pose is sampled on the device (default), or given as
+    local rotations ("fuse_fk" = 1), every workgroup of the deform kernel solves the bone hierarchy itself (sampling, append
+    rotate / move, overrides, level loop, palette) and compacts the morph weights — no rz_fk_kernel, no rz_prep_kernel. The
+    frame must have the same bits as the three-kernel frame (fuse_fk = 0), the world matrices must match the float64
+    restatement, the mesh the oracle. 300 bones (more than one bone per thread), append bones, translations, overrides."""
+    V, B = 9000, 300
+    mesh = synth.make_mesh(V, B, seed=33)
+    rng = np.random.default_rng(34)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    M, deltas = 0, None
+    if morphs == "dense":
+        M = 150                                               # more than the 128 the kernel-argument list holds
+        deltas, _ = synth.make_morphs_dense(V, M, seed=35)
+        c.upload_morphs_dense(deltas)
+    elif morphs == "sparse":
+        M = 25
+        off, vi, d3, _ = synth.make_morphs_sparse(V, M, seed=35)
+        c.upload_morphs_sparse(off, vi, d3)
+        deltas = synth.sparse_to_dense(V, off, vi, d3)
+    ap = np.full(B, -1, dtype=np.int32)
+    ratio = np.ones(B, dtype=np.float32)
+    move = np.zeros(B, dtype=np.uint8)
+    for k, b in enumerate(rng.choice(B, size=20, replace=False)):
+        ap[b] = int(rng.integers(0, B)); ratio[b] = [0.5, -0.75, 1.5, -2.0, 1.0][k % 5]; move[b] = k % 2
+    c.upload_skeleton_topology(mesh["parents"], mesh["bind"], ap, ratio, move)
+    nk = 5
+    kq = rng.normal(size=(B, nk, 4)).astype(np.float32)
+    kq /= np.linalg.norm(kq, axis=2, keepdims=True)
+    anim = dict(track_bone=np.arange(B), key_off=np.arange(B + 1) * nk, key_frame=np.tile(np.arange(nk) * 8.0, B), key_rot=kq,
+                key_pos=(rng.random((B, nk, 3), dtype=np.float32) - 0.5) * 0.4, key_interp=rng.integers(0, 128, size=(B * nk, 16)).astype(np.uint8))
+    if M:
+        anim.update(mkey_off=np.arange(M + 1) * 2, mkey_frame=np.tile(np.array([0.0, 32.0], np.float32), M),
+                    mkey_weight=(rng.random(2 * M) * (rng.random(2 * M) < 0.8)).astype(np.float32), feed_off=np.arange(M + 1), feed_track=np.arange(M),
+                    feed_ratio=np.ones(M, np.float32))
+    c.upload_animation(anim["track_bone"], anim["key_off"], anim["key_frame"], anim["key_rot"], anim["key_pos"], anim["key_interp"],
+                       anim.get("mkey_off"), anim.get("mkey_frame"), anim.get("mkey_weight"), anim.get("feed_off"), anim.get("feed_track"), anim.get("feed_ratio"))
+    q = rng.normal(size=(B, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    t = (rng.random((B, 3), dtype=np.float32) - 0.5)
+    mw = (rng.random(M) * (rng.random(M) < 0.7)).astype(np.float32) if M else None
+    ovr_b = np.array([7, 123], dtype=np.uint32)
+    ovr_m = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=900 + k)[int(b)] for k, b in enumerate(ovr_b)])
+
+    def frame(kind, fuse, overrides):
+        c.set_tuning(fuse_fk=fuse)
+        c.override_world(ovr_b if overrides else [], ovr_m if overrides else None)
+        if kind == "sampled":
+            c.set_pose_sampled(np.array([13.37], np.float32))
+        else:
+            c.set_pose_local(q, mw, t)
+        want = 1 if (fuse == 1 or (fuse == -1 and kind == "sampled")) else 0
+        assert c.get_tuning("effective_fuse_fk") == want
+        c.deform()
+        if want:
+            assert c.time_frames(3)["prep_kernel_ms"] < 1e-4          # no front kernel at all
+        out = (c.read(), c.read_world(0), c.read_palette(0))
+        c.deform_n(3)                                                 # replays of the fused frame
+        again = c.read()
+        assert np.array_equal(out[0][0], again[0]) and np.array_equal(out[0][1], again[1])
+        return out
+    for kind in ("sampled", "local"):
+        for overrides in (False, True):
+            ref3 = frame(kind, 0, overrides)                          # rz_fk_kernel (+ rz_prep_kernel) + deform kernel
+            fused = frame(kind, 1 if kind == "local" else -1, overrides)
+            assert np.array_equal(ref3[1], fused[1]), "world matrices (%s, overrides=%s)" % (kind, overrides)
+            assert np.array_equal(ref3[2], fused[2]), "palette (%s, overrides=%s)" % (kind, overrides)
+            assert np.array_equal(ref3[0][0], fused[0][0]) and np.array_equal(ref3[0][1], fused[0][1]), "mesh (%s, overrides=%s)" % (kind, overrides)
+            if kind == "sampled":
+                qs, ts, ws = sample_reference(anim, 13.37, B, M)
+            else:
+                qs, ts, ws = q, t, (np.zeros(0) if mw is None else mw)
+            world = fk_reference(mesh["parents"], mesh["bind"], qs, ts, ap, ratio, move)
+            if overrides:
+                world[ovr_b] = ovr_m
+            assert np.abs(fused[1] - world).max() <= 1e-4 * max(1.0, np.abs(world).max())
+            pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], fused[1], mesh["inv_bind"], deltas, np.asarray(ws, np.float32) if M else None)
+            assert_parity(fused[0][0], fused[0][1], pr, nr, "fused frame (%s, %s, overrides=%s)" % (kind, morphs, overrides))
+    c.close()
