@@ -1713,7 +1713,7 @@ int rz_time_frames(rz_ctx *c, uint32_t frames, rz_timing *out)
     out->deform_kernel_ms = ms / frames;
     // the front kernels alone (only part of the frame when the plan is not the one-launch FAST form); everything has
     // drained at this point, so they may run on the context's stream whatever the protocol
-    if (pl.prep || c->pose_local) {
+    if ((pl.prep || c->pose_local) && !pl.fuse_fk) {
         HIP_TRY(hipStreamSynchronize(c->up_stream));
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
         for (uint32_t f = 0; f < frames; ++f)
@@ -1865,7 +1865,7 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "effective_nt")) *value = make_plan(c).v.nt && c->morph_mode == 1 ? 1 : 0;
     else if (!strcmp(key, "effective_nt_store")) *value = make_plan(c).v.nts ? 1 : 0;
     else if (!strcmp(key, "effective_geo")) *value = make_plan(c).v.geo ? 1 : 0;
-    else if (!strcmp(key, "effective_prep")) *value = (make_plan(c).prep || c->pose_local) ? 1 : 0;
+    else if (!strcmp(key, "effective_prep")) { const Plan pl = make_plan(c); *value = ((pl.prep || c->pose_local) && !pl.fuse_fk) ? 1 : 0; }
     else if (!strcmp(key, "effective_split")) *value = make_plan(c).v.S;
     else if (!strcmp(key, "effective_unroll")) *value = make_plan(c).v.U;
     else if (!strcmp(key, "effective_fast")) *value = make_plan(c).v.fast ? 1 : 0;
