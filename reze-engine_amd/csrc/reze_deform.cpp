@@ -520,11 +520,13 @@ Plan make_plan(const rz_ctx *c)
     v.geo = c->t_geo != 0;
     // one-launch frame: single instance, and (dense) the active list fits the kernel arguments
     // Device-animated single character: the hierarchy solve (and the motion sampling) runs as the prologue of every
-    // workgroup of the deform kernel — one launch per frame, no rz_fk_kernel / rz_prep_kernel in front of it. Sampled
-    // poses by default (nothing of the pose has to be fetched: the frame number rides in the kernel arguments); local
-    // poses on request ("fuse_fk" = 1), since there every workgroup reads the rotations from the pose slot.
-    pl.fuse_fk = c->I == 1 && c->pose_local && c->has_topology && (c->t_fusefk == 1 || (c->t_fusefk < 0 && c->pose_sampled)) &&
-                 (size_t)c->B * 104 + 4096 <= 160 * 1024;
+    // workgroup of the deform kernel — one launch per frame, no rz_fk_kernel / rz_prep_kernel in front of it. Measured
+    // (tools/fk_fuse_bench.py, 30 k vertices / 200 bones): sampled poses 11.5-17.3 -> 9.2-13.5 us per frame in every morph
+    // mode (and 27.7 -> 24.5 us on a 1/8 shard of C5); local poses 12.7-14.4 -> 9.8-12.8 us without dense morphs, no gain
+    // with them (there the three-kernel frame keeps its kernel-argument morph list and streams from its first instruction).
+    // Automatic mode follows that; "fuse_fk" = 0 / 1 forces it.
+    pl.fuse_fk = c->I == 1 && c->pose_local && c->has_topology && (size_t)c->B * 104 + 4096 <= 160 * 1024 &&
+                 (c->t_fusefk == 1 || (c->t_fusefk < 0 && (c->pose_sampled || c->morph_mode != 1)));
     const bool can_fast = c->I == 1 && !pl.fuse_fk && (v.mode != 1 || c->ml.count >= 0);
     v.fast = can_fast && c->t_fast != 0;
     pl.dma = false;
@@ -1827,7 +1829,7 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
         if (value < -1 || value == 1 || value > 16) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off), 2..8 / 10..16 (poses per workgroup, LDS form) or 9 (register form)");
         c->t_instloop = value;
     } else if (!strcmp(key, "fuse_fk")) {
-        if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "fuse_fk must be -1 (auto: sampled single poses), 0 (always rz_fk_kernel) or 1 (local poses too)");
+        if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "fuse_fk must be -1 (auto), 0 (always rz_fk_kernel in front) or 1 (every device-animated single character)");
         c->t_fusefk = value;
     } else if (!strcmp(key, "zero_copy")) {
         if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "zero_copy must be -1 (auto = on for one character), 0 (every pose is copied to the device) or 1");

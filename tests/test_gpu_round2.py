@@ -504,7 +504,7 @@ def test_fused_hierarchy_solve_is_the_same_frame(rz, oracle, morphs):
             c.set_pose_sampled(np.array([13.37], np.float32))
         else:
             c.set_pose_local(q, mw, t)
-        want = 1 if (fuse == 1 or (fuse == -1 and kind == "sampled")) else 0
+        want = 1 if (fuse == 1 or (fuse == -1 and (kind == "sampled" or morphs != "dense"))) else 0
         assert c.get_tuning("effective_fuse_fk") == want
         c.deform()
         if want:
@@ -514,6 +514,9 @@ def test_fused_hierarchy_solve_is_the_same_frame(rz, oracle, morphs):
         again = c.read()
         assert np.array_equal(out[0][0], again[0]) and np.array_equal(out[0][1], again[1])
         return out
+    c.set_tuning(fuse_fk=-1)                                           # automatic: sampled always, local unless dense morphs stream
+    c.set_pose_local(q, mw, t)
+    assert c.get_tuning("effective_fuse_fk") == (0 if morphs == "dense" else 1)
     for kind in ("sampled", "local"):
         for overrides in (False, True):
             ref3 = frame(kind, 0, overrides)                          # rz_fk_kernel (+ rz_prep_kernel) + deform kernel
