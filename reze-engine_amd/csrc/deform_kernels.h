@@ -24,17 +24,17 @@ struct RzPrepParams {
 // counterpart — its loader drops positions and interpolation bytes, engine/src/vmd-loader.ts:129-140).
 struct RzSampleParams {
     const float *frames;          // [I] fractional frame (30 fps) each instance is posed at; nullptr = no sampling
-    const int *bone_track;        // [B] track of each bone, -1 = the motion does not key it (identity / zero)
-    const uint32_t *key_off;      // [n_tracks + 1]
+    const uint2 *bone_range;      // [B] (first key, one past the last key) of the track that drives the bone; (0, 0) = the motion
+                                  //     does not key it (identity / zero). One load instead of bone -> track -> offsets.
     const float *key_frame;       // [K] ascending inside a track
     const float4 *key_rot;        // [K]
     const float *key_pos;         // [K][3]
     const uint4 *key_interp;      // [K] first 16 interpolation bytes of each key (nullptr = linear)
-    const uint32_t *mkey_off;     // [n_morph_tracks + 1]
+
     const float *mkey_frame;      // [Km]
     const float *mkey_weight;     // [Km]
     const uint32_t *feed_off;     // [M + 1] per vertex morph: the tracks that feed it ...
-    const int *feed_track;        //   ... own track first, then group-morph tracks in ascending group index
+    const uint2 *feed_range;      //   ... as (first key, one past the last key) into mkey_*: own track first, then group-morph tracks ascending
     const float *feed_ratio;
     float *morph_w;               // [I][M] out
     int M;

@@ -175,25 +175,36 @@ __device__ __forceinline__ float bezier_y(float x, float x1, float y1, float x2,
     return 3.0f * s * s * t * y1 + 3.0f * s * t * t * y2 + t * t * t;
 }
 
-// keys[lo] <= frame < keys[hi] (clamped to the ends); returns the linear parameter
+// keys[lo] <= frame < keys[hi] (clamped to the ends); returns the linear parameter. The span is the one a binary search for
+// the LAST key <= frame finds (host/vmd-sampler.js: span()); it is looked for with one interpolated probe first — keys of a
+// baked motion are evenly spaced, so the probe hits and the chain of dependent loads is 2 instead of 2 + log2(keys) — and
+// falls back to the bisection of what the probe left when it misses (uneven keys, duplicate frames).
 __device__ __forceinline__ float key_span(const float *kf, uint32_t b, uint32_t e, float frame, uint32_t &i0, uint32_t &i1)
 {
     uint32_t lo = b, hi = e - 1;
-    if (frame <= kf[lo]) { i0 = i1 = lo; return 0.0f; }
-    if (frame >= kf[hi]) { i0 = i1 = hi; return 0.0f; }
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (kf[mid] <= frame) lo = mid; else hi = mid; }
+    const float f_lo = kf[lo], f_hi = kf[hi];
+    if (frame <= f_lo) { i0 = i1 = lo; return 0.0f; }
+    if (frame >= f_hi) { i0 = i1 = hi; return 0.0f; }
+    if (hi - lo > 1) {
+        uint32_t g = lo + (uint32_t)((frame - f_lo) / (f_hi - f_lo) * (float)(hi - lo));
+        g = min(g, hi - 1);
+        const float f_g = kf[g], f_g1 = kf[g + 1];
+        if (f_g <= frame && frame < f_g1) { i0 = g; i1 = g + 1; return (frame - f_g) / (f_g1 - f_g); }
+        if (f_g <= frame) lo = g; else hi = g;            // the invariant kf[lo] <= frame < kf[hi] holds on either side
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (kf[mid] <= frame) lo = mid; else hi = mid; }
+    }
     i0 = lo; i1 = hi;
     return (frame - kf[lo]) / (kf[hi] - kf[lo]);
 }
 
 __device__ __forceinline__ void sample_bone(const RzSampleParams &p, float frame, int bone, float4 &q, float &tx, float &ty, float &tz)
 {
-    const int tr = p.bone_track[bone];
+    const uint2 kr = p.bone_range[bone];
     q = make_float4(0.f, 0.f, 0.f, 1.f);
     tx = ty = tz = 0.f;
-    if (tr < 0 || p.key_off[tr + 1] == p.key_off[tr]) return;
+    if (kr.y == kr.x) return;
     uint32_t i0, i1;
-    const float x = key_span(p.key_frame, p.key_off[tr], p.key_off[tr + 1], frame, i0, i1);
+    const float x = key_span(p.key_frame, kr.x, kr.y, frame, i0, i1);
     const float4 a = p.key_rot[i0];
     const float *pa = p.key_pos + (size_t)i0 * 3;
     if (i0 == i1) { q = a; tx = pa[0]; ty = pa[1]; tz = pa[2]; return; }
@@ -227,10 +238,10 @@ __device__ __forceinline__ float sample_morph(const RzSampleParams &p, float fra
 {
     float w = 0.0f;
     for (uint32_t f = p.feed_off[m]; f < p.feed_off[m + 1]; ++f) {
-        const int tr = p.feed_track[f];
-        if (p.mkey_off[tr + 1] == p.mkey_off[tr]) continue;
+        const uint2 kr = p.feed_range[f];
+        if (kr.y == kr.x) continue;
         uint32_t i0, i1;
-        const float x = key_span(p.mkey_frame, p.mkey_off[tr], p.mkey_off[tr + 1], frame, i0, i1);
+        const float x = key_span(p.mkey_frame, kr.x, kr.y, frame, i0, i1);
         const float wk = p.mkey_weight[i0] + (p.mkey_weight[i1] - p.mkey_weight[i0]) * x;
         w += wk * p.feed_ratio[f];
     }

@@ -127,8 +127,8 @@ struct rz_ctx {
     bool pose_local_t = false;
     // device-side motion sampling (rz_upload_animation / rz_set_pose_sampled)
     bool has_animation = false, pose_sampled = false;
-    int *an_bone_track = nullptr, *an_feed_track = nullptr;
-    uint32_t *an_key_off = nullptr, *an_mkey_off = nullptr, *an_feed_off = nullptr;
+    uint2 *an_bone_range = nullptr, *an_feed_range = nullptr;     // (first key, end) per bone / per morph feed
+    uint32_t *an_feed_off = nullptr;
     float *an_key_frame = nullptr, *an_key_pos = nullptr, *an_mkey_frame = nullptr, *an_mkey_weight = nullptr, *an_feed_ratio = nullptr;
     float4 *an_key_rot = nullptr;
     uint4 *an_key_interp = nullptr;
@@ -398,7 +398,7 @@ int ensure_pose_buffers(rz_ctx *c)
 void free_animation(rz_ctx *c)
 {
     drop_graph(c);
-    dfree(c->an_bone_track); dfree(c->an_feed_track); dfree(c->an_key_off); dfree(c->an_mkey_off); dfree(c->an_feed_off);
+    dfree(c->an_bone_range); dfree(c->an_feed_range); dfree(c->an_feed_off);
     dfree(c->an_key_frame); dfree(c->an_key_pos); dfree(c->an_mkey_frame); dfree(c->an_mkey_weight); dfree(c->an_feed_ratio);
     dfree(c->an_key_rot); dfree(c->an_key_interp);
     c->has_animation = false;
@@ -644,10 +644,10 @@ RzFkParams fk_params(const rz_ctx *c)
     if (c->pose_sampled) {
         RzSampleParams &q = p.sample;
         q.frames = c->frames_inline ? nullptr : c->an_frames; q.frames_inline = c->frames_inline ? 1 : 0; q.frame0 = c->frame0;
-        q.bone_track = c->an_bone_track; q.key_off = c->an_key_off; q.key_frame = c->an_key_frame;
+        q.bone_range = c->an_bone_range; q.key_frame = c->an_key_frame;
         q.key_rot = c->an_key_rot; q.key_pos = c->an_key_pos; q.key_interp = c->an_key_interp;
-        q.mkey_off = c->an_mkey_off; q.mkey_frame = c->an_mkey_frame; q.mkey_weight = c->an_mkey_weight;
-        q.feed_off = c->an_feed_off; q.feed_track = c->an_feed_track; q.feed_ratio = c->an_feed_ratio;
+        q.mkey_frame = c->an_mkey_frame; q.mkey_weight = c->an_mkey_weight;
+        q.feed_off = c->an_feed_off; q.feed_range = c->an_feed_range; q.feed_ratio = c->an_feed_ratio;
         q.morph_w = c->morph_w; q.M = (int)c->M;
     }
     return p;
@@ -1387,19 +1387,24 @@ int rz_upload_animation(rz_ctx *c, const rz_animation *a)
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_animation(c);
-    const uint32_t zero_off[2] = {0, 0};
-    if (int r = to_device(&c->an_bone_track, bone_track.data(), c->B)) return r;
-    if (int r = to_device(&c->an_key_off, n ? a->key_off : zero_off, (size_t)n + 1)) return r;
+    // per bone / per morph feed: the key range itself, so the sampler's chain of dependent loads starts one level lower
+    std::vector<uint2> bone_range(c->B), feed_range(F);
+    for (uint32_t b = 0; b < c->B; ++b) {
+        const int t = bone_track[b];
+        bone_range[b].x = t < 0 ? 0u : a->key_off[t];
+        bone_range[b].y = t < 0 ? 0u : a->key_off[t + 1];
+    }
+    for (uint32_t f = 0; f < F; ++f) { feed_range[f].x = a->mkey_off[a->feed_track[f]]; feed_range[f].y = a->mkey_off[a->feed_track[f] + 1]; }
+    if (int r = to_device(&c->an_bone_range, bone_range.data(), c->B)) return r;
     if (int r = to_device(&c->an_key_frame, a->key_frame, K)) return r;
     if (int r = to_device(&c->an_key_rot, a->key_rot4, K)) return r;
     if (int r = to_device(&c->an_key_pos, a->key_pos3, (size_t)K * 3)) return r;
     if (a->key_interp16 && K)
         if (int r = to_device(&c->an_key_interp, a->key_interp16, K)) return r;
-    if (int r = to_device(&c->an_mkey_off, mt ? a->mkey_off : zero_off, (size_t)mt + 1)) return r;
     if (int r = to_device(&c->an_mkey_frame, a->mkey_frame, Km)) return r;
     if (int r = to_device(&c->an_mkey_weight, a->mkey_weight, Km)) return r;
     if (int r = to_device(&c->an_feed_off, feed_off.data(), (size_t)c->M + 1)) return r;
-    if (int r = to_device(&c->an_feed_track, a->feed_track, F)) return r;
+    if (int r = to_device(&c->an_feed_range, feed_range.data(), F)) return r;
     if (int r = to_device(&c->an_feed_ratio, a->feed_ratio, F)) return r;
     c->an_M = c->M;
     c->has_animation = true;
