@@ -24,8 +24,9 @@ struct RzPrepParams {
 // counterpart — its loader drops positions and interpolation bytes, engine/src/vmd-loader.ts:129-140).
 struct RzSampleParams {
     const float *frames;          // [I] fractional frame (30 fps) each instance is posed at; nullptr = no sampling
-    const uint2 *bone_range;      // [B] (first key, one past the last key) of the track that drives the bone; (0, 0) = the motion
-                                  //     does not key it (identity / zero). One load instead of bone -> track -> offsets.
+    const uint4 *bone_range;      // [B] (first key, one past the last key, bits(frame of the first key), bits(frame of the last key)) of
+                                  //     the track that drives the bone; first == end = the motion does not key it (identity / zero).
+                                  //     One load gives the sampler everything it needs to guess the key span.
     const float *key_frame;       // [K] ascending inside a track
     const float4 *key_rot;        // [K]
     const float *key_pos;         // [K][3]
@@ -34,7 +35,7 @@ struct RzSampleParams {
     const float *mkey_frame;      // [Km]
     const float *mkey_weight;     // [Km]
     const uint32_t *feed_off;     // [M + 1] per vertex morph: the tracks that feed it ...
-    const uint2 *feed_range;      //   ... as (first key, one past the last key) into mkey_*: own track first, then group-morph tracks ascending
+    const uint4 *feed_range;      //   ... as (first key, end, bits(first frame), bits(last frame)) into mkey_*: own track first, then group-morph tracks ascending
     const float *feed_ratio;
     float *morph_w;               // [I][M] out
     int M;

@@ -175,50 +175,70 @@ __device__ __forceinline__ float bezier_y(float x, float x1, float y1, float x2,
     return 3.0f * s * s * t * y1 + 3.0f * s * t * t * y2 + t * t * t;
 }
 
-// keys[lo] <= frame < keys[hi] (clamped to the ends); returns the linear parameter. The span is the one a binary search for
-// the LAST key <= frame finds (host/vmd-sampler.js: span()); it is looked for with one interpolated probe first — keys of a
-// baked motion are evenly spaced, so the probe hits and the chain of dependent loads is 2 instead of 2 + log2(keys) — and
-// falls back to the bisection of what the probe left when it misses (uneven keys, duplicate frames).
-__device__ __forceinline__ float key_span(const float *kf, uint32_t b, uint32_t e, float frame, uint32_t &i0, uint32_t &i1)
+// Key spans. A track's keys are sorted by frame (duplicates allowed); the span of `frame` is (i0, i1 = i0 + 1) with i0 the
+// LAST key whose frame is <= `frame` — what host/vmd-sampler.js: span() bisects for — clamped to the first / last key.
+// The sampler does not bisect first: the track record carries the first and last key's frames, so the span is GUESSED by
+// linear interpolation (baked motions have evenly spaced keys: the guess is right) and the keys of the guessed span are
+// loaded speculatively together with their frames; only a wrong guess (uneven keys, duplicates) pays for a bisection of
+// what the guess left. Chain of dependent loads per bone: record -> keys, instead of bone -> track -> offsets -> ends ->
+// log2(n) probes -> keys.
+struct KeyRange { uint32_t b, e; float f0, f1; };
+__device__ __forceinline__ KeyRange key_range(const uint4 r) { return KeyRange{r.x, r.y, __uint_as_float(r.z), __uint_as_float(r.w)}; }
+
+// 0 = clamped to key `i0` (before the first / after the last / single key); 1 = interior: g is the guessed first key of the span
+__device__ __forceinline__ int span_guess(const KeyRange &k, float frame, uint32_t &g)
 {
-    uint32_t lo = b, hi = e - 1;
-    const float f_lo = kf[lo], f_hi = kf[hi];
-    if (frame <= f_lo) { i0 = i1 = lo; return 0.0f; }
-    if (frame >= f_hi) { i0 = i1 = hi; return 0.0f; }
-    if (hi - lo > 1) {
-        uint32_t g = lo + (uint32_t)((frame - f_lo) / (f_hi - f_lo) * (float)(hi - lo));
-        g = min(g, hi - 1);
-        const float f_g = kf[g], f_g1 = kf[g + 1];
-        if (f_g <= frame && frame < f_g1) { i0 = g; i1 = g + 1; return (frame - f_g) / (f_g1 - f_g); }
-        if (f_g <= frame) lo = g; else hi = g;            // the invariant kf[lo] <= frame < kf[hi] holds on either side
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (kf[mid] <= frame) lo = mid; else hi = mid; }
-    }
-    i0 = lo; i1 = hi;
-    return (frame - kf[lo]) / (kf[hi] - kf[lo]);
+    const uint32_t n = k.e - k.b;
+    if (n == 1 || frame <= k.f0) { g = k.b; return 0; }
+    if (frame >= k.f1) { g = k.e - 1; return 0; }
+    g = k.b + min((uint32_t)((frame - k.f0) / (k.f1 - k.f0) * (float)(n - 1)), n - 2);
+    return 1;
+}
+
+// the guess missed: bisect [b, e) around it for the last key <= frame (kf[g] has been loaded as f_g)
+__device__ __forceinline__ uint32_t span_bisect(const float *kf, const KeyRange &k, float frame, uint32_t g, float f_g)
+{
+    uint32_t lo = k.b, hi = k.e - 1;
+    if (f_g <= frame) lo = g; else hi = g;                 // kf[lo] <= frame < kf[hi] holds on either side
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (kf[mid] <= frame) lo = mid; else hi = mid; }
+    return lo;
 }
 
 __device__ __forceinline__ void sample_bone(const RzSampleParams &p, float frame, int bone, float4 &q, float &tx, float &ty, float &tz)
 {
-    const uint2 kr = p.bone_range[bone];
+    const KeyRange kr = key_range(p.bone_range[bone]);
     q = make_float4(0.f, 0.f, 0.f, 1.f);
     tx = ty = tz = 0.f;
-    if (kr.y == kr.x) return;
-    uint32_t i0, i1;
-    const float x = key_span(p.key_frame, kr.x, kr.y, frame, i0, i1);
-    const float4 a = p.key_rot[i0];
+    if (kr.e == kr.b) return;
+    uint32_t i0;
+    if (!span_guess(kr, frame, i0)) {                       // clamped: the key itself
+        const float *pa = p.key_pos + (size_t)i0 * 3;
+        q = p.key_rot[i0]; tx = pa[0]; ty = pa[1]; tz = pa[2];
+        return;
+    }
+    // speculative: everything the guessed span needs, requested together
+    float f_a = p.key_frame[i0], f_b = p.key_frame[i0 + 1];
+    float4 a = p.key_rot[i0], b = p.key_rot[i0 + 1];
     const float *pa = p.key_pos + (size_t)i0 * 3;
-    if (i0 == i1) { q = a; tx = pa[0]; ty = pa[1]; tz = pa[2]; return; }
+    float pa0 = pa[0], pa1 = pa[1], pa2 = pa[2], pb0 = pa[3], pb1 = pa[4], pb2 = pa[5];
+    uint4 ip = p.key_interp ? p.key_interp[i0 + 1] : make_uint4(0, 0, 0, 0);
+    if (!(f_a <= frame && frame < f_b)) {
+        i0 = span_bisect(p.key_frame, kr, frame, i0, f_a);
+        f_a = p.key_frame[i0]; f_b = p.key_frame[i0 + 1];
+        a = p.key_rot[i0]; b = p.key_rot[i0 + 1];
+        pa = p.key_pos + (size_t)i0 * 3;
+        pa0 = pa[0]; pa1 = pa[1]; pa2 = pa[2]; pb0 = pa[3]; pb1 = pa[4]; pb2 = pa[5];
+        if (p.key_interp) ip = p.key_interp[i0 + 1];
+    }
+    const float x = (frame - f_a) / (f_b - f_a);
     float cx = x, cy = x, cz = x, cr = x;
-    if (p.key_interp) {
-        const uint4 ip = p.key_interp[i1];          // bytes [X_x1 Y_x1 Z_x1 R_x1 | X_y1 .. | X_x2 .. | X_y2 ..]
+    if (p.key_interp) {                                     // bytes [X_x1 Y_x1 Z_x1 R_x1 | X_y1 .. | X_x2 .. | X_y2 ..] of the LATER key
         auto byte = [](uint32_t w, int k) { return (float)((w >> (8 * k)) & 255u) * (1.0f / 127.0f); };
         cx = bezier_y(x, byte(ip.x, 0), byte(ip.y, 0), byte(ip.z, 0), byte(ip.w, 0));
         cy = bezier_y(x, byte(ip.x, 1), byte(ip.y, 1), byte(ip.z, 1), byte(ip.w, 1));
         cz = bezier_y(x, byte(ip.x, 2), byte(ip.y, 2), byte(ip.z, 2), byte(ip.w, 2));
         cr = bezier_y(x, byte(ip.x, 3), byte(ip.y, 3), byte(ip.z, 3), byte(ip.w, 3));
     }
-    float4 b = p.key_rot[i1];
-    const float *pb = p.key_pos + (size_t)i1 * 3;
     // Quat.slerp (math.ts:156-189)
     float c = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
     if (c < 0.0f) { c = -c; b.x = -b.x; b.y = -b.y; b.z = -b.z; b.w = -b.w; }
@@ -231,18 +251,27 @@ __device__ __forceinline__ void sample_bone(const RzSampleParams &p, float frame
         const float ka = sinf(th0 - th) / sn, kb = sinf(th) / sn;
         q = make_float4(ka * a.x + kb * b.x, ka * a.y + kb * b.y, ka * a.z + kb * b.z, ka * a.w + kb * b.w);
     }
-    tx = pa[0] + (pb[0] - pa[0]) * cx; ty = pa[1] + (pb[1] - pa[1]) * cy; tz = pa[2] + (pb[2] - pa[2]) * cz;
+    tx = pa0 + (pb0 - pa0) * cx; ty = pa1 + (pb1 - pa1) * cy; tz = pa2 + (pb2 - pa2) * cz;
 }
 
 __device__ __forceinline__ float sample_morph(const RzSampleParams &p, float frame, int m)
 {
     float w = 0.0f;
     for (uint32_t f = p.feed_off[m]; f < p.feed_off[m + 1]; ++f) {
-        const uint2 kr = p.feed_range[f];
-        if (kr.y == kr.x) continue;
-        uint32_t i0, i1;
-        const float x = key_span(p.mkey_frame, kr.x, kr.y, frame, i0, i1);
-        const float wk = p.mkey_weight[i0] + (p.mkey_weight[i1] - p.mkey_weight[i0]) * x;
+        const KeyRange kr = key_range(p.feed_range[f]);
+        if (kr.e == kr.b) continue;
+        uint32_t i0;
+        float wk;
+        if (!span_guess(kr, frame, i0)) {
+            wk = p.mkey_weight[i0];
+        } else {
+            float f_a = p.mkey_frame[i0], f_b = p.mkey_frame[i0 + 1], w_a = p.mkey_weight[i0], w_b = p.mkey_weight[i0 + 1];
+            if (!(f_a <= frame && frame < f_b)) {
+                i0 = span_bisect(p.mkey_frame, kr, frame, i0, f_a);
+                f_a = p.mkey_frame[i0]; f_b = p.mkey_frame[i0 + 1]; w_a = p.mkey_weight[i0]; w_b = p.mkey_weight[i0 + 1];
+            }
+            wk = w_a + (w_b - w_a) * ((frame - f_a) / (f_b - f_a));
+        }
         w += wk * p.feed_ratio[f];
     }
     return w;

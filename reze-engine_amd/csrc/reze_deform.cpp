@@ -127,7 +127,7 @@ struct rz_ctx {
     bool pose_local_t = false;
     // device-side motion sampling (rz_upload_animation / rz_set_pose_sampled)
     bool has_animation = false, pose_sampled = false;
-    uint2 *an_bone_range = nullptr, *an_feed_range = nullptr;     // (first key, end) per bone / per morph feed
+    uint4 *an_bone_range = nullptr, *an_feed_range = nullptr;     // (first key, end, first frame, last frame) per bone / per morph feed
     uint32_t *an_feed_off = nullptr;
     float *an_key_frame = nullptr, *an_key_pos = nullptr, *an_mkey_frame = nullptr, *an_mkey_weight = nullptr, *an_feed_ratio = nullptr;
     float4 *an_key_rot = nullptr;
@@ -1388,13 +1388,17 @@ int rz_upload_animation(rz_ctx *c, const rz_animation *a)
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_animation(c);
     // per bone / per morph feed: the key range itself, so the sampler's chain of dependent loads starts one level lower
-    std::vector<uint2> bone_range(c->B), feed_range(F);
-    for (uint32_t b = 0; b < c->B; ++b) {
-        const int t = bone_track[b];
-        bone_range[b].x = t < 0 ? 0u : a->key_off[t];
-        bone_range[b].y = t < 0 ? 0u : a->key_off[t + 1];
-    }
-    for (uint32_t f = 0; f < F; ++f) { feed_range[f].x = a->mkey_off[a->feed_track[f]]; feed_range[f].y = a->mkey_off[a->feed_track[f] + 1]; }
+    std::vector<uint4> bone_range(c->B), feed_range(F);
+    auto record = [](const uint32_t *off, const float *kf, int t) {
+        uint4 r; r.x = r.y = r.z = r.w = 0;
+        if (t < 0 || off[t + 1] == off[t]) return r;
+        r.x = off[t]; r.y = off[t + 1];
+        memcpy(&r.z, &kf[off[t]], 4);
+        memcpy(&r.w, &kf[off[t + 1] - 1], 4);
+        return r;
+    };
+    for (uint32_t b = 0; b < c->B; ++b) bone_range[b] = record(a->key_off, a->key_frame, bone_track[b]);
+    for (uint32_t f = 0; f < F; ++f) feed_range[f] = record(a->mkey_off, a->mkey_frame, a->feed_track[f]);
     if (int r = to_device(&c->an_bone_range, bone_range.data(), c->B)) return r;
     if (int r = to_device(&c->an_key_frame, a->key_frame, K)) return r;
     if (int r = to_device(&c->an_key_rot, a->key_rot4, K)) return r;
