@@ -943,33 +943,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
 
-// Prefetch of the NEXT vertex's attributes, hidden from the compiler's wait-count bookkeeping. vmcnt retires loads and stores in
-// order, and the prefetch is issued BEFORE the current vertex's 2 x G output stores: consuming it only needs "at most 2 x G
-// operations still outstanding". The compiler cannot know G, so for ordinary loads it emits s_waitcnt vmcnt(0) at the top of
-// every vertex step — each wave then drains ALL of its stores before it may decode the next vertex, sixteen 768-byte stores at
-// a time — which held the C4 kernel at 5.3 TB/s no matter how large the crowd. Loads issued from inline asm are invisible to
-// that pass; pf_wait<N> is the wait that belongs to them and ties the nine registers to itself.
-__device__ __forceinline__ void pf_load(uint32_t &dst, const void *ptr)
-{
-    asm volatile("global_load_dword %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void pf_wait(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, uint32_t &e, uint32_t &f, uint32_t &g, uint32_t &h, uint32_t &i)
-{
-    asm volatile("s_waitcnt vmcnt(%9)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i) : "n"(N) : "memory");
-}
-// `younger` = VMEM operations issued after the prefetch that are certain to be in the queue (0 .. 32, even)
-__device__ __forceinline__ void pf_wait_n(int younger, uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, uint32_t &e, uint32_t &f, uint32_t &g, uint32_t &h, uint32_t &i)
-{
-    switch (younger >> 1) {
-#define RZ_PF_CASE(K) case K: pf_wait<2 * K>(a, b, c, d, e, f, g, h, i); break;
-        RZ_PF_CASE(1) RZ_PF_CASE(2) RZ_PF_CASE(3) RZ_PF_CASE(4) RZ_PF_CASE(5) RZ_PF_CASE(6) RZ_PF_CASE(7) RZ_PF_CASE(8)
-        RZ_PF_CASE(9) RZ_PF_CASE(10) RZ_PF_CASE(11) RZ_PF_CASE(12) RZ_PF_CASE(13) RZ_PF_CASE(14) RZ_PF_CASE(15) RZ_PF_CASE(16)
-#undef RZ_PF_CASE
-        default: pf_wait<0>(a, b, c, d, e, f, g, h, i); break;
-    }
-}
-
 // BLOCK threads per workgroup (256: two workgroups per CU; 512 / 1024: one, with 8 / 16 waves sharing one staged palette
 // group — half / a quarter of the palette traffic per CU). NB = how many influences the pose loop gathers: the host picks
 // nothing here, every wave decides per vertex step from a ballot over its lanes' weights (wave-uniform, so no divergence):
@@ -1084,11 +1057,12 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
     }
     for (uint32_t vb = v_begin; vb < v_end; vb += BLOCK, v += BLOCK) {   // workgroup-uniform trip count (the ballots below need whole waves)
         const uint32_t vn = v + BLOCK;
-        uint32_t pf[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // x y z nx ny nz (bits) j01 j23 wq of the next vertex
+        float xn = 0, yn = 0, zn = 0, nxn = 0, nyn = 0, nzn = 0;
+        uint32_t j01n = 0, j23n = 0, wqn = 0;
         if (vn < v_end) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) pf_load(pf[k], p.geom + (size_t)k * Vp + vn);
-            pf_load(pf[6], p.joints01 + vn); pf_load(pf[7], p.joints23 + vn); pf_load(pf[8], p.weights + vn);
+            xn = p.geom[0 * Vp + vn]; yn = p.geom[1 * Vp + vn]; zn = p.geom[2 * Vp + vn];
+            nxn = p.geom[3 * Vp + vn]; nyn = p.geom[4 * Vp + vn]; nzn = p.geom[5 * Vp + vn];
+            j01n = p.joints01[vn]; j23n = p.joints23[vn]; wqn = p.weights[vn];
         }
         const bool live = v < v_end;
         // decode once per vertex (engine.ts:255-258)
@@ -1116,9 +1090,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
                     st3<NTS>(dp, x, y, z); st3<NTS>(dn, nx, ny, nz);
                     dp += Vp * 3; dn += Vp * 3;
                 }
-            pf_wait_n(0, pf[0], pf[1], pf[2], pf[3], pf[4], pf[5], pf[6], pf[7], pf[8]);
-            x = __uint_as_float(pf[0]); y = __uint_as_float(pf[1]); z = __uint_as_float(pf[2]);
-            nx = __uint_as_float(pf[3]); ny = __uint_as_float(pf[4]); nz = __uint_as_float(pf[5]); j01 = pf[6]; j23 = pf[7]; wq = pf[8];
+            x = xn; y = yn; z = zn; nx = nxn; ny = nyn; nz = nzn; j01 = j01n; j23 = j23n; wq = wqn;
             continue;
         }
 #endif
@@ -1166,16 +1138,11 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         };
         const bool any34 = __ballot((wq >> 16) != 0u) != 0ull;
         const bool any2 = __ballot(((wq >> 8) & 255u) != 0u) != 0ull;
-        const bool any_live = __ballot(live) != 0ull;
-        if (!any_live) {}                                   // a wave past the end of the run (last step only)
+        if (__ballot(live) == 0ull) {}                     // a wave past the end of the run (last step only)
         else if (any34) pose_loop(std::integral_constant<int, 4>{});
         else if (any2) pose_loop(std::integral_constant<int, 2>{});
         else pose_loop(std::integral_constant<int, 1>{});
-        // the pose loop has issued exactly two stores per pose behind the prefetch (none when the wave had nothing to do, or
-        // in the tools-only build's store-less ablation): that many operations may stay in flight
-        pf_wait_n((any_live && RZ_DBG(p) == 0) ? 2 * ng : 0, pf[0], pf[1], pf[2], pf[3], pf[4], pf[5], pf[6], pf[7], pf[8]);
-        x = __uint_as_float(pf[0]); y = __uint_as_float(pf[1]); z = __uint_as_float(pf[2]);
-        nx = __uint_as_float(pf[3]); ny = __uint_as_float(pf[4]); nz = __uint_as_float(pf[5]); j01 = pf[6]; j23 = pf[7]; wq = pf[8];
+        x = xn; y = yn; z = zn; nx = nxn; ny = nyn; nz = nzn; j01 = j01n; j23 = j23n; wq = wqn;
     }
 }
 
