@@ -20,21 +20,26 @@
  *
  * PARITY STATUS. The reference has no tests and no golden vectors for this path, its skinning is
  * WGSL inside a vertex shader (engine.ts:245-276) whose outputs are never written to a buffer, and
- * the image has no WebGPU / WGSL executor and no tsc. Therefore:
- *   - rzo_palette (row a6): PINNED TO REFERENCE EXECUTION. engine.ts:926-928 is the column-major product
+ * the image has no WebGPU / WGSL executor and no tsc. What the oracle is held to instead:
+ *   - THE REFERENCE'S OWN SHADER TEXT, INTERPRETED. tools/wgsl_eval.py parses the bodies of `@vertex fn vs`
+ *     (engine.ts:245-276) and of the skin-matrix compute shader's `fn main` (:919-928) out of the reference checkout and
+ *     evaluates them statement by statement (binary32 per operation; matrix products summed column by column, left to
+ *     right — the association WGSL leaves to the implementation, fixed below as this oracle's canonical one). On the
+ *     reference's 349-bone model under three reference-produced poses, rzo_palette and rzo_skin agree with that
+ *     interpretation BIT FOR BIT: every palette element, the 256-vertex slices and every 7th vertex of the model
+ *     (4 121 vertices, 234 bones, all three influence types) — tests/test_oracle.py, tests/golden/ref_wgsl.npz,
+ *     tools/ref_wgsl_run.py. The formula is therefore the shader's text, not this file's re-typing of it. (Still not a
+ *     GPU executing the shader: a real driver may contract to FMA or reassociate; that is what the 1e-4 tolerance is for.)
+ *   - rzo_palette (row a6) ALSO pinned to reference EXECUTION: engine.ts:926-928 is the column-major product
  *     world * inverseBind, which the reference's own Mat4.multiply (math.ts:303-320) computes; tools/ref_erased_run.py
- *     runs that method on the real 349-bone model for two poses and tests/test_oracle.py holds this file to the stored
- *     result within the rounding the two evaluations can differ by (doubles + one f32 store there, four f32 roundings
- *     here): |diff| <= 2^-22 * SUM_k |a_k * b_k| per element.
- *   - rzo_skin (rows a1-a3): the WGSL of vs() itself cannot be executed here (no WebGPU / naga / tint), so the shader
- *     stays UNPINNED BY SHADER EXECUTION; what IS pinned: the same fixture run evaluates vs()'s formula
- *     (engine.ts:255-272) on 256 real vertices with the reference's Mat4 / Vec3 primitives (every M_i * vec4 is a
- *     Mat4.multiply; for the 173 BDEF1 vertices of the slice the position is Mat4.multiply alone), and this file agrees
- *     with it to 2e-7 relative (bar in the test: 1e-6); the same on every 7th vertex of the model (4 121 vertices, 234
- *     bones, three poses): 3.2e-7. On top of that: analytic known-answer tests (identity pose =>
- *     rest mesh, single-bone rigid motion about a pivot, hand-computed 2-bone blend, zero-weight and zero-normal
- *     branches) and bit-exact three-way agreement between this file, the NumPy twin (oracle/rz_oracle_np.py) and the
- *     JS Math.fround twin (oracle/js/skin_f32.js).
+ *     runs that method on the same model and poses: |diff| <= 2^-22 * SUM_k |a_k * b_k| per element (doubles + one f32
+ *     store there, four f32 roundings here).
+ *   - rzo_skin (rows a1-a3) ALSO checked against vs()'s formula evaluated in the reference run with math.ts' Mat4 / Vec3
+ *     primitives in doubles (every M_i * vec4 is a Mat4.multiply; for BDEF1 vertices the position is Mat4.multiply alone):
+ *     2e-7 relative on the slices, 3.2e-7 on the wide sample (bar in the tests: 1e-6). On top of that: analytic
+ *     known-answer tests (identity pose => rest mesh, single-bone rigid motion about a pivot, hand-computed 2-bone blend,
+ *     zero-weight and zero-normal branches) and bit-exact three-way agreement between this file, the NumPy twin
+ *     (oracle/rz_oracle_np.py) and the JS Math.fround twin (oracle/js/skin_f32.js).
  *   - the inputs they consume (world matrices, inverse bind, joints, weights: rows a9-a12) ARE pinned
  *     to the reference's own code: tools/ref_erased_run.py runs math.ts/model.ts/pmx-loader.ts/
  *     vmd-loader.ts with their TypeScript types erased on the reference's assets and stores numeric

@@ -429,6 +429,11 @@ def test_wide_sample_of_the_real_model_against_reference_execution(rz, oracle, p
     c.deform()
     pg, ng = c.read()
     assert_parity(pg, ng, ref[:, :3], ref[:, 3:], "wide real sample vs REFERENCE EXECUTION (%s)" % pose)
+    # ... and with the reference's own vs() / skin-matrix shader TEXT, interpreted (tests/golden/ref_wgsl.npz, tools/ref_wgsl_run.py)
+    wg = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_wgsl.npz"))
+    assert_parity(pg, ng, wg["wide_" + pose][:, :3], wg["wide_" + pose][:, 3:], "wide real sample vs the reference's WGSL text (%s)" % pose)
+    ref_pal = np.transpose(wg["palette_" + pose].reshape(-1, 4, 4), (0, 2, 1))[:, :3, :].reshape(-1, 12)
+    assert (np.abs(c.read_palette() - ref_pal) <= 1e-5 * np.maximum(1.0, np.abs(ref_pal).max(axis=1, keepdims=True))).all()
     pr, nr = oracle.deform(pos, nrm, g["wide_joints"], g["wide_weights"], g["world_" + pose], g["inv_bind"])
     assert_parity(pg, ng, pr, nr, "wide real sample vs oracle (%s)" % pose)
     # the same vertices sorted by influence count (real models cluster them by mesh part), as a crowd of 5 poses

@@ -217,3 +217,74 @@ def test_skin_pinned_on_a_wide_sample_of_the_real_model(oracle, pose):
     # the numpy twin lands on the same bits as the C oracle here too
     p2, n2 = oracle.np_twin.skin(np.ascontiguousarray(v[:, 0:3]), np.ascontiguousarray(v[:, 3:6]), g["wide_joints"], g["wide_weights"], S)
     assert np.array_equal(p, p2) and np.array_equal(n, n2)
+
+
+# ---- the reference's own WGSL TEXT, interpreted (tests/golden/ref_wgsl.npz, written by tools/ref_wgsl_run.py) ----
+def _wgsl():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_wgsl.npz"))
+
+
+@pytest.mark.parametrize("pose", ["pose0", "tween150", "tween500"])
+def test_oracle_is_bit_identical_to_the_reference_shader_text_interpreted(oracle, pose):
+    """tools/wgsl_eval.py parses the bodies of the reference's `@vertex fn vs` (engine.ts:245-276) and of its skin-matrix
+    compute shader (:919-928) out of the reference checkout and evaluates them statement by statement (binary32 per
+    operation, matrix products summed column by column left to right). The formula is the shader's text, not a
+    re-typing of it. On the reference's 349-bone model under three reference-produced poses — palette, the 256-vertex
+    slices and every 7th vertex (4 121) — the C oracle, its NumPy twin and that interpretation agree BIT FOR BIT."""
+    g, w = _golden(), _wgsl()
+    S = oracle.palette(g["world_" + pose], g["inv_bind"])
+    assert np.array_equal(S.reshape(-1, 16), w["palette_" + pose])
+    for tag in ("slice", "wide"):
+        v = g[tag + "_vertices"]
+        pos, nrm = np.ascontiguousarray(v[:, 0:3]), np.ascontiguousarray(v[:, 3:6])
+        p, n = oracle.skin(pos, nrm, g[tag + "_joints"], g[tag + "_weights"], S)
+        ref = w["%s_%s" % (tag, pose)]
+        assert np.array_equal(p, ref[:, :3]) and np.array_equal(n, ref[:, 3:]), "%s %s" % (tag, pose)
+        p2, n2 = oracle.np_twin.skin(pos, nrm, g[tag + "_joints"], g[tag + "_weights"], S)
+        assert np.array_equal(p2, ref[:, :3]) and np.array_equal(n2, ref[:, 3:])
+    # the one statement of vs() that was not evaluated is the camera projection, which is not part of the deformation
+    assert [str(s) for s in w["skipped_statements"]] == ["output.position  (needs camera)"]
+    assert len(str(w["vs_sha256"])) == 64 and len(str(w["cs_sha256"])) == 64
+
+
+def test_wgsl_interpreter_on_hand_computed_cases():
+    """The interpreter itself: a hand-written shader with known answers, f32 rounding per operation, and loud failure on
+    syntax outside its subset (it must never skip shader code silently)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import wgsl_eval as W
+    src = """
+    fn f(a: vec3f) -> vec4f {
+      var acc = vec4f(0.0, 0.0, 0.0, 0.0);
+      let m = mats[1u];
+      for (var i = 0u; i < 3u; i++) {
+        acc += (m * vec4f(a, 1.0)) * w[i];
+      }
+      let s = select(2.0, 0.5, acc.x > 100.0);
+      out.v = acc * s;
+      out.n = normalize(vec3f(3.0, 0.0, 4.0));
+      if (k >= 7u) { return out; }
+      out.v = vec4f(9.0, 9.0, 9.0, 9.0);
+      return out;
+    }"""
+    ident = W.Mat(np.eye(4, dtype=np.float32))
+    shift = W.Mat([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [10, 20, 30, 1]])
+    env, skipped, head = W.run_function(src, r"fn\s+f\s*\(", {"a": np.array([1, 2, 3], np.float32), "mats": [ident, shift],
+                                                                 "w": np.array([0.5, 0.25, 0.25], np.float32), "k": 7, "out": {}})
+    o = env["__return__"]
+    assert np.array_equal(o["v"], np.array([22.0, 44.0, 66.0, 2.0], np.float32)) and skipped == [] and "fn f" in head
+    assert np.array_equal(o["n"], np.array([0.6, 0.0, 0.8], np.float32))
+    env, _, _ = W.run_function(src, r"fn\s+f\s*\(", {"a": np.array([1, 2, 3], np.float32), "mats": [ident, shift],
+                                                      "w": np.array([0.5, 0.25, 0.25], np.float32), "k": 6, "out": {}})
+    assert np.array_equal(env["__return__"]["v"], np.full(4, 9.0, np.float32))
+    # binary32 per operation: 1e8 + 1 - 1e8 is 0 in f32
+    env, _, _ = W.run_function("fn g() { let x = 100000000.0 + 1.0 - 100000000.0; return x; }", r"fn\s+g\s*\(", {})
+    assert env["__return__"] == np.float32(0.0)
+    # a binding the caller did not supply: the statement is reported, not silently dropped
+    env, skipped, _ = W.run_function("fn h() { let y = cam.view * 2.0; let z = 1.0; return z; }", r"fn\s+h\s*\(", {})
+    assert skipped == ["y  (needs cam)"] and env["__return__"] == np.float32(1.0)
+    for bad in ("fn b() { let x = sin(1.0); }", "fn b() { while (true) { } }", "fn b() { x <<= 2; }"):
+        with pytest.raises((SyntaxError, AssertionError, KeyError)):
+            W.run_function(bad, r"fn\s+b\s*\(", {"x": 1})
