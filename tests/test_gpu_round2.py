@@ -436,6 +436,12 @@ def test_wide_sample_of_the_real_model_against_reference_execution(rz, oracle, p
     assert (np.abs(c.read_palette() - ref_pal) <= 1e-5 * np.maximum(1.0, np.abs(ref_pal).max(axis=1, keepdims=True))).all()
     pr, nr = oracle.deform(pos, nrm, g["wide_joints"], g["wide_weights"], g["world_" + pose], g["inv_bind"])
     assert_parity(pg, ng, pr, nr, "wide real sample vs oracle (%s)" % pose)
+    # the fused outline hull against the outline pass's vs() text, interpreted (engine.ts:431-463)
+    from helpers import assert_hull
+    c.upload_edge_scale(wg["hull_edge"])
+    c.deform()
+    assert_hull(c.read_hull(), wg["hull_wide_" + pose], "hull vs the reference's outline shader text (%s)" % pose)
+    c.upload_edge_scale(None)
     # the same vertices sorted by influence count (real models cluster them by mesh part), as a crowd of 5 poses
     order = np.argsort((g["wide_weights"] > 0).sum(axis=1), kind="stable")
     c.upload_mesh_interleaved(v[order], g["wide_joints"][order], g["wide_weights"][order])

@@ -243,6 +243,11 @@ def test_oracle_is_bit_identical_to_the_reference_shader_text_interpreted(oracle
         assert np.array_equal(p, ref[:, :3]) and np.array_equal(n, ref[:, 3:]), "%s %s" % (tag, pose)
         p2, n2 = oracle.np_twin.skin(pos, nrm, g[tag + "_joints"], g[tag + "_weights"], S)
         assert np.array_equal(p2, ref[:, :3]) and np.array_equal(n2, ref[:, 3:])
+    # row f4: the outline pass's vs() (engine.ts:431-463), interpreted the same way: expandedPos = worldPos + worldNormal *
+    # material.edgeSize * 0.01 on the wide sample with edge sizes 0 / 0.4 / 1.0 / 1.5 == oracle.hull of the deformed mesh
+    ref = w["wide_" + pose]
+    h = oracle.hull(np.ascontiguousarray(ref[:, :3]), np.ascontiguousarray(ref[:, 3:]), w["hull_edge"])
+    assert np.array_equal(h, w["hull_wide_" + pose]) and np.array_equal(h[::4], ref[::4, :3])
     # the one statement of vs() that was not evaluated is the camera projection, which is not part of the deformation
     assert [str(s) for s in w["skipped_statements"]] == ["output.position  (needs camera)"]
     assert len(str(w["vs_sha256"])) == 64 and len(str(w["cs_sha256"])) == 64

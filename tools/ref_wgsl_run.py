@@ -31,7 +31,9 @@ def main():
     g = np.load(os.path.join(ROOT, "tests", "golden", "ref_c1_pose0.npz"))
     vs_body, vs_head = W.function_body(src, r"@vertex\s+fn\s+vs\s*\(")
     cs_body, cs_head = W.function_body(src, r"fn\s+main\s*\(\s*@builtin\(global_invocation_id\)")
-    assert "skinMats" in vs_body and "normalizedWeights" in vs_body and "skinMatrices[boneIndex]" in cs_body
+    ol_body, ol_head = W.function_body(src, r"@vertex\s+fn\s+vs\s*\(", containing="expandedPos")      # the outline pass (engine.ts:431-463)
+    assert "skinMats" in vs_body and "normalizedWeights" in vs_body and "skinMatrices[boneIndex]" in cs_body and "expandedPos" not in vs_body
+    ol_tokens = W.tokenize(ol_body)
     out = {"vs_sha256": hashlib.sha256(vs_body.encode()).hexdigest(), "cs_sha256": hashlib.sha256(cs_body.encode()).hexdigest()}
     vs_tokens, cs_tokens = W.tokenize(vs_body), W.tokenize(cs_body)
     B = len(g["inv_bind"])
@@ -67,7 +69,21 @@ def main():
                     res[k, 0:3] = o["worldPos"]
                     res[k, 3:6] = o["normal"]
                 out["%s_%s" % (tag, pose)] = res
+            # the outline pass's vs(): the same skinning, then  expandedPos = worldPos + worldNormal * material.edgeSize * 0.01
+            v, joints, weights = g["wide_vertices"], g["wide_joints"], g["wide_weights"]
+            edge = np.array([0.0, 0.4, 1.0, 1.5], dtype=F)[np.arange(len(v)) % 4]      # materials without / with an outline
+            hull = np.zeros((len(v), 3), dtype=F)
+            for k in range(len(v)):
+                env = {"position": v[k, 0:3].astype(F), "normal": v[k, 3:6].astype(F), "joints0": joints[k].astype(np.uint32),
+                       "weights0": (weights[k].astype(F) / F(255.0)).astype(F), "skinMats": skin, "material": {"edgeSize": F(edge[k])}}
+                it = W.Interp(ol_tokens, env)
+                e = it.run()
+                skipped_all.update(it.skipped)
+                hull[k] = e["expandedPos"]
+            out["hull_wide_" + pose] = hull
+            out["hull_edge"] = edge
             print(pose, "done")
+    out["ol_sha256"] = hashlib.sha256(ol_body.encode()).hexdigest()
     out["skipped_statements"] = np.array(sorted(skipped_all))
     print("statements skipped for lack of bindings:", sorted(skipped_all))
     assert all(s.startswith("output.position") for s in skipped_all), skipped_all

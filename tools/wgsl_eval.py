@@ -59,8 +59,15 @@ def tokenize(src):
     return out
 
 
-def function_body(source, header_regex):
-    """Text between the braces of the first function whose header matches `header_regex`, and the header itself."""
+def function_body(source, header_regex, containing=None):
+    """Text between the braces of the first function whose header matches `header_regex` (and whose body contains
+    `containing`, when given: the reference has three `@vertex fn vs`), and the header itself."""
+    if containing is not None:
+        for m in re.finditer(header_regex, source):
+            body, head = function_body(source[m.start():], header_regex)
+            if containing in body:
+                return body, head
+        raise ValueError("no function matching %s contains %r" % (header_regex, containing))
     m = re.search(header_regex, source)
     if not m:
         raise ValueError("function not found: " + header_regex)
