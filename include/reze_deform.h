@@ -205,11 +205,19 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * "geo_lds" (0/1: rest geometry transposed through LDS vs 4-byte loads), "nontemporal" (0/1,
  * morph-stream loads), "nt_store" (0/1, output stores), "fast" (-1 auto, 0 always run the
  * separate prep kernel, 1 one-launch frame when possible), "out_cap" (-1 auto, 0 off, else vertices a wave
- * parks in LDS before writing them out in one burst), "inst_loop" (-1 auto, 0 off, 2..8 poses
- * per workgroup in instanced morph-free frames, 9 = the register-resident form), "graph" (0/1: rz_deform_n replays
- * hipGraphs of 16 captured frames instead of launching every kernel — for launch-bound replay of small frames). rz_get_tuning also answers
- * "effective_split" / "effective_unroll" / "effective_grid" / "effective_fast" / "effective_out_cap".
- * Unknown keys return RZ_ERR_INVALID. */
+ * parks in LDS before writing them out in one burst), "inst_loop" (-1 auto, 0 off, 2..8 / 10..16 poses
+ * per workgroup in instanced morph-free frames, 9 = the register-resident form), "inst_block" (0 auto, 256 / 512 / 1024 threads per
+ * workgroup of the instanced kernel; for crowds "fast" -1 / 1 = palettes formed inside the skin kernel, one launch per frame, 0 =
+ * rz_prep_kernel in front), "graph" (0/1: rz_deform_n replays hipGraphs of 16 captured frames instead of launching every kernel —
+ * for launch-bound replay of small frames), "zero_copy" (-1 auto = on, 0: every pose is copied to the device; one character's
+ * per-frame inputs are otherwise read by the frame's kernels straight from a pinned, device-mapped slot), "fuse_fk" (-1 auto, 0, 1:
+ * a device-animated single character solves its bone hierarchy inside the deform kernel — one launch per frame — instead of
+ * rz_fk_kernel [+ rz_prep_kernel] in front), "overlap" (-1 / 0 off, 1: crowds run their front kernels on the upload stream under
+ * the previous frame's skin kernel — measured slower on this runtime, kept for experiments). There is no key that makes a frame
+ * emit anything but the deformed mesh: ablation switches exist only in a tools-only build and "dbg" is rejected here.
+ * rz_get_tuning also answers "effective_split" / "effective_unroll" / "effective_grid" / "effective_fast" / "effective_out_cap" /
+ * "effective_inst_group" / "effective_inst_block" / "effective_fuse_fk" / "effective_overlap" / "pose_resident" and the counts
+ * "verts" / "bones" / "morphs" / "instances". Unknown keys return RZ_ERR_INVALID. */
 int rz_set_tuning(rz_ctx *ctx, const char *key, int value);
 int rz_get_tuning(rz_ctx *ctx, const char *key, int *value);
 
