@@ -64,9 +64,13 @@ template <class F> double timeit(F f)
 }
 int main()
 {
-    const int V = 30000, Vp = 30720, I = 256;
+    const int V = 30000, I = 256;
     float *pos, *nrm;
-    const size_t bytes = (size_t)I * Vp * 3 * 4;
+    const size_t bytes = (size_t)I * 32768 * 3 * 4;
+    // instance stride (vertices): 30720 puts every pose's line for the same vertex on the same L2 channel (368 640 B = 1440 x 256 B,
+    // 1440 % 16 == 0); the others rotate the channel from pose to pose
+    for (int Vp : {30720, 30784, 30848, 30976, 31744}) {
+    printf("---- instance stride %d vertices = %d B (%d x 256 B, mod 16 = %d)\n", Vp, Vp * 12, Vp * 12 / 256, (Vp * 12 / 256) % 16);
     CK(hipMalloc(&pos, bytes)); CK(hipMalloc(&nrm, bytes));
     CK(hipFuncSetAttribute((const void *)k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CK(hipFuncSetAttribute((const void *)k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -74,8 +78,8 @@ int main()
     CK(hipFuncSetAttribute((const void *)k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     const double mb = 2.0 * I * V * 12 / 1e6;
     for (int lds : {0, 77 * 1024})
-        for (int G : {8, 4})
-            for (int runs : {8, 16, 32}) {
+        for (int G : {8})
+            for (int runs : {8, 16}) {
                 const int per = ((V + runs - 1) / runs + 63) / 64 * 64;
                 dim3 grid((V + per - 1) / per, I / G);
                 double a = timeit([&] { k<0><<<grid, 256, lds>>>(pos, nrm, V, Vp, G, per); });
@@ -84,6 +88,8 @@ int main()
                 double f = timeit([&] { k<3><<<grid, 256, lds>>>(pos, nrm, V, Vp, G, per); });
                 printf("lds=%dK G=%d runs=%d wgs=%d : A %.1f us (%.0f GB/s)  B %.1f us  C %.1f us  F(48 lanes x 16 B) %.1f us (%.0f GB/s)\n", lds >> 10, G, runs, grid.x * grid.y, a, mb / a * 1e3, b, c, f, mb / f * 1e3);
             }
+    }
+    const int Vp = 30720;
     for (int grid : {512, 1024, 4096, 8192}) {
         double e = timeit([&] { k_lin<<<grid, 256>>>(pos, (size_t)I * Vp); k_lin<<<grid, 256>>>(nrm, (size_t)I * Vp); });
         printf("linear fill3 x2 grid=%d : %.1f us (%.0f GB/s)\n", grid, e, 2.0 * I * Vp * 12 / 1e6 / e * 1e3);
