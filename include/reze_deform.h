@@ -117,6 +117,18 @@ int rz_set_pose(rz_ctx *ctx, const float *world, const float *morph_weights);
 int rz_upload_skeleton_topology(rz_ctx *ctx, uint32_t B, const int32_t *parents, const float *bind_translation3,
                                 const int32_t *append_parent, const float *append_ratio, const uint8_t *append_move);
 int rz_set_pose_local(rz_ctx *ctx, const float *local_rotations4, const float *local_translations3, const float *morph_weights);
+/* PMX bone morphs (morph type 2; SURVEY §8f rank 3 "then 2 bone-morph"). The reference's loader only skips the section
+ * (engine/src/pmx-loader.ts:489-497), so the semantics are this build's, the usual MMD ones: a morph with weight w adds
+ * w * translation to the bone's local translation and right-multiplies its local rotation by slerp(identity, rotation, w)
+ * (Quat.slerp math.ts:156-189, Quat.multiply math.ts:77-85), entries of one bone folded in ascending morph order, BEFORE
+ * append rotation / the hierarchy solve (so an append child follows a morphed append parent). n entries, each naming a morph
+ * of the uploaded morph set (rz_upload_morphs_* first; a model whose only morphs are bone morphs uploads an empty sparse
+ * set) and a bone; the weights are the pose's morph weights (rz_set_pose_local's morph_weights, or the sampled tracks of
+ * rz_set_pose_sampled — group morphs feed bone morphs like vertex morphs). Acts on device-solved poses only: with
+ * rz_set_pose the host owns the world matrices and folds bone morphs itself (host/model.js). n = 0 clears. Dropped by a
+ * new skeleton or morph set. */
+int rz_upload_bone_morphs(rz_ctx *ctx, uint32_t n, const uint32_t *morph, const uint32_t *bone, const float *translation3,
+                          const float *rotation4);
 
 /* ---- motion sampling on the device (SURVEY §8f ranks 1 + 2 combined; optional) ----
  * The caller of the path in the reference is Engine.playAnimation (engine/src/engine.ts:1515-1553) fed by

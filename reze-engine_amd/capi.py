@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libreze_deform.so")
 SYMBOLS = [
     "rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_destroy", "rz_shard_range",
     "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
-    "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_upload_animation", "rz_set_pose_sampled", "rz_override_world", "rz_read_world", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
+    "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_upload_bone_morphs", "rz_upload_animation", "rz_set_pose_sampled", "rz_override_world", "rz_read_world", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
     "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_autotune", "rz_output_ptrs",
     "rz_comm_unique_id", "rz_rccl_info", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_gather_fence", "rz_upload_edge_scale", "rz_read_hull", "rz_enable_aabb", "rz_read_aabb",
 ]
@@ -80,6 +80,7 @@ def load():
     L.rz_upload_animation.argtypes = [vp, ctypes.POINTER(RzAnimation)]
     L.rz_set_pose_sampled.argtypes = [vp, fp]
     L.rz_override_world.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), fp]
+    L.rz_upload_bone_morphs.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), fp, fp]
     L.rz_read_world.argtypes = [vp, u32, fp]
     L.rz_deform.argtypes = [vp]
     L.rz_deform_n.argtypes = [vp, u32]
@@ -320,6 +321,20 @@ class DeformContext:
         f = _f32(np.atleast_1d(frames)).reshape(-1)
         assert f.size == self.I
         _chk(self._L.rz_set_pose_sampled(self._h, _fptr(f)))
+
+    def upload_bone_morphs(self, morph, bone, translation3, rotation4):
+        """PMX bone morphs (type 2) for device-solved poses: entry k moves `bone[k]` by weight(morph[k]) * translation and
+        right-multiplies its local rotation by slerp(identity, rotation, weight). Empty arrays clear."""
+        m = np.ascontiguousarray(morph, dtype=np.uint32).reshape(-1)
+        if m.size == 0:
+            _chk(self._L.rz_upload_bone_morphs(self._h, 0, None, None, None, None))
+            return
+        b = np.ascontiguousarray(bone, dtype=np.uint32).reshape(-1)
+        t = _f32(translation3).reshape(-1)
+        q = _f32(rotation4).reshape(-1)
+        assert b.size == m.size and t.size == m.size * 3 and q.size == m.size * 4
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        _chk(self._L.rz_upload_bone_morphs(self._h, int(m.size), m.ctypes.data_as(u32p), b.ctypes.data_as(u32p), _fptr(t), _fptr(q)))
 
     def override_world(self, bones, world16, instances=None):
         """Physics hand-off for device-solved poses (engine.ts:2379-2381): world matrices that replace the solved ones of

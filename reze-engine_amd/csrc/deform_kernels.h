@@ -64,6 +64,16 @@ struct RzFkParams {
     const int *ovr_off;         // [I + 1] or nullptr
     const int *ovr_bone;        // [n]
     const float *ovr_world;     // [n][16] column-major
+    // PMX bone morphs (morph type 2: a weight-scaled translation + rotation offset on a bone's LOCAL pose; the reference's
+    // loader skips the section, engine/src/pmx-loader.ts:489-497). Stored per bone; applied after the pose is staged /
+    // sampled and before the local matrices are formed:  t += w * t_e ;  q = q * slerp(I, q_e, w)  for its entries in
+    // ascending morph order (host twin: host/model.js posedLocals()).
+    const uint32_t *bm_off;     // [B + 1] or nullptr = the model has no bone morphs
+    const uint32_t *bm_morph;   // [n] morph index of each entry, ascending inside a bone
+    const float4 *bm_rot;       // [n] x y z w
+    const float4 *bm_tr;        // [n] x y z (w unused)
+    const float *bm_w;          // [I][bm_M] morph weights of an uploaded (not sampled) pose
+    int bm_M;
     RzSampleParams sample;      // sample.frames != nullptr: local_q / local_t are ignored, the pose is sampled in the kernel
 };
 

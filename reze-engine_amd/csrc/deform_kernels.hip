@@ -277,6 +277,24 @@ __device__ __forceinline__ float sample_morph(const RzSampleParams &p, float fra
     return w;
 }
 
+// Quat.slerp(identity, a, t)  (math.ts:156-189): the append rotation (model.ts:367-386) and the bone-morph rotation use it
+__device__ __forceinline__ float4 slerp_from_identity(float4 a, const float t)
+{
+    float c = a.w;
+    if (c < 0.0f) { c = -c; a.x = -a.x; a.y = -a.y; a.z = -a.z; a.w = -a.w; }
+    float sx, sy, sz, sw;
+    if (c > 0.9995f) {
+        sx = t * a.x; sy = t * a.y; sz = t * a.z; sw = 1.0f + t * (a.w - 1.0f);
+        const float il = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz + sw * sw);
+        sx *= il; sy *= il; sz *= il; sw *= il;
+    } else {
+        const float th0 = acosf(c), sn = sinf(th0), th = th0 * t;
+        const float s0 = sinf(th0 - th) / sn, s1 = sinf(th) / sn;
+        sx = s1 * a.x; sy = s1 * a.y; sz = s1 * a.z; sw = s0 + s1 * a.w;
+    }
+    return make_float4(sx, sy, sz, sw);
+}
+
 // The body of the hierarchy solve, shared by rz_fk_kernel (one workgroup per pose, results to global memory) and by the
 // FUSED single-character frame, where every workgroup of rz_deform_kernel runs it as its prologue: `wl` is then the deform
 // kernel's LDS palette (it ends up holding rows 0..2 of W * inverseBind), `scr` aliases its wave scratch, the sampled morph
@@ -296,7 +314,8 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
     const float4 *lq = p.local_q + (size_t)inst * p.B;
     const float *glt = p.local_t ? p.local_t + (size_t)inst * p.B * 3 : nullptr;
     const bool sampled = p.sample.frames != nullptr || p.sample.frames_inline;      // rz_set_pose_sampled: the pose is evaluated right here
-    const bool has_t = sampled || glt != nullptr;
+    const bool bone_morphs = p.bm_off != nullptr;
+    const bool has_t = sampled || glt != nullptr || bone_morphs;
     const float *lt = has_t ? s_lt : nullptr;
     const float frame = sampled ? (p.sample.frames_inline ? p.sample.frame0 : p.sample.frames[inst]) : 0.0f;
     float *world = p.world + (size_t)inst * p.B * 16;
@@ -321,15 +340,40 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         } else {
             sq[i] = lq[i];
             if (glt) { s_lt[i * 3] = glt[i * 3]; s_lt[i * 3 + 1] = glt[i * 3 + 1]; s_lt[i * 3 + 2] = glt[i * 3 + 2]; }
+            else if (bone_morphs) { s_lt[i * 3] = 0.0f; s_lt[i * 3 + 1] = 0.0f; s_lt[i * 3 + 2] = 0.0f; }
         }
     }
     if (sampled)        // vertex-morph weights of this pose: consumed by the prep / deform kernels that follow (FUSED: by this very workgroup)
         for (int m = tid; m < p.sample.M; m += kBlock) {
             const float w = sample_morph(p.sample, frame, m);
-            if (FUSED) lds_mw[m] = w;
+            if (FUSED || bone_morphs) lds_mw[m] = w;
             if (to_global) p.sample.morph_w[(size_t)inst * p.sample.M + m] = w;
         }
+    else if (bone_morphs && !FUSED)         // (FUSED: the caller has staged the uploaded weights already)
+        for (int m = tid; m < p.bm_M; m += kBlock) lds_mw[m] = p.bm_w[(size_t)inst * p.bm_M + m];
     __syncthreads();
+    if (bone_morphs) {
+        // PMX bone morphs on the staged local pose: every bone folds its own entries, ascending morph index
+        for (int b = tid; b < p.B; b += kBlock) {
+            const uint32_t e0 = p.bm_off[b], e1 = p.bm_off[b + 1];
+            if (e0 == e1) continue;
+            float4 q = sq[b];
+            float tx = s_lt[b * 3], ty = s_lt[b * 3 + 1], tz = s_lt[b * 3 + 2];
+            for (uint32_t e = e0; e < e1; ++e) {
+                const float w = lds_mw[p.bm_morph[e]];
+                if (w == 0.0f) continue;
+                const float4 t4 = p.bm_tr[e];
+                tx += w * t4.x; ty += w * t4.y; tz += w * t4.z;
+                const float4 r = slerp_from_identity(p.bm_rot[e], w);
+                q = make_float4(q.w * r.x + q.x * r.w + q.y * r.z - q.z * r.y,          // Hamilton product q * r (math.ts Quat.multiply)
+                                q.w * r.y - q.x * r.z + q.y * r.w + q.z * r.x,
+                                q.w * r.z + q.x * r.y - q.y * r.x + q.z * r.w,
+                                q.w * r.w - q.x * r.x - q.y * r.y - q.z * r.z);
+            }
+            sq[b] = q; s_lt[b * 3] = tx; s_lt[b * 3 + 1] = ty; s_lt[b * 3 + 2] = tz;
+        }
+        __syncthreads();
+    }
     // Pass A, every bone in parallel: its LOCAL matrix L = T(bind + t) * R * T(add) (rows 0..2), parked in the slot that
     // will hold its world matrix. The level loop below is then only W = W_parent * L — the quaternion / append / slerp
     // math is off the level-by-level critical path.
@@ -349,19 +393,8 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
                 float4 a = sq[ap];
                 const float t = fabsf(ratio);
                 if (ratio < 0.0f) { a.x = -a.x; a.y = -a.y; a.z = -a.z; }
-                // Quat.slerp(identity, a, t)  (math.ts:156-189)
-                float c = a.w;
-                if (c < 0.0f) { c = -c; a.x = -a.x; a.y = -a.y; a.z = -a.z; a.w = -a.w; }
-                float sx, sy, sz, sw;
-                if (c > 0.9995f) {
-                    sx = t * a.x; sy = t * a.y; sz = t * a.z; sw = 1.0f + t * (a.w - 1.0f);
-                    const float il = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz + sw * sw);
-                    sx *= il; sy *= il; sz *= il; sw *= il;
-                } else {
-                    const float th0 = acosf(c), sn = sinf(th0), th = th0 * t;
-                    const float s0 = sinf(th0 - th) / sn, s1 = sinf(th) / sn;
-                    sx = s1 * a.x; sy = s1 * a.y; sz = s1 * a.z; sw = s0 + s1 * a.w;
-                }
+                const float4 sl = slerp_from_identity(a, t);
+                const float sx = sl.x, sy = sl.y, sz = sl.z, sw = sl.w;
                 float A[9], X[9];
                 quat_to_rows(sx, sy, sz, sw, A);
 #pragma unroll
@@ -455,7 +488,8 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
 __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    fk_solve<false>(p, (int)blockIdx.x, reinterpret_cast<float4 *>(smem), smem + (size_t)p.B * 48, nullptr, true);
+    unsigned char *scr = smem + (size_t)p.B * 48;
+    fk_solve<false>(p, (int)blockIdx.x, reinterpret_cast<float4 *>(smem), scr, reinterpret_cast<float *>(scr + (((size_t)p.B * 56 + 15) & ~(size_t)15)), true);
 }
 
 
@@ -592,7 +626,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         unsigned char *fscr = reinterpret_cast<unsigned char *>(scratch_all);
         float *lds_mw = reinterpret_cast<float *>(fscr + (((size_t)p.B * 56 + 15) & ~(size_t)15));
         const bool sampled = p.fk.sample.frames != nullptr || p.fk.sample.frames_inline;
-        if (MODE != 0 && !sampled) {
+        if ((MODE != 0 || p.fk.bm_off) && !sampled) {
             for (int i = tid; i < p.M; i += kBlock) lds_mw[i] = p.morph_w[i];       // uploaded weights (pinned slot or device block)
         }
         fk_solve<true>(p.fk, 0, pal, fscr, lds_mw, blockIdx.x == 0);             // ends with a barrier: pal and lds_mw are complete
@@ -1288,7 +1322,8 @@ hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t
 
 hipError_t rz_launch_fk(const RzFkParams &p, uint32_t instances, hipStream_t st)
 {
-    const size_t lds = (size_t)p.B * (48 + 16 + 4 * 4 + 12 + 12);
+    size_t lds = (size_t)p.B * 48 + (((size_t)p.B * (16 + 4 * 4 + 12 + 12) + 15) & ~(size_t)15);
+    if (p.bm_off) lds += (size_t)std::max(std::max(p.bm_M, p.sample.M), 1) * 4;      // the pose's morph weights, for the bone morphs
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rz_fk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

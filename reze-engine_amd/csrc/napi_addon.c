@@ -383,6 +383,20 @@ static napi_value fn_override_world(napi_env env, napi_callback_info info)
     return rc ? throw_rz(env, rc) : undef(env);
 }
 
+static napi_value fn_upload_bone_morphs(napi_env env, napi_callback_info info)
+{
+    ARGS(5);
+    CTX(0);
+    void *m = NULL, *b = NULL, *t = NULL, *q = NULL;
+    size_t nm = 0, nb = 0, nt = 0, nq = 0;
+    if (!get_ta(env, argv[1], napi_uint32_array, 1, &m, &nm) || !get_ta(env, argv[2], napi_uint32_array, 1, &b, &nb) ||
+        !get_ta(env, argv[3], napi_float32_array, 1, &t, &nt) || !get_ta(env, argv[4], napi_float32_array, 1, &q, &nq))
+        return throw_msg(env, "uploadBoneMorphs(ctx, Uint32Array|null morph, Uint32Array|null bone, Float32Array|null translation3, Float32Array|null rotation4)");
+    if (nb != nm || nt != nm * 3 || nq != nm * 4) return throw_msg(env, "uploadBoneMorphs: array lengths disagree");
+    int rc = rz_upload_bone_morphs(ctx, (uint32_t)nm, (const uint32_t *)m, (const uint32_t *)b, (const float *)t, (const float *)q);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
 static napi_value fn_read_world(napi_env env, napi_callback_info info)
 {
     ARGS(3);
@@ -705,7 +719,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "timeFrames", fn_time_frames }, { "setTuning", fn_set_tuning }, { "getTuning", fn_get_tuning },
         { "commUniqueId", fn_comm_unique_id }, { "rcclInfo", fn_rccl_info }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },
         { "readGathered", fn_read_gathered }, { "commInitAll", fn_comm_init_all }, { "allgatherAll", fn_allgather_all },
-        { "autotune", fn_autotune }, { "uploadAnimation", fn_upload_animation }, { "setPoseSampled", fn_set_pose_sampled }, { "overrideWorld", fn_override_world }, { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
+        { "autotune", fn_autotune }, { "uploadAnimation", fn_upload_animation }, { "setPoseSampled", fn_set_pose_sampled }, { "overrideWorld", fn_override_world }, { "uploadBoneMorphs", fn_upload_bone_morphs }, { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value f;

@@ -147,6 +147,10 @@ struct rz_ctx {
     float *ovr_world = nullptr;
     uint32_t ovr_count = 0;
     size_t ovr_alloc = 0, ovr_off_alloc = 0;
+    // PMX bone morphs (rz_upload_bone_morphs): entries grouped by bone, ascending morph index inside a bone
+    uint32_t *bm_off = nullptr, *bm_morph = nullptr;
+    float4 *bm_rot = nullptr, *bm_tr = nullptr;
+    uint32_t bm_count = 0;
 
     // morphs
     int morph_mode = 0;                 // 0 none, 1 dense, 2 sparse
@@ -405,6 +409,14 @@ void free_animation(rz_ctx *c)
     if (c->pose_sampled) { c->pose_sampled = false; c->pose_set = false; }
 }
 
+void free_bone_morphs(rz_ctx *c)
+{
+    if (!c->bm_off) return;
+    drop_graph(c);
+    dfree(c->bm_off); dfree(c->bm_morph); dfree(c->bm_rot); dfree(c->bm_tr);
+    c->bm_count = 0;
+}
+
 template <typename T> int to_device(T **dst, const void *src, size_t count)
 {
     *dst = nullptr;
@@ -426,6 +438,7 @@ void free_morphs(rz_ctx *c)
     forget_search(c);
     drop_graph(c);
     dfree(c->dense); dfree(c->sp_ptr); dfree(c->sp_entries);
+    free_bone_morphs(c);                  // their entries name morphs of the old set
     c->morph_mode = 0; c->M = 0; c->Mpad = 12; c->sp_count = 0;
     c->pose_set = false;                  // morph weights belong to the old target set
 }
@@ -525,7 +538,7 @@ Plan make_plan(const rz_ctx *c)
     // mode (and 27.7 -> 24.5 us on a 1/8 shard of C5); local poses 12.7-14.4 -> 9.8-12.8 us without dense morphs, no gain
     // with them (there the three-kernel frame keeps its kernel-argument morph list and streams from its first instruction).
     // Automatic mode follows that; "fuse_fk" = 0 / 1 forces it.
-    pl.fuse_fk = c->I == 1 && c->pose_local && c->has_topology && (size_t)c->B * 104 + 4096 <= 160 * 1024 &&
+    pl.fuse_fk = c->I == 1 && c->pose_local && c->has_topology && (size_t)c->B * 104 + (size_t)c->M * 12 + 4096 <= 160 * 1024 &&
                  (c->t_fusefk == 1 || (c->t_fusefk < 0 && (c->pose_sampled || c->morph_mode != 1)));
     const bool can_fast = c->I == 1 && !pl.fuse_fk && (v.mode != 1 || c->ml.count >= 0);
     v.fast = can_fast && c->t_fast != 0;
@@ -641,6 +654,10 @@ RzFkParams fk_params(const rz_ctx *c)
     p.append_ratio = c->fk_append_ratio; p.order = c->fk_order; p.level_off = c->fk_level_off; p.inv_bind = c->inv_bind;
     p.world = c->world; p.palette = c->palette; p.B = (int)c->B; p.n_levels = c->fk_levels;
     if (c->ovr_count) { p.ovr_off = c->ovr_off; p.ovr_bone = c->ovr_bone; p.ovr_world = c->ovr_world; }
+    if (c->bm_count && c->M) {
+        p.bm_off = c->bm_off; p.bm_morph = c->bm_morph; p.bm_rot = c->bm_rot; p.bm_tr = c->bm_tr;
+        p.bm_w = src_morph_w(c); p.bm_M = (int)c->M;
+    }
     if (c->pose_sampled) {
         RzSampleParams &q = p.sample;
         q.frames = c->frames_inline ? nullptr : c->an_frames; q.frames_inline = c->frames_inline ? 1 : 0; q.frame0 = c->frame0;
@@ -886,6 +903,7 @@ int rz_destroy(rz_ctx *c)
     free_animation(c); dfree(c->an_frames);
     dfree(c->fk_append_ratio); dfree(c->fk_append_move); dfree(c->pose_blk[0]); dfree(c->pose_blk[1]);
     dfree(c->ovr_off); dfree(c->ovr_bone); dfree(c->ovr_world);
+    free_bone_morphs(c);
     free_morphs(c);
     for (int k = 0; k < 2; ++k) {
         if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]);
@@ -978,6 +996,7 @@ int rz_upload_skeleton(rz_ctx *c, uint32_t B, const float *inverse_bind16)
     c->B = B;
     c->pose_set = false;
     c->has_topology = false;            // belongs to the previous skeleton
+    free_bone_morphs(c);                // ... as do bone morphs (their entries name its bones)
     free_animation(c);                  // ... and so does an uploaded motion (its tracks name bones of that skeleton)
     return ensure_pose_buffers(c);
 }
@@ -1332,6 +1351,50 @@ int rz_upload_skeleton_topology(rz_ctx *c, uint32_t B, const int32_t *parents, c
     HIP_TRY(hipMemcpy(c->fk_append_ratio, ratio.data(), B * sizeof(float), hipMemcpyHostToDevice));
     c->fk_levels = n_levels;
     c->has_topology = true;
+    return RZ_OK;
+}
+
+int rz_upload_bone_morphs(rz_ctx *c, uint32_t n, const uint32_t *morph, const uint32_t *bone, const float *translation3, const float *rotation4)
+{
+    if (int r = use(c)) return r;
+    if (n == 0) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        free_bone_morphs(c);
+        return RZ_OK;
+    }
+    if (!c->has_topology) return fail(RZ_ERR_INVALID, "bone morphs act on device-solved poses: call rz_upload_skeleton_topology first");
+    if (c->M == 0) return fail(RZ_ERR_INVALID, "upload the morph set first (rz_upload_morphs_*): bone-morph entries name its morphs");
+    if (!morph || !bone || !translation3 || !rotation4) return fail(RZ_ERR_INVALID, "null bone-morph arrays");
+    for (uint32_t k = 0; k < n; ++k) {
+        if (morph[k] >= c->M) return fail(RZ_ERR_INVALID, "bone-morph entry %u names morph %u of %u", k, morph[k], c->M);
+        if (bone[k] >= c->B) return fail(RZ_ERR_INVALID, "bone-morph entry %u names bone %u of %u", k, bone[k], c->B);
+        for (int j = 0; j < 7; ++j) {
+            const float x = j < 3 ? translation3[(size_t)k * 3 + j] : rotation4[(size_t)k * 4 + j - 3];
+            if (!(x == x) || x - x != 0.0f) return fail(RZ_ERR_INVALID, "bone-morph entry %u is not finite", k);
+        }
+    }
+    // group by bone; inside a bone ascending morph index, file order among equal morphs (a stable sort of the entry list)
+    std::vector<uint32_t> idx(n);
+    for (uint32_t k = 0; k < n; ++k) idx[k] = k;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return bone[a] != bone[b] ? bone[a] < bone[b] : morph[a] < morph[b]; });
+    std::vector<uint32_t> off(c->B + 1, 0), mo(n);
+    std::vector<float4> rot(n), tr(n);
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t e = idx[k];
+        off[bone[e] + 1]++;
+        mo[k] = morph[e];
+        rot[k] = make_float4(rotation4[(size_t)e * 4], rotation4[(size_t)e * 4 + 1], rotation4[(size_t)e * 4 + 2], rotation4[(size_t)e * 4 + 3]);
+        tr[k] = make_float4(translation3[(size_t)e * 3], translation3[(size_t)e * 3 + 1], translation3[(size_t)e * 3 + 2], 0.0f);
+    }
+    for (uint32_t b = 0; b < c->B; ++b) off[b + 1] += off[b];
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_bone_morphs(c);
+    drop_graph(c);
+    if (int r = to_device(&c->bm_off, off.data(), off.size())) return r;
+    if (int r = to_device(&c->bm_morph, mo.data(), n)) return r;
+    if (int r = to_device(&c->bm_rot, rot.data(), n)) return r;
+    if (int r = to_device(&c->bm_tr, tr.data(), n)) return r;
+    c->bm_count = n;
     return RZ_OK;
 }
 

@@ -198,6 +198,9 @@ class Engine {
           }
           n.uploadMorphsSparse(s.ctx, off, Uint32Array.from(vi), Float32Array.from(dl))
         }
+        // PMX bone morphs: with the hierarchy solved on the GPU they are folded there (host FK: Model.posedLocals())
+        const be = morphs.boneEntries
+        if (this.deviceFK && be && be.morph.length > 0) n.uploadBoneMorphs(s.ctx, be.morph, be.bone, be.translation, be.rotation)
       }
     }
     if (this.outline) {

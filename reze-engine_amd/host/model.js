@@ -92,6 +92,10 @@ class Model {
     this.effectiveMorphWeights = new Float32Array(m) // group morphs flattened onto their children
     this.morphNameIndex = {}
     for (let i = 0; i < m; i++) this.morphNameIndex[this.morphs.names[i]] = i
+    // PMX bone morphs (type 2): the local pose the hierarchy solve sees = the runtime's local pose with them folded in
+    this.hasBoneMorphs = !!(this.morphs && this.morphs.boneEntries && this.morphs.boneEntries.morph.length > 0)
+    this.poseRotations = new Float32Array(this.hasBoneMorphs ? n * 4 : 0)
+    this.poseTranslations = new Float32Array(this.hasBoneMorphs ? n * 3 : 0)
   }
 
   static parentFirstOrder(bones) {
@@ -191,6 +195,42 @@ class Model {
   }
 
   /**
+   * The local pose the hierarchy solve consumes. Without bone morphs (or with all of them at weight 0) these ARE the
+   * runtime arrays (model.ts:55-56). A PMX bone morph (type 2; the reference only skips the section,
+   * pmx-loader.ts:489-497, so the semantics are this build's, the usual MMD ones) with effective weight w adds
+   * w * translation to its bone's local translation and right-multiplies the local rotation by
+   * Quat.slerp(identity, rotation, w) (math.ts:156-189, :77-85); entries fold in ascending morph order; the runtime arrays
+   * (tween / animation state) are left untouched. GPU twin: fk_solve's bone-morph pass (csrc/deform_kernels.hip).
+   */
+  posedLocals() {
+    const rs = this.runtimeSkeleton
+    const raw = { rot: rs.localRotations, tra: rs.localTranslations, moved: false }
+    if (!this.hasBoneMorphs) return raw
+    const w = this.getEffectiveMorphWeights()
+    const be = this.morphs.boneEntries
+    const n = be.morph.length
+    let any = false
+    for (let k = 0; k < n && !any; k++) any = w[be.morph[k]] !== 0
+    if (!any) return raw
+    const rot = this.poseRotations, tra = this.poseTranslations
+    rot.set(rs.localRotations); tra.set(rs.localTranslations)
+    const s = this._q
+    for (let k = 0; k < n; k++) {
+      const wk = w[be.morph[k]]
+      if (wk === 0) continue
+      const b = be.bone[k], qi = b * 4, ti = b * 3
+      tra[ti] += wk * be.translation[k * 3]; tra[ti + 1] += wk * be.translation[k * 3 + 1]; tra[ti + 2] += wk * be.translation[k * 3 + 2]
+      slerpInto(s, 0, 0, 0, 1, be.rotation[k * 4], be.rotation[k * 4 + 1], be.rotation[k * 4 + 2], be.rotation[k * 4 + 3], wk)
+      const x = rot[qi], y = rot[qi + 1], z = rot[qi + 2], ww = rot[qi + 3] // Hamilton product local * s
+      rot[qi] = ww * s[0] + x * s[3] + y * s[2] - z * s[1]
+      rot[qi + 1] = ww * s[1] - x * s[2] + y * s[3] + z * s[0]
+      rot[qi + 2] = ww * s[2] + x * s[1] - y * s[0] + z * s[3]
+      rot[qi + 3] = ww * s[3] - x * s[0] - y * s[1] - z * s[2]
+    }
+    return { rot, tra, moved: true }
+  }
+
+  /**
    * model.ts:330-420. Per bone: R = fromQuat(q); append-rotation R = fromQuat(slerp(I, +-q_append,
    * |ratio|)) * R when appendRotate && valid parent && |clamp(ratio,-1,1)| > 1e-6; append-move only
    * inside that branch; L = T(bind) * R * T(add); W = W_parent * L.
@@ -198,8 +238,8 @@ class Model {
   computeWorldMatrices() {
     const bones = this.skeleton.bones
     const n = bones.length
-    const rot = this.runtimeSkeleton.localRotations
-    const tra = this.runtimeSkeleton.localTranslations
+    const { rot, tra, moved } = this.posedLocals()
+    const useT = this.applyLocalTranslations || moved
     const world = this.runtimeSkeleton.worldMatrices
     const R = this._rot, A = this._app, T = this._tr, X = this._tmpA, L = this._tmpB
     const q = this._q
@@ -232,7 +272,7 @@ class Model {
       // L = T(bind) * rotM * T(add), each product stored as f32 like the reference's Mat4.multiply chain
       identityInto(T, 0)
       T[12] += b.bindTranslation[0]; T[13] += b.bindTranslation[1]; T[14] += b.bindTranslation[2]
-      if (this.applyLocalTranslations) { T[12] += tra[i * 3]; T[13] += tra[i * 3 + 1]; T[14] += tra[i * 3 + 2] }
+      if (useT) { T[12] += tra[i * 3]; T[13] += tra[i * 3 + 1]; T[14] += tra[i * 3 + 2] }
       mulInto(L, 0, T, 0, rotM, 0)
       identityInto(T, 0)
       T[12] += ax; T[13] += ay; T[14] += az
@@ -286,20 +326,20 @@ class Model {
   getMorphWeights() { return this.morphWeights }
 
   /**
-   * Weights the GPU consumes: vertex morphs (type 1) keep their own weight plus, for every group
-   * morph (type 0) that lists them, w_group * ratio (pmx-loader.ts:479-482). Other morph types
-   * (bone / UV / material / flip / impulse) have no vertex deltas and contribute nothing.
+   * Weights the deformation consumes: vertex morphs (type 1) and bone morphs (type 2) keep their own weight plus, for
+   * every group morph (type 0) that lists them, w_group * ratio (pmx-loader.ts:479-482). Other morph types
+   * (UV / material / flip / impulse) touch neither positions nor bones and contribute nothing.
    */
   getEffectiveMorphWeights() {
     const out = this.effectiveMorphWeights
     if (!this.morphs) return out
     const { types, groups } = this.morphs
     const w = this.morphWeights
-    for (let i = 0; i < out.length; i++) out[i] = types[i] === 1 ? w[i] : 0
+    for (let i = 0; i < out.length; i++) out[i] = types[i] === 1 || types[i] === 2 ? w[i] : 0
     for (let g = 0; g < out.length; g++) {
       if (types[g] !== 0 || w[g] === 0 || !groups[g]) continue
       for (const [child, ratio] of groups[g]) {
-        if (child >= 0 && child < out.length && types[child] === 1) out[child] += w[g] * ratio
+        if (child >= 0 && child < out.length && (types[child] === 1 || types[child] === 2)) out[child] += w[g] * ratio
       }
     }
     return out

@@ -77,7 +77,7 @@ class PmxLoader {
     const textures = this.guard('textures', () => this.textures(), [])
     const materials = this.guard('materials', () => this.materials(), [])
     const bones = this.guard('bones', () => this.bones(), [])
-    const morphs = this.guard('morphs', () => this.morphs(geo.count), null)
+    const morphs = this.guard('morphs', () => this.morphs(geo.count, bones.length), null)
     let rigidbodies = [], joints = []
     if (morphs !== null && this.guard('display frames', () => this.displayFrames(), false)) {
       rigidbodies = this.guard('rigidbodies', () => this.rigidbodies(), [])
@@ -238,14 +238,14 @@ class PmxLoader {
   }
 
   // Morph section. Layout as documented by the reference's skipMorphs() (pmx-loader.ts:462-541).
-  morphs(vertexCount) {
+  morphs(vertexCount, boneCount) {
     const c = this.cur, h = this.h
     const n = c.i32()
     if (n < 0 || n > 100000) throw new RangeError('Suspicious morph count: ' + n)
     const names = [], types = new Uint8Array(n), panels = new Uint8Array(n), groups = new Array(n).fill(null)
     const offsets = new Uint32Array(n + 1)
     const vidx = [], dxyz = []
-    const ENTRY_BYTES = { 2: 28, 3: 16, 4: 16, 5: 16, 6: 16, 7: 16 } // after the leading index
+    const bmMorph = [], bmBone = [], bmT = [], bmQ = [] // bone-morph entries (type 2), ascending morph index
     for (let m = 0; m < n; m++) {
       names.push(this.text())
       this.text()
@@ -265,7 +265,12 @@ class PmxLoader {
           if (v >= 0 && v < vertexCount) { vidx.push(v); dxyz.push(x, y, z) }
         }
       } else if (type === 2) {
-        for (let k = 0; k < cnt; k++) { c.index(h.boneIndexSize); c.skip(ENTRY_BYTES[2]) }
+        // bone index, translation vec3, rotation quaternion x y z w (28 B; the reference's skipper reads 24, pmx-loader.ts:489-497)
+        for (let k = 0; k < cnt; k++) {
+          const b = c.index(h.boneIndexSize)
+          const tx = c.f32(), ty = c.f32(), tz = c.f32(), qx = c.f32(), qy = c.f32(), qz = c.f32(), qw = c.f32()
+          if (b >= 0 && b < boneCount) { bmMorph.push(m); bmBone.push(b); bmT.push(tx, ty, tz); bmQ.push(qx, qy, qz, qw) }
+        }
       } else if (type >= 3 && type <= 7) {
         // PMX 2.0: UV offsets are vec4 (16 B) and bone-morph offsets vec3 + quaternion (28 B). The reference's
         // skipper reads 8 B (:498-507) and 24 B (:489-497) and so loses sync on models that carry such morphs;
@@ -282,7 +287,10 @@ class PmxLoader {
       }
     }
     offsets[n] = vidx.length
-    return { names, types, panels, groups, offsets, vertexIndex: Uint32Array.from(vidx), deltas: Float32Array.from(dxyz) }
+    const boneEntries = {
+      morph: Uint32Array.from(bmMorph), bone: Uint32Array.from(bmBone), translation: Float32Array.from(bmT), rotation: Float32Array.from(bmQ),
+    }
+    return { names, types, panels, groups, offsets, vertexIndex: Uint32Array.from(vidx), deltas: Float32Array.from(dxyz), boneEntries }
   }
 
   displayFrames() {

@@ -96,6 +96,36 @@ def fk_reference(parents, bind, quats, trans=None, append_parent=None, append_ra
     return np.transpose(world, (0, 2, 1)).reshape(B, 16)
 
 
+def bone_morph_reference(quats, trans, morph, bone, t3, q4, weights):
+    """PMX bone morphs (type 2) folded into a local pose, float64 (host/model.js posedLocals(), fk_solve's bone-morph pass):
+    entries in order (ascending morph index), weight w = weights[morph]: t[bone] += w * t_e ;
+    q[bone] = q[bone] * slerp(identity, q_e, w) (Hamilton product, math.ts:77-85; slerp math.ts:156-189). Test infrastructure."""
+    import numpy as np
+    q = np.array(quats, dtype=np.float64).copy()
+    t = np.zeros((len(q), 3)) if trans is None else np.array(trans, dtype=np.float64).copy()
+    for k in range(len(morph)):
+        w = float(weights[int(morph[k])])
+        if w == 0.0:
+            continue
+        b = int(bone[k])
+        t[b] += w * np.asarray(t3[k], dtype=np.float64)
+        e = np.array(q4[k], dtype=np.float64)
+        c = e[3]
+        if c < 0:
+            e, c = -e, -c
+        if c > 0.9995:
+            s = np.array([w * e[0], w * e[1], w * e[2], 1 + w * (e[3] - 1)])
+            s /= np.linalg.norm(s)
+        else:
+            th0 = np.arccos(c)
+            s0, s1 = np.sin(th0 - th0 * w) / np.sin(th0), np.sin(th0 * w) / np.sin(th0)
+            s = np.array([s1 * e[0], s1 * e[1], s1 * e[2], s0 + s1 * e[3]])
+        x, y, z, ww = q[b]
+        q[b] = [ww * s[0] + x * s[3] + y * s[2] - z * s[1], ww * s[1] - x * s[2] + y * s[3] + z * s[0],
+                ww * s[2] + x * s[1] - y * s[0] + z * s[3], ww * s[3] - x * s[0] - y * s[1] - z * s[2]]
+    return q, t
+
+
 def bezier_reference(x, x1, y1, x2, y2):
     """host/vmd-sampler.js bezier() in float64: y(x) of the cubic (0,0) (x1,y1) (x2,y2) (1,1)."""
     if x <= 0:

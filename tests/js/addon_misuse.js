@@ -43,6 +43,14 @@ if (process.argv[2] === '--live') { // on a GPU box: the same with a LIVE contex
   let threwOv = false
   try { a.overrideWorld(ctx, new Uint32Array([1]), new Float32Array(15), null) } catch (e) { threwOv = e instanceof Error }
   if (!threwOv) throw new Error('overrideWorld accepted a short matrix array')
+  let threwBm = 0
+  for (const args of [[new Uint32Array([0]), new Uint32Array([0, 1]), new Float32Array(3), new Float32Array(4)],
+    [new Uint32Array([0]), new Uint32Array([0]), new Float32Array(2), new Float32Array(4)], [new Uint32Array([0]), null, null, null],
+    [new Uint32Array([0]), new Uint32Array([0]), new Float32Array(3), new Float32Array(4)] /* no topology on this context */]) {
+    try { a.uploadBoneMorphs(ctx, ...args) } catch (e) { threwBm += e instanceof Error ? 1 : 0 }
+  }
+  if (threwBm !== 4) throw new Error('uploadBoneMorphs accepted ' + (4 - threwBm) + ' malformed calls')
+  a.uploadBoneMorphs(ctx, null, null, null, null)   // n = 0 clears, always legal
   a.setPose(ctx, ib, null); a.deform(ctx)           // still usable
   const pos = new Float32Array(V * 3), nrm = new Float32Array(V * 3)
   a.read(ctx, 0, 0, V, pos, nrm)

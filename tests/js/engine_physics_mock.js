@@ -7,7 +7,7 @@ const path = require('path')
 const { Engine, Model } = require(path.join(__dirname, '..', '..', 'reze-engine_amd', 'host'))
 const calls = []
 const native = {
-  create: () => ({}), destroy: () => {}, uploadMesh: () => {}, uploadSkeleton: () => {}, uploadSkeletonTopology: () => calls.push(['topology']),
+  create: () => ({}), destroy: () => {}, uploadMesh: () => {}, uploadSkeleton: () => {}, uploadSkeletonTopology: () => calls.push(['topology']), uploadBoneMorphs: () => calls.push(['boneMorphs']),
   setPose: (c, w) => calls.push(['setPose', Array.from(w)]), setPoseLocal: () => calls.push(['setPoseLocal']), deform: () => calls.push(['deform']),
   overrideWorld: (c, b, w, i) => calls.push(['overrideWorld', b && Array.from(b), w && Array.from(w), i && Array.from(i)]),
   read: () => {}, shardRange: (v) => [0, v],

@@ -4,6 +4,7 @@
  *   parse <pmx> <outdir>                 -> vertices/joints/weights/invbind/indices + info.json (+ morphs)
  *   pose  <fixture.json> <outdir>        -> FK from a skeleton description: world matrices for pose0 + tweens
  *   vmd   <vmd> <out.json>
+ *   bonemorph <pmx> <spec.json> <outdir> -> world matrices with / without the morph weights of the spec applied
  */
 const fs = require('fs'), path = require('path')
 const host = require(path.join(__dirname, '..', '..', 'reze-engine_amd', 'host'))
@@ -27,6 +28,8 @@ if (mode === 'parse') {
     info.morphNames = mo.names; info.morphTypes = Array.from(mo.types); info.morphGroups = mo.groups
     dump(path.join(out, 'morph_offsets.u32'), mo.offsets); dump(path.join(out, 'morph_vidx.u32'), mo.vertexIndex)
     dump(path.join(out, 'morph_deltas.f32'), mo.deltas)
+    const be = mo.boneEntries
+    info.boneMorph = { morph: Array.from(be.morph), bone: Array.from(be.bone), translation: Array.from(be.translation), rotation: Array.from(be.rotation) }
   }
   fs.writeFileSync(path.join(out, 'info.json'), JSON.stringify(info))
 } else if (mode === 'pose') {
@@ -60,6 +63,23 @@ if (mode === 'parse') {
   now = 1500
   model.evaluatePose()
   dump(path.join(out, 'world_tween500.f32'), model.getBoneWorldMatrices())
+} else if (mode === 'bonemorph') {
+  const m = PmxLoader.loadFromBuffer(fs.readFileSync(process.argv[3]))
+  const spec = JSON.parse(fs.readFileSync(process.argv[4], 'utf8'))
+  const out = process.argv[5]
+  const bones = m.getSkeleton().bones
+  m.setClock(() => 0)
+  m.rotateBones(bones.map((b) => b.name), spec.rot.map((q) => new Quat(q[0], q[1], q[2], q[3])), 0)
+  m.evaluatePose()
+  dump(path.join(out, 'world_unmorphed.f32'), m.getBoneWorldMatrices())
+  m.setMorphWeights(Object.keys(spec.weights), Object.values(spec.weights))
+  dump(path.join(out, 'effective.f32'), m.getEffectiveMorphWeights())
+  m.evaluatePose()
+  dump(path.join(out, 'world_morphed.f32'), m.getBoneWorldMatrices())
+  dump(path.join(out, 'localrot_after.f32'), m.runtimeSkeleton.localRotations)
+  fs.writeFileSync(path.join(out, 'bm_info.json'), JSON.stringify({ parents: bones.map((b) => b.parentIndex), bind: bones.map((b) => b.bindTranslation),
+    appendParent: bones.map((b) => (b.appendRotate && b.appendParentIndex !== undefined && b.appendParentIndex !== null ? b.appendParentIndex : -1)),
+    appendRatio: bones.map((b) => (b.appendRatio === undefined || b.appendRatio === null ? 1 : b.appendRatio)) }))
 } else if (mode === 'vmd') {
   const k = VMDLoader.loadFromBuffer(fs.readFileSync(process.argv[3]))
   fs.writeFileSync(process.argv[4], JSON.stringify({

@@ -11,7 +11,9 @@ def _text(s):
 
 def write_pmx(V=5000, B=40, n_vertex_morphs=6, seed=5, max_depth=None):
     """A PMX with V vertices (BDEF1/2/4 mix), a B-bone tree (one append-rotate bone), `n_vertex_morphs`
-    sparse vertex morphs named v0.., plus 'blink' (vertex) and 'grp' (group of v0 x0.5 + blink x1.0)."""
+    sparse vertex morphs named v0.., plus 'blink' (vertex), 'twist' (a BONE morph, PMX type 2: bone 1 — the append parent of
+    bone B/2 — bone 3 — whose translation the append-move bone follows — and bone 7) and 'grp' (group of v0 x0.5 + blink x1.0
+    + twist x0.5)."""
     rng = np.random.default_rng(seed)
     out = bytearray(b"PMX ") + struct.pack("<f", 2.0) + bytes([8, 0, 0, 4, 1, 1, 2, 2, 1])
     out += _text("synthetic") + _text("") + _text("") + _text("")
@@ -56,7 +58,7 @@ def write_pmx(V=5000, B=40, n_vertex_morphs=6, seed=5, max_depth=None):
         elif flags == 0x0300:
             out += struct.pack("<hf", 3, 1.5)
     names = ["v%d" % i for i in range(n_vertex_morphs)] + ["blink"]
-    out += struct.pack("<i", len(names) + 1)
+    out += struct.pack("<i", len(names) + 2)
     for n in names:
         k = int(rng.integers(V // 50, V // 10))
         start = int(rng.integers(0, V - k))
@@ -65,7 +67,14 @@ def write_pmx(V=5000, B=40, n_vertex_morphs=6, seed=5, max_depth=None):
         out += _text(n) + _text("") + bytes([1, 1]) + struct.pack("<i", len(idx))
         for i in range(len(idx)):
             out += struct.pack("<i", int(idx[i])) + d[i].tobytes()
-    out += _text("grp") + _text("") + bytes([1, 0]) + struct.pack("<i", 2) + struct.pack("<hf", 0, 0.5) + struct.pack("<hf", len(names) - 1, 1.0)
+    twist = [(1, (0.0, 0.0, 0.0), (0.0, 0.0, 0.38268343, 0.92387953)), (3, (0.4, -0.3, 0.2), (0.25881905, 0.0, 0.0, 0.96592583)),
+             (7, (0.0, 0.5, 0.0), (0.0, -0.5, 0.0, 0.8660254))]
+    twist = [e for e in twist if e[0] < B]
+    out += _text("twist") + _text("") + bytes([1, 2]) + struct.pack("<i", len(twist))
+    for b, t, q in twist:
+        out += struct.pack("<h", b) + struct.pack("<3f", *t) + struct.pack("<4f", *q)
+    out += _text("grp") + _text("") + bytes([1, 0]) + struct.pack("<i", 3) + struct.pack("<hf", 0, 0.5) + struct.pack("<hf", len(names) - 1, 1.0)
+    out += struct.pack("<hf", len(names), 0.5)
     out += struct.pack("<i", 0) + struct.pack("<i", 0) + struct.pack("<i", 0)      # display frames, rigid bodies, joints
     return bytes(out)
 

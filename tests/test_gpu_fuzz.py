@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_hull, assert_parity, fk_reference, sample_reference
+from helpers import assert_hull, assert_parity, bone_morph_reference, fk_reference, sample_reference
 from reze_engine_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -37,8 +37,30 @@ class Walk:
         self.kind, self.topology, self.edge = None, False, None      # a new mesh drops morphs / edge scale; new skeleton: topology
         self.anim = None                                               # ... and the motion was flattened for the old skeleton
         self.M = 0
+        self.bm = None                                                 # bone morphs name bones of the old skeleton
+
+    def new_bone_morphs(self):
+        """PMX bone morphs for device-solved poses: a random entry set (or none) over the current skeleton and morph set."""
+        B, rng = len(self.mesh["parents"]), self.rng
+        n = int(rng.choice([0, 1, 5, 30]))
+        if n == 0:
+            self.c.upload_bone_morphs([], [], [], [])
+            self.bm = None
+            return
+        q = rng.normal(size=(n, 4)).astype(np.float32)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        self.bm = (rng.integers(0, self.M, size=n).astype(np.uint32), rng.integers(0, B, size=n).astype(np.uint32),
+                   (rng.random((n, 3), dtype=np.float32) - 0.5), q)
+        self.c.upload_bone_morphs(*self.bm)
+
+    def morphed(self, q, t, w):
+        if self.bm is None:
+            return q, t
+        o = np.argsort(self.bm[0], kind="stable")
+        return bone_morph_reference(q, t, self.bm[0][o], self.bm[1][o], self.bm[2][o], self.bm[3][o], w)
 
     def new_morphs(self):
+        self.bm = None                                                 # ... and morphs of the old set
         V = len(self.mesh["pos"])
         which = self.rng.choice(["dense", "sparse", "none"])
         if which == "none":
@@ -116,6 +138,8 @@ class Walk:
                 a = self.anim
                 self.c.upload_animation(a["track_bone"], a["key_off"], a["key_frame"], a["key_rot"], a["key_pos"], a["key_interp"],
                                         a.get("mkey_off"), a.get("mkey_frame"), a.get("mkey_weight"), a.get("feed_off"), a.get("feed_track"), a.get("feed_ratio"))
+            if self.M and rng.random() < 0.3:
+                self.new_bone_morphs()
             fr = (rng.random(I) * 30 - 3).astype(np.float32)
             self.c.set_pose_sampled(fr)
             mw = None
@@ -126,6 +150,8 @@ class Walk:
             q = rng.normal(size=(I, B, 4)).astype(np.float32)
             q /= np.linalg.norm(q, axis=2, keepdims=True)
             t = (rng.random((I, B, 3), dtype=np.float32) - 0.5) if rng.random() < 0.5 else None
+            if self.M and rng.random() < 0.3:
+                self.new_bone_morphs()
             self.c.set_pose_local(q, mw, t)
         else:
             worlds = np.stack([synth.make_pose(m["parents"], m["bind"], B, seed=int(rng.integers(1 << 30))) for _ in range(I)])
@@ -144,10 +170,10 @@ class Walk:
         world = self.c.read_world(i) if local else worlds[i]
         if sampled:
             qs, ts, ws = sample_reference(self.anim, float(fr[i]), B, self.M if self.anim.get("mkey_off") is not None else 0)
-            ref = fk_reference(m["parents"], m["bind"], qs, ts)
+            ref = fk_reference(m["parents"], m["bind"], *self.morphed(qs, ts, ws))
             assert np.abs(world - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
         elif local:
-            ref = fk_reference(m["parents"], m["bind"], q[i], None if t is None else t[i])
+            ref = fk_reference(m["parents"], m["bind"], *self.morphed(q[i], None if t is None else t[i], np.zeros(self.M) if mw is None else mw[i]))
             assert np.abs(world - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
         w = np.zeros(self.M, dtype=np.float32) if mw is None else mw[i]     # no weights given: all zero
         if sampled and self.M and self.anim.get("mkey_off") is not None:

@@ -76,6 +76,9 @@ expect_fail("ablation key absent from the product", L.rz_set_tuning(h, b"dbg", 3
 expect_fail("inst_block 300", L.rz_set_tuning(h, b"inst_block", 300))
 expect_fail("overlap 7", L.rz_set_tuning(h, b"overlap", 7))
 expect_fail("override_world without topology", L.rz_override_world(h, 1, N, (ctypes.c_uint32 * 1)(0), m["world"].ctypes.data_as(fp)))
+u1 = (ctypes.c_uint32 * 1)(0)
+expect_fail("bone morphs without topology", L.rz_upload_bone_morphs(h, 1, u1, u1, m["bind"].ctypes.data_as(fp), m["quats"].ctypes.data_as(fp)))
+if L.rz_upload_bone_morphs(h, 0, N, N, N, N) != 0: bad.append("rz_upload_bone_morphs(n = 0) clears and is always legal")
 if L.rz_rccl_info(N, 0, N, N) not in (0, -6): bad.append("rccl_info(NULLs) must be OK or UNSUPPORTED")
 expect_fail("tuning NULL key", L.rz_set_tuning(h, N, 1))
 expect_fail("get_tuning NULL out", L.rz_get_tuning(h, b"bones", N))

@@ -482,7 +482,7 @@ def test_engine_device_sampling_matches_host_sampling_through_napi(tmp_path):
          ("bone3", 0, (s, 0, 0, 0.92387953), (0.3, -0.2, 0.1)), ("bone3", 20, (0, 0, s, 0.92387953), (-0.5, 0.4, 0.25), curve),
          ("bone0", 0, (0, 0, 0, 1), (0, 0.5, 0)), ("bone0", 25, (0, 0, 0, 1), (1.0, 0.25, -0.5), curve), ("bone20", 30, (0, 0, -s, 0.92387953)),
          ("nosuchbone", 5, (0, 0, 0, 1))],
-        [("v1", 0, 0.8), ("v1", 20, 0.1), ("v2", 6, 0.4), ("grp", 0, 0.0), ("grp", 30, 1.0), ("blink", 10, 0.5)]))
+        [("v1", 0, 0.8), ("v1", 20, 0.1), ("v2", 6, 0.4), ("grp", 0, 0.0), ("grp", 30, 1.0), ("blink", 10, 0.5), ("twist", 0, 0.2), ("twist", 30, 0.9)]))
     for layout, devs in (("sparse", "0"), ("dense", "0,0")):
         out = tmp_path / (layout + devs.replace(",", "_"))
         out.mkdir()

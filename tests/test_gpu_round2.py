@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_parity, fk_reference, sample_reference
+from helpers import assert_parity, bone_morph_reference, fk_reference, sample_reference
 from reze_engine_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -545,4 +545,142 @@ def test_fused_hierarchy_solve_is_the_same_frame(rz, oracle, morphs):
             assert np.abs(fused[1] - world).max() <= 1e-4 * max(1.0, np.abs(world).max())
             pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], fused[1], mesh["inv_bind"], deltas, np.asarray(ws, np.float32) if M else None)
             assert_parity(fused[0][0], fused[0][1], pr, nr, "fused frame (%s, %s, overrides=%s)" % (kind, morphs, overrides))
+    c.close()
+
+
+@pytest.mark.parametrize("morphs", ["bone-only", "dense", "sparse"])
+def test_bone_morphs_fold_into_device_solved_poses(rz, oracle, morphs):
+    """PMX bone morphs (type 2; SURVEY §8f rank 3 — no reference counterpart, pmx-loader.ts:489-497 only skips them): entry
+    (morph, bone, t, q) adds w * t to the bone's local translation and right-multiplies its rotation by slerp(I, q, w), w = the
+    pose's weight of that morph, entries of a bone in ascending morph order, before append rotation and the hierarchy solve.
+    Device-solved poses only: local rotations (three-kernel and fused frame), sampled poses (weights from morph tracks, sampled
+    in the same kernel), one character and a crowd. World matrices vs the float64 restatement, mesh vs the oracle."""
+    V, B = 6000, 120
+    mesh = synth.make_mesh(V, B, seed=71)
+    rng = np.random.default_rng(72)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    deltas = None
+    if morphs == "dense":
+        M = 20
+        deltas, _ = synth.make_morphs_dense(V, M, seed=73)
+        deltas[M - 6:] = 0                                    # the last six morphs are bone morphs: no vertex deltas
+        c.upload_morphs_dense(deltas)
+    elif morphs == "sparse":
+        M = 20
+        off, vi, d3, _ = synth.make_morphs_sparse(V, M, seed=73)
+        c.upload_morphs_sparse(off, vi, d3)
+        deltas = synth.sparse_to_dense(V, off, vi, d3)
+    else:                                                     # a model whose only morphs are bone morphs (the reference's 武器.pmx)
+        M = 6
+        c.upload_morphs_sparse(np.zeros(M + 1, np.uint32), np.zeros(0, np.uint32), np.zeros((0, 3), np.float32))
+        deltas = np.zeros((M, V, 3), np.float32)
+    ap = np.full(B, -1, dtype=np.int32)
+    ratio = np.ones(B, dtype=np.float32)
+    move = np.zeros(B, dtype=np.uint8)
+    for k, b in enumerate(rng.choice(B, size=12, replace=False)):
+        ap[b] = int(rng.integers(0, B)); ratio[b] = [0.5, -0.75, 1.5, 1.0][k % 4]; move[b] = k % 2
+    with pytest.raises(rz.RzError):                           # needs the topology (device-solved poses)
+        c.upload_bone_morphs([0], [0], np.zeros(3), [0, 0, 0, 1])
+    c.upload_skeleton_topology(mesh["parents"], mesh["bind"], ap, ratio, move)
+    # 16 entries over the six bone morphs; some bones are moved by several morphs, two entries share (morph, bone);
+    # the append parents are among the morphed bones so their children must follow the morphed rotation
+    n = 16
+    bm_m = np.sort(rng.integers(M - 6, M, size=n)).astype(np.uint32)
+    targets = np.concatenate([ap[ap >= 0][:4], rng.integers(0, B, size=6)])
+    bm_b = targets[rng.integers(0, len(targets), size=n)].astype(np.uint32)
+    bm_b[1], bm_m[1] = bm_b[0], bm_m[0]
+    bm_t = ((rng.random((n, 3)) - 0.5) * 0.8).astype(np.float32)
+    bm_q = rng.normal(size=(n, 4)).astype(np.float32)
+    bm_q /= np.linalg.norm(bm_q, axis=1, keepdims=True)
+    bm_q[2] = [0.0, 0.0, 0.01, 1.0]; bm_q[2] /= np.linalg.norm(bm_q[2])       # the near-identity (lerp) branch of slerp
+    perm = rng.permutation(n)                                  # the ABI takes entries in any order and folds equal (bone, morph) in the order given
+    bm_m, bm_b, bm_t, bm_q = bm_m[perm], bm_b[perm], bm_t[perm], bm_q[perm]
+    for bad in (dict(morph=[M]), dict(bone=[B]), dict(t=[np.nan, 0, 0]), dict(q=[0, np.inf, 0, 1])):
+        with pytest.raises(rz.RzError):
+            c.upload_bone_morphs(bad.get("morph", [0]), bad.get("bone", [0]), bad.get("t", [0, 0, 0]), bad.get("q", [0, 0, 0, 1]))
+    order = np.argsort(bm_m, kind="stable")                    # ascending morph; ties in given order — what the restatement folds
+    c.upload_bone_morphs(bm_m, bm_b, bm_t, bm_q)
+    nk = 4
+    kq = rng.normal(size=(B, nk, 4)).astype(np.float32)
+    kq /= np.linalg.norm(kq, axis=2, keepdims=True)
+    anim = dict(track_bone=np.arange(B), key_off=np.arange(B + 1) * nk, key_frame=np.tile(np.arange(nk) * 10.0, B), key_rot=kq,
+                key_pos=(rng.random((B, nk, 3), dtype=np.float32) - 0.5) * 0.4, key_interp=rng.integers(0, 128, size=(B * nk, 16)).astype(np.uint8))
+    # morph tracks: one per morph + one "group" track feeding the last bone morph at ratio 0.5 (group morphs feed bone morphs too)
+    mkw = (rng.random(2 * (M + 1)) * (rng.random(2 * (M + 1)) < 0.85)).astype(np.float32)
+    feed_off = np.concatenate([np.arange(M), [M + 1]]).astype(np.uint32)
+    anim.update(mkey_off=np.arange(M + 2) * 2, mkey_frame=np.tile(np.array([0.0, 30.0], np.float32), M + 1), mkey_weight=mkw,
+                feed_off=feed_off, feed_track=np.arange(M + 1), feed_ratio=np.concatenate([np.ones(M), [0.5]]).astype(np.float32))
+    c.upload_animation(anim["track_bone"], anim["key_off"], anim["key_frame"], anim["key_rot"], anim["key_pos"], anim["key_interp"],
+                       anim["mkey_off"], anim["mkey_frame"], anim["mkey_weight"], anim["feed_off"], anim["feed_track"], anim["feed_ratio"])
+
+    def expect(q, t, w):
+        q2, t2 = bone_morph_reference(q, t, bm_m[order], bm_b[order], bm_t[order], bm_q[order], w)
+        return fk_reference(mesh["parents"], mesh["bind"], q2, t2, ap, ratio, move)
+
+    def check(got_world, got_mesh, q, t, w, what):
+        world = expect(q, t, w)
+        assert np.abs(got_world - world).max() <= 1e-4 * max(1.0, np.abs(world).max()), what
+        plain = fk_reference(mesh["parents"], mesh["bind"], q, t, ap, ratio, move)
+        assert np.abs(world - plain).max() > 1e-2, "the morphs of this case must move something"
+        pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], got_world, mesh["inv_bind"], deltas, np.asarray(w, np.float32))
+        assert_parity(got_mesh[0], got_mesh[1], pr, nr, what)
+
+    q = rng.normal(size=(B, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    t = (rng.random((B, 3), dtype=np.float32) - 0.5)
+    mw = rng.random(M).astype(np.float32)
+    mw[M - 5] = 0.0                                            # a bone morph at rest is skipped, not slerped by 0
+    worlds = {}
+    for fuse in (0, 1):
+        c.set_tuning(fuse_fk=fuse)
+        for with_t in (True, False):                           # without uploaded translations the morphs' translations still apply
+            c.set_pose_local(q, mw, t if with_t else None)
+            assert c.get_tuning("effective_fuse_fk") == fuse
+            c.deform()
+            got = (c.read_world(0), c.read())
+            check(got[0], got[1], q, t if with_t else np.zeros((B, 3)), mw, "local pose, fuse_fk=%d, translations=%s" % (fuse, with_t))
+            worlds[(fuse, with_t)] = got
+        c.set_pose_sampled(np.array([17.25], np.float32))
+        c.deform()
+        got = (c.read_world(0), c.read())
+        qs, ts, ws = sample_reference(anim, 17.25, B, M)
+        check(got[0], got[1], qs, ts, ws, "sampled pose, fuse_fk=%d" % fuse)
+        worlds[(fuse, "sampled")] = got
+    for key in (True, False, "sampled"):                       # one launch or three: the same bits
+        assert np.array_equal(worlds[(0, key)][0], worlds[(1, key)][0]) and np.array_equal(worlds[(0, key)][1][0], worlds[(1, key)][1][0])
+    # all weights zero = the plain solve, bit for bit
+    c.set_tuning(fuse_fk=-1)
+    c.set_pose_local(q, np.zeros(M, np.float32), t)
+    c.deform()
+    w0 = c.read_world(0)
+    c.upload_bone_morphs([], [], [], [])
+    c.set_pose_local(q, np.zeros(M, np.float32), t)
+    c.deform()
+    assert np.array_equal(w0, c.read_world(0))
+    # a crowd: every instance folds its own weights
+    c.upload_bone_morphs(bm_m, bm_b, bm_t, bm_q)
+    I = 3
+    c.set_instances(I)
+    qI = rng.normal(size=(I, B, 4)).astype(np.float32)
+    qI /= np.linalg.norm(qI, axis=2, keepdims=True)
+    mwI = rng.random((I, M)).astype(np.float32)
+    c.set_pose_local(qI, mwI, None)
+    c.deform()
+    for i in range(I):
+        check(c.read_world(i), c.read(instance=i), qI[i], np.zeros((B, 3)), mwI[i], "crowd instance %d, local" % i)
+    frames = np.array([3.5, 17.25, 29.0], np.float32)
+    c.set_pose_sampled(frames)
+    c.deform()
+    for i in range(I):
+        qs, ts, ws = sample_reference(anim, float(frames[i]), B, M)
+        check(c.read_world(i), c.read(instance=i), qs, ts, ws, "crowd instance %d, sampled" % i)
+    # a new morph set drops the entries (they name morphs of the old set)
+    c.set_instances(1)
+    c.upload_morphs_sparse(np.zeros(3, np.uint32), np.zeros(0, np.uint32), np.zeros((0, 3), np.float32))
+    c.set_pose_local(q, np.ones(2, np.float32), t)
+    c.deform()
+    plain = fk_reference(mesh["parents"], mesh["bind"], q, t, ap, ratio, move)
+    assert np.abs(c.read_world(0) - plain).max() <= 1e-4 * max(1.0, np.abs(plain).max())
     c.close()

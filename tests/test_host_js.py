@@ -224,9 +224,16 @@ def write_pmx(bone_index_size=1, vertex_index_size=2):
     for k, v in enumerate([1, 4, 6]):
         out += struct.pack(vi, v) + d0[k].tobytes()
     morphs.append(("smile", 1, [1, 4, 6], d0))
-    out += pmx_text("grp") + pmx_text("") + bytes([1, 0]) + struct.pack("<i", 2) + struct.pack("<bf", 0, 0.5) + struct.pack("<bf", 5, 2.0)
-    morphs.append(("grp", 0, [(0, 0.5), (5, 2.0)], None))
-    out += pmx_text("bonem") + pmx_text("") + bytes([1, 2]) + struct.pack("<i", 1) + struct.pack(bi, 1) + struct.pack("<7f", *([0.0] * 7))
+    out += pmx_text("grp") + pmx_text("") + bytes([1, 0]) + struct.pack("<i", 3) + struct.pack("<bf", 0, 0.5) + struct.pack("<bf", 5, 2.0) + struct.pack("<bf", 2, 0.25)
+    morphs.append(("grp", 0, [(0, 0.5), (5, 2.0), (2, 0.25)], None))
+    # bone morph: bone 1 and bone 3 (the append child of 1), plus an entry naming a bone the model lacks (dropped)
+    bq = rng.normal(size=(3, 4))
+    bq = (bq / np.linalg.norm(bq, axis=1, keepdims=True)).astype(np.float32)
+    bt = rng.normal(size=(3, 3)).astype(np.float32)
+    bone_of = [1, 3, 9 if bone_index_size == 1 else 77]
+    out += pmx_text("bonem") + pmx_text("") + bytes([1, 2]) + struct.pack("<i", 3)
+    for k in range(3):
+        out += struct.pack(bi, bone_of[k]) + bt[k].tobytes() + bq[k].tobytes()
     morphs.append(("bonem", 2, [], None))
     out += pmx_text("uvm") + pmx_text("") + bytes([1, 3]) + struct.pack("<i", 2) + (struct.pack(vi, 0) + struct.pack("<4f", 0, 0, 0, 0)) * 2
     morphs.append(("uvm", 3, [], None))
@@ -242,7 +249,8 @@ def write_pmx(bone_index_size=1, vertex_index_size=2):
     out += struct.pack("<i", 1) + pmx_text("rb") + pmx_text("") + struct.pack(bi, 1) + bytes([0]) + struct.pack("<H", 0xFFFF) + bytes([0])
     out += struct.pack("<9f", *([1.0] * 9)) + struct.pack("<5f", 1, 0.5, 0.5, 0, 0.5) + bytes([1])
     out += struct.pack("<i", 1) + pmx_text("jt") + pmx_text("") + bytes([0]) + struct.pack("<bb", 0, 0) + struct.pack("<24f", *([0.0] * 24))
-    return bytes(out), dict(pos=pos, nrm=nrm, uv=uv, joints=exp_j, weights=exp_w, bpos=bpos, parents=parents, morphs=morphs, idx=idx)
+    return bytes(out), dict(pos=pos, nrm=nrm, uv=uv, joints=exp_j, weights=exp_w, bpos=bpos, parents=parents, morphs=morphs, idx=idx,
+                            bone_morph=dict(morph=[2, 2], bone=[1, 3], t=bt[:2], q=bq[:2]))
 
 
 @pytest.mark.parametrize("bone_index_size,vertex_index_size", [(1, 1), (2, 2), (4, 4)])
@@ -279,7 +287,46 @@ def test_pmx_parser_on_synthetic_file(tmp_path, bone_index_size, vertex_index_si
     assert off.tolist() == [0, 3, 3, 3, 3, 3, 5]
     assert vidx.tolist() == [1, 4, 6, 0, 7]
     assert np.array_equal(dl[:3], exp["morphs"][0][3]) and np.array_equal(dl[3:], exp["morphs"][5][3])
-    assert info["morphGroups"][1] == [[0, 0.5], [5, 2.0]]
+    assert info["morphGroups"][1] == [[0, 0.5], [5, 2.0], [2, 0.25]]
+    # bone-morph entries (type 2): 28 bytes behind the bone index; the entry naming a missing bone is dropped
+    bm = exp["bone_morph"]
+    assert info["boneMorph"]["morph"] == bm["morph"] and info["boneMorph"]["bone"] == bm["bone"]
+    assert np.array_equal(np.array(info["boneMorph"]["translation"], dtype=np.float32).reshape(-1, 3), bm["t"])
+    assert np.array_equal(np.array(info["boneMorph"]["rotation"], dtype=np.float32).reshape(-1, 4), bm["q"])
+
+
+def test_bone_morphs_move_the_local_pose_before_the_hierarchy_solve(tmp_path):
+    """PMX bone morphs (type 2, no reference counterpart: pmx-loader.ts:489-497 skips them). Host FK with a bone morph fed
+    by its own weight AND a group morph, on a skeleton with an append child of the morphed bone, against the float64
+    restatement (helpers.bone_morph_reference + fk_reference). Weight 0 must leave the reference-pinned path untouched."""
+    from helpers import bone_morph_reference, fk_reference
+    data, exp = write_pmx(1, 2)
+    f = tmp_path / "t.pmx"
+    f.write_bytes(data)
+    rng = np.random.default_rng(11)
+    q = rng.normal(size=(5, 4))
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    spec = dict(rot=q.tolist(), weights={"bonem": 0.6, "grp": 0.4, "smile": 0.3})
+    (tmp_path / "spec.json").write_text(json.dumps(spec))
+    node("bonemorph", str(f), str(tmp_path / "spec.json"), str(tmp_path))
+    eff = np.fromfile(str(tmp_path / "effective.f32"), dtype=np.float32)
+    assert np.allclose(eff, [0.3 + 0.4 * 0.5, 0, np.float32(0.6) + np.float32(0.4) * 0.25, 0, 0, 0.4 * 2.0], atol=1e-7)
+    info = json.load(open(tmp_path / "bm_info.json"))
+    bm = exp["bone_morph"]
+    parents, bind = info["parents"], np.array(info["bind"])
+    ap, ar = np.array(info["appendParent"]), np.array(info["appendRatio"])
+    q2, t2 = bone_morph_reference(q, np.zeros((5, 3)), bm["morph"], bm["bone"], bm["t"], bm["q"], eff)
+    assert not np.allclose(q2[1], q[1]) and not np.allclose(q2[3], q[3]) and np.array_equal(q2[0], q[0].astype(np.float64))
+    want = fk_reference(parents, bind, q2, t2, ap, ar, np.zeros(5, dtype=bool))
+    got = np.fromfile(str(tmp_path / "world_morphed.f32"), dtype=np.float32).reshape(-1, 16)
+    assert np.abs(got - want).max() < 5e-6, np.abs(got - want).max()
+    # the morphed bone's append child (bone 3, ratio 0.5) follows the MORPHED rotation of bone 1
+    plain = fk_reference(parents, bind, q, None, ap, ar, None)
+    assert np.abs(got[3] - plain[3]).max() > 1e-3
+    rest = np.fromfile(str(tmp_path / "world_unmorphed.f32"), dtype=np.float32).reshape(-1, 16)
+    assert np.abs(rest - plain).max() < 5e-6
+    # runtime state (tweens / animation) is never written by a morph
+    assert np.array_equal(np.fromfile(str(tmp_path / "localrot_after.f32"), dtype=np.float32).reshape(-1, 4), q)
 
 
 def test_vmd_parser_bone_and_morph_blocks(tmp_path):
@@ -350,7 +397,7 @@ def test_addon_exports_and_loud_failure_without_gpu():
     for k in ("create", "destroy", "uploadMesh", "uploadSkeleton", "uploadMorphsDense", "uploadMorphsSparse", "setInstances",
               "setPose", "deform", "sync", "read", "timeFrames", "commUniqueId", "commInit", "allgather", "shardRange",
               "uploadSkeletonTopology", "setPoseLocal", "readWorld", "autotune", "gatherDirect", "gatherFence", "readGathered",
-              "overrideWorld", "rcclInfo", "uploadAnimation", "setPoseSampled"):
+              "overrideWorld", "rcclInfo", "uploadAnimation", "setPoseSampled", "uploadBoneMorphs"):
         assert k in r["keys"], k
     import re
     header = open(os.path.join(ROOT, "include", "reze_deform.h")).read()
