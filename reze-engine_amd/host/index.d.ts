@@ -55,6 +55,7 @@ export class Engine {
   playAnimation(options?: { breathBones?: string[] | Record<string, number>; breathDuration?: number }): void
   stopAnimation(): void
   rotateBones(bones: string[], rotations: Quat[], durationMs?: number): void
+  /** Vertex morphs move vertices, bone morphs (PMX type 2) move bones before the hierarchy solve, group morphs feed both. */
   setMorphWeights(namesOrIndices: Array<string | number>, weights: number[]): void
   render(): void
   step(timeMs: number): void

@@ -684,3 +684,29 @@ def test_bone_morphs_fold_into_device_solved_poses(rz, oracle, morphs):
     plain = fk_reference(mesh["parents"], mesh["bind"], q, t, ap, ratio, move)
     assert np.abs(c.read_world(0) - plain).max() <= 1e-4 * max(1.0, np.abs(plain).max())
     c.close()
+
+
+@pytest.mark.parametrize("fuse", [0, 1])
+def test_real_bone_morph_on_the_device_against_reference_execution(rz, oracle, fuse):
+    """The reference's 武器.pmx bone morph through the device path: rz_upload_bone_morphs + rz_set_pose_local (base rotations, the
+    morph's weight riding with the morph weights), hierarchy solved on the GPU. World matrices and the skinned half of the mesh
+    against what the REFERENCE's own quaternion, hierarchy and matrix code produced (tests/golden/ref_bone_morph.npz)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_bone_morph.npz"))
+    v = g["vertices"]
+    B = len(g["parents"])
+    c = rz.DeformContext(0)
+    c.upload_mesh(v[:, 0:3], v[:, 3:6], g["joints"], g["weights"])
+    c.upload_skeleton(g["inv_bind"])
+    c.upload_morphs_sparse(np.zeros(2, np.uint32), np.zeros(0, np.uint32), np.zeros((0, 3), np.float32))     # one morph, a bone morph: no vertex deltas
+    c.upload_skeleton_topology(g["parents"], g["bind"].astype(np.float32))
+    c.upload_bone_morphs(g["entry_morph"], g["entry_bone"], g["entry_translation"], g["entry_rotation"])
+    c.set_tuning(fuse_fk=fuse)
+    for k, w in enumerate(g["morph_weights"]):
+        c.set_pose_local(g["base_rotations"], np.array([w], np.float32), None)
+        assert c.get_tuning("effective_fuse_fk") == fuse
+        c.deform()
+        world = c.read_world(0)
+        assert world.shape == (B, 16) and np.abs(world - g["world"][k]).max() <= 1e-5 * max(1.0, np.abs(g["world"][k]).max()), (k, np.abs(world - g["world"][k]).max())
+        pg, ng = c.read()
+        assert_parity(pg, ng, g["skinned"][k][:, 0:3], g["skinned"][k][:, 3:6], "device bone morph vs reference execution, weight %g" % w)
+    c.close()

@@ -128,6 +128,29 @@ def test_parsers_reproduce_reference_arrays_on_real_assets(tmp_path, gold):
         assert json.load(open(o))["keyTimes"] == ref[name]["keyTimes"]
 
 
+@pytest.mark.skipif(not os.path.isdir(ASSETS), reason="reference assets only exist in the build container")
+def test_real_bone_morph_through_the_host_loader_and_model(tmp_path):
+    """武器.pmx, the one reference asset with a bone morph ("变形", two entries): this build's loader must find the entries the
+    fixture was generated from, and the host Model must reproduce the world matrices the REFERENCE's Quat.slerp / multiply /
+    rotateBones / evaluatePose produced for them (tests/golden/ref_bone_morph.npz, tools/ref_bone_morph_run.py)."""
+    g = np.load(os.path.join(GOLD, "ref_bone_morph.npz"))
+    pmx = os.path.join(ASSETS, "models/塞尔凯特/武器.pmx")
+    out = tmp_path / "parse"
+    out.mkdir()
+    node("parse", pmx, str(out))
+    bm = json.load(open(out / "info.json"))["boneMorph"]
+    assert bm["morph"] == g["entry_morph"].tolist() and bm["bone"] == g["entry_bone"].tolist()
+    assert np.array_equal(np.array(bm["rotation"], np.float32).reshape(-1, 4), g["entry_rotation"])
+    assert np.array_equal(np.array(bm["translation"], np.float32).reshape(-1, 3), g["entry_translation"])
+    for k, w in enumerate(g["morph_weights"].tolist()):
+        o = tmp_path / ("w%d" % k)
+        o.mkdir()
+        (o / "spec.json").write_text(json.dumps(dict(rot=g["base_rotations"].astype(np.float64).tolist(), weights={"变形": w})))
+        node("bonemorph", pmx, str(o / "spec.json"), str(o))
+        world = np.fromfile(str(o / "world_morphed.f32"), dtype=np.float32).reshape(-1, 16)
+        assert np.abs(world - g["world"][k]).max() < 2e-6 * max(1.0, np.abs(g["world"][k]).max()), (k, np.abs(world - g["world"][k]).max())
+
+
 # ---------------------------------------------------------------------------------------------
 # synthetic byte-level files
 # ---------------------------------------------------------------------------------------------

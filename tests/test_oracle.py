@@ -293,3 +293,28 @@ def test_wgsl_interpreter_on_hand_computed_cases():
     for bad in ("fn b() { let x = sin(1.0); }", "fn b() { while (true) { } }", "fn b() { x <<= 2; }"):
         with pytest.raises((SyntaxError, AssertionError, KeyError)):
             W.run_function(bad, r"fn\s+b\s*\(", {"x": 1})
+
+
+# ---- bone morphs (PMX type 2) pinned to reference execution (tests/golden/ref_bone_morph.npz, tools/ref_bone_morph_run.py) ----
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_bone_morph_restatement_pinned_to_reference_quaternion_and_fk_code(oracle, k):
+    """The reference has no bone morphs; the semantics (q' = q * slerp(I, q_m, w), t' = t + w t_m) are this build's. On the one
+    reference asset that carries a bone morph (武器.pmx: two blade bones turned about z, no translation) the whole frame was
+    produced by the reference's OWN Quat.slerp / Quat.multiply / Model.rotateBones + evaluatePose / Mat4-Vec3 skin. The
+    float64 restatement the GPU tests compare with (helpers.bone_morph_reference + fk_reference) must reproduce those world
+    matrices (f32-store tolerance: the reference rounds every matrix product to f32, and rotateBones renormalises q'), and
+    the oracle's skin of the fixture's vertices under them the reference-skinned sample."""
+    import os
+    from helpers import assert_parity, bone_morph_reference, fk_reference
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_bone_morph.npz"))
+    w = np.zeros(1)
+    w[0] = g["morph_weights"][k]
+    q2, t2 = bone_morph_reference(g["base_rotations"], None, g["entry_morph"], g["entry_bone"], g["entry_translation"], g["entry_rotation"], w)
+    assert np.abs(q2 - g["local_rotations"][k]).max() < 2e-7                    # the reference's own q * slerp(I, q_m, w), stored as f32
+    world = fk_reference(g["parents"], g["bind"], q2, t2)
+    assert np.abs(world - g["world"][k]).max() < 5e-6 * max(1.0, np.abs(g["world"][k]).max())
+    if k:
+        assert np.abs(g["world"][k] - g["world"][0]).max() > 0.05              # the morph really turns the blades
+    v = g["vertices"]
+    pr, nr = oracle.skin(v[:, 0:3], v[:, 3:6], g["joints"], g["weights"], oracle.palette(g["world"][k], g["inv_bind"]))
+    assert_parity(pr, nr, g["skinned"][k][:, 0:3], g["skinned"][k][:, 3:6], "oracle vs reference-skinned weapon, weight %g" % w[0])
