@@ -231,6 +231,9 @@ class Engine {
     if (this.currentModel) this.currentModel.rotateBones(bones, rotations, durationMs)
   }
 
+  /** uv with the UV morphs (PMX type 3) applied, V x 2 — host-side: UVs never pass through the deformation kernel (engine.ts:273) */
+  getMorphedUVs() { return this.currentModel ? this.currentModel.getMorphedUVs() : new Float32Array(0) }
+
   setMorphWeights(namesOrIndices, weights) {
     if (this.currentModel) this.currentModel.setMorphWeights(namesOrIndices, weights)
   }

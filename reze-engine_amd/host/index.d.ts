@@ -55,6 +55,8 @@ export class Engine {
   playAnimation(options?: { breathBones?: string[] | Record<string, number>; breathDuration?: number }): void
   stopAnimation(): void
   rotateBones(bones: string[], rotations: Quat[], durationMs?: number): void
+  /** uv + UV morphs (PMX type 3), V x 2; a host-side sparse update — UVs never pass through the deformation kernel. */
+  getMorphedUVs(): Float32Array
   /** Vertex morphs move vertices, bone morphs (PMX type 2) move bones before the hierarchy solve, group morphs feed both. */
   setMorphWeights(namesOrIndices: Array<string | number>, weights: number[]): void
   render(): void

@@ -330,19 +330,45 @@ class Model {
    * every group morph (type 0) that lists them, w_group * ratio (pmx-loader.ts:479-482). Other morph types
    * (UV / material / flip / impulse) touch neither positions nor bones and contribute nothing.
    */
-  getEffectiveMorphWeights() {
-    const out = this.effectiveMorphWeights
+  getEffectiveMorphWeights() { return this._flattenGroups(this.effectiveMorphWeights, 1, 2) }
+
+  // own weight of the morphs whose type lies in [lo, hi], plus what group morphs feed them
+  _flattenGroups(out, lo, hi) {
     if (!this.morphs) return out
     const { types, groups } = this.morphs
     const w = this.morphWeights
-    for (let i = 0; i < out.length; i++) out[i] = types[i] === 1 || types[i] === 2 ? w[i] : 0
+    for (let i = 0; i < out.length; i++) out[i] = types[i] >= lo && types[i] <= hi ? w[i] : 0
     for (let g = 0; g < out.length; g++) {
       if (types[g] !== 0 || w[g] === 0 || !groups[g]) continue
       for (const [child, ratio] of groups[g]) {
-        if (child >= 0 && child < out.length && (types[child] === 1 || types[child] === 2)) out[child] += w[g] * ratio
+        if (child >= 0 && child < out.length && types[child] >= lo && types[child] <= hi) out[child] += w[g] * ratio
       }
     }
     return out
+  }
+
+  /**
+   * Texture coordinates with the UV morphs (PMX type 3) applied: uv + sum over entries of w_morph * (du, dv), ascending
+   * morph order, f32. UVs never pass through the deformation kernel — vs() forwards them untouched (engine.ts:273) and a
+   * renderer binds them from the static vertex buffer — so this is a sparse host-side update of a V x 2 array, not GPU
+   * work. The reference has no counterpart (its loader skips the section, pmx-loader.ts:498-507).
+   */
+  getMorphedUVs() {
+    const V = this.vertexCount
+    if (!this._uv) this._uv = new Float32Array(V * 2)
+    const uv = this._uv, vd = this.vertexData
+    for (let v = 0; v < V; v++) { uv[v * 2] = vd[v * VERTEX_STRIDE + 6]; uv[v * 2 + 1] = vd[v * VERTEX_STRIDE + 7] }
+    const ue = this.morphs && this.morphs.uvEntries
+    if (!ue || ue.morph.length === 0) return uv
+    if (!this._uvWeights) this._uvWeights = new Float32Array(this.morphWeights.length)
+    const w = this._flattenGroups(this._uvWeights, 3, 3)
+    for (let k = 0; k < ue.morph.length; k++) {
+      const wk = w[ue.morph[k]]
+      if (wk === 0) continue
+      const v = ue.vertex[k]
+      uv[v * 2] += wk * ue.delta[k * 2]; uv[v * 2 + 1] += wk * ue.delta[k * 2 + 1]
+    }
+    return uv
   }
 }
 

@@ -246,6 +246,7 @@ class PmxLoader {
     const offsets = new Uint32Array(n + 1)
     const vidx = [], dxyz = []
     const bmMorph = [], bmBone = [], bmT = [], bmQ = [] // bone-morph entries (type 2), ascending morph index
+    const uvMorph = [], uvVertex = [], uvDelta = [] // UV-morph entries (type 3: the vertex buffer's own uv channel)
     for (let m = 0; m < n; m++) {
       names.push(this.text())
       this.text()
@@ -274,8 +275,14 @@ class PmxLoader {
       } else if (type >= 3 && type <= 7) {
         // PMX 2.0: UV offsets are vec4 (16 B) and bone-morph offsets vec3 + quaternion (28 B). The reference's
         // skipper reads 8 B (:498-507) and 24 B (:489-497) and so loses sync on models that carry such morphs;
-        // this loader follows the file format.
-        for (let k = 0; k < cnt; k++) { c.vertexIndex(h.vertexIndexSize); c.skip(16) }
+        // this loader follows the file format. Type 3 moves the uv the vertex buffer carries (first two components);
+        // types 4-7 move the additional UV channels, which the vertex buffer does not hold (pmx-loader.ts:101-106).
+        for (let k = 0; k < cnt; k++) {
+          const v = c.vertexIndex(h.vertexIndexSize)
+          const du = c.f32(), dv = c.f32()
+          c.skip(8)
+          if (type === 3 && v >= 0 && v < vertexCount) { uvMorph.push(m); uvVertex.push(v); uvDelta.push(du, dv) }
+        }
       } else if (type === 8) {
         for (let k = 0; k < cnt; k++) { c.index(h.materialIndexSize); c.skip(1 + 28 * 4) }
       } else if (type === 9) { // PMX 2.1 flip: morphIndex + ratio
@@ -290,7 +297,8 @@ class PmxLoader {
     const boneEntries = {
       morph: Uint32Array.from(bmMorph), bone: Uint32Array.from(bmBone), translation: Float32Array.from(bmT), rotation: Float32Array.from(bmQ),
     }
-    return { names, types, panels, groups, offsets, vertexIndex: Uint32Array.from(vidx), deltas: Float32Array.from(dxyz), boneEntries }
+    const uvEntries = { morph: Uint32Array.from(uvMorph), vertex: Uint32Array.from(uvVertex), delta: Float32Array.from(uvDelta) }
+    return { names, types, panels, groups, offsets, vertexIndex: Uint32Array.from(vidx), deltas: Float32Array.from(dxyz), boneEntries, uvEntries }
   }
 
   displayFrames() {

@@ -141,7 +141,7 @@ class VMDSampler {
     out.feedOff = new Uint32Array(M + 1)
     for (let i = 0; i < M; i++) {
       out.feedOff[i] = feeds.length
-      if (morphs.types[i] !== 1 && morphs.types[i] !== 2) continue // vertex morphs carry deltas, bone morphs move bones; the rest is not on the path
+      if (morphs.types[i] !== 1 && morphs.types[i] !== 2) continue // vertex morphs carry deltas, bone morphs move bones; the rest is not on the GPU path
       if (trackOf[i] >= 0) feeds.push([trackOf[i], 1])
       for (let g = 0; g < M; g++) {
         if (morphs.types[g] !== 0 || trackOf[g] < 0 || !morphs.groups[g]) continue

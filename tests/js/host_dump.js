@@ -29,6 +29,7 @@ if (mode === 'parse') {
     dump(path.join(out, 'morph_offsets.u32'), mo.offsets); dump(path.join(out, 'morph_vidx.u32'), mo.vertexIndex)
     dump(path.join(out, 'morph_deltas.f32'), mo.deltas)
     const be = mo.boneEntries
+    info.uvMorph = { morph: Array.from(mo.uvEntries.morph), vertex: Array.from(mo.uvEntries.vertex), delta: Array.from(mo.uvEntries.delta) }
     info.boneMorph = { morph: Array.from(be.morph), bone: Array.from(be.bone), translation: Array.from(be.translation), rotation: Array.from(be.rotation) }
   }
   fs.writeFileSync(path.join(out, 'info.json'), JSON.stringify(info))
@@ -72,8 +73,10 @@ if (mode === 'parse') {
   m.rotateBones(bones.map((b) => b.name), spec.rot.map((q) => new Quat(q[0], q[1], q[2], q[3])), 0)
   m.evaluatePose()
   dump(path.join(out, 'world_unmorphed.f32'), m.getBoneWorldMatrices())
+  dump(path.join(out, 'uv_rest.f32'), m.getMorphedUVs())
   m.setMorphWeights(Object.keys(spec.weights), Object.values(spec.weights))
   dump(path.join(out, 'effective.f32'), m.getEffectiveMorphWeights())
+  dump(path.join(out, 'uv_morphed.f32'), m.getMorphedUVs())
   m.evaluatePose()
   dump(path.join(out, 'world_morphed.f32'), m.getBoneWorldMatrices())
   dump(path.join(out, 'localrot_after.f32'), m.runtimeSkeleton.localRotations)

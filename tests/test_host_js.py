@@ -247,8 +247,8 @@ def write_pmx(bone_index_size=1, vertex_index_size=2):
     for k, v in enumerate([1, 4, 6]):
         out += struct.pack(vi, v) + d0[k].tobytes()
     morphs.append(("smile", 1, [1, 4, 6], d0))
-    out += pmx_text("grp") + pmx_text("") + bytes([1, 0]) + struct.pack("<i", 3) + struct.pack("<bf", 0, 0.5) + struct.pack("<bf", 5, 2.0) + struct.pack("<bf", 2, 0.25)
-    morphs.append(("grp", 0, [(0, 0.5), (5, 2.0), (2, 0.25)], None))
+    out += pmx_text("grp") + pmx_text("") + bytes([1, 0]) + struct.pack("<i", 4) + struct.pack("<bf", 0, 0.5) + struct.pack("<bf", 5, 2.0) + struct.pack("<bf", 2, 0.25) + struct.pack("<bf", 3, -1.0)
+    morphs.append(("grp", 0, [(0, 0.5), (5, 2.0), (2, 0.25), (3, -1.0)], None))
     # bone morph: bone 1 and bone 3 (the append child of 1), plus an entry naming a bone the model lacks (dropped)
     bq = rng.normal(size=(3, 4))
     bq = (bq / np.linalg.norm(bq, axis=1, keepdims=True)).astype(np.float32)
@@ -258,7 +258,8 @@ def write_pmx(bone_index_size=1, vertex_index_size=2):
     for k in range(3):
         out += struct.pack(bi, bone_of[k]) + bt[k].tobytes() + bq[k].tobytes()
     morphs.append(("bonem", 2, [], None))
-    out += pmx_text("uvm") + pmx_text("") + bytes([1, 3]) + struct.pack("<i", 2) + (struct.pack(vi, 0) + struct.pack("<4f", 0, 0, 0, 0)) * 2
+    out += pmx_text("uvm") + pmx_text("") + bytes([1, 3]) + struct.pack("<i", 3)
+    out += struct.pack(vi, 0) + struct.pack("<4f", 0.25, -0.5, 9, 9) + struct.pack(vi, 5) + struct.pack("<4f", -0.125, 0.0625, 9, 9) + struct.pack(vi, 0) + struct.pack("<4f", 0.5, 0.5, 9, 9)
     morphs.append(("uvm", 3, [], None))
     out += pmx_text("matm") + pmx_text("") + bytes([1, 8]) + struct.pack("<i", 1) + struct.pack("<b", 0) + bytes([0]) + struct.pack("<28f", *([1.0] * 28))
     morphs.append(("matm", 8, [], None))
@@ -310,7 +311,9 @@ def test_pmx_parser_on_synthetic_file(tmp_path, bone_index_size, vertex_index_si
     assert off.tolist() == [0, 3, 3, 3, 3, 3, 5]
     assert vidx.tolist() == [1, 4, 6, 0, 7]
     assert np.array_equal(dl[:3], exp["morphs"][0][3]) and np.array_equal(dl[3:], exp["morphs"][5][3])
-    assert info["morphGroups"][1] == [[0, 0.5], [5, 2.0], [2, 0.25]]
+    assert info["morphGroups"][1] == [[0, 0.5], [5, 2.0], [2, 0.25], [3, -1.0]]
+    # UV-morph entries (type 3): vertex index + vec4, the first two components move the vertex buffer's uv
+    assert info["uvMorph"] == {"morph": [3, 3, 3], "vertex": [0, 5, 0], "delta": [0.25, -0.5, -0.125, 0.0625, 0.5, 0.5]}
     # bone-morph entries (type 2): 28 bytes behind the bone index; the entry naming a missing bone is dropped
     bm = exp["bone_morph"]
     assert info["boneMorph"]["morph"] == bm["morph"] and info["boneMorph"]["bone"] == bm["bone"]
@@ -329,7 +332,7 @@ def test_bone_morphs_move_the_local_pose_before_the_hierarchy_solve(tmp_path):
     rng = np.random.default_rng(11)
     q = rng.normal(size=(5, 4))
     q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
-    spec = dict(rot=q.tolist(), weights={"bonem": 0.6, "grp": 0.4, "smile": 0.3})
+    spec = dict(rot=q.tolist(), weights={"bonem": 0.6, "grp": 0.4, "smile": 0.3, "uvm": 0.5})
     (tmp_path / "spec.json").write_text(json.dumps(spec))
     node("bonemorph", str(f), str(tmp_path / "spec.json"), str(tmp_path))
     eff = np.fromfile(str(tmp_path / "effective.f32"), dtype=np.float32)
@@ -348,6 +351,14 @@ def test_bone_morphs_move_the_local_pose_before_the_hierarchy_solve(tmp_path):
     assert np.abs(got[3] - plain[3]).max() > 1e-3
     rest = np.fromfile(str(tmp_path / "world_unmorphed.f32"), dtype=np.float32).reshape(-1, 16)
     assert np.abs(rest - plain).max() < 5e-6
+    # UV morphs (type 3): own weight 0.5 and the group's 0.4 * -1.0 -> 0.1; two entries on vertex 0, one on vertex 5
+    uv = np.fromfile(str(tmp_path / "uv_morphed.f32"), dtype=np.float32).reshape(-1, 2)
+    want_uv = exp["uv"].astype(np.float64).copy()
+    wu = float(np.float32(0.5) + np.float32(0.4) * np.float32(-1.0))
+    want_uv[0] += wu * np.array([0.25, -0.5]) + wu * np.array([0.5, 0.5])
+    want_uv[5] += wu * np.array([-0.125, 0.0625])
+    assert np.abs(uv - want_uv).max() < 1e-6 and np.array_equal(uv[1:5], exp["uv"][1:5])
+    assert np.array_equal(np.fromfile(str(tmp_path / "uv_rest.f32"), dtype=np.float32).reshape(-1, 2), exp["uv"])
     # runtime state (tweens / animation) is never written by a morph
     assert np.array_equal(np.fromfile(str(tmp_path / "localrot_after.f32"), dtype=np.float32).reshape(-1, 4), q)
 
