@@ -220,7 +220,8 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * parks in LDS before writing them out in one burst), "inst_loop" (-1 auto, 0 off, 2..8 / 10..16 poses
  * per workgroup in instanced morph-free frames, 9 = the register-resident form), "inst_block" (0 auto, 256 / 512 / 1024 threads per
  * workgroup of the instanced kernel; for crowds "fast" -1 / 1 = palettes formed inside the skin kernel, one launch per frame, 0 =
- * rz_prep_kernel in front), "graph" (0/1: rz_deform_n replays hipGraphs of 16 captured frames instead of launching every kernel —
+ * rz_prep_kernel in front), "inst_order" (1 default / 0: which workgroups of the instanced kernel an XCD gets — 1: every vertex run
+ * of ITS pose groups, so an XCD's L2 pulls one eighth of the poses' matrices; 0: one vertex run of every pose group), "graph" (0/1: rz_deform_n replays hipGraphs of 16 captured frames instead of launching every kernel —
  * for launch-bound replay of small frames), "zero_copy" (-1 auto = on, 0: every pose is copied to the device; one character's
  * per-frame inputs are otherwise read by the frame's kernels straight from a pinned, device-mapped slot), "fuse_fk" (-1 auto, 0, 1:
  * a device-animated single character solves its bone hierarchy inside the deform kernel — one launch per frame — instead of

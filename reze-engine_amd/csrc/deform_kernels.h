@@ -118,6 +118,7 @@ struct RzDeformParams {
 #ifdef RZ_ABLATE
     int dbg;                    // ablation switch — tools-only build (see RZ_DBG in deform_kernels.hip); absent from the product
 #endif
+    int inst_order;             // instanced skin: 0 = an XCD takes one vertex run of every pose group, 1 = every vertex run of its pose groups
     int dma;                    // FAST: stage raw matrices by LDS-DMA (else plain loads after the first morph phase)
     int B;
     int M;

@@ -989,7 +989,12 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *pal = reinterpret_cast<float4 *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int inst0 = blockIdx.y * G;
+    // Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest). inst_order 0: x = vertex run — an XCD sees every
+    // pose group and one eighth of the mesh; 1: consecutive workgroups take consecutive pose groups — an XCD sees one eighth of
+    // the poses' matrices and the whole mesh.
+    const uint32_t n_groups = gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const uint32_t wg_group = p.inst_order ? lin % n_groups : blockIdx.y, wg_run = p.inst_order ? lin / n_groups : blockIdx.x;
+    const int inst0 = (int)wg_group * G;
     const int ng = min(G, n_inst - inst0);
     const int rows = p.B * 3;                       // float4 per palette, in global memory and (finished) in LDS
     constexpr int rstride = 3;                      // float4 per bone of a finished palette
@@ -1001,7 +1006,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         // same 48-byte stride. (Leaving them in the 64-byte slots made every fourth bone share its LDS banks: 52 % of the
         // skin loop's LDS cycles were bank conflicts, against 11 % at 48 bytes — profiles/r2_sq_counters_c4.txt.)
         const float4 *src = p.dma ? p.palette + (size_t)inst0 * rows : reinterpret_cast<const float4 *>(p.world) + (size_t)inst0 * p.B * 4;
-        const int n = (RZ_DBG(p) == 6 || RZ_DBG(p) == 7) ? 0 : (p.dma ? ng * rows : ng * p.B * 4);   // dbg 6 / 7 (tools-only build): no palette staging
+        const int n = (RZ_DBG(p) == 6 || RZ_DBG(p) == 7 || RZ_DBG(p) == 8) ? 0 : (p.dma ? ng * rows : ng * p.B * 4);   // dbg 6 / 7 (tools-only build): no palette staging
         for (int c = wave * 64; c < n; c += BLOCK) {
             const int e = c + lane;
             if (e < n) {
@@ -1024,7 +1029,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         ib0 = gi[0]; ib1 = gi[1]; ib2 = gi[2]; ib3 = gi[3];
     }
     const size_t Vp = p.Vp;
-    const uint32_t v_begin = blockIdx.x * verts_per_wg;
+    const uint32_t v_begin = wg_run * verts_per_wg;
     const uint32_t v_end = min(p.n_quads * 4u, v_begin + verts_per_wg);
     const uint32_t bmax = (uint32_t)(p.B - 1);
     // software-pipelined vertex loop: the next vertex's nine attribute loads are issued before the current
@@ -1039,7 +1044,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // palettes / world matrices (and the first vertex) have landed
     __syncthreads();
-    if (!p.dma) {
+    if (!p.dma && RZ_DBG(p) != 8) {                  // dbg 8 (tools-only build): neither staging nor conversion
         // in-place conversion: slot (g, b) = rows 0..2 of world * inverseBind (engine.ts:926-928). Packed math: the
         // inverse bind matrix is held as column PAIRS (c0,c1),(c2,c3) per k, so each result row is two v_pk_fma
         // chains (the same chain as rz_prep_kernel: ((a0*b0 + a1*b1) + a2*b2) + a3*b3); the next pose's cells are read
@@ -1084,7 +1089,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
             // keep the skinMatrixBuffer observable (rz_read_palette): the vertex runs of a pose group each copy one
             // slice of the finished palettes out of LDS, coalesced
             const int n = ng * rows, per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
-            const int lo = (int)blockIdx.x * per, hi = min(n, lo + per);
+            const int lo = (int)wg_run * per, hi = min(n, lo + per);
             float4 *gp = p.palette + (size_t)inst0 * rows;
             for (int i = lo + tid; i < hi; i += BLOCK) gp[i] = pal[i];
         }

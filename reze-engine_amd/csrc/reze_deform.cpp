@@ -244,7 +244,7 @@ struct rz_ctx {
     RzMorphList ml;
 
     // tuning (0 / -1 = automatic)
-    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1, t_instblock = 0, t_overlap = -1, t_zerocopy = -1, t_fusefk = -1;
+    int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1, t_instblock = 0, t_instorder = 1, t_overlap = -1, t_zerocopy = -1, t_fusefk = -1;
     int t_graph = 0;                    // "graph" tuning key: rz_deform_n replays captured hipGraphs of kGraphFrames frames
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_sig = 0;             // signature of everything the captured launches depend on
@@ -504,6 +504,7 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     p.n_verts = c->V;
     p.Vp = c->Vp; p.n_quads = pl.n_quads; p.quads_per_wave = pl.quads_per_wave; p.dma = pl.dma ? 1 : 0;
     p.B = (int)c->B; p.M = (int)c->M; p.Mpad = (int)c->Mpad;
+    p.inst_order = c->t_instorder;
 #ifdef RZ_ABLATE
     p.dbg = c->t_dbg;
 #endif
@@ -1909,6 +1910,9 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
     } else if (!strcmp(key, "overlap")) {
         if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "overlap must be -1 (auto = off), 0 (off) or 1 (crowds: front kernels on the upload stream)");
         c->t_overlap = value;
+    } else if (!strcmp(key, "inst_order")) {
+        if (value != 0 && value != 1) return fail(RZ_ERR_INVALID, "inst_order must be 0 (an XCD takes one vertex run of every pose group) or 1 (every vertex run of its pose groups)");
+        c->t_instorder = value;
     } else if (!strcmp(key, "inst_block")) {
         if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(RZ_ERR_INVALID, "inst_block must be 0 (auto), 256, 512 or 1024 threads per workgroup");
         c->t_instblock = value;
@@ -1945,6 +1949,7 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "effective_fast")) *value = make_plan(c).v.fast ? 1 : 0;
     else if (!strcmp(key, "inst_loop")) *value = c->t_instloop;
     else if (!strcmp(key, "inst_block")) *value = c->t_instblock;
+    else if (!strcmp(key, "inst_order")) *value = c->t_instorder;
     else if (!strcmp(key, "overlap")) *value = c->t_overlap;
     else if (!strcmp(key, "zero_copy")) *value = c->t_zerocopy;
     else if (!strcmp(key, "fuse_fk")) *value = c->t_fusefk;

@@ -87,10 +87,10 @@ class Walk:
 
     def new_tuning(self):
         key = self.rng.choice(["morph_split", "unroll", "grid_cap", "geo_lds", "nontemporal", "nt_store", "fast", "out_cap", "inst_loop", "graph",
-                               "inst_block", "overlap", "zero_copy", "fuse_fk"])
+                               "inst_block", "overlap", "zero_copy", "fuse_fk", "inst_order"])
         val = {"morph_split": [0, 1, 2, 4, 8], "unroll": [0, 4, 8], "grid_cap": [0, 1, 7, 64, 2048], "geo_lds": [0, 1], "nontemporal": [0, 1],
                "nt_store": [-1, 0, 1], "fast": [-1, 0, 1], "out_cap": [-1, 0, 64, 640], "inst_loop": [-1, 0, 2, 5, 8, 9, 12, 16], "graph": [0, 1],
-               "inst_block": [0, 256, 512, 1024], "overlap": [-1, 0, 1], "zero_copy": [-1, 0, 1], "fuse_fk": [-1, 0, 1]}[key]
+               "inst_block": [0, 256, 512, 1024], "overlap": [-1, 0, 1], "zero_copy": [-1, 0, 1], "fuse_fk": [-1, 0, 1], "inst_order": [0, 1]}[key]
         v = int(self.rng.choice(val))
         self.c.set_tuning(**{key: v})
         self.tuning[key] = v

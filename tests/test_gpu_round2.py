@@ -64,6 +64,17 @@ def test_c4_full_size_256x30k_200b(rz, oracle):
         # palettes of the crowd are observable too (engine.ts:926-928)
         S = oracle.palette(worlds[rnd], mesh["inv_bind"]).reshape(-1, 4, 4)
         np.testing.assert_allclose(c.read_palette(rnd), np.transpose(S, (0, 2, 1))[:, :3, :].reshape(-1, 12), rtol=1e-6, atol=1e-6)
+    # which XCD runs which workgroup (inst_order) is a pure scheduling choice: the other order gives the same bits
+    assert c.get_tuning("inst_order") == 1
+    ref = {k: c.read(instance=k) for k in picks}
+    pal_ref = c.read_palette(rnd)
+    c.set_tuning(inst_order=0)
+    c.deform()
+    for k in picks:
+        pg, ng = c.read(instance=k)
+        assert np.array_equal(pg, ref[k][0]) and np.array_equal(ng, ref[k][1]), "instance %d: inst_order 0 vs 1" % k
+    assert np.array_equal(pal_ref, c.read_palette(rnd))
+    c.set_tuning(inst_order=1)
     # identity pose in EVERY instance == rest mesh, all 256 read back
     ident = np.tile(_identity_world(mesh, B)[None], (I, 1, 1))
     c.set_pose(ident)

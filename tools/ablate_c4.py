@@ -14,8 +14,11 @@ ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); ctx.
 ctx.set_instances(256)
 worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], 200, seed=1000 + i) for i in range(256)])
 ctx.set_pose(worlds)
-for blk, il, cap in ((256, 8, 512), (1024, 8, 256)):
-    for dbg in (0, 1, 2, 6, 7):
-        ctx.set_tuning(inst_block=blk, inst_loop=il, grid_cap=cap, dbg=dbg)
+forms = [(256, 8, 512, 0), (1024, 8, 256, 0)] if len(sys.argv) < 2 else [(512, 8, 256, 0), (512, 8, 256, -1)]
+if len(sys.argv) > 2:
+    ctx.set_tuning(inst_order=int(sys.argv[2]))     # any argument: the default shape, prep-kernel and one-launch form
+for blk, il, cap, fast in forms:
+    for dbg in (0, 1, 2, 6, 7) + ((8,) if fast else ()):       # 8 (one-launch form): neither staging nor the in-kernel palette product
+        ctx.set_tuning(inst_block=blk, inst_loop=il, grid_cap=cap, dbg=dbg, fast=fast)
         t = min((ctx.time_frames(200) for _ in range(3)), key=lambda t: t["deform_kernel_ms"])
-        print("block=%d G=%d cap=%d dbg=%d kernel %.2f us frame %.2f us" % (blk, il, cap, dbg, t["deform_kernel_ms"] * 1e3, t["frame_ms"] * 1e3), flush=True)
+        print("%s block=%d G=%d cap=%d dbg=%d kernel %.2f us frame %.2f us" % ("one-launch" if fast else "prep-form ", blk, il, cap, dbg, t["deform_kernel_ms"] * 1e3, t["frame_ms"] * 1e3), flush=True)
