@@ -101,10 +101,14 @@ for name, (title, V, B, M, I) in WORK.items():
         "raw_FETCH_SIZE_KiB": fetch_kib, "raw_WRITE_SIZE_KiB": write_kib,
         "algorithmic_read_bytes": alg_read, "algorithmic_write_bytes": alg_write,
         "traffic_over_algorithmic": (read_b + write_b) / (alg_read + alg_write),
-        "note": ("reads of this kernel are 4-byte loads + LDS-DMA served mostly from L2 / Infinity Cache (whose hits FETCH_SIZE counts); the x2 "
-                 "factor calibrated on 16 B/lane streams is applied as an upper bound") if I > 1 else "",
+        "note": ("one-launch frame: the kernel reads the mesh and the world + inverse-bind matrices and writes the output plus the palette copy "
+                 "that keeps the skinMatrixBuffer observable (rz_read_palette). Its reads are 4-byte loads + LDS-DMA served mostly from L2 / "
+                 "Infinity Cache (whose hits FETCH_SIZE counts); the x2 factor calibrated on 16 B/lane streams is applied as an UPPER bound "
+                 "(traffic_over_algorithmic), the raw counter gives traffic_over_algorithmic_raw_fetch") if I > 1 else "",
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- " + title.split(" (")[0] + " --no-cpu-baseline --no-sampled-loop",
     }
+    if I > 1:
+        rec["V%d_B%d_M%d_I%d" % (V, B, M, I)]["traffic_over_algorithmic_raw_fetch"] = (fetch_kib * 1024 + write_b) / (alg_read + alg_write)
 rec["_calibration"] = {"FETCH_SIZE_factor_nt_16B_reads": f_read, "FETCH_SIZE_factor_plain_16B_reads": f_read_plain,
                        "WRITE_SIZE_factor_nt_12B_stores": f_write3, "WRITE_SIZE_factor_plain_12B_stores": f_write3_plain,
                        "WRITE_SIZE_factor_16B_stores": f_write4, "known_bytes": "tools/membench quick: 828 MiB read / filled per launch"}
