@@ -700,7 +700,7 @@ def test_bone_morphs_fold_into_device_solved_poses(rz, oracle, morphs):
 @pytest.mark.parametrize("fuse", [0, 1])
 def test_real_bone_morph_on_the_device_against_reference_execution(rz, oracle, fuse):
     """The reference's 武器.pmx bone morph through the device path: rz_upload_bone_morphs + rz_set_pose_local (base rotations, the
-    morph's weight riding with the morph weights), hierarchy solved on the GPU. World matrices and the skinned half of the mesh
+    morph's weight riding with the morph weights), hierarchy solved on the GPU. World matrices and the skinned quarter of the mesh
     against what the REFERENCE's own quaternion, hierarchy and matrix code produced (tests/golden/ref_bone_morph.npz)."""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_bone_morph.npz"))
     v = g["vertices"]

@@ -13,7 +13,7 @@ palette -> skin) can be produced by reference code alone:
   entries        parsed by this build's loader (the reference has no parser for them)
   q'             reference Quat.multiply(q, Quat.slerp(identity, q_morph, w))
   world          reference Model.rotateBones(names, q', 0) + evaluatePose()
-  skinned        reference Mat4.multiply / Vec3 composed as vs(), every second vertex of the mesh
+  skinned        reference Mat4.multiply / Vec3 composed as vs(), every fourth vertex of the mesh
 
 Output: tests/golden/ref_bone_morph.npz (numbers only). tests/test_oracle.py pins the float64 restatement on it, tests/
 test_host_js.py the host loader + Model (container only: needs the asset), tests/test_gpu_round2.py the device path.
@@ -50,7 +50,7 @@ const dump = (name, ta) => fs.writeFileSync(path.join(OUT, name), Buffer.from(ta
     names: bones.map((b) => b.name), append: bones.filter((b) => b.appendRotate || b.appendMove).length }))
   const v = m.getVertices(), sk = m.getSkinning(), V = m.getVertexCount()
   const sample = []
-  for (let i = 0; i < V; i += 2) sample.push(i)
+  for (let i = 0; i < V; i += 4) sample.push(i)
   spec.weights.forEach((w, k) => {
     // the local pose with the morph folded in, by the reference's own quaternion code
     const q = spec.base.map((a) => new Quat(a[0], a[1], a[2], a[3]))
@@ -123,7 +123,7 @@ def main():
     assert info["append"] == 0
     rd = lambda n, dt: np.fromfile(os.path.join(out, n), dtype=dt)  # noqa: E731
     v = rd("vertices.f32", np.float32).reshape(-1, 8)
-    sample = np.arange(0, len(v), 2)
+    sample = np.arange(0, len(v), 4)
     e = mine["entries"]
     np.savez_compressed(
         os.path.join(ROOT, "tests", "golden", "ref_bone_morph.npz"),
