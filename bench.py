@@ -56,6 +56,9 @@ def parse_args():
     ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs of 16 frames in the timed loop (rz_set_tuning graph=1): for launch-bound small frames")
     ap.add_argument("--tune", default="", help="comma list key=value passed to rz_set_tuning (disables the autotune pass)")
     ap.add_argument("--clock-warm-seconds", type=float, default=2.5, help="untimed setup: run frames this long before the warmup steps so the GPU is at its sustained clocks")
+    ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=1,
+                    help="2: the timed steps alternate between the context and a fork of it (rz_fork: shared static data, own stream and outputs), so the tail of frame f overlaps the ramp of frame f + 1")
+    ap.add_argument("--no-pair-loop", action="store_true", help="skip the secondary loop with two frames in flight")
     ap.add_argument("--no-sampled-loop", action="store_true", help="skip the secondary per-frame loop with the motion sampled on the GPU")
     ap.add_argument("--no-autotune", action="store_true", help="skip rz_autotune (setup-time search over launch shapes) and use the built-in heuristics")
     return ap.parse_args()
@@ -202,14 +205,15 @@ def main():
             raise SystemExit("--device-sampling needs --device-fk")
         frames = upload_motion()
 
-    def put_pose():
+    def put_pose(c=None):
+        c = ctx if c is None else c
         if frames is not None:
             tick[0] += 1
-            ctx.set_pose_sampled((frames + 0.5 * tick[0]) % 70.0)
+            c.set_pose_sampled((frames + 0.5 * tick[0]) % 70.0)
         elif quats is not None:
-            ctx.set_pose_local(quats, mws)
+            c.set_pose_local(quats, mws)
         else:
-            ctx.set_pose(worlds, mws)
+            c.set_pose(worlds, mws)
 
     def frame_table(fr):
         """64 rows of per-instance frame numbers marching through the 70-frame motion (cycled by the per-frame loop)."""
@@ -255,19 +259,56 @@ def main():
     # Each rank stamps t1 when ITS K steps have drained (stream sync + torch.cuda.synchronize()), the closing
     # barrier follows, and the reported time is the MAX over ranks: the wall time until the slowest GPU finished,
     # without charging the collective latency of the closing barrier itself to an 18-us-per-step workload.
-    ctx.deform_n(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    ctx.deform_n(args.steps)
-    ctx.sync()
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # Two frames in flight (rz_fork): a second context that borrows this one's static buffers and owns its stream, pose
+    # slots and outputs; frames alternate between the two, so the tail of frame f overlaps the launch ramp of frame f + 1 —
+    # what a WebGPU queue does with consecutive command buffers. The roofline below is always that of ONE kernel on one
+    # stream (rz_time_frames); with --frames-in-flight 2 the timed steps themselves alternate.
+    fork = None
+    if (args.frames_in_flight == 2 or not args.no_pair_loop) and not args.allgather:
+        try:
+            fork = ctx.fork()
+            put_pose(fork)
+        except Exception as e:          # noqa: BLE001
+            sys.stderr.write("[bench] rz_fork failed: %r\n" % (e,))
+            fork = None
+
+    def timed(run, sync_all):
+        barrier()
+        t0 = time.perf_counter()
+        run()
+        sync_all()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def sync_pair():
+        ctx.sync()
+        fork.sync()
+
+    in_flight = 2 if (args.frames_in_flight == 2 and fork is not None) else 1
+    if in_flight == 2:
+        ctx.deform_pair(fork, args.warmup)
+        sync_pair()
+        elapsed = timed(lambda: ctx.deform_pair(fork, args.steps), sync_pair)
+        other_ms = None
+    else:
+        ctx.deform_n(args.warmup)
+        elapsed = timed(lambda: ctx.deform_n(args.steps), ctx.sync)
+        # secondary: the same K steps with two frames in flight
+        other_ms = None
+        if fork is not None:
+            ctx.deform_pair(fork, args.warmup)
+            sync_pair()
+            other_ms = timed(lambda: ctx.deform_pair(fork, args.steps), sync_pair) / args.steps * 1e3
+    if fork is not None:
+        fork.close()
+        fork = None
 
     # ---- roofline of the dominant kernel: HIP events on the context's own stream ----
     timing = ctx.time_frames(max(20, min(args.steps, 200)))
@@ -411,6 +452,9 @@ def main():
                 "prep_kernel_ms": timing["prep_kernel_ms"],
                 "frame_ms_with_pose_upload": with_upload_ms,
                 "frame_ms_device_sampled_pose": sampled_ms,
+                "frames_in_flight": in_flight,
+                "ms_per_step_two_frames_in_flight": other_ms if in_flight == 1 else elapsed / args.steps * 1e3,
+                "frames_in_flight_note": "2 = frames alternate between the context and an rz_fork of it (shared static data, own stream + outputs): the tail of frame f overlaps the ramp of frame f + 1; roofline.* is always one kernel on one stream",
                 "per_frame_loops": "max over ranks, raw C ABI calls; with_pose_upload = rz_set_pose%s + rz_deform per frame, device_sampled_pose = rz_set_pose_sampled (1 float / instance) + rz_deform"
                                    % ("_local" if args.device_fk else ""),
                 "allgather_ms": ag_ms,

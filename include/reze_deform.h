@@ -185,6 +185,22 @@ int rz_deform(rz_ctx *ctx);
  * in between (steady-state replay; same kernels as rz_deform). Asynchronous. */
 int rz_deform_n(rz_ctx *ctx, uint32_t frames);
 
+/* ---- frames in flight ----
+ * WebGPU queues frames: while the GPU drains frame f the application is already encoding frame f + 1 into its own command
+ * buffer and the renderer reads frame f's output. A context has ONE compute stream and ONE set of output buffers, so its
+ * frames run strictly one after the other and every frame pays its own launch ramp and tail — 1 us of a 16 us frame on a
+ * 1/8 shard of C5, 2 us of a 6 us frame on a 30 k-vertex character. rz_fork makes a second context on the same GPU that
+ * BORROWS every static device buffer of `ctx` (mesh, skeleton, topology, morph targets, bone morphs, motion, edge scale — no
+ * copy, no extra HBM) and owns everything per-frame (streams, pose slots, palettes, outputs, tuning state copied from `ctx`
+ * at fork time). Alternate frames between the two (rz_set_pose* + rz_deform on one while the other's frame is in flight, or
+ * rz_deform_pair for a replay) and the tail of frame f overlaps the ramp of frame f + 1: measured 16.3 -> 15.2 us per frame
+ * on the 1/8 shard, 6.3 -> 4.4 us on the character (tools/shard_two_streams.py). While forks exist, static uploads fail on
+ * both sides with RZ_ERR_INVALID; destroy the forks before the context they were forked from (rz_destroy refuses otherwise).
+ * A fork cannot be forked and takes no part in gathers. */
+int rz_fork(rz_ctx *ctx, rz_ctx **fork_out);
+/* `frames` frames of the resident poses, alternating a, b, a, b ... (each on its own stream, into its own outputs). */
+int rz_deform_pair(rz_ctx *a, rz_ctx *b, uint32_t frames);
+
 int rz_sync(rz_ctx *ctx);
 
 /* Blocking readback of deformed positions / normals of instance `instance`, vertices

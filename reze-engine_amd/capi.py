@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libreze_deform.so")
 SYMBOLS = [
     "rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_destroy", "rz_shard_range",
     "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
-    "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_upload_bone_morphs", "rz_upload_animation", "rz_set_pose_sampled", "rz_override_world", "rz_read_world", "rz_deform", "rz_deform_n", "rz_sync", "rz_read",
+    "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_upload_bone_morphs", "rz_upload_animation", "rz_set_pose_sampled", "rz_override_world", "rz_read_world", "rz_deform", "rz_deform_n", "rz_fork", "rz_deform_pair", "rz_sync", "rz_read",
     "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_autotune", "rz_output_ptrs",
     "rz_comm_unique_id", "rz_rccl_info", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_gather_fence", "rz_upload_edge_scale", "rz_read_hull", "rz_enable_aabb", "rz_read_aabb",
 ]
@@ -84,6 +84,8 @@ def load():
     L.rz_read_world.argtypes = [vp, u32, fp]
     L.rz_deform.argtypes = [vp]
     L.rz_deform_n.argtypes = [vp, u32]
+    L.rz_fork.argtypes = [vp, ctypes.POINTER(vp)]
+    L.rz_deform_pair.argtypes = [vp, vp, u32]
     L.rz_sync.argtypes = [vp]
     L.rz_read.argtypes = [vp, u32, u32, u32, fp, fp]
     L.rz_read_palette.argtypes = [vp, u32, fp]
@@ -190,8 +192,30 @@ class DeformContext:
 
     def close(self):
         if getattr(self, "_h", None):
+            for f in list(getattr(self, "_forks", [])):       # forks borrow this context's static buffers: they go first
+                f.close()
             self._L.rz_destroy(self._h)
             self._h = None
+            lender = getattr(self, "_lender", None)
+            if lender is not None and self in lender._forks:
+                lender._forks.remove(self)
+
+    def fork(self):
+        """A second context on the same GPU that borrows this one's static data (no copy) and owns its own streams, pose
+        slots and outputs: alternate frames between the two to keep two frames in flight (rz_fork)."""
+        h = ctypes.c_void_p()
+        _chk(self._L.rz_fork(self._h, ctypes.byref(h)))
+        f = DeformContext.__new__(DeformContext)
+        f._L, f._h, f.V, f.B, f.M, f.I = self._L, h, self.V, self.B, self.M, self.I
+        f._lender = self
+        if not hasattr(self, "_forks"):
+            self._forks = []
+        self._forks.append(f)
+        return f
+
+    def deform_pair(self, other, frames):
+        """`frames` frames alternating between this context and `other` (each on its own stream, into its own outputs)."""
+        _chk(self._L.rz_deform_pair(self._h, other._h, int(frames)))
 
     __del__ = close
 

@@ -383,6 +383,35 @@ static napi_value fn_override_world(napi_env env, napi_callback_info info)
     return rc ? throw_rz(env, rc) : undef(env);
 }
 
+static napi_value fn_fork(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    CTX(0);
+    rz_ctx *f = NULL;
+    int rc = rz_fork(ctx, &f);
+    if (rc) return throw_rz(env, rc);
+    rz_ctx **slot = (rz_ctx **)malloc(sizeof *slot);
+    *slot = f;
+    napi_value ext;
+    if (napi_create_external(env, slot, finalize_ctx, NULL, &ext) != napi_ok) {
+        rz_destroy(f);
+        free(slot);
+        return throw_msg(env, "napi_create_external failed");
+    }
+    return ext;
+}
+
+static napi_value fn_deform_pair(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    CTX(0);
+    rz_ctx *other = NULL;
+    uint32_t n;
+    if (!get_ctx(env, argv[1], &other) || !get_u32(env, argv[2], &n)) return throw_msg(env, "deformPair(ctx, forkCtx, frames)");
+    int rc = rz_deform_pair(ctx, other, n);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
 static napi_value fn_upload_bone_morphs(napi_env env, napi_callback_info info)
 {
     ARGS(5);
@@ -719,7 +748,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "timeFrames", fn_time_frames }, { "setTuning", fn_set_tuning }, { "getTuning", fn_get_tuning },
         { "commUniqueId", fn_comm_unique_id }, { "rcclInfo", fn_rccl_info }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },
         { "readGathered", fn_read_gathered }, { "commInitAll", fn_comm_init_all }, { "allgatherAll", fn_allgather_all },
-        { "autotune", fn_autotune }, { "uploadAnimation", fn_upload_animation }, { "setPoseSampled", fn_set_pose_sampled }, { "overrideWorld", fn_override_world }, { "uploadBoneMorphs", fn_upload_bone_morphs }, { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
+        { "autotune", fn_autotune }, { "uploadAnimation", fn_upload_animation }, { "setPoseSampled", fn_set_pose_sampled }, { "overrideWorld", fn_override_world }, { "uploadBoneMorphs", fn_upload_bone_morphs }, { "fork", fn_fork }, { "deformPair", fn_deform_pair }, { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value f;

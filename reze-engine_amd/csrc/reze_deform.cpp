@@ -258,6 +258,11 @@ struct rz_ctx {
     // peer-direct gather (rz_gather_direct): this context's kernels store straight into the root's gathered buffer
     float *ext_pos = nullptr, *ext_nrm = nullptr;
     rz_ctx *gather_root = nullptr;              // set on every contributor (the root contributes too)
+    // rz_fork: a fork borrows every STATIC device buffer of its lender (mesh, skeleton, topology, morph targets, bone morphs,
+    // motion, edge scale) and owns everything per-frame (streams, pose slots, palettes, outputs). While forks exist neither
+    // side may replace static data.
+    rz_ctx *lender = nullptr;
+    int n_forks = 0;
     std::vector<rz_ctx *> contributors;         // set on the root
     hipEvent_t ev_done = nullptr;               // "my last frame has been enqueued up to here" for rz_gather_fence
 };
@@ -268,6 +273,14 @@ int use(rz_ctx *c)
 {
     if (!c) return fail(RZ_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    return RZ_OK;
+}
+
+// static data shared between a context and its forks cannot be replaced
+int static_unlocked(const rz_ctx *c, const char *what)
+{
+    if (c->lender) return fail(RZ_ERR_INVALID, "%s on a fork: static data belongs to the context it was forked from", what);
+    if (c->n_forks) return fail(RZ_ERR_INVALID, "%s while %d fork(s) of this context share its static data: destroy them first", what, c->n_forks);
     return RZ_OK;
 }
 
@@ -892,9 +905,20 @@ int rz_create(int device, rz_ctx **out)
 int rz_destroy(rz_ctx *c)
 {
     if (!c) return RZ_OK;
+    if (c->n_forks) return fail(RZ_ERR_INVALID, "%d fork(s) still borrow this context's static data: destroy them first", c->n_forks);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
+    if (c->lender) {                      // a fork frees nothing it borrowed
+        c->geom = nullptr; c->j01 = c->j23 = c->wq = nullptr; c->inv_bind = nullptr;
+        c->fk_parents = c->fk_append_parent = c->fk_order = c->fk_level_off = nullptr; c->fk_bind = c->fk_append_ratio = nullptr; c->fk_append_move = nullptr;
+        c->an_bone_range = c->an_feed_range = nullptr; c->an_feed_off = nullptr;
+        c->an_key_frame = c->an_key_pos = c->an_mkey_frame = c->an_mkey_weight = c->an_feed_ratio = nullptr; c->an_key_rot = nullptr; c->an_key_interp = nullptr;
+        c->bm_off = c->bm_morph = nullptr; c->bm_rot = c->bm_tr = nullptr;
+        c->dense = nullptr; c->sp_ptr = nullptr; c->sp_entries = nullptr; c->edge = nullptr;
+        c->lender->n_forks--;
+        c->lender = nullptr;
+    }
     drop_direct_gather(c);
     drop_graph(c);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
@@ -933,6 +957,44 @@ int rz_destroy(rz_ctx *c)
     return RZ_OK;
 }
 
+int rz_fork(rz_ctx *parent, rz_ctx **out)
+{
+    if (!out) return fail(RZ_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (int r = use(parent)) return r;
+    if (parent->lender) return fail(RZ_ERR_INVALID, "rz_fork of a fork: fork the context that owns the static data");
+    if (parent->V == 0 || !parent->geom || parent->B == 0 || !parent->inv_bind) return fail(RZ_ERR_INVALID, "rz_fork needs a mesh and a skeleton (rz_upload_mesh, rz_upload_skeleton)");
+    if (parent->comm || parent->gather_root) return fail(RZ_ERR_UNSUPPORTED, "rz_fork of a context that takes part in a gather");
+    rz_ctx *c = nullptr;
+    if (int r = rz_create(parent->device, &c)) return r;
+    HIP_TRY(hipStreamSynchronize(parent->stream));        // every static upload of the lender has landed
+    c->V = parent->V; c->Vp = parent->Vp; c->geom = parent->geom; c->j01 = parent->j01; c->j23 = parent->j23; c->wq = parent->wq;
+    c->B = parent->B; c->inv_bind = parent->inv_bind;
+    c->has_topology = parent->has_topology; c->fk_parents = parent->fk_parents; c->fk_append_parent = parent->fk_append_parent;
+    c->fk_order = parent->fk_order; c->fk_level_off = parent->fk_level_off; c->fk_append_move = parent->fk_append_move;
+    c->fk_bind = parent->fk_bind; c->fk_append_ratio = parent->fk_append_ratio; c->fk_levels = parent->fk_levels;
+    c->has_animation = parent->has_animation; c->an_bone_range = parent->an_bone_range; c->an_feed_range = parent->an_feed_range;
+    c->an_feed_off = parent->an_feed_off; c->an_key_frame = parent->an_key_frame; c->an_key_pos = parent->an_key_pos;
+    c->an_mkey_frame = parent->an_mkey_frame; c->an_mkey_weight = parent->an_mkey_weight; c->an_feed_ratio = parent->an_feed_ratio;
+    c->an_key_rot = parent->an_key_rot; c->an_key_interp = parent->an_key_interp; c->an_M = parent->an_M;
+    c->bm_off = parent->bm_off; c->bm_morph = parent->bm_morph; c->bm_rot = parent->bm_rot; c->bm_tr = parent->bm_tr; c->bm_count = parent->bm_count;
+    c->morph_mode = parent->morph_mode; c->M = parent->M; c->Mpad = parent->Mpad; c->dense = parent->dense;
+    c->sp_ptr = parent->sp_ptr; c->sp_entries = parent->sp_entries; c->sp_count = parent->sp_count;
+    c->edge = parent->edge; c->aabb_on = parent->aabb_on; c->aabb_rearm = parent->aabb_on;
+    c->I = parent->I;
+    c->t_split = parent->t_split; c->t_unroll = parent->t_unroll; c->t_grid_cap = parent->t_grid_cap; c->t_nt = parent->t_nt; c->t_nts = parent->t_nts;
+    c->t_geo = parent->t_geo; c->t_fast = parent->t_fast; c->t_instloop = parent->t_instloop; c->t_outcap = parent->t_outcap; c->t_instblock = parent->t_instblock;
+    c->t_instorder = parent->t_instorder; c->t_overlap = parent->t_overlap; c->t_zerocopy = parent->t_zerocopy; c->t_fusefk = parent->t_fusefk;
+    c->t_graph = parent->t_graph; c->tuned_by_search = parent->tuned_by_search;
+    c->lender = parent;
+    parent->n_forks++;
+    int rc = ensure_pose_buffers(c);
+    if (rc == RZ_OK) rc = ensure_outputs(c);
+    if (rc != RZ_OK) { rz_destroy(c); return rc; }
+    *out = c;
+    return RZ_OK;
+}
+
 int rz_shard_range(uint32_t v_total, int nranks, int rank, uint32_t *begin, uint32_t *count)
 {
     if (nranks < 1 || rank < 0 || rank >= nranks || !begin || !count)
@@ -949,6 +1011,7 @@ int rz_shard_range(uint32_t v_total, int nranks, int rank, uint32_t *begin, uint
 int rz_upload_mesh(rz_ctx *c, uint32_t V, const float *interleaved8, const uint16_t *joints4, const uint8_t *weights4)
 {
     if (int r = use(c)) return r;
+    if (int r = static_unlocked(c, "rz_upload_mesh")) return r;
     if (V == 0 || !interleaved8 || !joints4 || !weights4) return fail(RZ_ERR_INVALID, "rz_upload_mesh: empty mesh or null array");
     if (int r = alloc_mesh(c, V)) return r;
     Scratch<float> scratch;
@@ -967,6 +1030,7 @@ int rz_upload_mesh_soa(rz_ctx *c, uint32_t V, const float *pos3, const float *nr
                        const uint8_t *weights4)
 {
     if (int r = use(c)) return r;
+    if (int r = static_unlocked(c, "rz_upload_mesh_soa")) return r;
     if (V == 0 || !pos3 || !nrm3 || !joints4 || !weights4) return fail(RZ_ERR_INVALID, "rz_upload_mesh_soa: empty mesh or null array");
     if (int r = alloc_mesh(c, V)) return r;
     Scratch<float> scratch;
@@ -986,6 +1050,7 @@ int rz_upload_mesh_soa(rz_ctx *c, uint32_t V, const float *pos3, const float *nr
 int rz_upload_skeleton(rz_ctx *c, uint32_t B, const float *inverse_bind16)
 {
     if (int r = use(c)) return r;
+    if (int r = static_unlocked(c, "rz_upload_skeleton")) return r;
     if (B == 0 || !inverse_bind16) return fail(RZ_ERR_INVALID, "rz_upload_skeleton: model has no bones");
     if ((size_t)B * 48 + 8192 > 160 * 1024) return fail(RZ_ERR_UNSUPPORTED, "more than %d bones do not fit the LDS palette", (160 * 1024 - 8192) / 48);
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1005,6 +1070,7 @@ int rz_upload_skeleton(rz_ctx *c, uint32_t B, const float *inverse_bind16)
 int rz_upload_morphs_dense(rz_ctx *c, uint32_t M, const float *deltas)
 {
     if (int r = use(c)) return r;
+    if (int r = static_unlocked(c, "rz_upload_morphs_dense")) return r;
     if (c->V == 0) return fail(RZ_ERR_INVALID, "upload the mesh before its morph targets");
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_morphs(c);
@@ -1036,6 +1102,7 @@ int rz_upload_morphs_dense(rz_ctx *c, uint32_t M, const float *deltas)
 int rz_upload_morphs_sparse(rz_ctx *c, uint32_t M, const uint32_t *morph_off, const uint32_t *vert_idx, const float *delta3)
 {
     if (int r = use(c)) return r;
+    if (int r = static_unlocked(c, "rz_upload_morphs_sparse")) return r;
     if (c->V == 0) return fail(RZ_ERR_INVALID, "upload the mesh before its morph targets");
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_morphs(c);
@@ -1301,6 +1368,7 @@ int rz_upload_skeleton_topology(rz_ctx *c, uint32_t B, const int32_t *parents, c
                                 const int32_t *append_parent, const float *append_ratio, const uint8_t *append_move)
 {
     if (int r = use(c)) return r;
+    if (int r = static_unlocked(c, "rz_upload_skeleton_topology")) return r;
     if (B == 0 || B != c->B) return fail(RZ_ERR_INVALID, "topology has %u bones but the uploaded skeleton has %u", B, c->B);
     if (!parents || !bind_translation3) return fail(RZ_ERR_INVALID, "null topology arrays");
     // hierarchy levels (parents may come in any order, like the reference's recursive solve; cycles are an error)
@@ -1358,6 +1426,7 @@ int rz_upload_skeleton_topology(rz_ctx *c, uint32_t B, const int32_t *parents, c
 int rz_upload_bone_morphs(rz_ctx *c, uint32_t n, const uint32_t *morph, const uint32_t *bone, const float *translation3, const float *rotation4)
 {
     if (int r = use(c)) return r;
+    if (int r = static_unlocked(c, "rz_upload_bone_morphs")) return r;
     if (n == 0) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         free_bone_morphs(c);
@@ -1414,6 +1483,7 @@ int rz_set_pose_local(rz_ctx *c, const float *local_rotations4, const float *loc
 int rz_upload_animation(rz_ctx *c, const rz_animation *a)
 {
     if (int r = use(c)) return r;
+    if (int r = static_unlocked(c, "rz_upload_animation")) return r;
     if (!a) return fail(RZ_ERR_INVALID, "null animation");
     if (c->B == 0) return fail(RZ_ERR_INVALID, "upload the skeleton before a motion");
     const uint32_t n = a->n_bone_tracks, mt = a->n_morph_tracks;
@@ -1674,6 +1744,24 @@ int rz_deform_n(rz_ctx *c, uint32_t frames)
     return RZ_OK;
 }
 
+int rz_deform_pair(rz_ctx *a, rz_ctx *b, uint32_t frames)
+{
+    if (!a || !b || a == b) return fail(RZ_ERR_INVALID, "rz_deform_pair needs two different contexts");
+    if (a->device != b->device) return fail(RZ_ERR_INVALID, "rz_deform_pair: the contexts live on devices %d and %d", a->device, b->device);
+    rz_ctx *cs[2] = { a, b };
+    Plan pl[2];
+    for (int k = 0; k < 2; ++k) {
+        if (int r = use(cs[k])) return r;
+        if (int r = check_ready(cs[k])) return r;
+        if (int r = ensure_outputs(cs[k])) return r;
+        pl[k] = make_plan(cs[k]);
+        if (int r = set_overlap(cs[k], want_overlap(cs[k], pl[k]))) return r;
+    }
+    for (uint32_t f = 0; f < frames; ++f)
+        if (int r = run_frame(cs[f & 1], pl[f & 1])) return r;
+    return RZ_OK;
+}
+
 int rz_sync(rz_ctx *c)
 {
     if (int r = use(c)) return r;
@@ -1708,6 +1796,7 @@ int rz_read_palette(rz_ctx *c, uint32_t instance, float *rows3x4)
 int rz_upload_edge_scale(rz_ctx *c, uint32_t V, const float *edge_size)
 {
     if (int r = use(c)) return r;
+    if (int r = static_unlocked(c, "rz_upload_edge_scale")) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
     drop_graph(c);
     if (!edge_size) { dfree(c->edge); return RZ_OK; }

@@ -59,6 +59,12 @@ class Engine {
     this.deviceSampling = o.deviceSampling === true && o.deviceFK === true
     this.instances = 1
     this.animationOnDevice = null
+    // framesInFlight: 2 = consecutive frames alternate between the context and a fork of it (rz_fork: the fork borrows the
+    // static buffers, owns its stream, pose slots and outputs), so the tail of frame f overlaps the launch ramp of frame
+    // f + 1 — what a WebGPU queue does with consecutive command buffers (engine.ts:2124-2136 submits one per frame).
+    // getDeformed() / getOutlineHull() / getBounds() read the frame rendered last. Single GPU, no gather.
+    this.framesInFlight = o.framesInFlight === 2 ? 2 : 1
+    this.overrides = null
     this.autotune = o.autotune === true // search launch shapes once, on the first rendered frame (rz_autotune)
     this.tuned = false
     this.ctx = null // context of shard 0 (the only one on a single GPU)
@@ -89,8 +95,9 @@ class Engine {
   // ---- lifecycle ----
   /** engine.ts:157-185: acquire the device. Throws when the addon or an MI355X is not available. */
   async init() {
+    if (this.framesInFlight === 2 && (this.devices.length > 1 || this.gather)) throw new Error('framesInFlight: 2 needs a single GPU and no gather')
     this.native = requireAddon()
-    this.shards = this.devices.map((d) => ({ ctx: this.native.create(d), begin: 0, count: 0 }))
+    this.shards = this.devices.map((d) => ({ ctx: this.native.create(d), begin: 0, count: 0, fork: null, last: null, flip: 0 }))
     this.ctx = this.shards[0].ctx
     this.lastFpsUpdate = this.now()
   }
@@ -99,9 +106,32 @@ class Engine {
     this.stopRenderLoop()
     this.stopAnimation()
     this.stopBreathing()
+    this.dropForks()
     for (const s of this.shards) this.native.destroy(s.ctx)
     this.shards = []
     this.ctx = null
+  }
+
+  // ---- frames in flight ----
+  /** Forks borrow the lender's static buffers: they go before anything static is replaced, and before the lender. */
+  dropForks() {
+    for (const s of this.shards) {
+      if (s.fork) { this.native.destroy(s.fork); s.fork = null }
+      s.last = null
+      s.flip = 0
+    }
+  }
+
+  /** The context the NEXT frame of shard `s` runs on. */
+  frameContext(s) {
+    if (this.framesInFlight !== 2 || (this.autotune && !this.tuned)) { s.last = s.ctx; return s.ctx }
+    if (!s.fork) { // made after the launch-shape search, so that it inherits the tuned plan
+      s.fork = this.native.fork(s.ctx)
+      if (this.overrides) this.native.overrideWorld(s.fork, this.overrides[0], this.overrides[1], this.overrides[2])
+    }
+    s.flip ^= 1
+    s.last = s.flip ? s.fork : s.ctx
+    return s.last
   }
 
   // ---- timers (window.setTimeout replacement that also works on a manual clock) ----
@@ -142,6 +172,7 @@ class Engine {
   /** engine.ts:1728-1832: one-off static upload (vertex / joints / weights / inverse bind [+ morph targets]). */
   async setupModelBuffers(model) {
     if (!this.ctx) throw new Error('Engine.init() has not been called')
+    this.dropForks()
     this.currentModel = model
     model.setClock(() => this.now())
     const n = this.native, skinning = model.getSkinning(), skeleton = model.getSkeleton()
@@ -364,9 +395,10 @@ class Engine {
     // per-frame inputs are replicated to every shard (16-22 KB); launches are asynchronous, so the GPUs run concurrently
     for (const s of this.shards) {
       if (s.count === 0) continue
-      if (gpuFK) this.native.setPoseLocal(s.ctx, model.runtimeSkeleton.localRotations, mw, tra)
-      else this.native.setPose(s.ctx, model.getBoneWorldMatrices(), mw)
-      this.native.deform(s.ctx)
+      const c = this.frameContext(s)
+      if (gpuFK) this.native.setPoseLocal(c, model.runtimeSkeleton.localRotations, mw, tra)
+      else this.native.setPose(c, model.getBoneWorldMatrices(), mw)
+      this.native.deform(c)
     }
     if (this.autotune && !this.tuned) { // the first frame supplied a pose: time the candidate launch shapes once per shard
       for (const s of this.shards) if (s.count > 0) this.native.autotune(s.ctx, 0)
@@ -398,6 +430,7 @@ class Engine {
     const model = this.currentModel
     if (this.animationOnDevice !== this.animationFrames || this.animationFor !== model) {
       const flat = this.sampler.flatten(model.runtimeSkeleton.nameIndex, model.getMorphCount() > 0 ? model.getMorphs() : null)
+      this.dropForks() // the motion is static data
       for (const s of this.shards) if (s.count > 0) this.native.uploadAnimation(s.ctx, flat)
       this.animationOnDevice = this.animationFrames
       this.animationFor = model
@@ -408,8 +441,9 @@ class Engine {
     if (f.length !== this.instances) throw new Error('seekFrame: ' + f.length + ' frames for ' + this.instances + ' instances')
     for (const s of this.shards) {
       if (s.count === 0) continue
-      this.native.setPoseSampled(s.ctx, f)
-      this.native.deform(s.ctx)
+      const c = this.frameContext(s)
+      this.native.setPoseSampled(c, f)
+      this.native.deform(c)
     }
     if (this.gather === 'direct' && this.shards.length > 1) this.native.gatherFence(this.ctx)
     else if (this.gather && this.shards.length > 1) this.native.allgatherAll(this.shards.map((s) => s.ctx), true)
@@ -429,7 +463,12 @@ class Engine {
     const b = boneIndices && boneIndices.length ? Uint32Array.from(boneIndices) : null
     const w = b ? (worldMatrices instanceof Float32Array ? worldMatrices : Float32Array.from(worldMatrices)) : null
     const i = b && instances ? Uint32Array.from(instances) : null
-    for (const s of this.shards) if (s.count > 0) this.native.overrideWorld(s.ctx, b, w, i)
+    this.overrides = b ? [b, w, i] : null
+    for (const s of this.shards) {
+      if (s.count === 0) continue
+      this.native.overrideWorld(s.ctx, b, w, i)
+      if (s.fork) this.native.overrideWorld(s.fork, b, w, i)
+    }
   }
 
   /** Deterministic stepping: move the clock to timeMs, fire the timers that came due, render one frame. */
@@ -450,6 +489,7 @@ class Engine {
     if (!this.deviceSampling) throw new Error('setInstanceCount needs new Engine(canvas, { deviceFK: true, deviceSampling: true })')
     if (this.shards.length > 1) throw new Error('instancing and vertex sharding are exclusive')
     if (this.outline || this.bounds) throw new Error('the outline hull and bounds are single-instance consumers')
+    this.dropForks() // a fork takes its instance count from the lender when it is made
     this.native.setInstances(this.ctx, n)
     this.instances = n
     this.tuned = false
@@ -462,7 +502,7 @@ class Engine {
       if (!(instance > 0 && instance < this.instances)) throw new Error('instance ' + instance + ' out of range')
       const V = this.currentModel.getVertexCount()
       const pos = new Float32Array(V * 3), nrm = new Float32Array(V * 3)
-      this.native.read(this.ctx, instance, 0, V, pos, nrm)
+      this.native.read(this.shards[0].last || this.ctx, instance, 0, V, pos, nrm)
       return { positions: pos, normals: nrm }
     }
     if (this.gather && this.shards.length > 1) { // shard 0's GPU holds the whole mesh (all-gather or peer-direct stores)
@@ -471,7 +511,7 @@ class Engine {
     }
     for (const s of this.shards) {
       if (s.count === 0) continue
-      this.native.read(s.ctx, 0, 0, s.count, this.outPos.subarray(s.begin * 3, (s.begin + s.count) * 3), this.outNrm.subarray(s.begin * 3, (s.begin + s.count) * 3))
+      this.native.read(s.last || s.ctx, 0, 0, s.count, this.outPos.subarray(s.begin * 3, (s.begin + s.count) * 3), this.outNrm.subarray(s.begin * 3, (s.begin + s.count) * 3))
     }
     return { positions: this.outPos, normals: this.outNrm }
   }
@@ -479,7 +519,7 @@ class Engine {
   /** Inverted-hull positions the outline pipeline draws: worldPos + worldNormal * edgeSize * 0.01 (needs { outline: true }). */
   getOutlineHull() {
     if (!this.outline) throw new Error('new Engine(canvas, { outline: true }) enables the outline hull')
-    for (const s of this.shards) if (s.count > 0) this.native.readHull(s.ctx, 0, 0, s.count, this.outHull.subarray(s.begin * 3, (s.begin + s.count) * 3))
+    for (const s of this.shards) if (s.count > 0) this.native.readHull(s.last || s.ctx, 0, 0, s.count, this.outHull.subarray(s.begin * 3, (s.begin + s.count) * 3))
     return this.outHull
   }
 
@@ -490,7 +530,7 @@ class Engine {
     const min = [Infinity, Infinity, Infinity], max = [-Infinity, -Infinity, -Infinity]
     for (const s of this.shards) {
       if (s.count === 0) continue
-      this.native.readAabb(s.ctx, 0, b)
+      this.native.readAabb(s.last || s.ctx, 0, b)
       for (let k = 0; k < 3; k++) { min[k] = Math.min(min[k], b[k]); max[k] = Math.max(max[k], b[3 + k]) }
     }
     return { min, max }

@@ -36,6 +36,7 @@ export interface EngineOptions {
   /** One context per listed GPU; the mesh is vertex-sharded across them. */ devices?: number[]
   /** With deviceFK: seekFrame() samples the motion on the GPU (rz_upload_animation once, one float per frame). */ deviceSampling?: boolean
   /** Search launch shapes (morph split, workgroups per CU) once on the first rendered frame. */ autotune?: boolean
+  /** 2: consecutive frames alternate between the context and a fork of it (own stream + outputs, shared static data), so frame f + 1 ramps up under frame f's tail. Single GPU, no gather. */ framesInFlight?: 1 | 2
   /** true: RCCL all-gather of the deformed mesh after every frame (distinct GPUs only); 'direct': every shard's kernel stores
    *  straight into the first GPU's gathered buffer over xGMI — no collective, GPUs may repeat in `devices`. */ gather?: boolean | 'direct'
   /** How PMX vertex morphs are laid out in HBM (default 'sparse'). */ morphLayout?: 'sparse' | 'dense'

@@ -27,7 +27,10 @@ if (process.argv[2] === '--live') { // on a GPU box: the same with a LIVE contex
     for (const args of tails) {
       if ((name === 'deformN' || name === 'timeFrames' || name === 'autotune') && typeof args[0] === 'number' && args[0] > 1000) continue // a legal, just very long, request
       const t0 = Date.now()
-      try { a[name](ctx, ...args); returned++ } catch (e) { if (!(e instanceof Error)) throw new Error(name + ' threw a non-Error'); thrown++ }
+      try {
+        const r = a[name](ctx, ...args); returned++
+        if (name === 'fork') a.destroy(r) // a fork freezes the lender's static data while it lives
+      } catch (e) { if (!(e instanceof Error)) throw new Error(name + ' threw a non-Error'); thrown++ }
       if (Date.now() - t0 > 300) console.error('SLOW ' + name + ' tail #' + tails.indexOf(args) + ' took ' + (Date.now() - t0) + ' ms')
       live++
     }
@@ -51,6 +54,15 @@ if (process.argv[2] === '--live') { // on a GPU box: the same with a LIVE contex
   }
   if (threwBm !== 4) throw new Error('uploadBoneMorphs accepted ' + (4 - threwBm) + ' malformed calls')
   a.uploadBoneMorphs(ctx, null, null, null, null)   // n = 0 clears, always legal
+  // forks: static uploads are refused on both sides while one lives, the lender cannot go first
+  const fk = a.fork(ctx)
+  let frozen = 0
+  for (const c of [ctx, fk]) { try { a.uploadSkeleton(c, ib) } catch (e) { frozen += e instanceof Error ? 1 : 0 } }
+  try { a.fork(fk) } catch (e) { frozen += e instanceof Error ? 1 : 0 }
+  if (frozen !== 3) throw new Error('a live fork must freeze static data on both sides and cannot be forked itself (' + frozen + '/3)')
+  a.setPose(ctx, ib, null); a.setPose(fk, ib, null); a.deformPair(ctx, fk, 5); a.sync(ctx); a.sync(fk)
+  a.destroy(fk)
+  a.uploadSkeleton(ctx, ib)                          // the lender owns its data again
   a.setPose(ctx, ib, null); a.deform(ctx)           // still usable
   const pos = new Float32Array(V * 3), nrm = new Float32Array(V * 3)
   a.read(ctx, 0, 0, V, pos, nrm)

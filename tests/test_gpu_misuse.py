@@ -79,6 +79,10 @@ expect_fail("override_world without topology", L.rz_override_world(h, 1, N, (cty
 u1 = (ctypes.c_uint32 * 1)(0)
 expect_fail("bone morphs without topology", L.rz_upload_bone_morphs(h, 1, u1, u1, m["bind"].ctypes.data_as(fp), m["quats"].ctypes.data_as(fp)))
 if L.rz_upload_bone_morphs(h, 0, N, N, N, N) != 0: bad.append("rz_upload_bone_morphs(n = 0) clears and is always legal")
+fk = ctypes.c_void_p()
+expect_fail("fork NULL out", L.rz_fork(h, N))
+expect_fail("deform_pair with itself", L.rz_deform_pair(h, h, 2))
+expect_fail("deform_pair NULL partner", L.rz_deform_pair(h, N, 2))
 if L.rz_rccl_info(N, 0, N, N) not in (0, -6): bad.append("rccl_info(NULLs) must be OK or UNSUPPORTED")
 expect_fail("tuning NULL key", L.rz_set_tuning(h, N, 1))
 expect_fail("get_tuning NULL out", L.rz_get_tuning(h, b"bones", N))

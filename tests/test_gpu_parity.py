@@ -938,3 +938,29 @@ def test_engine_through_napi_matches_oracle(tmp_path, oracle):
         assert seen_morph
         st = json.load(open(out / "stats.json"))
         assert st["t"]["frameMs"] > 0 and st["st"]["vertsPerSec"] > 0
+
+
+@pytest.mark.parametrize("device_fk", [0, 1])
+def test_engine_frames_in_flight_through_napi(tmp_path, device_fk):
+    """new Engine(null, { framesInFlight: 2 }): frames alternate between the context and an rz_fork of it (shared static data, own
+    stream + outputs). Clock steps, tweens, morph weights (vertex, group, bone morph) and frame seeks; host FK and device FK +
+    device sampling. Every frame must be bit-identical to the plain engine's, hull and bounds included."""
+    import json
+    import shutil
+    import subprocess
+    import os
+    from pmx_synth import write_pmx, write_vmd
+    if shutil.which("node") is None:
+        pytest.skip("node is not installed on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "m.pmx").write_bytes(write_pmx())
+    s = 0.38268343
+    (tmp_path / "a.vmd").write_bytes(write_vmd(
+        [("bone1", 0, (0, 0, s, 0.92387953)), ("bone3", 0, (s, 0, 0, 0.92387953), (0.3, -0.2, 0.1)), ("bone1", 15, (0, s, 0, 0.92387953)),
+         ("bone3", 20, (0, 0, s, 0.92387953), (-0.5, 0.4, 0.25)), ("bone0", 0, (0, 0, 0, 1), (0, 0.5, 0)), ("bone0", 25, (0, 0, 0, 1), (1.0, 0.25, -0.5))],
+        [("v1", 0, 0.8), ("v2", 6, 0.4), ("twist", 0, 0.1), ("twist", 30, 0.9)]))
+    out = tmp_path / "r.json"
+    subprocess.check_call(["node", os.path.join(root, "tests", "js", "engine_inflight.js"), str(tmp_path / "m.pmx"), str(tmp_path / "a.vmd"), str(out), str(device_fk)], timeout=300)
+    r = json.load(open(out))
+    assert r["frames"] == 9 and r["mismatches"] == [], r
+    assert r["forked"] is True and r["moved"] > 0.2

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_parity, bone_morph_reference, fk_reference, sample_reference
+from helpers import assert_hull, assert_parity, bone_morph_reference, fk_reference, sample_reference
 from reze_engine_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -721,3 +721,120 @@ def test_real_bone_morph_on_the_device_against_reference_execution(rz, oracle, f
         pg, ng = c.read()
         assert_parity(pg, ng, g["skinned"][k][:, 0:3], g["skinned"][k][:, 3:6], "device bone morph vs reference execution, weight %g" % w)
     c.close()
+
+
+def test_fork_keeps_two_frames_in_flight_on_shared_static_data(rz, oracle):
+    """rz_fork: a second context that BORROWS the lender's static buffers (mesh, skeleton, topology, dense morph targets, motion,
+    bone morphs, edge scale) and owns its streams, pose slots and outputs — the WebGPU queue's 'encode frame f + 1 while frame f
+    runs' for this ABI. Different poses alternate between the two contexts (world-matrix, local and sampled poses; the hull and
+    bounding-box consumers on); every frame must match the oracle and be bit-identical to the same pose run on the lender alone.
+    Static uploads are refused on both sides while the fork lives, the lender cannot be destroyed before its fork, a fork
+    cannot be forked; after the fork is gone the lender accepts new static data again."""
+    V, B, M = 20000, 96, 12
+    mesh = synth.make_mesh(V, B, seed=81)
+    deltas, _ = synth.make_morphs_dense(V, M, seed=82)
+    rng = np.random.default_rng(83)
+    a = rz.DeformContext(0)
+    with pytest.raises(rz.RzError):
+        a.fork()                                               # nothing to share yet
+    a.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    a.upload_skeleton(mesh["inv_bind"])
+    a.upload_morphs_dense(deltas)
+    a.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+    edge = rng.random(V).astype(np.float32)
+    a.upload_edge_scale(edge)
+    a.enable_aabb(True)
+    nk = 3
+    kq = rng.normal(size=(B, nk, 4)).astype(np.float32)
+    kq /= np.linalg.norm(kq, axis=2, keepdims=True)
+    anim = dict(track_bone=np.arange(B), key_off=np.arange(B + 1) * nk, key_frame=np.tile(np.arange(nk) * 10.0, B), key_rot=kq,
+                key_pos=(rng.random((B, nk, 3), dtype=np.float32) - 0.5) * 0.3, key_interp=None,
+                mkey_off=np.arange(M + 1) * 2, mkey_frame=np.tile(np.array([0.0, 20.0], np.float32), M), mkey_weight=rng.random(2 * M).astype(np.float32),
+                feed_off=np.arange(M + 1), feed_track=np.arange(M), feed_ratio=np.ones(M, np.float32))
+    a.upload_animation(anim["track_bone"], anim["key_off"], anim["key_frame"], anim["key_rot"], anim["key_pos"], None,
+                       anim["mkey_off"], anim["mkey_frame"], anim["mkey_weight"], anim["feed_off"], anim["feed_track"], anim["feed_ratio"])
+    bm = (np.array([M - 1, M - 2], np.uint32), np.array([5, 40], np.uint32), (rng.random((2, 3)) - 0.5).astype(np.float32), kq[:2, 0])
+    a.upload_bone_morphs(*bm)
+    world0 = synth.make_pose(mesh["parents"], mesh["bind"], B, seed=84)
+    a.set_pose(world0, rng.random(M).astype(np.float32))
+    a.deform()
+    a.autotune(0)                                              # the fork inherits the tuned plan
+    b = a.fork()
+    assert b.get_tuning("effective_split") == a.get_tuning("effective_split") and b.get_tuning("effective_grid") == a.get_tuning("effective_grid")
+    with pytest.raises(rz.RzError):
+        b.fork()
+    for ctx in (a, b):                                         # static data is frozen on both sides
+        with pytest.raises(rz.RzError):
+            ctx.upload_morphs_dense(deltas)
+        with pytest.raises(rz.RzError):
+            ctx.upload_skeleton(mesh["inv_bind"])
+        with pytest.raises(rz.RzError):
+            ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+        with pytest.raises(rz.RzError):
+            ctx.upload_bone_morphs(*bm)
+        with pytest.raises(rz.RzError):
+            ctx.upload_edge_scale(edge)
+    assert a._L.rz_destroy(a._h) != 0                          # the lender outlives its forks
+
+    def pose(kind, seed):
+        r = np.random.default_rng(seed)
+        w = (r.random(M) * (r.random(M) < 0.7)).astype(np.float32)
+        if kind == "world":
+            return ("world", synth.make_pose(mesh["parents"], mesh["bind"], B, seed=seed), w)
+        if kind == "local":
+            q = r.normal(size=(B, 4)).astype(np.float32)
+            return ("local", q / np.linalg.norm(q, axis=1, keepdims=True), w, (r.random((B, 3), dtype=np.float32) - 0.5))
+        return ("sampled", np.array([r.random() * 20], np.float32))
+
+    def apply(ctx, ps):
+        if ps[0] == "world":
+            ctx.set_pose(ps[1], ps[2])
+        elif ps[0] == "local":
+            ctx.set_pose_local(ps[1], ps[2], ps[3])
+        else:
+            ctx.set_pose_sampled(ps[1])
+
+    def result(ctx):
+        return ctx.read(), ctx.read_hull(), ctx.read_aabb(0)
+
+    kinds = ["world", "local", "sampled", "world", "sampled", "local", "world", "world"]
+    poses = [pose(k, 900 + i) for i, k in enumerate(kinds)]
+    # frames alternate between the contexts WITHOUT a sync in between: two frames in flight
+    got = []
+    for i in range(0, len(poses), 2):
+        apply(a, poses[i]); a.deform()
+        apply(b, poses[i + 1]); b.deform()
+        got.append(result(a)); got.append(result(b))
+    # the same poses on the lender alone
+    for i, ps in enumerate(poses):
+        apply(a, ps); a.deform()
+        ref = result(a)
+        assert np.array_equal(ref[0][0], got[i][0][0]) and np.array_equal(ref[0][1], got[i][0][1]), "frame %d (%s): fork vs lender" % (i, ps[0])
+        assert np.array_equal(ref[1], got[i][1]) and np.array_equal(ref[2], got[i][2])
+        if ps[0] == "world":
+            pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], ps[1], mesh["inv_bind"], deltas, ps[2])
+            assert_parity(got[i][0][0], got[i][0][1], pr, nr, "forked frame %d" % i)
+            assert_hull(got[i][1], oracle.hull(pr, nr, edge), "forked frame %d hull" % i)
+    # a replay that alternates inside the library
+    apply(a, poses[0]); apply(b, poses[3])
+    a.deform_pair(b, 41)
+    ra, rb = a.read(), b.read()
+    assert np.array_equal(ra[0], got[0][0][0]) and np.array_equal(rb[0], got[3][0][0])
+    with pytest.raises(rz.RzError):
+        a.deform_pair(a, 2)
+    # instance counts are per context
+    b.set_instances(3)
+    b.set_pose(np.stack([poses[0][1], poses[3][1], poses[6][1]]), None)
+    b.deform()
+    a.deform()
+    assert np.array_equal(a.read()[0], got[0][0][0])
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], poses[6][1], mesh["inv_bind"], deltas, np.zeros(M, np.float32))
+    pg, ng = b.read(instance=2)
+    assert_parity(pg, ng, pr, nr, "crowd on the fork")
+    b.close()
+    a.upload_morphs_dense(deltas[:4])                          # the lender owns its static data again
+    a.set_pose(world0, np.ones(4, np.float32))
+    a.deform()
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], world0, mesh["inv_bind"], deltas[:4], np.ones(4, np.float32))
+    assert_parity(*a.read(), pr, nr, "lender after its fork is gone")
+    a.close()

@@ -421,6 +421,25 @@ def test_engine_physics_hand_off_seam():
     assert r["deviceOrder"].index("overrideWorld") < r["deviceOrder"].index("setPoseLocal")
 
 
+def test_engine_frames_in_flight_alternates_between_the_context_and_one_fork():
+    """{ framesInFlight: 2 } (rz_fork): the first frame and the launch-shape search run on the lender, then ONE fork is made and
+    frames alternate fork / lender; reads go to the context of the frame rendered last; bone overrides reach both; the fork is
+    destroyed before static data is replaced and before the lender; a multi-GPU engine refuses the option. Recording stand-in
+    for the addon (the GPU side is tests/test_gpu_round2.py::test_fork_keeps_two_frames_in_flight_on_shared_static_data and
+    tests/test_gpu_parity.py::test_engine_frames_in_flight_through_napi)."""
+    out = subprocess.check_output(["node", os.path.join(ROOT, "tests", "js", "engine_inflight_mock.js")], timeout=60)
+    r = json.loads(out.decode().strip().splitlines()[-1])
+    fork = [f for f in r["frames"] if f.startswith("fork:")]
+    assert len(fork) == 1 and r["frames"][:3] == ["deform:ctx1", "autotune:ctx1", "read:ctx1"]
+    name = fork[0].split(":", 2)[2]
+    seq = [f for f in r["frames"] if f.startswith(("deform:", "read:"))][2:]
+    assert seq == ["deform:" + name, "read:" + name, "deform:ctx1", "read:ctx1", "deform:" + name, "read:" + name, "deform:ctx1", "read:ctx1"]
+    assert r["overrides"] == ["ctx1", name]
+    assert r["reload"][0] == "destroy:" + name and r["reload"][1] == "uploadMesh:ctx1" and "fork:ctx1" in r["reload"]
+    assert r["reload"].index("fork:ctx1") < [i for i, c in enumerate(r["reload"]) if c.startswith("overrideWorld:fork")][0]
+    assert r["dispose"][0].startswith("destroy:fork") and r["dispose"][1] == "destroy:ctx1" and r["multiGpuRefused"] is True
+
+
 def test_addon_exports_and_loud_failure_without_gpu():
     """The N-API shim binds every data-path entry point of the C ABI and refuses to run without a device."""
     js = ("const a=require('%s/reze-engine_amd/host/addon.js').requireAddon();"
@@ -431,7 +450,7 @@ def test_addon_exports_and_loud_failure_without_gpu():
     for k in ("create", "destroy", "uploadMesh", "uploadSkeleton", "uploadMorphsDense", "uploadMorphsSparse", "setInstances",
               "setPose", "deform", "sync", "read", "timeFrames", "commUniqueId", "commInit", "allgather", "shardRange",
               "uploadSkeletonTopology", "setPoseLocal", "readWorld", "autotune", "gatherDirect", "gatherFence", "readGathered",
-              "overrideWorld", "rcclInfo", "uploadAnimation", "setPoseSampled", "uploadBoneMorphs"):
+              "overrideWorld", "rcclInfo", "uploadAnimation", "setPoseSampled", "uploadBoneMorphs", "fork", "deformPair"):
         assert k in r["keys"], k
     import re
     header = open(os.path.join(ROOT, "include", "reze_deform.h")).read()
