@@ -11,6 +11,7 @@ echo "== bench"
 timeout 600 python bench.py 2>$O/bench.err | tail -1 > $O/bench_c5.json
 for c in c4 c3 c2; do timeout 600 python bench.py --config $c --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_$c.json; done
 timeout 600 python bench.py --verts 125952 --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_shard8.json
+timeout 600 python bench.py --verts 125952 --no-cpu-baseline --frames-in-flight 2 2>>$O/bench.err | tail -1 > $O/bench_shard8_inflight2.json
 timeout 600 python bench.py --config c4 --device-fk --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c4_devicefk.json
 timeout 600 python bench.py --config c4 --device-fk --device-sampling --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c4_sampled.json
 REZE_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --allgather --steps 100 --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c5_allgather1.json
@@ -19,8 +20,8 @@ import json, glob
 for f in sorted(glob.glob('gpurun_out/full/bench_*.json')):
     try:
         d = json.load(open(f)); c = d['config']; r = d['roofline']
-        print('%-26s value %.4g verts/s  ms/step %.5f  kernel %s %.5f ms frac %.3f frame_frac %.3f | upload loop %s sampled loop %s' % (
-            f.split('/')[-1], d['value'], d['ms_per_step'], r['kernel'], r['kernel_ms'], r['frac'], r['frame_frac'], c['frame_ms_with_pose_upload'], c['frame_ms_device_sampled_pose']))
+        print('%-30s value %.4g verts/s  ms/step %.5f (in flight %d; two in flight %s)  kernel %s %.5f ms frac %.3f frame_frac %.3f | upload loop %s sampled loop %s' % (
+            f.split('/')[-1], d['value'], d['ms_per_step'], c.get('frames_in_flight', 1), c.get('ms_per_step_two_frames_in_flight'), r['kernel'], r['kernel_ms'], r['frac'], r['frame_frac'], c['frame_ms_with_pose_upload'], c['frame_ms_device_sampled_pose']))
     except Exception as e:
         print(f, 'unreadable', e)
 P
