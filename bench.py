@@ -56,8 +56,10 @@ def parse_args():
     ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs of 16 frames in the timed loop (rz_set_tuning graph=1): for launch-bound small frames")
     ap.add_argument("--tune", default="", help="comma list key=value passed to rz_set_tuning (disables the autotune pass)")
     ap.add_argument("--clock-warm-seconds", type=float, default=2.5, help="untimed setup: run frames this long before the warmup steps so the GPU is at its sustained clocks")
-    ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=1,
-                    help="2: the timed steps alternate between the context and a fork of it (rz_fork: shared static data, own stream and outputs), so the tail of frame f overlaps the ramp of frame f + 1")
+    ap.add_argument("--frames-in-flight", choices=["auto", "1", "2"], default="auto",
+                    help="2: the timed steps alternate between the context and a fork of it (rz_fork: shared static data, own stream and outputs), so the tail of frame f "
+                         "overlaps the ramp of frame f + 1. auto (default): an untimed calibration during the warm-up picks 2 only when it is >= 3 %% faster on every rank's clock "
+                         "(small frames: shards at N >= 4, single characters); the C5 frame at N = 1 stays on one stream")
     ap.add_argument("--no-pair-loop", action="store_true", help="skip the secondary loop with two frames in flight")
     ap.add_argument("--no-sampled-loop", action="store_true", help="skip the secondary per-frame loop with the motion sampled on the GPU")
     ap.add_argument("--no-autotune", action="store_true", help="skip rz_autotune (setup-time search over launch shapes) and use the built-in heuristics")
@@ -264,7 +266,7 @@ def main():
     # what a WebGPU queue does with consecutive command buffers. The roofline below is always that of ONE kernel on one
     # stream (rz_time_frames); with --frames-in-flight 2 the timed steps themselves alternate.
     fork = None
-    if (args.frames_in_flight == 2 or not args.no_pair_loop) and not args.allgather:
+    if (args.frames_in_flight != "1" or not args.no_pair_loop) and not args.allgather:
         try:
             fork = ctx.fork()
             put_pose(fork)
@@ -291,21 +293,36 @@ def main():
         ctx.sync()
         fork.sync()
 
-    in_flight = 2 if (args.frames_in_flight == 2 and fork is not None) else 1
+    # untimed calibration (part of the warm-up, like rz_autotune): the same number of frames in both modes, three rounds,
+    # best of each, max over ranks; two frames in flight must win by 3 % to be chosen
+    calib = None
+    in_flight = 1
+    if fork is not None:
+        if args.frames_in_flight == "2":
+            in_flight = 2
+        elif args.frames_in_flight == "auto":
+            nc = max(20, min(args.steps, 200))
+            t1 = min(timed(lambda: ctx.deform_n(nc), ctx.sync) for _ in range(3)) / nc * 1e3
+            t2 = min(timed(lambda: ctx.deform_pair(fork, nc), sync_pair) for _ in range(3)) / nc * 1e3
+            in_flight = 2 if t2 < 0.97 * t1 else 1
+            calib = {"frames": nc, "one_stream_ms": t1, "two_in_flight_ms": t2, "rule": "two in flight when >= 3 % faster (max over ranks, best of 3)"}
+    one_stream = lambda: timed(lambda: ctx.deform_n(args.steps), ctx.sync)                     # noqa: E731
+    paired = lambda: timed(lambda: ctx.deform_pair(fork, args.steps), sync_pair)                # noqa: E731
+    other_ms = None
     if in_flight == 2:
         ctx.deform_pair(fork, args.warmup)
         sync_pair()
-        elapsed = timed(lambda: ctx.deform_pair(fork, args.steps), sync_pair)
-        other_ms = None
+        elapsed = paired()
+        if not args.no_pair_loop:      # secondary: the same K steps on one stream
+            ctx.deform_n(args.warmup)
+            other_ms = one_stream() / args.steps * 1e3
     else:
         ctx.deform_n(args.warmup)
-        elapsed = timed(lambda: ctx.deform_n(args.steps), ctx.sync)
-        # secondary: the same K steps with two frames in flight
-        other_ms = None
-        if fork is not None:
+        elapsed = one_stream()
+        if fork is not None and not args.no_pair_loop:      # secondary: the same K steps with two frames in flight
             ctx.deform_pair(fork, args.warmup)
             sync_pair()
-            other_ms = timed(lambda: ctx.deform_pair(fork, args.steps), sync_pair) / args.steps * 1e3
+            other_ms = paired() / args.steps * 1e3
     if fork is not None:
         fork.close()
         fork = None
@@ -453,6 +470,8 @@ def main():
                 "frame_ms_with_pose_upload": with_upload_ms,
                 "frame_ms_device_sampled_pose": sampled_ms,
                 "frames_in_flight": in_flight,
+                "frames_in_flight_choice": ("--frames-in-flight " + args.frames_in_flight) if calib is None else calib,
+                "ms_per_step_one_stream": elapsed / args.steps * 1e3 if in_flight == 1 else other_ms,
                 "ms_per_step_two_frames_in_flight": other_ms if in_flight == 1 else elapsed / args.steps * 1e3,
                 "frames_in_flight_note": "2 = frames alternate between the context and an rz_fork of it (shared static data, own stream + outputs): the tail of frame f overlaps the ramp of frame f + 1; roofline.* is always one kernel on one stream",
                 "per_frame_loops": "max over ranks, raw C ABI calls; with_pose_upload = rz_set_pose%s + rz_deform per frame, device_sampled_pose = rz_set_pose_sampled (1 float / instance) + rz_deform"

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/c4cnt; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-C4="python $R/bench.py --config c4 --steps 30 --warmup 3 --no-cpu-baseline --no-autotune --no-sampled-loop --clock-warm-seconds 0.2"
+C4="python $R/bench.py --config c4 --steps 30 --warmup 3 --no-cpu-baseline --no-autotune --no-sampled-loop --frames-in-flight 1 --no-pair-loop --clock-warm-seconds 0.2"
 G1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 G2="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"
 G3="GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"

@@ -10,7 +10,8 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | 
 echo "== bench"
 timeout 600 python bench.py 2>$O/bench.err | tail -1 > $O/bench_c5.json
 for c in c4 c3 c2; do timeout 600 python bench.py --config $c --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_$c.json; done
-timeout 600 python bench.py --verts 125952 --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_shard8.json
+timeout 600 python bench.py --verts 125952 --no-cpu-baseline --frames-in-flight 1 2>>$O/bench.err | tail -1 > $O/bench_shard8.json
+timeout 600 python bench.py --verts 125952 --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_shard8_auto.json
 timeout 600 python bench.py --verts 125952 --no-cpu-baseline --frames-in-flight 2 2>>$O/bench.err | tail -1 > $O/bench_shard8_inflight2.json
 timeout 600 python bench.py --config c4 --device-fk --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c4_devicefk.json
 timeout 600 python bench.py --config c4 --device-fk --device-sampling --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c4_sampled.json

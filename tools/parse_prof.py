@@ -105,7 +105,7 @@ for name, (title, V, B, M, I) in WORK.items():
                  "that keeps the skinMatrixBuffer observable (rz_read_palette). Its reads are 4-byte loads + LDS-DMA served mostly from L2 / "
                  "Infinity Cache (whose hits FETCH_SIZE counts); the x2 factor calibrated on 16 B/lane streams is applied as an UPPER bound "
                  "(traffic_over_algorithmic), the raw counter gives traffic_over_algorithmic_raw_fetch") if I > 1 else "",
-        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- " + title.split(" (")[0] + " --no-cpu-baseline --no-sampled-loop",
+        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- " + title.split(" (")[0] + " --no-cpu-baseline --no-sampled-loop --frames-in-flight 1 --no-pair-loop",
     }
     if I > 1:
         rec["V%d_B%d_M%d_I%d" % (V, B, M, I)]["traffic_over_algorithmic_raw_fetch"] = (fetch_kib * 1024 + write_b) / (alg_read + alg_write)
