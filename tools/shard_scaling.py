@@ -1,6 +1,6 @@
 """What each GPU runs at N = 1, 2, 4, 8 (strong scaling of C5): one shard of rz_shard_range(1 M, N, 0) on this GPU.
 Prints frame time, the projected N-GPU speed-up (t1 / tN) and the shard's algorithmic GB/s."""
-import sys, os, json
+import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import reze_engine_amd as rz
@@ -9,6 +9,7 @@ V, B, M = 1000000, 256, 64
 mesh = synth.make_mesh(V, B)
 deltas, mw = synth.make_morphs_dense(V, M)
 t1 = None
+t1_wall = None
 for N in (1, 2, 4, 8):
     b, n, _ = rz.shard.shard_of(V, N, 0)
     shard, d = rz.shard.cut_mesh(mesh, deltas, b, n)
@@ -25,4 +26,16 @@ for N in (1, 2, 4, 8):
     ctx.autotune()
     t = min((ctx.time_frames(300) for _ in range(5)), key=lambda t: t["frame_ms"])
     print(json.dumps({"N": N, "autotuned_frame_us": round(t["frame_ms"] * 1e3, 2), "split": ctx.get_tuning("effective_split"), "grid": ctx.get_tuning("effective_grid"), "projected_speedup_vs_untuned_t1": round(t1 / (t["frame_ms"] * 1e3), 2)}))
+    # the same shard with two frames in flight (rz_fork: shared static data, own stream + outputs), wall clock per frame
+    fk = ctx.fork()
+    fk.set_pose(mesh["world"], mw)
+    def wall(run, sync, n=1000):
+        sync(); t0 = time.perf_counter(); run(n); sync(); return (time.perf_counter() - t0) / n * 1e6
+    both = lambda: (ctx.sync(), fk.sync())          # noqa: E731
+    one = min(wall(ctx.deform_n, ctx.sync) for _ in range(4))
+    two = min(wall(lambda n: ctx.deform_pair(fk, n), both) for _ in range(4))
+    t1_wall = one if N == 1 else t1_wall
+    print(json.dumps({"N": N, "wall_us_one_stream": round(one, 2), "wall_us_two_frames_in_flight": round(two, 2),
+                      "projected_speedup_best_mode_vs_N1_one_stream": round(t1_wall / min(one, two), 2)}))
+    fk.close()
     ctx.close()
