@@ -387,6 +387,32 @@ def main():
     else:
         primary_call = ctx.frame_call("world", worlds, mws)
     with_upload_ms = per_frame_loop(*primary_call)
+    # the same per-frame loop with two frames in flight: pose f + 1 is uploaded and its frame enqueued on the fork while frame f
+    # still runs on the context (and the other way round)
+    with_upload_pair_ms = None
+    if not args.no_pair_loop and not args.allgather:
+        fk2 = None
+        try:
+            fk2 = ctx.fork()
+            kind = "sampled" if frames is not None else ("local" if quats is not None else "world")
+            call_b = fk2.frame_call(kind, frame_table(frames)) if frames is not None else fk2.frame_call(kind, quats if quats is not None else worlds, mws)
+            fa, fb, flip = primary_call[0], call_b[0], [0]
+
+            def both():
+                flip[0] ^= 1
+                (fb if flip[0] else fa)()
+
+            def check_both():
+                fk2.sync()
+                primary_call[1]()
+                call_b[1]()
+            with_upload_pair_ms = per_frame_loop(both, check_both)
+        except Exception as e:          # noqa: BLE001
+            sys.stderr.write("[bench] two-in-flight per-frame loop failed: %r\n" % (e,))
+            with_upload_pair_ms = rank_max(None)
+        finally:
+            if fk2 is not None:
+                fk2.close()
     # ... and the same loop when the motion lives on the GPU (rz_set_pose_sampled: ONE float per instance per frame, bones
     # sampled + hierarchy solved by rz_fk_kernel): the per-frame loop that does not pay for the pose upload at any N
     sampled_ms = None
@@ -469,6 +495,7 @@ def main():
                 "prep_kernel_ms": timing["prep_kernel_ms"],
                 "frame_ms_with_pose_upload": with_upload_ms,
                 "frame_ms_device_sampled_pose": sampled_ms,
+                "frame_ms_with_pose_upload_two_in_flight": with_upload_pair_ms,
                 "frames_in_flight": in_flight,
                 "frames_in_flight_choice": ("--frames-in-flight " + args.frames_in_flight) if calib is None else calib,
                 "ms_per_step_one_stream": elapsed / args.steps * 1e3 if in_flight == 1 else other_ms,
