@@ -445,6 +445,10 @@ class Engine {
       this.native.setPoseSampled(c, f)
       this.native.deform(c)
     }
+    if (this.autotune && !this.tuned) { // as in render(): the first frame supplied a pose
+      for (const s of this.shards) if (s.count > 0) this.native.autotune(s.ctx, 0)
+      this.tuned = true
+    }
     if (this.gather === 'direct' && this.shards.length > 1) this.native.gatherFence(this.ctx)
     else if (this.gather && this.shards.length > 1) this.native.allgatherAll(this.shards.map((s) => s.ctx), true)
     this.updateStats(wallClock() - t0)
