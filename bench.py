@@ -12,6 +12,12 @@ deformed positions is timed separately and reported in `config`.
 Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` (HIP-event
 timing of the dominant kernel against the ~8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle —
 all-core JavaScript skin when Node is available, else the threaded C port — on a bounded sample).
+
+`--gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment) re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N`: a plain `python bench.py --gpus 8` IS an 8-rank run. A launcher whose
+world size differs from --gpus, or fewer visible GPUs than ranks (without --share-gpu), is an error, never a silent N = 1.
+At N > 1 every rank joins an RCCL communicator built through the library's own entry points (rz_comm_init) and reports what
+the communicator says about itself (`config.ranks[].rccl`); the all-gather of deformed positions is timed OUTSIDE `value`.
 """
 import argparse
 import json
@@ -39,13 +45,16 @@ def parse_args():
     ap.add_argument("--bones", type=int, default=256)
     ap.add_argument("--morphs", type=int, default=64)
     ap.add_argument("--instances", type=int, default=1, help="C4-style instancing (single GPU only)")
-    ap.add_argument("--config", choices=["c5", "c4", "c3", "c2"], default=None,
-                    help="BASELINE.json shortcut: c5 = 1M/256/64 (default), c4 = 256 x 30k/200/0, c3 = 30k/200/64, c2 = 30k/200/0")
+    ap.add_argument("--config", choices=["c5", "c4", "c3", "c2", "demo", "sparse2"], default=None,
+                    help="BASELINE.json shortcut: c5 = 1M/256/64 (default), c4 = 256 x 30k/200/0, c3 = 30k/200/64, c2 = 30k/200/0; "
+                         "demo = the demo model's shape: 28 842 verts / 349 bones / 60 SPARSE vertex morphs with its statistics (36 397 offsets, "
+                         "largest 1 718, all on one 1 800-vertex face region); sparse2 = the same with the offsets spread at 2 %% density (SURVEY 8d)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong: --verts is the whole mesh, sharded over ranks; weak: --verts per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-verts", type=int, default=200000)
-    ap.add_argument("--allgather", action="store_true", help="also time the RCCL all-gather of positions")
+    ap.add_argument("--allgather", action="store_true", help="time the RCCL all-gather of positions at N = 1 too (at N > 1 it always is, outside `value`)")
+    ap.add_argument("--no-allgather", action="store_true", help="N > 1: skip the RCCL communicator + all-gather timing")
     ap.add_argument("--device-fk", action="store_true",
                     help="solve the bone hierarchy on the GPU: frames start from local rotations (rz_set_pose_local)")
     ap.add_argument("--device-sampling", action="store_true",
@@ -66,11 +75,27 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(args, mesh, deltas, mw):
+def cpu_baseline(args, mesh, deltas, mw, sparse=None):
     """Bounded CPU sample of the same workload: first `cpu_sample_verts` vertices, all morphs.
     Preferred: the all-core JavaScript f32 skin (oracle/js/cpu_baseline.js, worker_threads).
-    Fallback: the threaded C oracle, labelled as a stand-in."""
+    Fallback: the threaded C oracle, labelled as a stand-in. Sparse-morph workloads use the C oracle's sparse accumulate
+    (the JavaScript baseline only knows dense targets) followed by its threaded skin."""
     import oracle
+    if sparse is not None:
+        cores = os.cpu_count() or 1
+        V = len(mesh["pos"])
+        frames = 0
+        t0 = time.perf_counter()
+        while True:
+            pm = oracle.morph_sparse(V, sparse[0], sparse[1], sparse[2], mw, mesh["pos"])
+            oracle.deform(pm, mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"], None, None, threads=cores)
+            frames += 1
+            el = time.perf_counter() - t0
+            if el > 10.0 or frames >= 2000:
+                break
+        return {"value": V * frames / el, "unit": "verts/s", "cores": cores, "kind": "port",
+                "sample": "%d verts x %d sparse morphs (%d offsets), %d frames, C oracle: sparse morph accumulate on one thread + skin on %d threads "
+                          "(C stand-in for the TypeScript baseline)" % (V, len(sparse[0]) - 1, int(sparse[0][-1]), frames, cores)}
     n = min(args.cpu_sample_verts, len(mesh["pos"]))     # rank 0's shard = the head of the mesh
     sub = {k: np.ascontiguousarray(mesh[k][:n]) for k in ("pos", "nrm", "joints", "weights")}
     d = None if deltas is None else np.ascontiguousarray(deltas[:, :n])
@@ -121,6 +146,23 @@ def cpu_baseline(args, mesh, deltas, mw):
                       % (n, 0 if d is None else d.shape[0], frames)}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: become one. Re-executes this script under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU, and exits with its
+    status — so a plain invocation can never quietly measure one rank and call it N."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("[bench] --gpus %d without a launcher: re-executing as %d ranks: %s\n" % (args.gpus, args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    env = dict(os.environ)
+    env["REZE_BENCH_SELF_LAUNCHED"] = "1"
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse_args()
     if args.config == "c4":
@@ -129,14 +171,29 @@ def main():
         args.verts, args.bones, args.morphs, args.instances = 30000, 200, 64, 1
     elif args.config == "c2":
         args.verts, args.bones, args.morphs, args.instances = 30000, 200, 0, 1
+    sparse_kind = None
+    if args.config in ("demo", "sparse2"):
+        args.verts, args.bones, args.morphs, args.instances = 28842, 349, 60, 1
+        sparse_kind = args.config
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)               # never returns
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world_size != args.gpus and world_size > 1:
-        args.gpus = world_size
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world_size != args.gpus:
+        # a launcher with another world size than --gpus (or --gpus left at its default under a launcher): refuse, do not guess
+        if rank == 0:
+            sys.stderr.write("[bench] --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a line for a run "
+                             "that is not the one asked for\n" % (args.gpus, world_size))
+        sys.exit(3)
 
     import torch
+    if world_size > 1 and not args.share_gpu and torch.cuda.device_count() < world_size:
+        if rank == 0:
+            sys.stderr.write("[bench] %d ranks but only %d GPU(s) visible: one process per GPU (--share-gpu rehearses N > 1 on fewer GPUs)\n"
+                             % (world_size, torch.cuda.device_count()))
+        sys.exit(4)
     dist = None
     # REZE_BENCH_FORCE_DIST=1 exercises the torch.distributed (RCCL) path with a single rank
     if world_size > 1 or os.environ.get("REZE_BENCH_FORCE_DIST") == "1":
@@ -161,7 +218,20 @@ def main():
     # every rank generates ITS OWN shard of the same block-seeded mesh (synth.make_mesh_range): an 8-rank node never
     # builds eight copies of the 1 M-vertex mesh + 768 MB of morph targets on the host, and N = 1 ... 8 deform the same mesh
     shard = synth.make_mesh_range(V_total, B, b, n)
-    deltas, mw = synth.make_morphs_dense_range(V_total, M, b, n) if M > 0 else (None, None)
+    deltas, mw, sparse = None, None, None
+    if sparse_kind is not None:
+        # sparse vertex morphs (PMX's on-disk form, engine/src/pmx-loader.ts:483-488) of the WHOLE mesh, cut to this rank's range
+        if sparse_kind == "demo":
+            off, idx, d3, mw = synth.make_morphs_demo_shape(V_total, M)
+        else:
+            off, idx, d3, mw = synth.make_morphs_sparse(V_total, M, density=0.02)
+        if world_size > 1:
+            keep = (idx >= b) & (idx < b + n)
+            off = np.concatenate([[0], np.cumsum([int(keep[off[m]:off[m + 1]].sum()) for m in range(M)])]).astype(np.uint32)
+            idx, d3 = (idx[keep] - b).astype(np.uint32), d3[keep]
+        sparse = (off, idx, d3)
+    elif M > 0:
+        deltas, mw = synth.make_morphs_dense_range(V_total, M, b, n)
     mesh = shard                         # skeleton / pose fields are the same on every rank
 
     ctx = rz.DeformContext(local_rank)
@@ -169,6 +239,8 @@ def main():
     ctx.upload_skeleton(mesh["inv_bind"])
     if deltas is not None:
         ctx.upload_morphs_dense(deltas)
+    if sparse is not None:
+        ctx.upload_morphs_sparse(*sparse)
     worlds = mesh["world"]
     mws = mw
     if I > 1:
@@ -221,12 +293,40 @@ def main():
         """64 rows of per-instance frame numbers marching through the 70-frame motion (cycled by the per-frame loop)."""
         return np.stack([(fr + 0.5 * k) % 70.0 for k in range(64)]).astype(np.float32)
     put_pose()
-    tuned = None
+
+    def gather(x):
+        """one entry per rank (a list of length 1 without torch.distributed)"""
+        if dist is None:
+            return [x]
+        vals = [None] * world_size
+        dist.all_gather_object(vals, x)
+        return vals
+
+    # ---- launch-shape search (untimed setup, like a GEMM library's find mode) ----
+    # Every rank measures the same candidate list on its own shard; the tables are reduced with MAX over the ranks (the frame
+    # time of a sharded mesh is its slowest GPU's) and every rank adopts the SAME entry: the heuristic plan unless a
+    # candidate beats it by >= 2 % (rz_autotune_pick). config.autotune_table carries the reduced table.
+    tuned, tune_table, tune_pick = None, None, None
     if not args.no_autotune and not args.tune:
         try:
-            tuned = ctx.autotune()      # setup-time search over launch shapes (untimed, like a GEMM library's find mode)
+            mine_tab = ctx.autotune_measure()
         except Exception as e:          # noqa: BLE001  (the heuristics are a complete fallback)
-            sys.stderr.write("[bench] autotune failed, using the heuristics: %r\n" % (e,))
+            sys.stderr.write("[bench] autotune failed on rank %d, using the heuristics: %r\n" % (rank, e))
+            mine_tab = None
+        tabs = gather(mine_tab)
+        key = lambda t: [(e["morph_split"], e["grid_cap"], e["inst_loop"]) for e in t]      # noqa: E731
+        if all(t is not None for t in tabs) and all(key(t) == key(tabs[0]) for t in tabs):
+            tune_table = [dict(e) for e in tabs[0]]
+            for k, e in enumerate(tune_table):
+                e["ms"] = max(t[k]["ms"] for t in tabs)
+                e["ms_min"] = min(t[k]["ms_min"] for t in tabs)
+                e["ms_max"] = max(t[k]["ms_max"] for t in tabs)
+                if any(t[k]["same_as"] != e["same_as"] for t in tabs):
+                    e["same_as"] = -1           # not the same launch on every rank: judged on its own
+            tune_pick = ctx.autotune_pick(tune_table)
+            ctx.autotune_apply(tune_table[tune_pick])
+            tuned = {k: ctx.get_tuning(k) for k in ("effective_split", "effective_grid", "effective_inst_group")}
+        else:
             ctx.set_tuning(morph_split=0, grid_cap=0, inst_loop=-1)
 
     if args.graph:
@@ -250,11 +350,7 @@ def main():
 
     def rank_max(x):
         """max over ranks of a host-side scalar (None stays None when every rank has None)."""
-        if dist is None:
-            return x
-        vals = [None] * world_size
-        dist.all_gather_object(vals, x)
-        vals = [v for v in vals if v is not None]
+        vals = [v for v in gather(x) if v is not None]
         return max(vals) if vals else None
 
     # ---- warmup, then EXACTLY K timed steps between barrier + synchronize on both sides ----
@@ -266,12 +362,19 @@ def main():
     # what a WebGPU queue does with consecutive command buffers. The roofline below is always that of ONE kernel on one
     # stream (rz_time_frames); with --frames-in-flight 2 the timed steps themselves alternate.
     fork = None
-    if (args.frames_in_flight != "1" or not args.no_pair_loop) and not args.allgather:
+    if args.frames_in_flight != "1" or not args.no_pair_loop:
         try:
             fork = ctx.fork()
             put_pose(fork)
         except Exception as e:          # noqa: BLE001
-            sys.stderr.write("[bench] rz_fork failed: %r\n" % (e,))
+            sys.stderr.write("[bench] rz_fork failed on rank %d: %r\n" % (rank, e))
+            if fork is not None:
+                fork.close()
+            fork = None
+        # every rank takes the same code path below (the timed loops contain collectives): one rank without a fork = nobody forks
+        if not all(gather(fork is not None)):
+            if fork is not None:
+                fork.close()
             fork = None
 
     def timed(run, sync_all):
@@ -306,47 +409,65 @@ def main():
             t2 = min(timed(lambda: ctx.deform_pair(fork, nc), sync_pair) for _ in range(3)) / nc * 1e3
             in_flight = 2 if t2 < 0.97 * t1 else 1
             calib = {"frames": nc, "one_stream_ms": t1, "two_in_flight_ms": t2, "rule": "two in flight when >= 3 % faster (max over ranks, best of 3)"}
-    one_stream = lambda: timed(lambda: ctx.deform_n(args.steps), ctx.sync)                     # noqa: E731
-    paired = lambda: timed(lambda: ctx.deform_pair(fork, args.steps), sync_pair)                # noqa: E731
-    other_ms = None
-    if in_flight == 2:
+
+    def one_stream():
+        ctx.deform_n(args.warmup)
+        return timed(lambda: ctx.deform_n(args.steps), ctx.sync)
+
+    def paired():
         ctx.deform_pair(fork, args.warmup)
         sync_pair()
-        elapsed = paired()
-        if not args.no_pair_loop:      # secondary: the same K steps on one stream
-            ctx.deform_n(args.warmup)
-            other_ms = one_stream() / args.steps * 1e3
-    else:
-        ctx.deform_n(args.warmup)
-        elapsed = one_stream()
-        if fork is not None and not args.no_pair_loop:      # secondary: the same K steps with two frames in flight
-            ctx.deform_pair(fork, args.warmup)
-            sync_pair()
-            other_ms = paired() / args.steps * 1e3
+        return timed(lambda: ctx.deform_pair(fork, args.steps), sync_pair)
+
+    def kernel_timing():
+        """roofline of the dominant kernel: HIP events on the context's own stream, one kernel at a time"""
+        return ctx.time_frames(max(20, min(args.steps, 200)))
+
+    # Order: the K steps on ONE stream (the timed steps themselves, or — when two frames in flight were chosen — the
+    # secondary number), then the kernel's own timing straight after them, in the same state of the GPU, then anything that
+    # runs two kernels at once. A kernel cannot take longer than the step that contains it: if the event timing disagrees
+    # with the one-stream step by more than 3 % it is measured again, once, and the line says so.
+    one_ms, pair_ms = None, None
+    if in_flight == 1 or not args.no_pair_loop:
+        one_el = one_stream()
+        one_ms = one_el / args.steps * 1e3
+    timing = kernel_timing()
+    kcheck = {"rule": "kernel_ms <= 1.03 x ms_per_step_one_stream", "remeasured": False}
+    if one_ms is not None and timing["deform_kernel_ms"] > 1.03 * one_ms:
+        timing = kernel_timing()
+        kcheck["remeasured"] = True
+    kcheck["ok"] = one_ms is None or timing["deform_kernel_ms"] <= 1.03 * one_ms
+    if fork is not None and (in_flight == 2 or not args.no_pair_loop):
+        pair_el = paired()
+        pair_ms = pair_el / args.steps * 1e3
+    elapsed = pair_el if in_flight == 2 else one_el
     if fork is not None:
         fork.close()
         fork = None
 
-    # ---- roofline of the dominant kernel: HIP events on the context's own stream ----
-    timing = ctx.time_frames(max(20, min(args.steps, 200)))
     kern_s = timing["deform_kernel_ms"] * 1e-3
     achieved = timing["algorithmic_bytes_per_frame"] / kern_s / 1e9
     kernel_name = ctx.kernel_name()
     # HBM bytes per launch from the PMC counters are collected OFFLINE (rocprofv3 cannot run inside this process):
-    # tools/gpu_profile.sh + tools/parse_prof.py store them per workload shape; this line only looks the shape up.
+    # tools/gpu_profile.sh + tools/parse_prof.py store them per (workload shape, kernel); this line looks up the kernel the
+    # plan ACTUALLY launches and carries no traffic figure when that kernel was never measured.
     traffic, traffic_source = None, None
     tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    shape_key = "V%d_B%d_M%d_I%d%s" % (n, B, M, I, "" if sparse_kind is None else "_" + sparse_kind)
     if os.path.exists(tj):
         try:
             rec = json.load(open(tj))
-            key = "V%d_B%d_M%d_I%d" % (n, B, M, I)
+            key = shape_key + "|" + kernel_name
             if key in rec:
                 traffic = rec[key]["hbm_bytes_per_launch"]
                 traffic_source = "stored: profiles/pmc_traffic.json[%s] (%s)" % (key, rec[key].get("command", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"))
+            else:
+                others = sorted(k.split("|", 1)[1] for k in rec if k.startswith(shape_key + "|"))
+                traffic_source = "none stored for this kernel on this workload shape (profiles/pmc_traffic.json has %s)" % (others or "nothing for the shape")
         except Exception:
             traffic = None
-    if traffic is None:
-        traffic_source = "none stored for this workload shape (profiles/pmc_traffic.json)"
+    if traffic_source is None:
+        traffic_source = "profiles/pmc_traffic.json missing"
     # the streaming ceiling measured on this kind of box (tools/membench): reads for the morph-stream frames, writes for crowds
     ceiling, ceiling_what = None, None
     cj = os.path.join(ROOT, "profiles", "ceilings.json")
@@ -362,24 +483,35 @@ def main():
     # (secondary numbers never take the line down with them: a failure here is reported as null)
     n_up = min(args.steps, 200)
 
-    def per_frame_loop(frame, check):
+    def per_frame_loop(frame, check, sync_all=None):
         """frame() = one pose upload + rz_deform through the raw C ABI (DeformContext.frame_call: arrays and pointers are
-        prepared up front, so the loop times the library and the GPU, not numpy conversions)."""
+        prepared up front, so the loop times the library and the GPU, not numpy conversions). The clock stops when EVERY
+        context the loop fed has drained (sync_all)."""
+        sync_all = sync_all or ctx.sync
+        dt = None
         try:
             for _ in range(400):        # the upload path's own warm-up: pinned ring, upload stream (the HIP runtime
                                         # stalls ~25 ms once, somewhere in the first few hundred two-stream frames)
                 frame()
+            sync_all()
+        except Exception as e:          # noqa: BLE001
+            sys.stderr.write("[bench] per-frame loop warm-up failed on rank %d: %r\n" % (rank, e))
+            frame = None
+        if not all(gather(frame is not None)):      # the barrier below is a collective: all ranks or none
+            return None
+        try:
             barrier()
             tp0 = time.perf_counter()
             for _ in range(n_up):
                 frame()
-            ctx.sync()
+            sync_all()
             dt = (time.perf_counter() - tp0) * 1e3 / n_up
             check()
-            return rank_max(dt)
         except Exception as e:          # noqa: BLE001
-            sys.stderr.write("[bench] per-frame upload timing failed: %r\n" % (e,))
-            return rank_max(None)
+            sys.stderr.write("[bench] per-frame upload timing failed on rank %d: %r\n" % (rank, e))
+            dt = None
+        vals = gather(dt)
+        return None if any(v is None for v in vals) else max(vals)
     if frames is not None:
         primary_call = ctx.frame_call("sampled", frame_table(frames))
     elif quats is not None:
@@ -390,12 +522,16 @@ def main():
     # the same per-frame loop with two frames in flight: pose f + 1 is uploaded and its frame enqueued on the fork while frame f
     # still runs on the context (and the other way round)
     with_upload_pair_ms = None
-    if not args.no_pair_loop and not args.allgather:
-        fk2 = None
+    if not args.no_pair_loop:
+        fk2, call_b = None, None
         try:
             fk2 = ctx.fork()
             kind = "sampled" if frames is not None else ("local" if quats is not None else "world")
             call_b = fk2.frame_call(kind, frame_table(frames)) if frames is not None else fk2.frame_call(kind, quats if quats is not None else worlds, mws)
+        except Exception as e:          # noqa: BLE001
+            sys.stderr.write("[bench] two-in-flight per-frame loop: rz_fork failed on rank %d: %r\n" % (rank, e))
+            call_b = None
+        if all(gather(call_b is not None)):
             fa, fb, flip = primary_call[0], call_b[0], [0]
 
             def both():
@@ -403,20 +539,20 @@ def main():
                 (fb if flip[0] else fa)()
 
             def check_both():
-                fk2.sync()
                 primary_call[1]()
                 call_b[1]()
-            with_upload_pair_ms = per_frame_loop(both, check_both)
-        except Exception as e:          # noqa: BLE001
-            sys.stderr.write("[bench] two-in-flight per-frame loop failed: %r\n" % (e,))
-            with_upload_pair_ms = rank_max(None)
-        finally:
-            if fk2 is not None:
-                fk2.close()
+
+            def sync_both():
+                ctx.sync()
+                fk2.sync()
+            with_upload_pair_ms = per_frame_loop(both, check_both, sync_both)
+        if fk2 is not None:
+            fk2.close()
     # ... and the same loop when the motion lives on the GPU (rz_set_pose_sampled: ONE float per instance per frame, bones
     # sampled + hierarchy solved by rz_fk_kernel): the per-frame loop that does not pay for the pose upload at any N
     sampled_ms = None
     if not args.no_sampled_loop:
+        sampled_call = None
         try:
             if frames is None:
                 if not args.device_fk:
@@ -424,48 +560,66 @@ def main():
                 fr2 = upload_motion()
             else:
                 fr2 = frames
-
-            sampled_ms = per_frame_loop(*ctx.frame_call("sampled", frame_table(fr2)))
+            sampled_call = ctx.frame_call("sampled", frame_table(fr2))
         except Exception as e:          # noqa: BLE001
-            sys.stderr.write("[bench] device-sampling loop failed: %r\n" % (e,))
-            sampled_ms = rank_max(None)
+            sys.stderr.write("[bench] device-sampling loop setup failed on rank %d: %r\n" % (rank, e))
+        if all(gather(sampled_call is not None)):
+            sampled_ms = per_frame_loop(*sampled_call)
         put_pose()                      # back to the primary pose kind
 
+    # ---- RCCL: at N > 1 every rank joins a communicator made by the library's own entry points, says what the
+    # communicator reports about itself, and the all-gather of deformed positions is timed — OUTSIDE `value` ----
     ag_ms, rccl = None, None
-    if args.allgather and I == 1:
-        uid = [rz.capi.comm_unique_id() if rank == 0 else None]
-        if dist is not None:
-            dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(world_size, rank, uid[0], V_total)
-        rccl = rz.capi.rccl_info()
-        for _ in range(5):
-            ctx.allgather()
-        barrier()
-        ta = time.perf_counter()
-        for _ in range(50):
-            ctx.allgather()
-        barrier()
-        ag_ms = (time.perf_counter() - ta) * 1e3 / 50
+    want_comm = I == 1 and ((world_size > 1 and not args.no_allgather and not args.share_gpu) or args.allgather)
+    if want_comm:
+        try:
+            uid = [rz.capi.comm_unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(world_size, rank, uid[0], V_total)
+            rccl = rz.capi.rccl_info()
+            rccl.update(ctx.comm_info())
+            rccl["expected_count"] = world_size
+            for _ in range(5):
+                ctx.allgather()
+            barrier()
+            ta = time.perf_counter()
+            for _ in range(50):
+                ctx.allgather()
+            barrier()
+            ag_ms = rank_max((time.perf_counter() - ta) * 1e3 / 50)
+        except Exception as e:          # noqa: BLE001
+            sys.stderr.write("[bench] RCCL communicator / all-gather failed on rank %d: %r\n" % (rank, e))
+            rccl = {"error": repr(e)}
+    elif world_size > 1:
+        rccl = {"skipped": "--share-gpu: ranks share a GPU, RCCL needs one GPU per rank" if args.share_gpu else "--no-allgather"}
 
     # one record per rank, so a slow or oddly planned GPU is visible in the scaling file
     mine = {"rank": rank, "device": local_rank, "verts": n, "kernel_ms": timing["deform_kernel_ms"], "frame_ms": timing["frame_ms"],
             "kernel": kernel_name, "grid": ctx.get_tuning("effective_grid"), "morph_split": ctx.get_tuning("effective_split"),
             "autotuned": tuned is not None, "rccl": rccl}
-    per_rank = [mine]
-    if dist is not None:
-        per_rank = [None] * world_size
-        dist.all_gather_object(per_rank, mine)
+    per_rank = gather(mine)
 
     cpu = None
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(args, mesh, deltas, mw)
+            cpu = cpu_baseline(args, mesh, deltas, mw, sparse)
         except Exception as e:          # noqa: BLE001
             sys.stderr.write("[bench] cpu baseline failed: %r\n" % (e,))
 
     if rank == 0:
         verts = V_total * I * args.steps
         kms = [r["kernel_ms"] for r in per_rank]
+        names = {(1000000, 256, 64, 1): "C5", (30000, 200, 0, 256): "C4", (30000, 200, 64, 1): "C3", (30000, 200, 0, 1): "C2"}
+        if sparse_kind == "demo":
+            wl = ("demo-shaped: %d-vert / %d-bone / %d SPARSE vertex morphs with the demo model's statistics (%d offsets, largest %d, "
+                  "all on one 1 800-vertex face region), vertex-sharded over %d GPU(s)" % (V_total, B, M, int(sparse[0][-1]) if world_size == 1 else -1,
+                                                                                      int(np.diff(sparse[0]).max()) if world_size == 1 else -1, world_size))
+        elif sparse_kind == "sparse2":
+            wl = "sparse-2%%: %d-vert / %d-bone / %d SPARSE vertex morphs at 2 %% density spread over the mesh, vertex-sharded over %d GPU(s)" % (V_total, B, M, world_size)
+        else:
+            wl = "%s: %d-vert / %d-bone / %d-dense-morph synthetic PMX%s, vertex-sharded over %d GPU(s)" % (
+                names.get((V_total, B, M, I), "custom"), V_total, B, M, (" x %d instances (per-instance palette in LDS)" % I) if I > 1 else "", world_size)
         out = {
             "metric": "deformed verts/sec at 1/2/4/8 GPU; achieved HBM GB/s vs ~8 TB/s roofline",
             "value": verts / elapsed,
@@ -480,17 +634,24 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s: %d-vert / %d-bone / %d-dense-morph synthetic PMX%s, vertex-sharded over %d GPU(s)"
-                            % ({(1000000, 256, 64, 1): "C5", (30000, 200, 0, 256): "C4", (30000, 200, 64, 1): "C3",
-                                (30000, 200, 0, 1): "C2"}.get((V_total, B, M, I), "custom"), V_total, B, M,
-                               (" x %d instances (per-instance palette in LDS)" % I) if I > 1 else "", world_size),
+                "workload": wl,
                 "verts_total": V_total, "verts_per_gpu": n, "bones": B, "morphs": M, "instances": I,
+                "morph_layout": "sparse CSR" if sparse_kind else ("dense planes" if M else "none"),
                 "parallelism": "vertex-shard x%d" % world_size,
+                "launched_by": "self (python -m torch.distributed.run, re-executed by bench.py)" if os.environ.get("REZE_BENCH_SELF_LAUNCHED") == "1"
+                               else ("external launcher (WORLD_SIZE in the environment)" if "WORLD_SIZE" in os.environ else "single process"),
                 "bone_hierarchy_solve": ("device (motion sampling + hierarchy solve in rz_fk_kernel)" if args.device_sampling else "device (rz_fk_kernel)") if args.device_fk else "host",
                 "autotune": tuned is not None,
+                "autotune_rule": "heuristic plan (entry 0) unless a candidate's median-of-3-rounds time, MAX over ranks, is >= 2 % faster; every rank adopts the same entry",
+                "autotune_pick": tune_pick,
+                "autotune_table": None if tune_table is None else [{k: (round(e[k], 6) if isinstance(e[k], float) else e[k]) for k in e} for e in tune_table],
                 "graph_replay": bool(args.graph),
                 "morph_split": ctx.get_tuning("effective_split"),
                 "grid": ctx.get_tuning("effective_grid"),
+                "inst_group": ctx.get_tuning("effective_inst_group"),
+                "inst_subsets": ctx.get_tuning("effective_subsets"),
+                "inst_subset_bones": ctx.get_tuning("effective_subset_bones"),
+                "inst_lds_bytes": ctx.get_tuning("effective_inst_lds"),
                 "frame_ms_events": timing["frame_ms"],
                 "prep_kernel_ms": timing["prep_kernel_ms"],
                 "frame_ms_with_pose_upload": with_upload_ms,
@@ -498,12 +659,15 @@ def main():
                 "frame_ms_with_pose_upload_two_in_flight": with_upload_pair_ms,
                 "frames_in_flight": in_flight,
                 "frames_in_flight_choice": ("--frames-in-flight " + args.frames_in_flight) if calib is None else calib,
-                "ms_per_step_one_stream": elapsed / args.steps * 1e3 if in_flight == 1 else other_ms,
-                "ms_per_step_two_frames_in_flight": other_ms if in_flight == 1 else elapsed / args.steps * 1e3,
+                "ms_per_step_one_stream": one_ms,
+                "ms_per_step_two_frames_in_flight": pair_ms,
+                "speedup_basis": "compare N-GPU lines mode for mode: ms_per_step_one_stream(1) / ms_per_step_one_stream(N), or the _two_frames_in_flight pair; "
+                                 "ms_per_step / value are the mode `frames_in_flight` names (auto picks per N)",
                 "frames_in_flight_note": "2 = frames alternate between the context and an rz_fork of it (shared static data, own stream + outputs): the tail of frame f overlaps the ramp of frame f + 1; roofline.* is always one kernel on one stream",
-                "per_frame_loops": "max over ranks, raw C ABI calls; with_pose_upload = rz_set_pose%s + rz_deform per frame, device_sampled_pose = rz_set_pose_sampled (1 float / instance) + rz_deform"
+                "per_frame_loops": "max over ranks, raw C ABI calls, clock stopped after every context drained; with_pose_upload = rz_set_pose%s + rz_deform per frame, device_sampled_pose = rz_set_pose_sampled (1 float / instance) + rz_deform"
                                    % ("_local" if args.device_fk else ""),
                 "allgather_ms": ag_ms,
+                "allgather_note": "ncclAllGather of the deformed positions over the library's own communicator, timed after and outside the K steps",
                 "kernel_ms_min_over_ranks": min(kms), "kernel_ms_max_over_ranks": max(kms),
                 "ranks": per_rank,
             },
@@ -521,6 +685,7 @@ def main():
                 "frac_of_measured_ceiling": (achieved / ceiling) if ceiling else None,
                 "algorithmic_bytes_per_launch": timing["algorithmic_bytes_per_frame"],
                 "kernel_ms": timing["deform_kernel_ms"],
+                "kernel_ms_check": kcheck,
                 "frame_frac": timing["algorithmic_bytes_per_frame"] / (timing["frame_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             },
             "cpu_baseline": cpu,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 3
+#define RZ_ABI_VERSION 4
 
 typedef struct rz_ctx rz_ctx;
 
@@ -233,8 +233,10 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * "geo_lds" (0/1: rest geometry transposed through LDS vs 4-byte loads), "nontemporal" (0/1,
  * morph-stream loads), "nt_store" (0/1, output stores), "fast" (-1 auto, 0 always run the
  * separate prep kernel, 1 one-launch frame when possible), "out_cap" (-1 auto, 0 off, else vertices a wave
- * parks in LDS before writing them out in one burst), "inst_loop" (-1 auto, 0 off, 2..8 / 10..16 poses
- * per workgroup in instanced morph-free frames, 9 = the register-resident form), "inst_block" (0 auto, 256 / 512 / 1024 threads per
+ * parks in LDS before writing them out in one burst), "inst_loop" (-1 auto, 0 off, 2..8 / 10..64 poses
+ * per workgroup in instanced morph-free frames, 9 = the register-resident form), "inst_subsets" (-1 auto / 1: a crowd workgroup stages
+ * only the bones its vertex run names when that list is shorter than the skeleton — same bits, a fraction of the LDS and of the
+ * per-workgroup front; 0: always the whole palette), "inst_block" (0 auto, 256 / 512 / 1024 threads per
  * workgroup of the instanced kernel; for crowds "fast" -1 / 1 = palettes formed inside the skin kernel, one launch per frame, 0 =
  * rz_prep_kernel in front), "inst_order" (1 default / 0: which workgroups of the instanced kernel an XCD gets — 1: every vertex run
  * of ITS pose groups, so an XCD's L2 pulls one eighth of the poses' matrices; 0: one vertex run of every pose group), "graph" (0/1: rz_deform_n replays hipGraphs of 16 captured frames instead of launching every kernel —
@@ -245,19 +247,38 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * the previous frame's skin kernel — measured slower on this runtime, kept for experiments). There is no key that makes a frame
  * emit anything but the deformed mesh: ablation switches exist only in a tools-only build and "dbg" is rejected here.
  * rz_get_tuning also answers "effective_split" / "effective_unroll" / "effective_grid" / "effective_fast" / "effective_out_cap" /
- * "effective_inst_group" / "effective_inst_block" / "effective_fuse_fk" / "effective_overlap" / "pose_resident" and the counts
+ * "effective_inst_group" / "effective_inst_block" / "effective_fuse_fk" / "effective_overlap" / "pose_resident" /
+ * "effective_subsets" / "effective_subset_bones" / "effective_inst_lds" and the counts
  * "verts" / "bones" / "morphs" / "instances". Unknown keys return RZ_ERR_INVALID. */
 int rz_set_tuning(rz_ctx *ctx, const char *key, int value);
 int rz_get_tuning(rz_ctx *ctx, const char *key, int *value);
 
 /* Setup-time search over launch shapes (like a GEMM library's "find" mode; no reference counterpart — WebGPU hides
- * the dispatch shape, engine.ts:2393-2402): times `frames` frames (0 = 30, at most 1000) of every distinct plan among morph split
- * {1,2,4,8} x {1,2,4} workgroups per CU (instanced frames: {4,8} poses per workgroup x {2,4} workgroups per CU) with
- * the CURRENT mesh / morphs / pose on this GPU and keeps the fastest as the "morph_split" / "grid_cap" / "inst_loop"
- * tuning values. Needs a pose; costs a few hundred frames; results stay within the parity tolerance for every
- * candidate (tests cover them all). The result belongs to the workload it was timed on: uploading another mesh or
- * other morph targets, or changing the instance count, returns the three keys to their heuristics, and so does
- * rz_set_tuning(key, 0 / -1). */
+ * the dispatch shape, engine.ts:2393-2402). Candidates: the built-in heuristic plan (entry 0) and every distinct plan among morph
+ * split {1,2,4,8} x {1,2,4} workgroups per CU (instanced frames: poses per workgroup x workgroups per CU), timed with the
+ * CURRENT mesh / morphs / pose on this GPU: `frames` frames per round (0 = 100, at most 1000), >= 3 rounds dealt round-robin over
+ * the candidates (so clock / thermal drift hits all of them alike), the MEDIAN round of each is its time.
+ *   rz_autotune_measure  fills `table` (at most `cap` entries, *count = how many) and changes nothing;
+ *   rz_autotune_apply    adopts one entry as the "morph_split" / "grid_cap" / "inst_loop" tuning values;
+ *   rz_autotune          = measure + rz_autotune_pick + apply. The heuristic plan is KEPT unless a candidate beats it by >= 2 %: the
+ *                        landscape is flat near the optimum and a search that follows noise returns a different plan on every run.
+ * Several GPUs deforming shards of one mesh (one process per GPU) take the element-wise MAX of their tables' `ms` over the
+ * ranks, then every rank picks from that one table with rz_autotune_pick and applies the same entry — one plan on all ranks,
+ * judged by the slowest GPU, which is what the frame time is (bench.py does this over torch.distributed).
+ * Every candidate is a plan the parity tests cover. The result belongs to the workload it was timed on: uploading
+ * another mesh or other morph targets, or changing the instance count, returns the three keys to their heuristics, and
+ * so does rz_set_tuning(key, 0 / -1). */
+typedef struct rz_tune_entry {
+    int morph_split, grid_cap, inst_loop;   /* the request (rz_set_tuning values; 0 / 0 / -1 = the heuristics) */
+    int eff_split, eff_grid, eff_inst_group;/* what it resolves to on this context */
+    int same_as;                            /* index of an earlier entry that resolves to the same launch (its time is shared), or -1 */
+    float ms;                               /* median round, ms per frame */
+    float ms_min, ms_max;                   /* fastest / slowest round */
+} rz_tune_entry;
+int rz_autotune_measure(rz_ctx *ctx, uint32_t frames, rz_tune_entry *table, int cap, int *count);
+/* index of the entry to adopt under the stability rule above (entry 0 unless some entry's ms < 0.98 x entry 0's) */
+int rz_autotune_pick(const rz_tune_entry *table, int count);
+int rz_autotune_apply(rz_ctx *ctx, const rz_tune_entry *entry);
 int rz_autotune(rz_ctx *ctx, uint32_t frames);
 
 /* Device pointers of the output buffers ([I][Vpad][3] floats each) and the padded vertex count,
@@ -275,6 +296,9 @@ int rz_comm_unique_id(char id[128]);
  * and whether it is a copy the process had ALREADY loaded (PyTorch ships its own librccl.so with the same soname): the
  * library looks for one with RTLD_NOLOAD first, so that a process never runs two RCCL runtimes side by side. */
 int rz_rccl_info(char *path, size_t path_bytes, int *version, int *reused);
+/* What the communicator itself says after rz_comm_init / rz_comm_init_all: ncclCommCount and ncclCommUserRank
+ * (evidence that RCCL really spans `nranks` ranks — bench.py prints it per rank). */
+int rz_comm_info(rz_ctx *ctx, int *comm_count, int *comm_user_rank);
 int rz_comm_init(rz_ctx *ctx, int nranks, int rank, const char id[128], uint32_t v_total);
 int rz_allgather(rz_ctx *ctx, int with_normals);
 int rz_read_gathered(rz_ctx *ctx, uint32_t v0, uint32_t n, float *pos3, float *nrm3);

@@ -17,8 +17,9 @@ SYMBOLS = [
     "rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_destroy", "rz_shard_range",
     "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
     "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_upload_bone_morphs", "rz_upload_animation", "rz_set_pose_sampled", "rz_override_world", "rz_read_world", "rz_deform", "rz_deform_n", "rz_fork", "rz_deform_pair", "rz_sync", "rz_read",
-    "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_autotune", "rz_output_ptrs",
-    "rz_comm_unique_id", "rz_rccl_info", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_gather_fence", "rz_upload_edge_scale", "rz_read_hull", "rz_enable_aabb", "rz_read_aabb",
+    "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_autotune", "rz_autotune_measure", "rz_autotune_pick",
+    "rz_autotune_apply", "rz_output_ptrs",
+    "rz_comm_unique_id", "rz_rccl_info", "rz_comm_info", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_gather_fence", "rz_upload_edge_scale", "rz_read_hull", "rz_enable_aabb", "rz_read_aabb",
 ]
 
 
@@ -37,6 +38,12 @@ class RzTiming(ctypes.Structure):
                 ("prep_kernel_ms", ctypes.c_double), ("verts_per_frame", ctypes.c_uint64),
                 ("algorithmic_bytes_per_frame", ctypes.c_uint64), ("frames", ctypes.c_uint32),
                 ("reserved", ctypes.c_uint32)]
+
+
+class RzTuneEntry(ctypes.Structure):
+    _fields_ = [("morph_split", ctypes.c_int), ("grid_cap", ctypes.c_int), ("inst_loop", ctypes.c_int),
+                ("eff_split", ctypes.c_int), ("eff_grid", ctypes.c_int), ("eff_inst_group", ctypes.c_int),
+                ("same_as", ctypes.c_int), ("ms", ctypes.c_float), ("ms_min", ctypes.c_float), ("ms_max", ctypes.c_float)]
 
 
 class RzError(RuntimeError):
@@ -91,6 +98,10 @@ def load():
     L.rz_read_palette.argtypes = [vp, u32, fp]
     L.rz_time_frames.argtypes = [vp, u32, ctypes.POINTER(RzTiming)]
     L.rz_autotune.argtypes = [vp, u32]
+    L.rz_autotune_measure.argtypes = [vp, u32, ctypes.POINTER(RzTuneEntry), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.rz_autotune_pick.argtypes = [ctypes.POINTER(RzTuneEntry), ctypes.c_int]
+    L.rz_autotune_apply.argtypes = [vp, ctypes.POINTER(RzTuneEntry)]
+    L.rz_comm_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.rz_set_tuning.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
     L.rz_get_tuning.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     L.rz_output_ptrs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u32)]
@@ -471,6 +482,35 @@ class DeformContext:
         _chk(self._L.rz_autotune(self._h, int(frames)))
         return {k: self.get_tuning(k) for k in ("effective_split", "effective_grid", "effective_inst_group")}
 
+    _TUNE_FIELDS = ("morph_split", "grid_cap", "inst_loop", "eff_split", "eff_grid", "eff_inst_group", "same_as", "ms", "ms_min", "ms_max")
+
+    def autotune_measure(self, frames=0):
+        """rz_autotune_measure: the candidate table (list of dicts; entry 0 = the heuristic plan), nothing adopted."""
+        tab = (RzTuneEntry * 32)()
+        n = ctypes.c_int(0)
+        _chk(self._L.rz_autotune_measure(self._h, int(frames), tab, 32, ctypes.byref(n)))
+        return [{k: getattr(tab[i], k) for k in self._TUNE_FIELDS} for i in range(n.value)]
+
+    def autotune_pick(self, table):
+        """rz_autotune_pick on a (possibly rank-reduced) table: entry 0 unless something beats it by >= 2 %."""
+        tab = (RzTuneEntry * len(table))()
+        for i, e in enumerate(table):
+            for k in self._TUNE_FIELDS:
+                setattr(tab[i], k, e[k])
+        return int(self._L.rz_autotune_pick(tab, len(table)))
+
+    def autotune_apply(self, entry):
+        e = RzTuneEntry()
+        for k in self._TUNE_FIELDS:
+            setattr(e, k, entry[k])
+        _chk(self._L.rz_autotune_apply(self._h, ctypes.byref(e)))
+
+    def comm_info(self):
+        """{count, user_rank} as the RCCL communicator reports them (ncclCommCount / ncclCommUserRank)."""
+        n, u = ctypes.c_int(0), ctypes.c_int(-1)
+        _chk(self._L.rz_comm_info(self._h, ctypes.byref(n), ctypes.byref(u)))
+        return {"comm_count": n.value, "comm_user_rank": u.value}
+
     def kernel_name(self):
         """The dominant kernel the CURRENT plan launches, spelled like rocprofv3's kernel trace spells it."""
         g = self.get_tuning
@@ -478,7 +518,7 @@ class DeformContext:
         if g("effective_poses_per_wg") > 0:
             return "rz_skin_instances_reg_kernel<8, %s>" % tf("effective_nt_store")
         if g("effective_inst_group") > 0:
-            return "rz_skin_instances_kernel<%d, %s>" % (g("effective_inst_block"), tf("effective_nt_store"))
+            return "rz_skin_instances_kernel<%d, %s, %s>" % (g("effective_inst_block"), tf("effective_nt_store"), tf("effective_subsets"))
         mode = g("morph_mode")
         s_, u = g("effective_split"), (g("effective_unroll") if mode == 1 else 1)
         if mode != 1:

@@ -119,6 +119,14 @@ struct RzDeformParams {
     int dbg;                    // ablation switch — tools-only build (see RZ_DBG in deform_kernels.hip); absent from the product
 #endif
     int inst_order;             // instanced skin: 0 = an XCD takes one vertex run of every pose group, 1 = every vertex run of its pose groups
+    // Instanced skin, BONE-SUBSET form: a vertex run only references a few of the skeleton's bones (PMX meshes are bone-local),
+    // so its workgroups stage just those — rz_run_subsets_kernel lists, per vertex run, the sorted set of bones its vertices
+    // name and rewrites the joints as slots of that list. null = the whole palette is staged and joints01 / joints23 are used.
+    const uint32_t *rj01;       // [Vp] slot(j0) | slot(j1) << 16   (joints already clamped to B - 1)
+    const uint32_t *rj23;       // [Vp] slot(j2) | slot(j3) << 16
+    const uint16_t *sub_list;   // [runs][sub_stride] ascending bone indices of each run's subset
+    const uint32_t *sub_count;  // [runs]
+    int sub_stride;
     int dma;                    // FAST: stage raw matrices by LDS-DMA (else plain loads after the first morph phase)
     int B;
     int M;
@@ -157,7 +165,12 @@ size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v);
 hipError_t rz_launch_skin_instances_reg(const RzDeformParams &p, int n_inst, int poses_per_wg, uint32_t grid_x, bool nts,
                                         hipStream_t st);
 hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
-                                    int block, bool nts, hipStream_t st);
+                                    int block, bool nts, size_t lds_bytes, hipStream_t st);
+// LDS bytes of the instanced skin kernel: G poses of `bones` staged bones (the whole skeleton, or the largest run subset)
+size_t rz_skin_instances_lds_bytes(int G, uint32_t bones, bool dma, bool subsets);
+// per vertex run of `per` vertices: the ascending list of bones its vertices name + the joints rewritten as slots of it
+hipError_t rz_launch_run_subsets(const uint32_t *j01, const uint32_t *j23, uint32_t v_lim, uint32_t per, uint32_t runs, uint32_t B,
+                                 uint16_t *list, uint32_t *count, uint32_t *rj01, uint32_t *rj23, hipStream_t st);
 uint32_t rz_quads_per_tile(int S);
 hipError_t rz_launch_deinterleave(const float *src, int stride, int offset, uint32_t n, float *px, float *py,
                                   float *pz, hipStream_t st);

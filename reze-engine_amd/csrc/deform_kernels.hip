@@ -982,8 +982,18 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 // nothing here, every wave decides per vertex step from a ballot over its lanes' weights (wave-uniform, so no divergence):
 // a step whose 64 vertices are all BDEF1 / BDEF2 (real PMX models cluster them by mesh part) reads 3 / 6 palette rows per
 // pose instead of 12. Skipped terms are w = 0, i.e. fma(0, row, m) = m: the result bits do not depend on the path taken.
-template <int BLOCK, bool NTS>
-__global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeformParams p, int G, int n_inst,
+//
+// SUB = bone-subset form. A vertex run names only a few of the skeleton's bones (PMX meshes are bone-local: the synthetic C4
+// mesh's 3 750-vertex runs touch ~34 of 200), and rz_run_subsets_kernel has listed them per run and rewritten the joints as
+// slots of that list. The workgroup stages ONLY those bones of its G poses: 8 x 34 matrices instead of 8 x 200 — the front of
+// every workgroup (LDS-DMA + palette product, during which the CU stores nothing) shrinks from 4.3 us to under 1 us, and the
+// group's LDS footprint from 102 KB to 30 KB. World matrices are staged behind the palette region, so the product needs no
+// in-place rounds. The palette rows a vertex gathers hold the same bits wherever they sit in LDS: outputs do not change.
+#ifndef RZ_SUB_WAVES
+#define RZ_SUB_WAVES 1
+#endif
+template <int BLOCK, bool NTS, bool SUB>
+__global__ void __launch_bounds__(BLOCK, (SUB && BLOCK == 512) ? RZ_SUB_WAVES : 1) rz_skin_instances_kernel(const RzDeformParams p, int G, int n_inst,
                                                                   uint32_t verts_per_wg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -998,8 +1008,31 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
     const int ng = min(G, n_inst - inst0);
     const int rows = p.B * 3;                       // float4 per palette, in global memory and (finished) in LDS
     constexpr int rstride = 3;                      // float4 per bone of a finished palette
-    const int lrows = rows;
-    {
+    // SUB: this run's bone list (workgroup-uniform: scalar loads)
+    const int ns = SUB ? (int)p.sub_count[wg_run] : 0;
+    const uint16_t *sub = SUB ? p.sub_list + (size_t)wg_run * p.sub_stride : nullptr;
+    const int lrows = SUB ? ns * 3 : rows;          // float4 per pose of the finished LDS palettes
+    float4 *stage = pal + (size_t)G * ns * 3;       // SUB, one-launch frame: staged world matrices sit behind the palette region
+    if constexpr (SUB) {
+        // prep-kernel / device-FK path (dma): the listed bones' finished rows, 3 float4 per bone, straight to their place.
+        // one-launch frame: the listed bones' world matrices, 4 float4 per bone, into the staging region.
+        // Either way element e of the linear LDS image is (pose g, slot s, cell k): a per-lane global address, a linear LDS one.
+        const int epb = p.dma ? 3 : 4;
+        const int n = ng * ns * epb;
+        const float4 *src = p.dma ? p.palette + (size_t)inst0 * rows : reinterpret_cast<const float4 *>(p.world) + (size_t)inst0 * p.B * 4;
+        float4 *dst = p.dma ? pal : stage;
+        for (int c = wave * 64; c < n; c += BLOCK) {
+            const int e = c + lane;
+            if (e < n) {
+                const int gs = p.dma ? e / 3 : e >> 2, k = e - gs * epb;
+                const int g = gs / ns, sl = gs - g * ns;
+                const float4 *a = src + ((size_t)g * p.B + sub[sl]) * epb + k;
+                typedef const __attribute__((address_space(1))) void *gptr_t;
+                typedef __attribute__((address_space(3))) void *lptr_t;
+                __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)a, (lptr_t)(uint32_t)(uintptr_t)(dst + c), 16, 0, 0);
+            }
+        }
+    } else {
         // prep-kernel path (dma): the group's finished palettes are contiguous in global memory -> one linear LDS-DMA copy.
         // one-launch frame (!dma): the group's WORLD matrices are staged instead, whole (64-byte slots, the same linear
         // 16-byte LDS-DMA); the conversion pass below multiplies by the inverse bind matrix and re-packs the rows to the
@@ -1019,13 +1052,15 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
     // One-launch frame (the host only plans it for B <= BLOCK): which (bone, pose stripe) this thread converts. With
     // B <= BLOCK / 2 the spare threads take a second, third ... stripe of the group's poses (stripe s converts poses s,
     // s + stripes, ...): 200 bones on 512 threads = 2 stripes.
-    const int stripes = !p.dma ? max(1, min(ng, BLOCK / p.B)) : 1;
-    const int cv_b0 = tid % p.B;
-    const int cv_g0 = tid / p.B;
-    const bool cv_on = !p.dma && cv_g0 < stripes;
+    // SUB: the same mapping over the run's ns listed bones (the host plans the form only for ns <= BLOCK).
+    const int cvB = SUB ? max(ns, 1) : p.B;
+    const int stripes = !p.dma ? max(1, min(ng, BLOCK / cvB)) : 1;
+    const int cv_b0 = tid % cvB;
+    const int cv_g0 = tid / cvB;
+    const bool cv_on = !p.dma && cv_g0 < stripes && (!SUB || ns > 0);
     float4 ib0 = {0, 0, 0, 0}, ib1 = ib0, ib2 = ib0, ib3 = ib0;
     if (cv_on) {                                    // requested first: lands while the staging copy is in flight
-        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + cv_b0 * 4;
+        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + (SUB ? (int)sub[cv_b0] : cv_b0) * 4;
         ib0 = gi[0]; ib1 = gi[1]; ib2 = gi[2]; ib3 = gi[3];
     }
     const size_t Vp = p.Vp;
@@ -1037,13 +1072,41 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
     uint32_t v = v_begin + tid;
     float x = 0, y = 0, z = 0, nx = 0, ny = 0, nz = 0;
     uint32_t j01 = 0, j23 = 0, wq = 0;
+    const uint32_t *jp01 = SUB ? p.rj01 : p.joints01, *jp23 = SUB ? p.rj23 : p.joints23;     // SUB: joints as slots of the run's list
     if (v < v_end) {
         x = p.geom[0 * Vp + v]; y = p.geom[1 * Vp + v]; z = p.geom[2 * Vp + v];
         nx = p.geom[3 * Vp + v]; ny = p.geom[4 * Vp + v]; nz = p.geom[5 * Vp + v];
-        j01 = p.joints01[v]; j23 = p.joints23[v]; wq = p.weights[v];
+        j01 = jp01[v]; j23 = jp23[v]; wq = p.weights[v];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // palettes / world matrices (and the first vertex) have landed
     __syncthreads();
+    if constexpr (SUB) {
+        if (!p.dma) {
+            // palette rows of the listed bones: slot (g, s) = rows 0..2 of world * inverseBind (engine.ts:926-928), the same
+            // packed FMA chain as below and as rz_prep_kernel — out of the staging region, into the palette region: no hazard,
+            // one barrier. With ns ~ 34 and 512 threads every (pose, bone) pair has a thread of its own.
+            const f2 px01 = {ib0.x, ib1.x}, px23 = {ib2.x, ib3.x}, py01 = {ib0.y, ib1.y}, py23 = {ib2.y, ib3.y};
+            const f2 pz01 = {ib0.z, ib1.z}, pz23 = {ib2.z, ib3.z}, pw01 = {ib0.w, ib1.w}, pw23 = {ib2.w, ib3.w};
+            auto row = [&](float e0, float e1, float e2, float e3, const f2 &bx, const f2 &by, const f2 &bz, const f2 &bw) {
+                return pk_fma(f2{e3, e3}, bw, pk_fma(f2{e2, e2}, bz, pk_fma(f2{e1, e1}, by, f2{e0, e0} * bx)));
+            };
+            if (cv_on)
+                for (int g = cv_g0; g < ng; g += stripes) {
+                    const float4 *slot = stage + ((size_t)g * ns + cv_b0) * 4;
+                    const float4 a0 = slot[0], a1 = slot[1], a2 = slot[2], a3 = slot[3];      // the world matrix's columns
+                    const f2 r0 = row(a0.x, a1.x, a2.x, a3.x, px01, py01, pz01, pw01), r1 = row(a0.x, a1.x, a2.x, a3.x, px23, py23, pz23, pw23);
+                    const f2 r2 = row(a0.y, a1.y, a2.y, a3.y, px01, py01, pz01, pw01), r3 = row(a0.y, a1.y, a2.y, a3.y, px23, py23, pz23, pw23);
+                    const f2 r4 = row(a0.z, a1.z, a2.z, a3.z, px01, py01, pz01, pw01), r5 = row(a0.z, a1.z, a2.z, a3.z, px23, py23, pz23, pw23);
+                    float4 *dst = pal + ((size_t)g * ns + cv_b0) * 3;
+                    dst[0] = make_float4(r0.x, r0.y, r1.x, r1.y);
+                    dst[1] = make_float4(r2.x, r2.y, r3.x, r3.y);
+                    dst[2] = make_float4(r4.x, r4.y, r5.x, r5.y);
+                }
+            __syncthreads();
+            // (the skinMatrixBuffer is not written here: a workgroup only holds its run's bones. rz_read_palette forms it on
+            // demand with rz_prep_kernel — the same chain, the same bits.)
+        }
+    } else
     if (!p.dma && RZ_DBG(p) != 8) {                  // dbg 8 (tools-only build): neither staging nor conversion
         // in-place conversion: slot (g, b) = rows 0..2 of world * inverseBind (engine.ts:926-928). Packed math: the
         // inverse bind matrix is held as column PAIRS (c0,c1),(c2,c3) per k, so each result row is two v_pk_fma
@@ -1101,7 +1164,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         if (vn < v_end) {
             xn = p.geom[0 * Vp + vn]; yn = p.geom[1 * Vp + vn]; zn = p.geom[2 * Vp + vn];
             nxn = p.geom[3 * Vp + vn]; nyn = p.geom[4 * Vp + vn]; nzn = p.geom[5 * Vp + vn];
-            j01n = p.joints01[vn]; j23n = p.joints23[vn]; wqn = p.weights[vn];
+            j01n = jp01[vn]; j23n = jp23[vn]; wqn = p.weights[vn];
         }
         const bool live = v < v_end;
         // decode once per vertex (engine.ts:255-258)
@@ -1110,8 +1173,9 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         const bool ok = isum != 0u;
         const float inv = __builtin_amdgcn_rcpf((float)(ok ? isum : 1u));
         const float w0 = ok ? (float)b0 * inv : 1.0f, w1 = (float)b1 * inv, w2 = (float)b2 * inv, w3 = (float)b3 * inv;
-        const uint32_t o0 = min(j01 & 0xffffu, bmax) * rstride, o1 = min(j01 >> 16, bmax) * rstride,
-                       o2 = min(j23 & 0xffffu, bmax) * rstride, o3 = min(j23 >> 16, bmax) * rstride;
+        const uint32_t jmax = SUB ? 0xffffu : bmax;     // SUB: slots are in range by construction
+        const uint32_t o0 = min(j01 & 0xffffu, jmax) * rstride, o1 = min(j01 >> 16, jmax) * rstride,
+                       o2 = min(j23 & 0xffffu, jmax) * rstride, o3 = min(j23 >> 16, jmax) * rstride;
         float *dp = p.out_pos + ((size_t)inst0 * Vp + v) * 3;
         float *dn = p.out_nrm + ((size_t)inst0 * Vp + v) * 3;
         // Packed-math form (v_pk_fma_f32 = two f32 FMAs per lane per instruction): palette rows are blended as
@@ -1314,6 +1378,52 @@ __global__ void rz_pack_skinning_kernel(const uint16_t *joints4, const uint8_t *
     wq[v] = reinterpret_cast<const uint32_t *>(weights4)[v];
 }
 
+// Plan-time pass of the bone-subset crowd frame (one-off per launch shape, not per frame): one workgroup per vertex run.
+// Marks the bones the run's vertices name (all four joints of every vertex, clamped to B - 1 like the skin kernels do — a
+// zero-weight influence still gathers its bone's rows, so it stays the SAME bone: fma(0, row, m) keeps m's bits only while the
+// row is the one the full-palette form would have read), ranks them ascending, writes the list and the joints as slots of it.
+__global__ void __launch_bounds__(kBlock) rz_run_subsets_kernel(const uint32_t *j01, const uint32_t *j23, uint32_t v_lim, uint32_t per,
+                                                                uint32_t B, uint16_t *list, uint32_t *count, uint32_t *rj01, uint32_t *rj23)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t nw = (B + 31) / 32;
+    uint32_t *bits = reinterpret_cast<uint32_t *>(smem);            // [nw] bone bitmap
+    uint32_t *before = bits + nw;                                    // [nw + 1] listed bones in front of each word
+    uint16_t *slot = reinterpret_cast<uint16_t *>(before + nw + 1);  // [B]
+    const uint32_t tid = threadIdx.x, run = blockIdx.x;
+    const uint32_t v0 = run * per, v1 = min(v_lim, v0 + per), bmax = B - 1;
+    for (uint32_t i = tid; i < nw; i += kBlock) bits[i] = 0;
+    __syncthreads();
+    for (uint32_t v = v0 + tid; v < v1; v += kBlock) {
+        const uint32_t a = j01[v], b = j23[v];
+        const uint32_t j[4] = { min(a & 0xffffu, bmax), min(a >> 16, bmax), min(b & 0xffffu, bmax), min(b >> 16, bmax) };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicOr(&bits[j[k] >> 5], 1u << (j[k] & 31u));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < nw; ++i) { before[i] = acc; acc += __popc(bits[i]); }
+        before[nw] = acc;
+        count[run] = acc;
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < B; b += kBlock) {
+        const uint32_t w = bits[b >> 5], m = 1u << (b & 31u);
+        if (w & m) {
+            const uint32_t sl = before[b >> 5] + __popc(w & (m - 1u));
+            slot[b] = (uint16_t)sl;
+            list[(size_t)run * B + sl] = (uint16_t)b;
+        }
+    }
+    __syncthreads();
+    for (uint32_t v = v0 + tid; v < v1; v += kBlock) {
+        const uint32_t a = j01[v], b = j23[v];
+        rj01[v] = (uint32_t)slot[min(a & 0xffffu, bmax)] | ((uint32_t)slot[min(a >> 16, bmax)] << 16);
+        rj23[v] = (uint32_t)slot[min(b & 0xffffu, bmax)] | ((uint32_t)slot[min(b >> 16, bmax)] << 16);
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1407,12 +1517,21 @@ hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, cons
     }
 }
 
+size_t rz_skin_instances_lds_bytes(int G, uint32_t bones, bool dma, bool subsets)
+{
+    // finished palettes are 48 B per (pose, bone). One-launch frame: the whole-palette form stages the world matrices in
+    // the palette region's place (64-byte slots, re-packed in place); the subset form stages them behind it (48 + 64).
+    const size_t per = dma ? 48 : (subsets ? 112 : 64);
+    return (size_t)G * bones * per;
+}
+
 template <int BLOCK>
 static hipError_t launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
-                                        bool nts, hipStream_t st)
+                                        bool nts, size_t lds, hipStream_t st)
 {
-    const size_t lds = (size_t)G * p.B * (p.dma ? 48 : 64);
-    auto k = nts ? rz_skin_instances_kernel<BLOCK, true> : rz_skin_instances_kernel<BLOCK, false>;
+    const bool sub = p.sub_list != nullptr;
+    auto k = sub ? (nts ? rz_skin_instances_kernel<BLOCK, true, true> : rz_skin_instances_kernel<BLOCK, false, true>)
+                 : (nts ? rz_skin_instances_kernel<BLOCK, true, false> : rz_skin_instances_kernel<BLOCK, false, false>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1423,11 +1542,21 @@ static hipError_t launch_skin_instances(const RzDeformParams &p, int G, int n_in
 }
 
 hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
-                                    int block, bool nts, hipStream_t st)
+                                    int block, bool nts, size_t lds_bytes, hipStream_t st)
 {
-    if (block == 1024) return launch_skin_instances<1024>(p, G, n_inst, verts_per_wg, grid_x, nts, st);
-    if (block == 512) return launch_skin_instances<512>(p, G, n_inst, verts_per_wg, grid_x, nts, st);
-    return launch_skin_instances<256>(p, G, n_inst, verts_per_wg, grid_x, nts, st);
+    if (block == 1024) return launch_skin_instances<1024>(p, G, n_inst, verts_per_wg, grid_x, nts, lds_bytes, st);
+    if (block == 512) return launch_skin_instances<512>(p, G, n_inst, verts_per_wg, grid_x, nts, lds_bytes, st);
+    return launch_skin_instances<256>(p, G, n_inst, verts_per_wg, grid_x, nts, lds_bytes, st);
+}
+
+hipError_t rz_launch_run_subsets(const uint32_t *j01, const uint32_t *j23, uint32_t v_lim, uint32_t per, uint32_t runs, uint32_t B,
+                                 uint16_t *list, uint32_t *count, uint32_t *rj01, uint32_t *rj23, hipStream_t st)
+{
+    if (runs == 0) return hipSuccess;
+    const uint32_t nw = (B + 31) / 32;
+    const size_t lds = (size_t)(2 * nw + 1) * 4 + (size_t)B * 2;
+    hipLaunchKernelGGL(rz_run_subsets_kernel, dim3(runs), dim3(kBlock), lds, st, j01, j23, v_lim, per, B, list, count, rj01, rj23);
+    return hipGetLastError();
 }
 
 hipError_t rz_launch_skin_instances_reg(const RzDeformParams &p, int n_inst, int poses_per_wg, uint32_t grid_x, bool nts,

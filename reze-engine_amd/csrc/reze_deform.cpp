@@ -61,6 +61,8 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*GetVersion)(int *) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     bool reused = false;                // bound to a copy the process had already loaded (e.g. PyTorch's)
 };
 Rccl g_rccl;
@@ -90,6 +92,8 @@ int rccl_bind()
     r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(h, "ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString || !r.CommInitAll ||
         !r.GroupStart || !r.GroupEnd)
         return fail(RZ_ERR_UNSUPPORTED, "RCCL symbols missing");
@@ -245,6 +249,17 @@ struct rz_ctx {
 
     // tuning (0 / -1 = automatic)
     int t_split = 0, t_unroll = 0, t_grid_cap = 0, t_nt = 1, t_nts = -1, t_geo = 0, t_fast = -1, t_instloop = -1, t_dbg = 0, t_outcap = -1, t_instblock = 0, t_instorder = 1, t_overlap = -1, t_zerocopy = -1, t_fusefk = -1;
+    // Bone-subset crowd frames: per vertex run of the CURRENT launch shape, the ascending list of bones the run's
+    // vertices name, and the joints rewritten as slots of that list. Derived from the static mesh, rebuilt (one small kernel +
+    // one readback of the counts) whenever the shape (vertices per run, runs), the mesh or the skeleton changes.
+    uint32_t *rj01 = nullptr, *rj23 = nullptr;      // [Vp]
+    uint16_t *sub_list = nullptr;                   // [sub_runs][sub_B]
+    uint32_t *sub_count = nullptr;                  // [sub_runs]
+    size_t sub_list_alloc = 0, sub_count_alloc = 0;
+    uint32_t sub_per = 0, sub_runs = 0, sub_B = 0, sub_max = 0;
+    bool sub_valid = false;
+    int t_subsets = -1;                 // "inst_subsets": -1 / 1 = stage only the bones a vertex run names when that is a gain, 0 = always the whole palette
+    bool palette_stale = false;         // the last crowd frame formed its palettes in LDS only (subset form): rz_read_palette forms them on demand
     int t_graph = 0;                    // "graph" tuning key: rz_deform_n replays captured hipGraphs of kGraphFrames frames
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_sig = 0;             // signature of everything the captured launches depend on
@@ -469,7 +484,7 @@ int auto_split(const rz_ctx *c)
     return S;
 }
 
-struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; int inst_block; bool fuse_fk; };
+struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; int inst_block; bool fuse_fk; bool subsets; uint32_t sub_bones; uint64_t inst_lds; };
 
 // Where the kernels read the current pose from: the device pose block, or (zero-copy, not yet resident) the pinned slot.
 const float *src_world(const rz_ctx *c)
@@ -522,8 +537,44 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     p.dbg = c->t_dbg;
 #endif
     p.out_cap = pl.out_cap;
+    if (pl.subsets) { p.rj01 = c->rj01; p.rj23 = c->rj23; p.sub_list = c->sub_list; p.sub_count = c->sub_count; p.sub_stride = (int)c->sub_B; }
     if (pl.fuse_fk) { p.fk = fk_params(c); p.fk_on = 1; }
     return p;
+}
+
+// Launch shape of an instanced, morph-free crowd frame (rz_skin_instances_kernel): G poses per workgroup share one decode of each
+// vertex; the grid is (vertex runs, pose groups), `total` workgroups in all.
+struct InstShape { int G, blk; bool want_in_kernel; uint32_t per, runs; };
+
+void inst_runs(const rz_ctx *c, int G, int blk, bool for_subsets, uint32_t *per, uint32_t *runs)
+{
+    // 256 threads = two workgroups per CU, 512 / 1024 = one whose 8 / 16 waves share one staged palette group — ONE round of
+    // workgroups. With bone subsets (15-30 KB of LDS) two 512-thread workgroups fit a CU and more, shorter runs name fewer
+    // bones (36 -> 17 per run at 1024 workgroups), but whether that pays depends on the box: tools/c4_subsets.py measured
+    // 256 / 512 / 768 / 1024 workgroups at 33.4 / 34.3 / 32.9 / 32.6 us on one MI355X and 33.1-33.4 / 42 / 42 / 42 us on two
+    // others (profiles/r3_c4_subsets.txt). One workgroup per CU is the shape that is good everywhere, so it is the default;
+    // rz_autotune tries the others on the box it runs on.
+    (void)for_subsets;
+    const uint32_t wg_per_cu = blk == 256 ? 2u : 1u;
+    const uint32_t groups = (c->I + G - 1) / G;
+    const uint32_t total = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : wg_per_cu * (uint32_t)c->n_cu;
+    const uint32_t gxi = std::max<uint32_t>(1, total / groups);
+    *per = round_up((c->V + gxi - 1) / gxi, 64);
+    *runs = (c->V + *per - 1) / *per;
+}
+
+// The shape the caller ASKS for (inst_loop / inst_block / grid_cap or the defaults), before LDS limits the group size; when
+// bone subsets are allowed it is the shape of the SUBSET form (the whole-palette fallback sizes its own grid).
+bool inst_shape(const rz_ctx *c, InstShape *s)
+{
+    const bool epilogues = c->edge != nullptr || c->aabb_on;   // only the generic kernel carries the fused consumers
+    if (!(c->morph_mode == 0 && c->I > 1 && c->t_instloop != 0 && c->t_instloop != 9 && !epilogues) || c->B == 0 || c->V == 0) return false;
+    s->want_in_kernel = c->t_fast != 0 && !c->pose_local;
+    s->blk = c->t_instblock == 256 || c->t_instblock == 512 || c->t_instblock == 1024 ? c->t_instblock : (s->want_in_kernel ? 512 : 256);
+    s->G = (int)std::min<uint32_t>(c->t_instloop > 0 ? (uint32_t)c->t_instloop : 8u, c->I);
+    if (s->G < 2) return false;
+    inst_runs(c, s->G, s->blk, c->t_subsets != 0, &s->per, &s->runs);
+    return true;
 }
 
 Plan make_plan(const rz_ctx *c)
@@ -593,35 +644,42 @@ Plan make_plan(const rz_ctx *c)
     //       multiplies by the inverse bind matrices in place — one launch per frame, 39.6-40 us: the staging costs
     //       what the extra launch did, so it is opt-in.
     const bool epilogues = c->edge != nullptr || c->aabb_on;   // only the generic kernel carries the fused consumers
-    if (v.mode == 0 && c->I > 1 && c->t_instloop != 0 && c->t_instloop != 9 && !epilogues) {
-        // Where the palettes come from. World-matrix poses (rz_set_pose): the skin kernel forms them itself — ONE launch
-        // per frame, measured 35.5 us on C4 against 39.0 us for rz_prep_kernel + launch boundary + skin kernel; it stages
-        // the group's world matrices in 64-byte slots, so the default shape for it is one 512-thread workgroup per CU
-        // (8 poses x 200 bones = 102 KB; two 256-thread workgroups of 6 poses each measured 39.5 us). Device-solved poses:
-        // rz_fk_kernel has written the palettes already, the skin kernel copies them in (48-byte slots, LDS-DMA).
-        // fast = 0 forces the prep-kernel form, fast = 1 / -1 (auto) the one-launch form.
-        const bool want_in_kernel = c->t_fast != 0 && !c->pose_local;
-        // workgroup size: 256 threads = two workgroups per CU (80 KB of palettes each); 512 / 1024 = one workgroup per CU
-        // whose 8 / 16 waves share one staged palette group (up to 156 KB)
-        const int blk = c->t_instblock == 256 || c->t_instblock == 512 || c->t_instblock == 1024 ? c->t_instblock : (want_in_kernel ? 512 : 256);
-        const bool in_kernel = want_in_kernel && c->B <= (uint32_t)blk;     // the conversion pass gives every bone its own thread
-        const uint32_t slot = in_kernel ? 64u : 48u;           // LDS bytes per bone per pose while staging (deform_kernels.hip)
-        const uint32_t wg_per_cu = blk == 256 ? 2u : 1u;
-        const uint32_t g_lds = ((blk == 256 ? 80u : 156u) * 1024u) / (c->B * slot);
-        int G = (int)std::min<uint32_t>(8, g_lds);
-        if (c->t_instloop > 0) G = (int)std::min<uint32_t>(g_lds, (uint32_t)c->t_instloop);
-        if (G >= 2) {
-            G = (int)std::min<uint32_t>((uint32_t)G, c->I);
-            const uint32_t groups = (c->I + G - 1) / G;
-            uint32_t total = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : wg_per_cu * (uint32_t)c->n_cu;
-            uint32_t gxi = std::max<uint32_t>(1, total / groups);
-            uint32_t per = round_up((c->V + gxi - 1) / gxi, 64);
-            pl.inst_group = G;
-            pl.inst_block = blk;
-            pl.verts_per_wg = per;
-            pl.prep = !in_kernel;
-            pl.dma = !in_kernel;
-            pl.grid_x = (c->V + per - 1) / per;
+    InstShape is;
+    if (inst_shape(c, &is)) {
+        // Where the palettes come from. World-matrix poses (rz_set_pose): the skin kernel forms them itself — ONE launch per
+        // frame (fast = 0 forces rz_prep_kernel in front). Device-solved poses: rz_fk_kernel has written the palettes already,
+        // the skin kernel copies them in (48-byte rows, LDS-DMA).
+        // What is staged: by default only the bones the workgroup's vertex run names (bone-subset form) — on C4
+        // ~34 of 200 bones, 30 KB of LDS instead of 102 KB and a front of < 1 us instead of 4.3 us per workgroup. It needs the
+        // run lists of exactly this launch shape (ensure_run_subsets, called by every entry point that launches frames) and
+        // is a gain only when the largest list is shorter than the skeleton; otherwise the whole palette is staged: 64-byte
+        // slots re-packed in place for the one-launch frame, which wants B <= block threads and, at 8 poses x 200 bones =
+        // 102 KB, one 512-thread workgroup per CU (measured 35.5 us on C4 against 39.0 us for prep kernel + launch boundary +
+        // 256-thread skin kernel, and 39.5 us for two 256-thread workgroups of 6 poses).
+        const int blk = is.blk;
+        const uint32_t lds_budget = (blk == 256 ? 80u : 156u) * 1024u;
+        bool sub = c->t_subsets != 0 && c->sub_valid && c->sub_per == is.per && c->sub_runs == is.runs && c->sub_B == c->B &&
+                   c->sub_max < c->B && c->sub_max <= (uint32_t)blk;
+        if (sub) {
+            const size_t lds = rz_skin_instances_lds_bytes(is.G, c->sub_max, !is.want_in_kernel, true);
+            if (lds > lds_budget) sub = false;
+            else {
+                pl.subsets = true; pl.sub_bones = c->sub_max; pl.inst_lds = lds;
+                pl.inst_group = is.G; pl.inst_block = blk; pl.verts_per_wg = is.per; pl.grid_x = is.runs;
+                pl.prep = !is.want_in_kernel; pl.dma = !is.want_in_kernel;
+            }
+        }
+        if (!sub) {
+            const bool in_kernel = is.want_in_kernel && c->B <= (uint32_t)blk;     // the in-place product gives every bone its own thread
+            const uint32_t g_lds = lds_budget / (c->B * (in_kernel ? 64u : 48u));
+            int G = (int)std::min<uint32_t>((uint32_t)is.G, g_lds);
+            if (G >= 2) {
+                uint32_t per = 0, runs = 0;
+                inst_runs(c, G, blk, false, &per, &runs);
+                pl.inst_group = G; pl.inst_block = blk; pl.verts_per_wg = per; pl.grid_x = runs;
+                pl.prep = !in_kernel; pl.dma = !in_kernel;
+                pl.inst_lds = rz_skin_instances_lds_bytes(G, c->B, !in_kernel, false);
+            }
         }
     }
     // register-resident instanced form: 2048-vertex runs, pose ranges sized for ~2 WGs per CU
@@ -637,6 +695,51 @@ Plan make_plan(const rz_ctx *c)
         pl.dma = true;
     }
     return pl;
+}
+
+// Bring the run lists of the bone-subset crowd frame in line with the launch shape the next frame asks for. One small kernel
+// and one readback of `runs` counters, only when the shape, the mesh or the skeleton changed — never per frame.
+int ensure_run_subsets(rz_ctx *c)
+{
+    InstShape is;
+    if (c->t_subsets == 0 || !inst_shape(c, &is)) return RZ_OK;
+    if (c->sub_valid && c->sub_per == is.per && c->sub_runs == is.runs && c->sub_B == c->B) return RZ_OK;
+    c->sub_valid = false;
+    HIP_TRY(hipStreamSynchronize(c->stream));       // a frame in flight may still read the old lists
+    drop_graph(c);
+    if (!c->rj01) HIP_TRY(hipMalloc(&c->rj01, (size_t)c->Vp * 4));
+    if (!c->rj23) HIP_TRY(hipMalloc(&c->rj23, (size_t)c->Vp * 4));
+    const size_t need_list = (size_t)is.runs * c->B;
+    if (need_list > c->sub_list_alloc) {
+        dfree(c->sub_list);
+        HIP_TRY(hipMalloc(&c->sub_list, need_list * sizeof(uint16_t)));
+        c->sub_list_alloc = need_list;
+    }
+    if (is.runs > c->sub_count_alloc) {
+        dfree(c->sub_count);
+        HIP_TRY(hipMalloc(&c->sub_count, (size_t)is.runs * sizeof(uint32_t)));
+        c->sub_count_alloc = is.runs;
+    }
+    const uint32_t v_lim = (c->V + 3) / 4 * 4;      // what the skin kernel walks: whole quads
+    HIP_TRY(hipMemsetAsync(c->rj01, 0, (size_t)c->Vp * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->rj23, 0, (size_t)c->Vp * 4, c->stream));
+    HIP_TRY(rz_launch_run_subsets(c->j01, c->j23, v_lim, is.per, is.runs, c->B, c->sub_list, c->sub_count, c->rj01, c->rj23, c->stream));
+    std::vector<uint32_t> counts(is.runs);
+    HIP_TRY(hipMemcpyAsync(counts.data(), c->sub_count, (size_t)is.runs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint32_t mx = 0;
+    for (uint32_t n : counts) mx = std::max(mx, n);
+    c->sub_per = is.per; c->sub_runs = is.runs; c->sub_B = c->B; c->sub_max = mx;
+    c->sub_valid = true;
+    return RZ_OK;
+}
+
+// Plan of the next frame: the run lists first (the plan only takes the subset form when they match its shape).
+int frame_plan(rz_ctx *c, Plan *pl)
+{
+    if (int r = ensure_run_subsets(c)) return r;
+    *pl = make_plan(c);
+    return RZ_OK;
 }
 
 RzPrepParams prep_params(const rz_ctx *c)
@@ -687,12 +790,14 @@ RzFkParams fk_params(const rz_ctx *c)
 int launch_fk(rz_ctx *c, hipStream_t st)
 {
     HIP_TRY(rz_launch_fk(fk_params(c), c->I, st));
+    c->palette_stale = false;
     return RZ_OK;
 }
 
 int launch_prep(rz_ctx *c, hipStream_t st)
 {
     HIP_TRY(rz_launch_prep(prep_params(c), c->I, st));
+    c->palette_stale = false;
     return RZ_OK;
 }
 
@@ -719,7 +824,8 @@ int launch_deform(rz_ctx *c, const Plan &pl)
         return RZ_OK;
     }
     if (pl.inst_group > 0) {
-        HIP_TRY(rz_launch_skin_instances(p, pl.inst_group, (int)c->I, pl.verts_per_wg, pl.grid_x, pl.inst_block, pl.v.nts, c->stream));
+        HIP_TRY(rz_launch_skin_instances(p, pl.inst_group, (int)c->I, pl.verts_per_wg, pl.grid_x, pl.inst_block, pl.v.nts, (size_t)pl.inst_lds, c->stream));
+        if (!pl.dma) c->palette_stale = pl.subsets;    // the whole-palette one-launch frame copies its palettes out, the subset form cannot
         return RZ_OK;
     }
     size_t lds = rz_deform_lds_bytes(p, pl.v);
@@ -830,6 +936,7 @@ int alloc_mesh(rz_ctx *c, uint32_t V)
     HIP_TRY(hipStreamSynchronize(c->stream));
     drop_direct_gather(c);                // shard sizes are about to change: back to private output buffers
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->edge);
+    dfree(c->rj01); dfree(c->rj23); c->sub_valid = false;      // the run lists name this mesh's joints
     free_morphs(c);                       // morph targets are per-vertex: a new mesh invalidates them
     c->V = V;
     c->Vp = round_up(V, kVertPad);
@@ -924,6 +1031,7 @@ int rz_destroy(rz_ctx *c)
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->inv_bind);
+    dfree(c->rj01); dfree(c->rj23); dfree(c->sub_list); dfree(c->sub_count);
     dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind);
     free_animation(c); dfree(c->an_frames);
     dfree(c->fk_append_ratio); dfree(c->fk_append_move); dfree(c->pose_blk[0]); dfree(c->pose_blk[1]);
@@ -965,9 +1073,9 @@ int rz_fork(rz_ctx *parent, rz_ctx **out)
     if (parent->lender) return fail(RZ_ERR_INVALID, "rz_fork of a fork: fork the context that owns the static data");
     if (parent->V == 0 || !parent->geom || parent->B == 0 || !parent->inv_bind) return fail(RZ_ERR_INVALID, "rz_fork needs a mesh and a skeleton (rz_upload_mesh, rz_upload_skeleton)");
     if (parent->comm || parent->gather_root) return fail(RZ_ERR_UNSUPPORTED, "rz_fork of a context that takes part in a gather");
+    HIP_TRY(hipStreamSynchronize(parent->stream));        // every static upload of the lender has landed (before anything is created: nothing to undo on failure)
     rz_ctx *c = nullptr;
     if (int r = rz_create(parent->device, &c)) return r;
-    HIP_TRY(hipStreamSynchronize(parent->stream));        // every static upload of the lender has landed
     c->V = parent->V; c->Vp = parent->Vp; c->geom = parent->geom; c->j01 = parent->j01; c->j23 = parent->j23; c->wq = parent->wq;
     c->B = parent->B; c->inv_bind = parent->inv_bind;
     c->has_topology = parent->has_topology; c->fk_parents = parent->fk_parents; c->fk_append_parent = parent->fk_append_parent;
@@ -985,7 +1093,7 @@ int rz_fork(rz_ctx *parent, rz_ctx **out)
     c->t_split = parent->t_split; c->t_unroll = parent->t_unroll; c->t_grid_cap = parent->t_grid_cap; c->t_nt = parent->t_nt; c->t_nts = parent->t_nts;
     c->t_geo = parent->t_geo; c->t_fast = parent->t_fast; c->t_instloop = parent->t_instloop; c->t_outcap = parent->t_outcap; c->t_instblock = parent->t_instblock;
     c->t_instorder = parent->t_instorder; c->t_overlap = parent->t_overlap; c->t_zerocopy = parent->t_zerocopy; c->t_fusefk = parent->t_fusefk;
-    c->t_graph = parent->t_graph; c->tuned_by_search = parent->tuned_by_search;
+    c->t_graph = parent->t_graph; c->tuned_by_search = parent->tuned_by_search; c->t_subsets = parent->t_subsets;
     c->lender = parent;
     parent->n_forks++;
     int rc = ensure_pose_buffers(c);
@@ -1060,6 +1168,8 @@ int rz_upload_skeleton(rz_ctx *c, uint32_t B, const float *inverse_bind16)
     HIP_TRY(hipMalloc(&c->inv_bind, (size_t)B * 16 * sizeof(float)));
     HIP_TRY(hipMemcpy(c->inv_bind, inverse_bind16, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice));
     c->B = B;
+    c->sub_valid = false;               // joints are clamped to the bone count when the run lists are built
+    c->palette_stale = false;
     c->pose_set = false;
     c->has_topology = false;            // belongs to the previous skeleton
     free_bone_morphs(c);                // ... as do bone morphs (their entries name its bones)
@@ -1601,8 +1711,10 @@ int rz_override_world(rz_ctx *c, uint32_t n, const uint32_t *instance, const uin
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t i = instance ? instance[k] : 0;
         if (i >= c->I || bone[k] >= c->B) return fail(RZ_ERR_INVALID, "override %u names instance %u bone %u (have %u x %u)", k, i, bone[k], c->I, c->B);
-        for (int e = 0; e < 16; ++e)
-            if (!(world16[(size_t)k * 16 + e] == world16[(size_t)k * 16 + e])) return fail(RZ_ERR_INVALID, "override %u holds a NaN", k);
+        for (int e = 0; e < 16; ++e) {
+            const float x = world16[(size_t)k * 16 + e];
+            if (!(x == x) || x - x != 0.0f) return fail(RZ_ERR_INVALID, "override %u is not finite", k);
+        }
         order[k] = k;
     }
     auto key = [&](uint32_t k) { return (uint64_t)(instance ? instance[k] : 0) * c->B + bone[k]; };
@@ -1666,7 +1778,8 @@ int rz_deform(rz_ctx *c)
     if (int r = use(c)) return r;
     if (int r = check_ready(c)) return r;
     if (int r = ensure_outputs(c)) return r;
-    const Plan pl = make_plan(c);
+    Plan pl;
+    if (int r = frame_plan(c, &pl)) return r;
     if (int r = set_overlap(c, want_overlap(c, pl))) return r;
     return run_frame(c, pl);
 }
@@ -1705,7 +1818,8 @@ int rz_deform_n(rz_ctx *c, uint32_t frames)
     if (int r = use(c)) return r;
     if (int r = check_ready(c)) return r;
     if (int r = ensure_outputs(c)) return r;
-    const Plan pl = make_plan(c);
+    Plan pl;
+    if (int r = frame_plan(c, &pl)) return r;
     if (int r = set_overlap(c, want_overlap(c, pl))) return r;      // never on while the graph key is set
     uint32_t f = 0;
     if (c->t_graph && frames >= 2 * kGraphFrames) {
@@ -1754,7 +1868,7 @@ int rz_deform_pair(rz_ctx *a, rz_ctx *b, uint32_t frames)
         if (int r = use(cs[k])) return r;
         if (int r = check_ready(cs[k])) return r;
         if (int r = ensure_outputs(cs[k])) return r;
-        pl[k] = make_plan(cs[k]);
+        if (int r = frame_plan(cs[k], &pl[k])) return r;
         if (int r = set_overlap(cs[k], want_overlap(cs[k], pl[k]))) return r;
     }
     for (uint32_t f = 0; f < frames; ++f)
@@ -1788,6 +1902,12 @@ int rz_read_palette(rz_ctx *c, uint32_t instance, float *rows3x4)
 {
     if (int r = use(c)) return r;
     if (instance >= c->I || !rows3x4 || !c->palette) return fail(RZ_ERR_INVALID, "bad palette read");
+    if (c->palette_stale) {
+        // the last frame was a bone-subset crowd frame: its workgroups formed the rows of their own bones in LDS and nobody
+        // wrote the skinMatrixBuffer. Form it now from the resident world matrices — rz_prep_kernel's chain is the skin
+        // kernel's chain, so these are the bits the frame used.
+        if (int r = launch_prep(c, c->stream)) return r;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(rows3x4, c->palette + (size_t)instance * c->B * 3, (size_t)c->B * 12 * sizeof(float), hipMemcpyDeviceToHost));
     return RZ_OK;
@@ -1850,7 +1970,8 @@ int rz_time_frames(rz_ctx *c, uint32_t frames, rz_timing *out)
     if (!out || frames == 0) return fail(RZ_ERR_INVALID, "rz_time_frames: bad arguments");
     if (int r = check_ready(c)) return r;
     if (int r = ensure_outputs(c)) return r;
-    const Plan pl = make_plan(c);
+    Plan pl;
+    if (int r = frame_plan(c, &pl)) return r;
     if (int r = set_overlap(c, want_overlap(c, pl))) return r;
     memset(out, 0, sizeof *out);
     float ms = 0.f;
@@ -1894,64 +2015,129 @@ int rz_time_frames(rz_ctx *c, uint32_t frames, rz_timing *out)
     return RZ_OK;
 }
 
-int rz_autotune(rz_ctx *c, uint32_t frames)
+int rz_autotune_measure(rz_ctx *c, uint32_t frames, rz_tune_entry *table, int cap, int *count)
 {
     if (int r = use(c)) return r;
+    if (!table || cap < 1 || !count) return fail(RZ_ERR_INVALID, "rz_autotune_measure: bad table");
+    *count = 0;
     if (int r = check_ready(c)) return r;
     if (int r = ensure_outputs(c)) return r;
-    if (frames == 0) frames = 30;
+    if (frames == 0) frames = 100;
     frames = std::min<uint32_t>(frames, 1000);      // a search, not a benchmark
-    // candidates: morph split x workgroups per CU (single mesh), poses per workgroup x workgroups per CU (instanced).
-    // Every candidate is a legal plan; the search only picks among the variants the parity tests already cover.
-    struct Cand { int split, cap, loop; };
-    std::vector<Cand> cands;
+    // Entry 0 = the heuristic plan. Then: morph split x workgroups per CU (single mesh), poses per workgroup x workgroups per
+    // CU (instanced). Every candidate is a legal plan; the search only picks among the variants the parity tests already cover.
+    std::vector<rz_tune_entry> cands;
+    auto add = [&](int split, int capv, int loop) {
+        rz_tune_entry e;
+        memset(&e, 0, sizeof e);
+        e.morph_split = split; e.grid_cap = capv; e.inst_loop = loop; e.same_as = -1;
+        cands.push_back(e);
+    };
     const int ncu = c->n_cu;
-    const bool instanced = c->morph_mode == 0 && c->I > 1 && c->t_instloop != 0 && c->t_instloop != 9 && !(c->edge || c->aabb_on);
+    const int keep_split = c->t_split, keep_cap = c->t_grid_cap, keep_loop = c->t_instloop;
+    const bool keep_tuned = c->tuned_by_search;
+    InstShape is;
+    c->t_split = 0; c->t_grid_cap = 0; c->t_instloop = -1;
+    const bool instanced = inst_shape(c, &is);
+    add(0, 0, -1);
     if (instanced) {
-        // total workgroups: one or two rounds of what the CUs hold at once (two 256-thread workgroups or one larger one)
-        const int base = (make_plan(c).inst_block > 256 ? 1 : 2) * ncu;
-        for (int loop : {8, 4})
-            for (int cap : {base, 2 * base}) cands.push_back({0, cap, loop});
+        // total workgroups: one or two rounds of what the CUs hold at once (two 256-thread workgroups or one larger one);
+        // with bone subsets the palettes of 16 poses still fit, which halves the number of workgroup fronts
+        for (int loop : {8, 4, 16})
+            for (int capv : {ncu, 2 * ncu, 3 * ncu, 4 * ncu}) add(0, capv, loop);
     } else {
         const int smax = c->morph_mode == 1 ? (int)std::min<uint32_t>(8, std::max<uint32_t>(1, c->M)) : 4;
         for (int sp = 1; sp <= smax; sp <<= 1)
-            for (int cap : {ncu, 2 * ncu, 4 * ncu}) cands.push_back({sp, (int)(cap * c->I), 0});
+            for (int capv : {ncu, 2 * ncu, 4 * ncu}) add(sp, (int)(capv * c->I), 0);
     }
-    const int keep_split = c->t_split, keep_cap = c->t_grid_cap, keep_loop = c->t_instloop;
-    float best_ms = 0.f;
-    int best = -1;
-    uint32_t seen_grid[32], seen_qpw[32];
-    int seen_s[32], seen_g[32], n_seen = 0;
-    for (size_t i = 0; i < cands.size(); ++i) {
-        c->t_split = cands[i].split; c->t_grid_cap = cands[i].cap;
-        if (instanced) c->t_instloop = cands[i].loop;
-        const Plan pl = make_plan(c);
-        if (int r = set_overlap(c, want_overlap(c, pl))) return r;
-        bool dup = false;              // different requests often resolve to the same launch
-        for (int k = 0; k < n_seen; ++k)
-            dup |= seen_grid[k] == pl.grid_x && seen_qpw[k] == pl.quads_per_wave && seen_s[k] == pl.v.S && seen_g[k] == pl.inst_group;
-        if (dup) continue;
-        if (n_seen < 32) { seen_grid[n_seen] = pl.grid_x; seen_qpw[n_seen] = pl.quads_per_wave; seen_s[n_seen] = pl.v.S; seen_g[n_seen++] = pl.inst_group; }
-        float cand_ms = 0.f;
-        for (int rep = 0; rep < 2; ++rep) {        // best of two, the first pass also warms the variant up
-            for (uint32_t f = 0; f < 5; ++f)
-                if (int r = run_frame(c, pl)) return r;
-            HIP_TRY(hipEventRecord(c->ev0, c->stream));
-            for (uint32_t f = 0; f < frames; ++f)
-                if (int r = run_frame(c, pl)) return r;
-            HIP_TRY(hipEventRecord(c->ev1, c->stream));
-            HIP_TRY(hipEventSynchronize(c->ev1));
+    if ((int)cands.size() > cap) cands.resize(cap);
+    const int n = (int)cands.size();
+    auto restore = [&]() { c->t_split = keep_split; c->t_grid_cap = keep_cap; c->t_instloop = keep_loop; c->tuned_by_search = keep_tuned; };
+    std::vector<Plan> plans(n);
+    for (int i = 0; i < n; ++i) {
+        c->t_split = cands[i].morph_split; c->t_grid_cap = cands[i].grid_cap; c->t_instloop = instanced ? cands[i].inst_loop : keep_loop;
+        if (int r = frame_plan(c, &plans[i])) { restore(); return r; }
+        const Plan &pl = plans[i];
+        cands[i].eff_split = pl.v.S; cands[i].eff_grid = (int)pl.grid_x; cands[i].eff_inst_group = pl.inst_group;
+        for (int k = 0; k < i && cands[i].same_as < 0; ++k)      // different requests often resolve to the same launch
+            if (plans[k].grid_x == pl.grid_x && (pl.inst_group > 0 || plans[k].quads_per_wave == pl.quads_per_wave) && plans[k].v.S == pl.v.S &&
+                plans[k].inst_group == pl.inst_group && plans[k].verts_per_wg == pl.verts_per_wg && plans[k].subsets == pl.subsets &&
+                plans[k].inst_block == pl.inst_block)
+                cands[i].same_as = cands[k].same_as >= 0 ? cands[k].same_as : k;
+    }
+    constexpr int kRounds = 3;
+    std::vector<float> t((size_t)n * kRounds, 0.f);
+    int rc = RZ_OK;
+    for (int round = -1; round < kRounds && rc == RZ_OK; ++round) {          // round -1 warms every variant up, untimed
+        for (int i = 0; i < n && rc == RZ_OK; ++i) {
+            if (cands[i].same_as >= 0) continue;
+            c->t_split = cands[i].morph_split; c->t_grid_cap = cands[i].grid_cap; c->t_instloop = instanced ? cands[i].inst_loop : keep_loop;
+            Plan pl;
+            if ((rc = frame_plan(c, &pl)) != RZ_OK) break;       // crowd shapes alternate: the run lists follow (a rebuild, untimed)
+            if ((rc = set_overlap(c, want_overlap(c, pl))) != RZ_OK) break;
+            const uint32_t nf = round < 0 ? 8 : frames;
+            for (uint32_t f = 0; f < 4 && rc == RZ_OK; ++f) rc = run_frame(c, pl);
+            if (rc != RZ_OK) break;
+            hipError_t he = hipEventRecord(c->ev0, c->stream);
+            for (uint32_t f = 0; f < nf && rc == RZ_OK; ++f) rc = run_frame(c, pl);
+            if (rc != RZ_OK) break;
+            if (he == hipSuccess) he = hipEventRecord(c->ev1, c->stream);
+            if (he == hipSuccess) he = hipEventSynchronize(c->ev1);
             float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-            if (rep == 0 || ms < cand_ms) cand_ms = ms;
+            if (he == hipSuccess) he = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            if (he != hipSuccess) { rc = fail(RZ_ERR_HIP, "rz_autotune_measure: %s", hipGetErrorString(he)); break; }
+            if (round >= 0) t[(size_t)i * kRounds + round] = ms / nf;
         }
-        if (best < 0 || cand_ms < best_ms) { best = (int)i; best_ms = cand_ms; }
     }
-    if (best < 0) { c->t_split = keep_split; c->t_grid_cap = keep_cap; c->t_instloop = keep_loop; return RZ_OK; }
-    c->t_split = cands[best].split; c->t_grid_cap = cands[best].cap;
-    c->t_instloop = instanced ? cands[best].loop : keep_loop;
+    restore();
+    if (rc != RZ_OK) return rc;
+    for (int i = 0; i < n; ++i) {
+        const int src = cands[i].same_as >= 0 ? cands[i].same_as : i;
+        float v[kRounds];
+        for (int k = 0; k < kRounds; ++k) v[k] = t[(size_t)src * kRounds + k];
+        std::sort(v, v + kRounds);
+        cands[i].ms = v[kRounds / 2]; cands[i].ms_min = v[0]; cands[i].ms_max = v[kRounds - 1];
+        table[i] = cands[i];
+    }
+    *count = n;
+    return RZ_OK;
+}
+
+int rz_autotune_pick(const rz_tune_entry *table, int count)
+{
+    if (!table || count < 1) return 0;
+    // entry 0 (the heuristics) stays unless something is >= 2 % faster; among those, the fastest
+    int best = 0;
+    float best_ms = table[0].ms * 0.98f;
+    for (int i = 1; i < count; ++i)
+        if (table[i].same_as != 0 && table[i].ms > 0.f && table[i].ms < best_ms) { best = i; best_ms = table[i].ms; }
+    return best;
+}
+
+int rz_autotune_apply(rz_ctx *c, const rz_tune_entry *e)
+{
+    if (int r = use(c)) return r;
+    if (!e) return fail(RZ_ERR_INVALID, "rz_autotune_apply: null entry");
+    const int sp = e->morph_split;
+    if (sp != 0 && sp != 1 && sp != 2 && sp != 4 && sp != 8) return fail(RZ_ERR_INVALID, "rz_autotune_apply: morph_split %d", sp);
+    if (e->grid_cap < 0 || e->inst_loop < -1 || e->inst_loop == 1 || e->inst_loop > 64) return fail(RZ_ERR_INVALID, "rz_autotune_apply: bad entry");
+    InstShape is;
+    c->t_split = sp; c->t_grid_cap = e->grid_cap;
+    const int keep_loop = c->t_instloop;
+    c->t_instloop = -1;
+    const bool instanced = inst_shape(c, &is);
+    c->t_instloop = instanced ? e->inst_loop : keep_loop;
     c->tuned_by_search = true;
     return RZ_OK;
+}
+
+int rz_autotune(rz_ctx *c, uint32_t frames)
+{
+    rz_tune_entry table[32];
+    int n = 0;
+    if (int r = rz_autotune_measure(c, frames, table, 32, &n)) return r;
+    if (n < 1) return RZ_OK;
+    return rz_autotune_apply(c, &table[rz_autotune_pick(table, n)]);
 }
 
 int rz_set_tuning(rz_ctx *c, const char *key, int value)
@@ -1988,8 +2174,11 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
         return fail(RZ_ERR_INVALID, "tuning key 'dbg' does not exist in the product library (tools-only build: make -C reze-engine_amd/csrc ablate)");
 #endif
     } else if (!strcmp(key, "inst_loop")) {
-        if (value < -1 || value == 1 || value > 16) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off), 2..8 / 10..16 (poses per workgroup, LDS form) or 9 (register form)");
+        if (value < -1 || value == 1 || value > 64) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off), 2..8 / 10..64 (poses per workgroup, LDS form) or 9 (register form)");
         c->t_instloop = value;
+    } else if (!strcmp(key, "inst_subsets")) {
+        if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "inst_subsets must be -1 (auto = on), 0 (crowd frames always stage the whole palette) or 1");
+        c->t_subsets = value;
     } else if (!strcmp(key, "fuse_fk")) {
         if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "fuse_fk must be -1 (auto), 0 (always rz_fk_kernel in front) or 1 (every device-animated single character)");
         c->t_fusefk = value;
@@ -2052,6 +2241,10 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "effective_inst_group")) *value = make_plan(c).inst_group;
     else if (!strcmp(key, "effective_poses_per_wg")) *value = make_plan(c).poses_per_wg;
     else if (!strcmp(key, "effective_grid")) *value = (int)make_plan(c).grid_x;
+    else if (!strcmp(key, "inst_subsets")) *value = c->t_subsets;
+    else if (!strcmp(key, "effective_subsets")) *value = make_plan(c).subsets ? 1 : 0;
+    else if (!strcmp(key, "effective_subset_bones")) *value = (int)make_plan(c).sub_bones;
+    else if (!strcmp(key, "effective_inst_lds")) *value = (int)make_plan(c).inst_lds;
     else return fail(RZ_ERR_INVALID, "unknown tuning key '%s'", key);
     return RZ_OK;
 }
@@ -2090,6 +2283,19 @@ int rz_rccl_info(char *path, size_t path_bytes, int *version, int *reused)
     }
     if (version) { *version = 0; if (g_rccl.GetVersion) (void)g_rccl.GetVersion(version); }
     if (reused) *reused = g_rccl.reused ? 1 : 0;
+    return RZ_OK;
+}
+
+int rz_comm_info(rz_ctx *c, int *comm_count, int *comm_user_rank)
+{
+    if (int r = use(c)) return r;
+    if (!c->comm) return fail(RZ_ERR_INVALID, "rz_comm_init has not been called");
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(RZ_ERR_UNSUPPORTED, "this RCCL lacks ncclCommCount / ncclCommUserRank");
+    int n = 0, u = -1;
+    NCCL_TRY(g_rccl.CommCount(c->comm, &n));
+    NCCL_TRY(g_rccl.CommUserRank(c->comm, &u));
+    if (comm_count) *comm_count = n;
+    if (comm_user_rank) *comm_user_rank = u;
     return RZ_OK;
 }
 

@@ -267,3 +267,39 @@ def make_morphs_dense_range(n_total, n_morphs, begin, count, seed=SEED + 1):
     deltas = np.ascontiguousarray(np.concatenate(parts, axis=1)) if parts else np.zeros((n_morphs, 0, 3), dtype=np.float32)
     w = np.random.default_rng([seed, 0]).random(n_morphs, dtype=np.float32)
     return deltas, w
+
+
+def make_morphs_demo_shape(n_verts, n_morphs=60, total=36397, largest=1718, region=None, seed=SEED + 3):
+    """Sparse vertex morphs with the DEMO MODEL's statistics (60 vertex morphs, 36 397 offsets in all, the largest
+    morph 1 718, mean 607 per morph) and its shape: every morph is a facial expression, so all of them sit on the same
+    face region (`region` = (first vertex, count); default 1 800 vertices in the upper part of the mesh) — a few vertices
+    carry dozens of entries each. Same return as make_morphs_sparse: morph_off [M+1], vert_idx [E], delta3 [E,3], weights [M].
+    The PMX on-disk layout this mirrors: engine/src/pmx-loader.ts:483-488 (vertex index + 3 floats per offset)."""
+    rng = np.random.default_rng(seed)
+    if region is None:
+        region = (int(n_verts * 0.62), min(1800, n_verts))
+    first, count = int(region[0]), int(min(region[1], n_verts - region[0]))
+    largest = min(largest, count)
+    # sizes: one morph of `largest`, the rest log-normal, scaled and nudged to sum to `total` exactly
+    raw = np.exp(rng.normal(0.0, 0.9, size=n_morphs - 1))
+    sizes = np.maximum(4, np.floor(raw / raw.sum() * (total - largest))).astype(np.int64)
+    sizes = np.minimum(sizes, largest)
+    sizes = np.concatenate([[largest], sizes])
+    k = 1
+    while sizes.sum() != total and total <= n_morphs * largest:
+        d = 1 if sizes.sum() < total else -1
+        if 4 <= sizes[k] + d <= largest:
+            sizes[k] += d
+        k = k + 1 if k + 1 < n_morphs else 1
+    order = rng.permutation(n_morphs)
+    sizes = sizes[order]
+    offs = np.zeros(n_morphs + 1, dtype=np.uint32)
+    idx = []
+    for m in range(n_morphs):
+        pick = np.sort(rng.choice(count, size=int(min(sizes[m], count)), replace=False)) + first
+        idx.append(pick.astype(np.uint32))
+        offs[m + 1] = offs[m] + len(pick)
+    vert_idx = np.concatenate(idx)
+    delta3 = ((rng.random((len(vert_idx), 3), dtype=np.float32) - np.float32(0.5)) * np.float32(0.1)).astype(np.float32)
+    w = rng.random(n_morphs, dtype=np.float32)
+    return offs, vert_idx, delta3, w

@@ -67,3 +67,59 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     d = _last_json(out)
     _check(d, 2, 20, 50000)
     assert d["scaling"] == "strong" and d["config"]["verts_per_gpu"] < 50000 and "x2" in d["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_without_a_launcher_is_a_two_rank_run():
+    """Round-2 review: `python bench.py --gpus N` run PLAINLY (no torch.distributed.run around it) must be an N-rank run —
+    it re-executes itself under the launcher — never one rank printing n_gpus 1."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3", "--verts", "50000", "--bones", "64",
+           "--morphs", "8", "--share-gpu", "--dist-backend", "gloo", "--no-cpu-baseline", "--clock-warm-seconds", "0.2"]
+    out = subprocess.check_output(cmd, cwd=ROOT, env=env, timeout=900, stderr=subprocess.STDOUT).decode()
+    d = _last_json(out)
+    _check(d, 2, 20, 50000)
+    assert "self" in d["config"]["launched_by"]
+    # both modes at every N, and how to read a scaling ratio
+    assert d["config"]["ms_per_step_one_stream"] > 0 and d["config"]["ms_per_step_two_frames_in_flight"] > 0 and d["config"]["speedup_basis"]
+    # one plan on all ranks (the search reduces its table over the ranks and every rank adopts the same entry)
+    ranks = d["config"]["ranks"]
+    assert len({(r["kernel"], r["morph_split"]) for r in ranks}) == 1, ranks      # (the grid follows each rank's shard size)
+    assert d["config"]["autotune_table"] and d["config"]["autotune_pick"] is not None
+    assert d["roofline"]["kernel_ms_check"]["ok"], d["roofline"]
+
+
+@pytest.mark.gpu
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """--gpus 1 under a 2-rank environment (or the reverse) is an error, not a line with another n_gpus."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2"], cwd=ROOT, env=env, timeout=300,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 3 and not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    # two ranks on a one-GPU box without --share-gpu: also an error (one process per GPU)
+    env2 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--no-cpu-baseline"], cwd=ROOT, env=env2,
+                           timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode != 0 and not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_rccl_evidence_and_sparse_configs():
+    """--allgather at N = 1 builds the RCCL communicator through rz_comm_init and reports what the communicator says
+    (ncclCommCount / ncclCommUserRank); --config demo / sparse2 are the sparse real-shape lines of SURVEY 8d."""
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--verts", "40000", "--bones", "64", "--morphs", "8", "--steps", "20",
+                                   "--warmup", "3", "--no-cpu-baseline", "--clock-warm-seconds", "0.2", "--allgather"], cwd=ROOT, timeout=600).decode()
+    d = _last_json(out)
+    rc = d["config"]["ranks"][0]["rccl"]
+    assert rc["comm_count"] == 1 and rc["comm_user_rank"] == 0 and rc["version"] > 0 and d["config"]["allgather_ms"] > 0
+    for cfg, verts in (("demo", 28842), ("sparse2", 28842)):
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "50", "--warmup", "5",
+                                       "--clock-warm-seconds", "0.2", "--no-sampled-loop"], cwd=ROOT, timeout=600).decode()
+        d = _last_json(out)
+        assert d["n_gpus"] == 1 and d["config"]["verts_total"] == verts and d["config"]["morph_layout"] == "sparse CSR"
+        assert "2, " in d["roofline"]["kernel"] or ", 2," in d["roofline"]["kernel"], d["roofline"]["kernel"]     # MODE 2 = sparse
+        assert d["cpu_baseline"]["value"] > 0 and "sparse" in d["cpu_baseline"]["sample"]
+        assert d["roofline"]["algorithmic_bytes_per_launch"] > verts * 60

@@ -75,6 +75,17 @@ def test_c4_full_size_256x30k_200b(rz, oracle):
         assert np.array_equal(pg, ref[k][0]) and np.array_equal(ng, ref[k][1]), "instance %d: inst_order 0 vs 1" % k
     assert np.array_equal(pal_ref, c.read_palette(rnd))
     c.set_tuning(inst_order=1)
+    # round 3: by default a workgroup stages only the bones its vertex run names (bone-subset form); staging the whole
+    # palette instead is the same arithmetic on the same rows, so the bits (and the observable palettes) are identical
+    assert c.get_tuning("effective_subsets") == 1 and 0 < c.get_tuning("effective_subset_bones") < B
+    c.set_tuning(inst_subsets=0)
+    c.deform()
+    assert c.get_tuning("effective_subsets") == 0
+    for k in picks:
+        pg, ng = c.read(instance=k)
+        assert np.array_equal(pg, ref[k][0]) and np.array_equal(ng, ref[k][1]), "instance %d: whole palette vs bone subsets" % k
+    assert np.array_equal(pal_ref, c.read_palette(rnd))
+    c.set_tuning(inst_subsets=-1)
     # identity pose in EVERY instance == rest mesh, all 256 read back
     ident = np.tile(_identity_world(mesh, B)[None], (I, 1, 1))
     c.set_pose(ident)

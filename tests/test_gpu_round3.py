@@ -1,0 +1,161 @@
+"""GPU tests added in round 3: the bone-subset form of the crowd kernel (rz_skin_instances_kernel<..., SUB>), the
+launch-shape search's stability rules, and the regression tests of the round-2 review."""
+import numpy as np
+import pytest
+
+from helpers import assert_parity
+from reze_engine_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _crowd(rz, mesh, worlds, **tuning):
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    c.set_instances(len(worlds))
+    c.set_tuning(**tuning)
+    c.set_pose(worlds)
+    return c
+
+
+def _poses(mesh, B, I, seed=4000):
+    return np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=seed + i) for i in range(I)])
+
+
+@pytest.mark.parametrize("V,B,I,tuning", [
+    (30000, 200, 24, {}),                                    # the C4 shape, three pose groups
+    (30000, 200, 24, {"inst_block": 256}),                   # two workgroups per CU
+    (30000, 200, 40, {"inst_loop": 16}),                     # 16 poses per workgroup, last group partial (40 = 16 + 16 + 8)
+    (30000, 200, 24, {"fast": 0}),                           # rz_prep_kernel in front: finished rows staged (48-byte DMA)
+    (4097, 33, 5, {"grid_cap": 64}),                         # ragged: last run short, last group partial, odd bone count
+    (1023, 40, 3, {}),                                       # fewer vertices than one workgroup step
+    (20000, 1500, 6, {"grid_cap": 256}),                     # skeleton far larger than the workgroup: only subsets fit one launch
+])
+def test_bone_subset_crowd_equals_whole_palette_crowd(rz, oracle, V, B, I, tuning):
+    """rz_skin_instances_kernel<.., SUB> (engine.ts:253-272 per instance): a workgroup stages only the bones its vertex run
+    names. Same rows, same FMA chains => every instance is BIT-IDENTICAL to the whole-palette form, and oracle-green."""
+    mesh = synth.make_mesh(V, B)
+    worlds = _poses(mesh, B, I)
+    c = _crowd(rz, mesh, worlds, **tuning)
+    c.deform()
+    assert c.get_tuning("effective_inst_group") >= 2
+    assert c.get_tuning("effective_subsets") == 1, "the synthetic mesh is bone-local: the subset form must be planned"
+    nb = c.get_tuning("effective_subset_bones")
+    assert 0 < nb < B
+    sub = [c.read(instance=k) for k in range(I)]
+    pal = [c.read_palette(k) for k in (0, I - 1)]
+    c.set_tuning(inst_subsets=0)
+    c.deform()
+    assert c.get_tuning("effective_subsets") == 0
+    for k in range(I):
+        pg, ng = c.read(instance=k)
+        assert np.array_equal(pg, sub[k][0]) and np.array_equal(ng, sub[k][1]), "instance %d: subset vs whole palette" % k
+    for a, k in zip(pal, (0, I - 1)):
+        S = oracle.palette(worlds[k], mesh["inv_bind"]).reshape(-1, 4, 4)
+        np.testing.assert_allclose(a, np.transpose(S, (0, 2, 1))[:, :3, :].reshape(-1, 12), rtol=1e-6, atol=1e-6)
+        if c.get_tuning("effective_inst_group") >= 2 and B <= 512:
+            assert np.array_equal(a, c.read_palette(k)), "palette formed on demand vs written by the frame"
+    for k in sorted({0, I // 2, I - 1}):
+        pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[k], mesh["inv_bind"], threads=4)
+        assert_parity(sub[k][0], sub[k][1], pr, nr, "subset crowd instance %d" % k)
+    c.close()
+
+
+def test_bone_subsets_follow_the_launch_shape_mesh_and_skeleton(rz, oracle):
+    """The run lists are derived data: a new shape (grid_cap / inst_loop / instance count), a new mesh or a new skeleton
+    must rebuild them — a stale list would gather the wrong bones. Also: joints beyond the skeleton are clamped the same
+    way in both forms, zero-weight influences keep their bone, and a mesh that is NOT bone-local falls back."""
+    V, B, I = 12000, 96, 12
+    mesh = synth.make_mesh(V, B)
+    worlds = _poses(mesh, B, I)
+    c = _crowd(rz, mesh, worlds)
+
+    def check(what):
+        c.deform()
+        got = [c.read(instance=k) for k in (0, I - 1)]
+        sub_on = c.get_tuning("effective_subsets")
+        c.set_tuning(inst_subsets=0)
+        c.deform()
+        for (pg, ng), k in zip(got, (0, I - 1)):
+            p0, n0 = c.read(instance=k)
+            assert np.array_equal(pg, p0) and np.array_equal(ng, n0), "%s: instance %d" % (what, k)
+        c.set_tuning(inst_subsets=-1)
+        return sub_on
+
+    assert check("first shape") == 1
+    for cap in (64, 512, 1024):
+        c.set_tuning(grid_cap=cap)
+        assert check("grid_cap %d" % cap) == 1
+    c.set_tuning(grid_cap=0, inst_loop=4)
+    assert check("inst_loop 4") == 1
+    c.set_tuning(inst_loop=-1)
+    c.set_instances(7)
+    c.set_pose(worlds[:7])
+    I = 7
+    assert check("7 instances") == 1
+    # a new mesh on the same context: other joints, other size
+    mesh2 = synth.make_mesh(9001, B, seed=77)
+    mesh2["joints"][::5] = 60000                    # out-of-range joints: clamped to B - 1 by both forms
+    mesh2["joints"][1::7, 1:] = B - 1               # zero-weight influences naming a far bone ...
+    mesh2["weights"][1::7] = np.array([255, 0, 0, 0], np.uint8)
+    c.upload_mesh(mesh2["pos"], mesh2["nrm"], mesh2["joints"], mesh2["weights"])
+    c.set_pose(worlds[:7])
+    assert check("new mesh") == 1
+    pg, ng = c.read(instance=3)
+    jc = np.minimum(mesh2["joints"], B - 1).astype(np.uint16)
+    pr, nr = oracle.deform(mesh2["pos"], mesh2["nrm"], jc, mesh2["weights"], worlds[3], mesh["inv_bind"], threads=4)
+    assert_parity(pg, ng, pr, nr, "new mesh, clamped joints")
+    # a new skeleton (fewer bones): joints are clamped to the NEW bone count
+    B2 = 40
+    m3 = synth.make_mesh(9001, B2, seed=5)
+    c.upload_skeleton(m3["inv_bind"])
+    w3 = _poses(m3, B2, 7, seed=9)
+    c.set_pose(w3)
+    check("new skeleton")
+    pg, ng = c.read(instance=6)
+    jc = np.minimum(mesh2["joints"], B2 - 1).astype(np.uint16)
+    pr, nr = oracle.deform(mesh2["pos"], mesh2["nrm"], jc, mesh2["weights"], w3[6], m3["inv_bind"], threads=4)
+    assert_parity(pg, ng, pr, nr, "new skeleton, clamped joints")
+    # joints scattered over the whole skeleton: every run names every bone -> no gain -> the whole palette is staged
+    rng = np.random.default_rng(3)
+    m4 = synth.make_mesh(9001, B2, seed=6)
+    m4["joints"] = rng.integers(0, B2, size=(9001, 4)).astype(np.uint16)
+    c.upload_mesh(m4["pos"], m4["nrm"], m4["joints"], m4["weights"])
+    c.set_pose(w3)
+    c.deform()
+    assert c.get_tuning("effective_subsets") == 0 and c.get_tuning("effective_inst_group") >= 2
+    pg, ng = c.read(instance=2)
+    pr, nr = oracle.deform(m4["pos"], m4["nrm"], m4["joints"], m4["weights"], w3[2], m3["inv_bind"], threads=4)
+    assert_parity(pg, ng, pr, nr, "scattered joints (fallback)")
+    c.close()
+
+
+def test_bone_subset_crowd_behind_the_device_hierarchy_solve(rz, oracle):
+    """Device-solved crowds (rz_set_pose_local -> rz_fk_kernel writes the palettes): the skin kernel stages the listed bones'
+    finished rows. Bit-identical to the whole-palette form; rz_read_palette still serves what rz_fk_kernel wrote."""
+    V, B, I = 16000, 120, 20
+    mesh = synth.make_mesh(V, B)
+    rng = np.random.default_rng(11)
+    q = rng.normal(size=(I, B, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=2, keepdims=True)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    c.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+    c.set_instances(I)
+    c.set_pose_local(q)
+    c.deform()
+    assert c.get_tuning("effective_subsets") == 1
+    sub = [c.read(instance=k) for k in range(I)]
+    pal = c.read_palette(I - 1)
+    c.set_tuning(inst_subsets=0)
+    c.deform()
+    for k in range(I):
+        pg, ng = c.read(instance=k)
+        assert np.array_equal(pg, sub[k][0]) and np.array_equal(ng, sub[k][1])
+    assert np.array_equal(pal, c.read_palette(I - 1))
+    world = synth.fk_world(mesh["parents"], mesh["bind"], q[I - 1])
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], world, mesh["inv_bind"], threads=4)
+    assert_parity(sub[I - 1][0], sub[I - 1][1], pr, nr, "device-solved subset crowd")
+    c.close()
