@@ -90,12 +90,30 @@ static napi_value undef(napi_env env)
     return u;
 }
 
+/* What an external handle points at. `ctx` comes first, so a (rz_ctx **) view of the slot still reads the context.
+ * A fork's slot holds a strong reference on its lender's external: the garbage collector finalizes in no particular order,
+ * and rz_destroy() refuses a lender whose forks are alive — with the reference the lender cannot be collected (and so cannot
+ * be leaked by a refused destroy) before its forks are gone. */
+typedef struct ctx_slot {
+    rz_ctx *ctx;
+    napi_ref lender;        /* forks only */
+} ctx_slot;
+
+static void release_lender(napi_env env, ctx_slot *slot)
+{
+    if (slot->lender) {
+        napi_delete_reference(env, slot->lender);
+        slot->lender = NULL;
+    }
+}
+
 static void finalize_ctx(napi_env env, void *data, void *hint)
 {
-    (void)env; (void)hint;
-    rz_ctx **slot = (rz_ctx **)data;
+    (void)hint;
+    ctx_slot *slot = (ctx_slot *)data;
     if (slot) {
-        if (*slot) rz_destroy(*slot);
+        if (slot->ctx) rz_destroy(slot->ctx);     /* a fork, or a lender whose forks are gone (they held it alive until now) */
+        release_lender(env, slot);
         free(slot);
     }
 }
@@ -126,8 +144,9 @@ static napi_value fn_create(napi_env env, napi_callback_info info)
     rz_ctx *c = NULL;
     int rc = rz_create(dev, &c);
     if (rc) return throw_rz(env, rc);
-    rz_ctx **slot = (rz_ctx **)malloc(sizeof *slot);
-    *slot = c;
+    ctx_slot *slot = (ctx_slot *)calloc(1, sizeof *slot);
+    if (!slot) { rz_destroy(c); return throw_msg(env, "out of memory"); }
+    slot->ctx = c;
     napi_value ext;
     if (napi_create_external(env, slot, finalize_ctx, NULL, &ext) != napi_ok) {
         rz_destroy(c);
@@ -142,8 +161,15 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info)
     ARGS(1);
     void *p = NULL;
     if (napi_get_value_external(env, argv[0], &p) != napi_ok || !p) return throw_msg(env, "invalid context");
-    rz_ctx **slot = (rz_ctx **)p;
-    if (*slot) { rz_destroy(*slot); *slot = NULL; }
+    ctx_slot *slot = (ctx_slot *)p;
+    if (slot->ctx) {
+        /* rz_destroy refuses a context whose forks are alive: the handle then STAYS valid (throwing away the pointer would
+         * leak the mesh and morph targets for good) and the caller hears about it */
+        int rc = rz_destroy(slot->ctx);
+        if (rc) return throw_rz(env, rc);
+        slot->ctx = NULL;
+        release_lender(env, slot);
+    }
     return undef(env);
 }
 
@@ -390,11 +416,14 @@ static napi_value fn_fork(napi_env env, napi_callback_info info)
     rz_ctx *f = NULL;
     int rc = rz_fork(ctx, &f);
     if (rc) return throw_rz(env, rc);
-    rz_ctx **slot = (rz_ctx **)malloc(sizeof *slot);
-    *slot = f;
+    ctx_slot *slot = (ctx_slot *)calloc(1, sizeof *slot);
+    if (!slot) { rz_destroy(f); return throw_msg(env, "out of memory"); }
+    slot->ctx = f;
     napi_value ext;
-    if (napi_create_external(env, slot, finalize_ctx, NULL, &ext) != napi_ok) {
+    if (napi_create_reference(env, argv[0], 1, &slot->lender) != napi_ok ||
+        napi_create_external(env, slot, finalize_ctx, NULL, &ext) != napi_ok) {
         rz_destroy(f);
+        release_lender(env, slot);
         free(slot);
         return throw_msg(env, "napi_create_external failed");
     }

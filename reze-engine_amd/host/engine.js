@@ -173,6 +173,7 @@ class Engine {
   async setupModelBuffers(model) {
     if (!this.ctx) throw new Error('Engine.init() has not been called')
     this.dropForks()
+    this.overrides = null // they name bones of the previous model; the library drops its copy with the skeleton (rz_upload_skeleton)
     this.currentModel = model
     model.setClock(() => this.now())
     const n = this.native, skinning = model.getSkinning(), skeleton = model.getSkeleton()
@@ -494,6 +495,7 @@ class Engine {
     if (this.shards.length > 1) throw new Error('instancing and vertex sharding are exclusive')
     if (this.outline || this.bounds) throw new Error('the outline hull and bounds are single-instance consumers')
     this.dropForks() // a fork takes its instance count from the lender when it is made
+    if (n !== this.instances) this.overrides = null // (instance, bone) pairs of the old crowd: rz_set_instances dropped them on the lender too
     this.native.setInstances(this.ctx, n)
     this.instances = n
     this.tuned = false

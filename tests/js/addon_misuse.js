@@ -61,6 +61,11 @@ if (process.argv[2] === '--live') { // on a GPU box: the same with a LIVE contex
   try { a.fork(fk) } catch (e) { frozen += e instanceof Error ? 1 : 0 }
   if (frozen !== 3) throw new Error('a live fork must freeze static data on both sides and cannot be forked itself (' + frozen + '/3)')
   a.setPose(ctx, ib, null); a.setPose(fk, ib, null); a.deformPair(ctx, fk, 5); a.sync(ctx); a.sync(fk)
+  // destroying the lender while its fork lives is REFUSED — and must neither kill the handle nor leak the context (round-2 advisor finding)
+  let refused = false
+  try { a.destroy(ctx) } catch (e) { refused = e instanceof Error }
+  if (!refused) throw new Error('destroy(lender) with a live fork must throw')
+  a.setPose(ctx, ib, null); a.deform(ctx); a.sync(ctx)   // the handle is still the live context
   a.destroy(fk)
   a.uploadSkeleton(ctx, ib)                          // the lender owns its data again
   a.setPose(ctx, ib, null); a.deform(ctx)           // still usable

@@ -28,7 +28,7 @@ fp = ctypes.POINTER(ctypes.c_float)
 # null context everywhere
 for name in rz.capi.SYMBOLS:
     if name in ("rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_shard_range", "rz_comm_unique_id",
-                "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_destroy", "rz_rccl_info"):      # rz_destroy(NULL) is a no-op, like free
+                "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_destroy", "rz_rccl_info", "rz_autotune_pick"):      # rz_destroy(NULL) is a no-op, like free; rz_autotune_pick takes a table and returns an index
         continue
     f = getattr(L, name)
     args = [None] + [0 if t in (ctypes.c_uint32, ctypes.c_int, ctypes.c_uint, ctypes.c_size_t) else None for t in f.argtypes[1:]]
@@ -96,6 +96,13 @@ expect_fail("gather_fence on a non-root", L.rz_gather_fence(h))
 expect_fail("allgather without comm", L.rz_allgather(h, 0))
 expect_fail("comm_init bad rank", L.rz_comm_init(h, 2, 7, ctypes.create_string_buffer(128), 300))
 expect_fail("time_frames NULL out", L.rz_time_frames(h, 3, N))
+expect_fail("autotune_measure NULL table", L.rz_autotune_measure(h, 3, N, 0, N))
+expect_fail("autotune_apply NULL entry", L.rz_autotune_apply(h, N))
+bad_entry = rz.capi.RzTuneEntry(); bad_entry.morph_split = 3
+expect_fail("autotune_apply bad split", L.rz_autotune_apply(h, ctypes.byref(bad_entry)))
+if L.rz_autotune_pick(N, 0) != 0: bad.append("rz_autotune_pick(NULL) must answer entry 0")
+expect_fail("comm_info without comm", L.rz_comm_info(h, N, N))
+expect_fail("inst_subsets 5", L.rz_set_tuning(h, b"inst_subsets", 5))
 # and the context still works afterwards
 c.deform(); p, n = c.read()
 assert np.isfinite(p).all()

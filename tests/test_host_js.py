@@ -436,7 +436,9 @@ def test_engine_frames_in_flight_alternates_between_the_context_and_one_fork():
     assert seq == ["deform:" + name, "read:" + name, "deform:ctx1", "read:ctx1", "deform:" + name, "read:" + name, "deform:ctx1", "read:ctx1"]
     assert r["overrides"] == ["ctx1", name]
     assert r["reload"][0] == "destroy:" + name and r["reload"][1] == "uploadMesh:ctx1" and "fork:ctx1" in r["reload"]
-    assert r["reload"].index("fork:ctx1") < [i for i, c in enumerate(r["reload"]) if c.startswith("overrideWorld:fork")][0]
+    # a new model drops the bone overrides everywhere: the library forgets them with the old skeleton (rz_upload_skeleton), so
+    # re-applying the stale set to the new fork alone would make odd and even frames differ (round-2 advisor finding)
+    assert not [c for c in r["reload"] if c.startswith("overrideWorld:")]
     assert r["dispose"][0].startswith("destroy:fork") and r["dispose"][1] == "destroy:ctx1" and r["multiGpuRefused"] is True
 
 
