@@ -53,17 +53,28 @@ class RzError(RuntimeError):
 
 
 _lib = None
+_libs = {}
+# the tools-only build that carries EVERY kernel variant (make -C reze-engine_amd/csrc variants): the parity tests reach the
+# variants the product does not ship through it; nothing in the product, bench.py or host/ loads it
+VARIANTS_LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "variants", "libreze_deform_variants.so")
 
 
-def load():
-    """dlopen the in-tree HIP library; raises (never falls back) when it is missing."""
+def load(path=None):
+    """dlopen the in-tree HIP library (or, for tests / tools, another build of it given by `path`); raises (never falls
+    back) when it is missing. Each build is bound once; their exported names are the same, so they are loaded RTLD_LOCAL
+    and linked -Bsymbolic-functions: a call inside one build never lands in another."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if path is None:
+        if _lib is not None:
+            return _lib
+        path = LIB_PATH
+    path = os.path.abspath(path)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise ImportError("%s not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
-                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
-    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
     vp = ctypes.c_void_p
     fp = ctypes.POINTER(ctypes.c_float)
     u32 = ctypes.c_uint32
@@ -121,13 +132,15 @@ def load():
     for name in SYMBOLS:
         if name != "rz_last_error":
             getattr(L, name).restype = ctypes.c_int
-    _lib = L
+    _libs[path] = L
+    if path == os.path.abspath(LIB_PATH):
+        _lib = L
     return L
 
 
-def _chk(code):
+def _chk(code, L=None):
     if code != 0:
-        raise RzError(code, load().rz_last_error().decode("utf-8", "replace"))
+        raise RzError(code, (L or load()).rz_last_error().decode("utf-8", "replace"))
 
 
 def _fptr(a):
@@ -191,15 +204,19 @@ def gather_direct(contexts, v_total, root=0):
 class DeformContext:
     """One GPU's deformation context (rz_ctx)."""
 
-    def __init__(self, device=0):
-        self._L = load()
+    def __init__(self, device=0, lib=None):
+        """lib: a library returned by load(path) (tests: the all-variants build); default = the product library."""
+        self._L = lib if lib is not None else load()
         h = ctypes.c_void_p()
-        _chk(self._L.rz_create(int(device), ctypes.byref(h)))
+        _chk(self._L.rz_create(int(device), ctypes.byref(h)), self._L)
         self._h = h
         self.V = 0
         self.B = 0
         self.M = 0
         self.I = 1
+
+    def _chk(self, code):
+        _chk(code, self._L)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -215,7 +232,7 @@ class DeformContext:
         """A second context on the same GPU that borrows this one's static data (no copy) and owns its own streams, pose
         slots and outputs: alternate frames between the two to keep two frames in flight (rz_fork)."""
         h = ctypes.c_void_p()
-        _chk(self._L.rz_fork(self._h, ctypes.byref(h)))
+        self._chk(self._L.rz_fork(self._h, ctypes.byref(h)))
         f = DeformContext.__new__(DeformContext)
         f._L, f._h, f.V, f.B, f.M, f.I = self._L, h, self.V, self.B, self.M, self.I
         f._lender = self
@@ -226,7 +243,7 @@ class DeformContext:
 
     def deform_pair(self, other, frames):
         """`frames` frames alternating between this context and `other` (each on its own stream, into its own outputs)."""
-        _chk(self._L.rz_deform_pair(self._h, other._h, int(frames)))
+        self._chk(self._L.rz_deform_pair(self._h, other._h, int(frames)))
 
     __del__ = close
 
@@ -242,7 +259,7 @@ class DeformContext:
         j = np.ascontiguousarray(joints4, dtype=np.uint16).reshape(-1, 4)
         w = np.ascontiguousarray(weights4, dtype=np.uint8).reshape(-1, 4)
         assert len(v) == len(j) == len(w)
-        _chk(self._L.rz_upload_mesh(self._h, len(v), _fptr(v), j.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
+        self._chk(self._L.rz_upload_mesh(self._h, len(v), _fptr(v), j.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
                                     w.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
         self.V = len(v)
         self.M = 0
@@ -253,7 +270,7 @@ class DeformContext:
         j = np.ascontiguousarray(joints4, dtype=np.uint16).reshape(-1, 4)
         w = np.ascontiguousarray(weights4, dtype=np.uint8).reshape(-1, 4)
         assert len(p) == len(n) == len(j) == len(w)
-        _chk(self._L.rz_upload_mesh_soa(self._h, len(p), _fptr(p), _fptr(n),
+        self._chk(self._L.rz_upload_mesh_soa(self._h, len(p), _fptr(p), _fptr(n),
                                         j.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
                                         w.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
         self.V = len(p)
@@ -261,17 +278,17 @@ class DeformContext:
 
     def upload_skeleton(self, inverse_bind):
         ib = _f32(inverse_bind).reshape(-1, 16)
-        _chk(self._L.rz_upload_skeleton(self._h, len(ib), _fptr(ib)))
+        self._chk(self._L.rz_upload_skeleton(self._h, len(ib), _fptr(ib)))
         self.B = len(ib)
 
     def upload_morphs_dense(self, deltas):
         if deltas is None or len(deltas) == 0:
-            _chk(self._L.rz_upload_morphs_dense(self._h, 0, None))
+            self._chk(self._L.rz_upload_morphs_dense(self._h, 0, None))
             self.M = 0
             return
         d = _f32(deltas)
         assert d.ndim == 3 and d.shape[1] == self.V and d.shape[2] == 3, d.shape
-        _chk(self._L.rz_upload_morphs_dense(self._h, d.shape[0], _fptr(d)))
+        self._chk(self._L.rz_upload_morphs_dense(self._h, d.shape[0], _fptr(d)))
         self.M = d.shape[0]
 
     def upload_morphs_sparse(self, morph_off, vert_idx, delta3):
@@ -279,12 +296,12 @@ class DeformContext:
         vi = np.ascontiguousarray(vert_idx, dtype=np.uint32)
         d = _f32(delta3).reshape(-1, 3)
         u32p = ctypes.POINTER(ctypes.c_uint32)
-        _chk(self._L.rz_upload_morphs_sparse(self._h, len(mo) - 1, mo.ctypes.data_as(u32p),
+        self._chk(self._L.rz_upload_morphs_sparse(self._h, len(mo) - 1, mo.ctypes.data_as(u32p),
                                              vi.ctypes.data_as(u32p), _fptr(d)))
         self.M = len(mo) - 1
 
     def set_instances(self, n):
-        _chk(self._L.rz_set_instances(self._h, int(n)))
+        self._chk(self._L.rz_set_instances(self._h, int(n)))
         self.I = int(n)
 
     # ---- per frame ----
@@ -294,9 +311,9 @@ class DeformContext:
         if morph_weights is not None and self.M > 0:
             mw = _f32(morph_weights).reshape(-1)
             assert mw.size == self.I * self.M
-            _chk(self._L.rz_set_pose(self._h, _fptr(w), _fptr(mw)))
+            self._chk(self._L.rz_set_pose(self._h, _fptr(w), _fptr(mw)))
         else:
-            _chk(self._L.rz_set_pose(self._h, _fptr(w), None))
+            self._chk(self._L.rz_set_pose(self._h, _fptr(w), None))
 
     def upload_skeleton_topology(self, parents, bind_translation, append_parent=None, append_ratio=None, append_move=None):
         par = np.ascontiguousarray(parents, dtype=np.int32)
@@ -305,7 +322,7 @@ class DeformContext:
         ap = None if append_parent is None else np.ascontiguousarray(append_parent, dtype=np.int32)
         ar = None if append_ratio is None else _f32(append_ratio)
         am = None if append_move is None else np.ascontiguousarray(append_move, dtype=np.uint8)
-        _chk(self._L.rz_upload_skeleton_topology(
+        self._chk(self._L.rz_upload_skeleton_topology(
             self._h, len(par), par.ctypes.data_as(i32p), _fptr(bind),
             None if ap is None else ap.ctypes.data_as(i32p), None if ar is None else _fptr(ar),
             None if am is None else am.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
@@ -321,7 +338,7 @@ class DeformContext:
         if morph_weights is not None and self.M > 0:
             mw = _f32(morph_weights).reshape(-1)
             assert mw.size == self.I * self.M
-        _chk(self._L.rz_set_pose_local(self._h, _fptr(q), None if t is None else _fptr(t), None if mw is None else _fptr(mw)))
+        self._chk(self._L.rz_set_pose_local(self._h, _fptr(q), None if t is None else _fptr(t), None if mw is None else _fptr(mw)))
 
     def upload_animation(self, track_bone, key_off, key_frame, key_rot, key_pos, key_interp=None,
                          mkey_off=None, mkey_frame=None, mkey_weight=None, feed_off=None, feed_track=None, feed_ratio=None):
@@ -349,34 +366,34 @@ class DeformContext:
         a.feed_off = arr(feed_off, np.uint32, ctypes.c_uint32)
         a.feed_track = arr(feed_track, np.int32, ctypes.c_int32)
         a.feed_ratio = arr(feed_ratio, np.float32, ctypes.c_float)
-        _chk(self._L.rz_upload_animation(self._h, ctypes.byref(a)))
+        self._chk(self._L.rz_upload_animation(self._h, ctypes.byref(a)))
 
     def set_pose_sampled(self, frames):
         """One (fractional, 30 fps) frame per instance; bones, morph weights and the hierarchy are evaluated on the GPU."""
         f = _f32(np.atleast_1d(frames)).reshape(-1)
         assert f.size == self.I
-        _chk(self._L.rz_set_pose_sampled(self._h, _fptr(f)))
+        self._chk(self._L.rz_set_pose_sampled(self._h, _fptr(f)))
 
     def upload_bone_morphs(self, morph, bone, translation3, rotation4):
         """PMX bone morphs (type 2) for device-solved poses: entry k moves `bone[k]` by weight(morph[k]) * translation and
         right-multiplies its local rotation by slerp(identity, rotation, weight). Empty arrays clear."""
         m = np.ascontiguousarray(morph, dtype=np.uint32).reshape(-1)
         if m.size == 0:
-            _chk(self._L.rz_upload_bone_morphs(self._h, 0, None, None, None, None))
+            self._chk(self._L.rz_upload_bone_morphs(self._h, 0, None, None, None, None))
             return
         b = np.ascontiguousarray(bone, dtype=np.uint32).reshape(-1)
         t = _f32(translation3).reshape(-1)
         q = _f32(rotation4).reshape(-1)
         assert b.size == m.size and t.size == m.size * 3 and q.size == m.size * 4
         u32p = ctypes.POINTER(ctypes.c_uint32)
-        _chk(self._L.rz_upload_bone_morphs(self._h, int(m.size), m.ctypes.data_as(u32p), b.ctypes.data_as(u32p), _fptr(t), _fptr(q)))
+        self._chk(self._L.rz_upload_bone_morphs(self._h, int(m.size), m.ctypes.data_as(u32p), b.ctypes.data_as(u32p), _fptr(t), _fptr(q)))
 
     def override_world(self, bones, world16, instances=None):
         """Physics hand-off for device-solved poses (engine.ts:2379-2381): world matrices that replace the solved ones of
         (instance, bone) after the hierarchy solve, until the next call; empty `bones` clears."""
         b = np.ascontiguousarray(bones, dtype=np.uint32).reshape(-1)
         if b.size == 0:
-            _chk(self._L.rz_override_world(self._h, 0, None, None, None))
+            self._chk(self._L.rz_override_world(self._h, 0, None, None, None))
             return
         w = _f32(world16).reshape(-1)
         assert w.size == b.size * 16
@@ -386,32 +403,32 @@ class DeformContext:
             i = np.ascontiguousarray(instances, dtype=np.uint32).reshape(-1)
             assert i.size == b.size
             ip = i.ctypes.data_as(u32p)
-        _chk(self._L.rz_override_world(self._h, int(b.size), ip, b.ctypes.data_as(u32p), _fptr(w)))
+        self._chk(self._L.rz_override_world(self._h, int(b.size), ip, b.ctypes.data_as(u32p), _fptr(w)))
 
     def read_world(self, instance=0):
         out = np.empty((self.B, 16), dtype=np.float32)
-        _chk(self._L.rz_read_world(self._h, int(instance), _fptr(out)))
+        self._chk(self._L.rz_read_world(self._h, int(instance), _fptr(out)))
         return out
 
     def upload_edge_scale(self, edge):
         if edge is None:
-            _chk(self._L.rz_upload_edge_scale(self._h, 0, None))
+            self._chk(self._L.rz_upload_edge_scale(self._h, 0, None))
             return
         e = _f32(edge).reshape(-1)
-        _chk(self._L.rz_upload_edge_scale(self._h, len(e), _fptr(e)))
+        self._chk(self._L.rz_upload_edge_scale(self._h, len(e), _fptr(e)))
 
     def read_hull(self, instance=0, v0=0, n=None):
         n = self.V - v0 if n is None else n
         out = np.empty((n, 3), dtype=np.float32)
-        _chk(self._L.rz_read_hull(self._h, int(instance), int(v0), int(n), _fptr(out)))
+        self._chk(self._L.rz_read_hull(self._h, int(instance), int(v0), int(n), _fptr(out)))
         return out
 
     def enable_aabb(self, on=True):
-        _chk(self._L.rz_enable_aabb(self._h, 1 if on else 0))
+        self._chk(self._L.rz_enable_aabb(self._h, 1 if on else 0))
 
     def read_aabb(self, instance=0):
         out = np.empty(6, dtype=np.float32)
-        _chk(self._L.rz_read_aabb(self._h, int(instance), _fptr(out)))
+        self._chk(self._L.rz_read_aabb(self._h, int(instance), _fptr(out)))
         return out
 
     def frame_call(self, kind, primary, morph_weights=None, translations=None):
@@ -457,29 +474,29 @@ class DeformContext:
         return call, check
 
     def deform(self):
-        _chk(self._L.rz_deform(self._h))
+        self._chk(self._L.rz_deform(self._h))
 
     def deform_n(self, frames):
-        _chk(self._L.rz_deform_n(self._h, int(frames)))
+        self._chk(self._L.rz_deform_n(self._h, int(frames)))
 
     def sync(self):
-        _chk(self._L.rz_sync(self._h))
+        self._chk(self._L.rz_sync(self._h))
 
     def read(self, instance=0, v0=0, n=None):
         n = self.V - v0 if n is None else n
         pos = np.empty((n, 3), dtype=np.float32)
         nrm = np.empty((n, 3), dtype=np.float32)
-        _chk(self._L.rz_read(self._h, int(instance), int(v0), int(n), _fptr(pos), _fptr(nrm)))
+        self._chk(self._L.rz_read(self._h, int(instance), int(v0), int(n), _fptr(pos), _fptr(nrm)))
         return pos, nrm
 
     def read_palette(self, instance=0):
         out = np.empty((self.B, 12), dtype=np.float32)
-        _chk(self._L.rz_read_palette(self._h, int(instance), _fptr(out)))
+        self._chk(self._L.rz_read_palette(self._h, int(instance), _fptr(out)))
         return out
 
     def autotune(self, frames=0):
         """Setup-time search over launch shapes with the current mesh / morphs / pose (rz_autotune)."""
-        _chk(self._L.rz_autotune(self._h, int(frames)))
+        self._chk(self._L.rz_autotune(self._h, int(frames)))
         return {k: self.get_tuning(k) for k in ("effective_split", "effective_grid", "effective_inst_group")}
 
     _TUNE_FIELDS = ("morph_split", "grid_cap", "inst_loop", "eff_split", "eff_grid", "eff_inst_group", "same_as", "ms", "ms_min", "ms_max")
@@ -488,7 +505,7 @@ class DeformContext:
         """rz_autotune_measure: the candidate table (list of dicts; entry 0 = the heuristic plan), nothing adopted."""
         tab = (RzTuneEntry * 32)()
         n = ctypes.c_int(0)
-        _chk(self._L.rz_autotune_measure(self._h, int(frames), tab, 32, ctypes.byref(n)))
+        self._chk(self._L.rz_autotune_measure(self._h, int(frames), tab, 32, ctypes.byref(n)))
         return [{k: getattr(tab[i], k) for k in self._TUNE_FIELDS} for i in range(n.value)]
 
     def autotune_pick(self, table):
@@ -503,12 +520,12 @@ class DeformContext:
         e = RzTuneEntry()
         for k in self._TUNE_FIELDS:
             setattr(e, k, entry[k])
-        _chk(self._L.rz_autotune_apply(self._h, ctypes.byref(e)))
+        self._chk(self._L.rz_autotune_apply(self._h, ctypes.byref(e)))
 
     def comm_info(self):
         """{count, user_rank} as the RCCL communicator reports them (ncclCommCount / ncclCommUserRank)."""
         n, u = ctypes.c_int(0), ctypes.c_int(-1)
-        _chk(self._L.rz_comm_info(self._h, ctypes.byref(n), ctypes.byref(u)))
+        self._chk(self._L.rz_comm_info(self._h, ctypes.byref(n), ctypes.byref(u)))
         return {"comm_count": n.value, "comm_user_rank": u.value}
 
     def kernel_name(self):
@@ -528,41 +545,41 @@ class DeformContext:
 
     def time_frames(self, frames):
         t = RzTiming()
-        _chk(self._L.rz_time_frames(self._h, int(frames), ctypes.byref(t)))
+        self._chk(self._L.rz_time_frames(self._h, int(frames), ctypes.byref(t)))
         return {k: getattr(t, k) for k, _ in RzTiming._fields_ if k != "reserved"}
 
     def set_tuning(self, **kw):
         for k, v in kw.items():
-            _chk(self._L.rz_set_tuning(self._h, k.encode(), int(v)))
+            self._chk(self._L.rz_set_tuning(self._h, k.encode(), int(v)))
 
     def get_tuning(self, key):
         v = ctypes.c_int(0)
-        _chk(self._L.rz_get_tuning(self._h, key.encode(), ctypes.byref(v)))
+        self._chk(self._L.rz_get_tuning(self._h, key.encode(), ctypes.byref(v)))
         return v.value
 
     def output_ptrs(self):
         p = ctypes.c_void_p()
         n = ctypes.c_void_p()
         vp = ctypes.c_uint32(0)
-        _chk(self._L.rz_output_ptrs(self._h, ctypes.byref(p), ctypes.byref(n), ctypes.byref(vp)))
+        self._chk(self._L.rz_output_ptrs(self._h, ctypes.byref(p), ctypes.byref(n), ctypes.byref(vp)))
         return p.value, n.value, vp.value
 
     # ---- multi-GPU ----
     def comm_init(self, nranks, rank, unique_id, v_total):
         assert len(unique_id) == 128
-        _chk(self._L.rz_comm_init(self._h, int(nranks), int(rank), unique_id, int(v_total)))
+        self._chk(self._L.rz_comm_init(self._h, int(nranks), int(rank), unique_id, int(v_total)))
         self.v_total = int(v_total)
 
     def allgather(self, with_normals=False):
-        _chk(self._L.rz_allgather(self._h, 1 if with_normals else 0))
+        self._chk(self._L.rz_allgather(self._h, 1 if with_normals else 0))
 
     def gather_fence(self):
         """Make this (root) context's stream wait for the frames the other contributors have enqueued."""
-        _chk(self._L.rz_gather_fence(self._h))
+        self._chk(self._L.rz_gather_fence(self._h))
 
     def read_gathered(self, v0=0, n=None):
         n = self.v_total - v0 if n is None else n
         pos = np.empty((n, 3), dtype=np.float32)
         nrm = np.empty((n, 3), dtype=np.float32)
-        _chk(self._L.rz_read_gathered(self._h, int(v0), int(n), _fptr(pos), _fptr(nrm)))
+        self._chk(self._L.rz_read_gathered(self._h, int(v0), int(n), _fptr(pos), _fptr(nrm)))
         return pos, nrm

@@ -172,6 +172,7 @@ size_t rz_skin_instances_lds_bytes(int G, uint32_t bones, bool dma, bool subsets
 hipError_t rz_launch_run_subsets(const uint32_t *j01, const uint32_t *j23, uint32_t v_lim, uint32_t per, uint32_t runs, uint32_t B,
                                  uint16_t *list, uint32_t *count, uint32_t *rj01, uint32_t *rj23, hipStream_t st);
 uint32_t rz_quads_per_tile(int S);
+bool rz_has_all_variants();      // false in the product: only the variants a plan can select by default are compiled in
 hipError_t rz_launch_deinterleave(const float *src, int stride, int offset, uint32_t n, float *px, float *py,
                                   float *pz, hipStream_t st);
 hipError_t rz_launch_pack_skinning(const uint16_t *joints4, const uint8_t *weights4, uint32_t n, uint32_t *j01,

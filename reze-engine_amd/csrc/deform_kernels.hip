@@ -1249,6 +1249,7 @@ __global__ void __launch_bounds__(BLOCK, (SUB && BLOCK == 512) ? RZ_SUB_WAVES : 
     }
 }
 
+#ifdef RZ_ALL_VARIANTS
 // ------------------------------------------------------------------------------------------------
 // instanced skin, register-resident form: a workgroup owns a run of KV*256 vertices and a RANGE of poses.
 // Each lane loads and decodes its KV vertices ONCE into registers (the static mesh is read once per
@@ -1354,6 +1355,8 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_reg_kernel(const RzD
         }
     }
 }
+
+#endif  // RZ_ALL_VARIANTS
 
 // ------------------------------------------------------------------------------------------------
 // upload-time re-layout kernels (one-off, not on the per-frame path)
@@ -1472,12 +1475,25 @@ static hipError_t launch_one(const RzDeformParams &p, const RzMorphList &ml, dim
     return hipGetLastError();
 }
 
+// Which variants the library carries. The PRODUCT instantiates what a plan can select by default or through rz_autotune:
+// rest geometry by 4-byte loads (GEO = false), nontemporal morph loads (NT = true, dense mode), 8 morphs in flight (U = 8) —
+// 16 + 8 + 8 kernels instead of 160. The variants measured slower everywhere (GEO = true, NT = false, U = 4: profiles/r1_*sweep*)
+// live in the tools-only build (-DRZ_ALL_VARIANTS, `make variants`), where the parity tests still cover every one of them;
+// in the product rz_set_tuning refuses the keys that would select them.
+#ifdef RZ_ALL_VARIANTS
+constexpr bool kAllVariants = true;
+#else
+constexpr bool kAllVariants = false;
+#endif
+
 template <int S, int U, int MODE, bool NT, bool NTS>
 static hipError_t launch_gf(const RzDeformParams &p, const RzMorphList &ml, const RzVariant &v, dim3 grid, size_t lds,
                             hipStream_t st)
 {
-    if (v.geo) return v.fast ? launch_one<S, U, MODE, NT, NTS, true, true>(p, ml, grid, lds, st)
-                             : launch_one<S, U, MODE, NT, NTS, true, false>(p, ml, grid, lds, st);
+    if constexpr (kAllVariants) {
+        if (v.geo) return v.fast ? launch_one<S, U, MODE, NT, NTS, true, true>(p, ml, grid, lds, st)
+                                 : launch_one<S, U, MODE, NT, NTS, true, false>(p, ml, grid, lds, st);
+    } else if (v.geo) return hipErrorInvalidValue;
     return v.fast ? launch_one<S, U, MODE, NT, NTS, false, true>(p, ml, grid, lds, st)
                   : launch_one<S, U, MODE, NT, NTS, false, false>(p, ml, grid, lds, st);
 }
@@ -1487,11 +1503,17 @@ static hipError_t launch_nt(const RzDeformParams &p, const RzMorphList &ml, cons
                             hipStream_t st)
 {
     if constexpr (MODE == 1) {           // the nontemporal load hint only exists on the dense morph stream
-        if (v.nt) return v.nts ? launch_gf<S, U, MODE, true, true>(p, ml, v, grid, lds, st)
-                               : launch_gf<S, U, MODE, true, false>(p, ml, v, grid, lds, st);
+        if (v.nt || !kAllVariants) {
+            if (!v.nt) return hipErrorInvalidValue;
+            return v.nts ? launch_gf<S, U, MODE, true, true>(p, ml, v, grid, lds, st)
+                         : launch_gf<S, U, MODE, true, false>(p, ml, v, grid, lds, st);
+        }
     }
-    return v.nts ? launch_gf<S, U, MODE, false, true>(p, ml, v, grid, lds, st)
-                 : launch_gf<S, U, MODE, false, false>(p, ml, v, grid, lds, st);
+    if constexpr (MODE != 1 || kAllVariants) {
+        return v.nts ? launch_gf<S, U, MODE, false, true>(p, ml, v, grid, lds, st)
+                     : launch_gf<S, U, MODE, false, false>(p, ml, v, grid, lds, st);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int S>
@@ -1499,8 +1521,11 @@ static hipError_t launch_dense(const RzDeformParams &p, const RzMorphList &ml, c
                                hipStream_t st)
 {
     if (v.U >= 8) return launch_nt<S, 8, 1>(p, ml, v, grid, lds, st);
-    return launch_nt<S, 4, 1>(p, ml, v, grid, lds, st);
+    if constexpr (kAllVariants) return launch_nt<S, 4, 1>(p, ml, v, grid, lds, st);
+    return hipErrorInvalidValue;
 }
+
+bool rz_has_all_variants() { return kAllVariants; }
 
 hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, const RzVariant &v, uint32_t grid_x,
                             uint32_t instances, hipStream_t st)
@@ -1562,6 +1587,7 @@ hipError_t rz_launch_run_subsets(const uint32_t *j01, const uint32_t *j23, uint3
 hipError_t rz_launch_skin_instances_reg(const RzDeformParams &p, int n_inst, int poses_per_wg, uint32_t grid_x, bool nts,
                                         hipStream_t st)
 {
+#ifdef RZ_ALL_VARIANTS
     constexpr int KV = 8;
     const size_t lds = (size_t)2 * p.B * 48;
     auto k = nts ? rz_skin_instances_reg_kernel<KV, true> : rz_skin_instances_reg_kernel<KV, false>;
@@ -1572,6 +1598,10 @@ hipError_t rz_launch_skin_instances_reg(const RzDeformParams &p, int n_inst, int
     dim3 grid(grid_x, (n_inst + poses_per_wg - 1) / poses_per_wg);
     hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p, n_inst, poses_per_wg);
     return hipGetLastError();
+#else
+    (void)p; (void)n_inst; (void)poses_per_wg; (void)grid_x; (void)nts; (void)st;
+    return hipErrorInvalidValue;       // the register-resident crowd kernel (measured slower, inst_loop = 9) is a tools-only variant
+#endif
 }
 
 hipError_t rz_launch_deinterleave(const float *src, int stride, int offset, uint32_t n, float *px, float *py,

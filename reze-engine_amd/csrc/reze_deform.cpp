@@ -2144,6 +2144,10 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
 {
     if (!c || !key) return fail(RZ_ERR_INVALID, "null argument");
     if (!strcmp(key, "morph_split") || !strcmp(key, "grid_cap") || !strcmp(key, "inst_loop")) c->tuned_by_search = false;   // the caller owns the shape now
+    // variants that were measured slower everywhere are compiled into the tools-only build (make variants), not the product
+    if (!rz_has_all_variants() && ((!strcmp(key, "unroll") && value == 4) || (!strcmp(key, "geo_lds") && value != 0) ||
+                                   (!strcmp(key, "nontemporal") && value == 0) || (!strcmp(key, "inst_loop") && value == 9)))
+        return fail(RZ_ERR_UNSUPPORTED, "%s = %d selects a kernel variant the product library does not carry (tools-only build: make -C reze-engine_amd/csrc variants)", key, value);
     if (!strcmp(key, "morph_split")) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
             return fail(RZ_ERR_INVALID, "morph_split must be 0 (auto),1,2,4,8");
@@ -2242,6 +2246,7 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "effective_poses_per_wg")) *value = make_plan(c).poses_per_wg;
     else if (!strcmp(key, "effective_grid")) *value = (int)make_plan(c).grid_x;
     else if (!strcmp(key, "inst_subsets")) *value = c->t_subsets;
+    else if (!strcmp(key, "all_variants")) *value = rz_has_all_variants() ? 1 : 0;
     else if (!strcmp(key, "effective_subsets")) *value = make_plan(c).subsets ? 1 : 0;
     else if (!strcmp(key, "effective_subset_bones")) *value = (int)make_plan(c).sub_bones;
     else if (!strcmp(key, "effective_inst_lds")) *value = (int)make_plan(c).inst_lds;

@@ -23,3 +23,13 @@ def oracle():
 def rz():
     import reze_engine_amd
     return reze_engine_amd
+
+
+@pytest.fixture(scope="session")
+def rzv(rz):
+    """The tools-only build that carries EVERY kernel variant (make -C reze-engine_amd/csrc variants): rest geometry through
+    LDS, plain morph loads, 4 morphs in flight, the register-resident crowd kernel. The product ships only the variants a
+    plan can select; the parity tests reach the others through this library. Same C ABI, bound next to the product's."""
+    import types
+    lib = rz.capi.load(rz.capi.VARIANTS_LIB_PATH)
+    return types.SimpleNamespace(DeformContext=lambda device=0: rz.DeformContext(device, lib=lib), lib=lib, capi=rz.capi)

@@ -16,6 +16,20 @@ def ctx(rz):
     c.close()
 
 
+@pytest.fixture(scope="module")
+def ctxv(rzv):
+    """a context of the all-variants build: the kernel variants the product does not ship (conftest.py: rzv)"""
+    c = rzv.DeformContext(0)
+    assert c.get_tuning("all_variants") == 1
+    yield c
+    c.close()
+
+
+def _variant_only(**t):
+    """does this tuning select a variant only the tools build carries?"""
+    return t.get("geo_lds", 0) == 1 or t.get("nontemporal", 1) == 0 or t.get("unroll", 0) == 4 or t.get("inst_loop", -1) == 9
+
+
 def run_gpu(ctx, mesh, world=None, deltas=None, mw=None, sparse=None, **tuning):
     ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
     ctx.upload_skeleton(mesh["inv_bind"])
@@ -24,18 +38,20 @@ def run_gpu(ctx, mesh, world=None, deltas=None, mw=None, sparse=None, **tuning):
     elif sparse is not None:
         ctx.upload_morphs_sparse(*sparse)
     ctx.set_instances(1)
-    ctx.set_tuning(morph_split=0, unroll=0, nontemporal=1, nt_store=1, geo_lds=1, grid_cap=0, fast=-1, out_cap=-1)
+    ctx.set_tuning(morph_split=0, unroll=0, nontemporal=1, nt_store=1, geo_lds=0, grid_cap=0, fast=-1, out_cap=-1)
     ctx.set_tuning(**tuning)
     ctx.set_pose(mesh["world"] if world is None else world, mw)
     ctx.deform()
     return ctx.read()
 
 
-def test_c2_lbs_30k_200_bones(ctx, oracle):
+def test_c2_lbs_30k_200_bones(ctx, ctxv, oracle):
     """config 2: 30k verts / 200 bones / 0 morphs, fp32, vs the vs() restatement."""
     mesh = synth.make_mesh(30000, 200)
     pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"])
+    product = ctx
     for geo in (1, 0):
+        ctx = ctxv if geo else product          # rest geometry through LDS is a tools-only variant
         for fast in (1, 0):
             pg, ng = run_gpu(ctx, mesh, geo_lds=geo, fast=fast)
             assert_parity(pg, ng, pr, nr, "C2 geo_lds=%d fast=%d" % (geo, fast))
@@ -73,13 +89,15 @@ def test_identity_pose_known_answer(ctx):
 @pytest.mark.parametrize("fast", [1, 0])
 @pytest.mark.parametrize("split", [1, 2, 4, 8])
 @pytest.mark.parametrize("unroll", [4, 8])
-def test_c3_fused_morph_skin_all_kernel_variants(ctx, oracle, split, unroll, fast):
+def test_c3_fused_morph_skin_all_kernel_variants(ctx, ctxv, oracle, split, unroll, fast):
     """config 3: 30k verts / 200 bones / 64 active morph targets, every morph-split x unroll variant,
     both as the one-launch frame (fast=1: palette fused, kernarg morph list) and with the prep kernel."""
     mesh = synth.make_mesh(30000, 200)
     deltas, mw = synth.make_morphs_dense(30000, 64)
     pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"],
                            mesh["inv_bind"], deltas, mw, threads=8)
+    if unroll == 4:
+        ctx = ctxv                              # 4 morphs in flight: tools-only variant
     pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, morph_split=split, unroll=unroll, fast=fast)
     assert_parity(pg, ng, pr, nr, "C3 S=%d U=%d fast=%d" % (split, unroll, fast))
     assert ctx.get_tuning("effective_split") == split
@@ -87,11 +105,13 @@ def test_c3_fused_morph_skin_all_kernel_variants(ctx, oracle, split, unroll, fas
 
 
 @pytest.mark.parametrize("nt,nts,geo", [(0, 0, 1), (0, 1, 0), (1, 0, 0), (0, 0, 0)])
-def test_c3_load_path_variants(ctx, oracle, nt, nts, geo):
+def test_c3_load_path_variants(ctx, ctxv, oracle, nt, nts, geo):
     mesh = synth.make_mesh(30000, 200)
     deltas, mw = synth.make_morphs_dense(30000, 64)
     pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"],
                            mesh["inv_bind"], deltas, mw, threads=8)
+    if _variant_only(nontemporal=nt, geo_lds=geo):
+        ctx = ctxv
     for fast in (1, 0):
         pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, nontemporal=nt, nt_store=nts, geo_lds=geo, fast=fast)
         assert_parity(pg, ng, pr, nr, "C3 nt=%d nts=%d geo=%d fast=%d" % (nt, nts, geo, fast))
@@ -268,11 +288,13 @@ def test_c4_instances_each_match_their_own_pose(ctx, oracle):
 
 @pytest.mark.parametrize("fast", [-1, 0, 1])
 @pytest.mark.parametrize("inst_loop", [-1, 0, 3, 9])
-def test_c4_instance_loop_kernel_and_ragged_groups(ctx, oracle, inst_loop, fast):
+def test_c4_instance_loop_kernel_and_ragged_groups(ctx, ctxv, oracle, inst_loop, fast):
     """19 poses do not divide into groups of 8: the pose-loop kernel (inst_loop != 0) and the generic kernel
     (inst_loop = 0) must both match every pose; 471 bones forces a smaller group (LDS). fast = 1 makes the pose-group
     kernel form its palettes itself (world matrices staged in LDS, converted in place) instead of reading
     rz_prep_kernel's output."""
+    if inst_loop == 9:
+        ctx = ctxv                              # the register-resident crowd kernel: tools-only variant
     for V, B, I in ((7001, 64, 19), (3000, 471, 5)):
         mesh = synth.make_mesh(V, B, seed=V)
         worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=300 + i) for i in range(I)])
@@ -290,7 +312,7 @@ def test_c4_instance_loop_kernel_and_ragged_groups(ctx, oracle, inst_loop, fast)
         elif inst_loop == 0:
             assert pp == 0 and g == 0                       # generic kernel, one pose per workgroup row
         else:
-            assert pp == 0 and 2 <= g <= 8                  # LDS pose-group form
+            assert pp == 0 and 2 <= g <= 8                  # LDS pose-group form (whole palette or bone subsets)
         for i in range(I):
             pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[i], mesh["inv_bind"])
             pg, ng = ctx.read(instance=i)

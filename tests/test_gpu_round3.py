@@ -159,3 +159,32 @@ def test_bone_subset_crowd_behind_the_device_hierarchy_solve(rz, oracle):
     pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], world, mesh["inv_bind"], threads=4)
     assert_parity(sub[I - 1][0], sub[I - 1][1], pr, nr, "device-solved subset crowd")
     c.close()
+
+
+@pytest.mark.parametrize("pose", ["pose0", "tween150", "tween500"])
+def test_gpu_sits_inside_the_envelope_of_legal_wgsl_evaluations(rz, oracle, pose):
+    """vs() (engine.ts:253-272) under every evaluation WGSL allows a driver (FMA contraction, re-associated matrix-vector sums,
+    normalize through inverseSqrt — tests/wgsl_latitude.py; their spread around the oracle is bounded in
+    tests/test_oracle.py::test_envelope_of_the_evaluations_wgsl_allows): the MI355X kernel's result on the wide sample of the
+    real model is within 1e-5 of EACH of them — ten times tighter than the 1e-4 parity bar, and the same order of magnitude
+    as the distance between two legal evaluations (3e-7)."""
+    import os
+    import wgsl_latitude as wl
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_c1_pose0.npz"))
+    v = g["wide_vertices"]
+    pos, nrm = np.ascontiguousarray(v[:, 0:3]), np.ascontiguousarray(v[:, 3:6])
+    S = oracle.palette(g["world_" + pose], g["inv_bind"])
+    c = rz.DeformContext(0)
+    c.upload_mesh_interleaved(v, g["wide_joints"], g["wide_weights"])
+    c.upload_skeleton(g["inv_bind"])
+    c.set_pose(g["world_" + pose])
+    c.deform()
+    pg, ng = c.read()
+    c.close()
+    worst = {}
+    for name, kw in wl.MODELS.items():
+        p, n = wl.vs(pos, nrm, g["wide_joints"], g["wide_weights"], S, **kw)
+        ep, en = wl.distances(pg, ng, p, n)
+        assert ep <= 1e-5 and en <= 1e-5, "GPU vs '%s': %.3e / %.3e" % (name, ep, en)
+        worst[name] = (ep, en)
+    print("GPU distance to each legal evaluation (%s): %s" % (pose, {k: "%.2e / %.2e" % v for k, v in worst.items()}))

@@ -318,3 +318,39 @@ def test_bone_morph_restatement_pinned_to_reference_quaternion_and_fk_code(oracl
     v = g["vertices"]
     pr, nr = oracle.skin(v[:, 0:3], v[:, 3:6], g["joints"], g["weights"], oracle.palette(g["world"][k], g["inv_bind"]))
     assert_parity(pr, nr, g["skinned"][k][:, 0:3], g["skinned"][k][:, 3:6], "oracle vs reference-skinned weapon, weight %g" % w[0])
+
+
+@pytest.mark.parametrize("pose", ["pose0", "tween150", "tween500"])
+def test_envelope_of_the_evaluations_wgsl_allows(oracle, pose):
+    """The reference's vs() (engine.ts:253-272) is WGSL, and WGSL leaves a driver latitude the oracle does not take: it may
+    contract a * b + c into an FMA, re-associate the four-term sums of `skinMatrix * position`, and implement normalize()
+    through inverseSqrt. Nothing here can execute the shader, but the spread of the LEGAL results can be bounded:
+    tests/wgsl_latitude.py evaluates vs() under each model (float64 emulation, rounded to binary32 where the model rounds)
+    on the wide sample of the real model (4 121 vertices, 234 bones, three reference-produced poses). With no option set it
+    reproduces the oracle BIT FOR BIT (so the emulation is the oracle's arithmetic); every other legal order — and this
+    build's own blended-matrix order — stays within 1e-5 of it (measured: 3.1e-7 positions, 1.9e-7 normals), i.e. the
+    1e-4 tolerance of the GPU tests is two orders of magnitude wider than anything a conforming driver could produce."""
+    import wgsl_latitude as wl
+    g = _golden()
+    v = g["wide_vertices"]
+    pos, nrm = np.ascontiguousarray(v[:, 0:3]), np.ascontiguousarray(v[:, 3:6])
+    S = oracle.palette(g["world_" + pose], g["inv_bind"])
+    po, no = oracle.skin(pos, nrm, g["wide_joints"], g["wide_weights"], S)
+    p0, n0 = wl.vs(pos, nrm, g["wide_joints"], g["wide_weights"], S)
+    assert np.array_equal(p0.astype(np.float32), po) and np.array_equal(n0.astype(np.float32), no), "the emulation IS the oracle's arithmetic"
+    worst = (0.0, 0.0)
+    results = {}
+    for name, kw in wl.MODELS.items():
+        p, n = wl.vs(pos, nrm, g["wide_joints"], g["wide_weights"], S, **kw)
+        ep, en = wl.distances(p, n, po.astype(np.float64), no.astype(np.float64))
+        assert ep <= 1e-5 and en <= 1e-5, (name, ep, en)
+        worst = (max(worst[0], ep), max(worst[1], en))
+        results[name] = (p, n)
+    assert worst[0] > 0 and worst[1] > 0          # the models really differ from the oracle (the test is not vacuous)
+    assert worst[0] <= 1e-6 and worst[1] <= 1e-6  # what was measured, with margin: 3.1e-7 / 1.9e-7
+    # ... and from each other: any two legal evaluations are within 1e-5 of one another
+    names = list(results)
+    for i in range(len(names)):
+        for j in range(i + 1, len(names)):
+            ep, en = wl.distances(results[names[i]][0], results[names[i]][1], results[names[j]][0], results[names[j]][1])
+            assert ep <= 1e-5 and en <= 1e-5, (names[i], names[j], ep, en)
