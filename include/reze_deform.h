@@ -234,7 +234,10 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * morph-stream loads), "nt_store" (0/1, output stores), "fast" (-1 auto, 0 always run the
  * separate prep kernel, 1 one-launch frame when possible), "out_cap" (-1 auto, 0 off, else vertices a wave
  * parks in LDS before writing them out in one burst), "inst_loop" (-1 auto, 0 off, 2..8 / 10..64 poses
- * per workgroup in instanced morph-free frames, 9 = the register-resident form), "inst_subsets" (-1 auto / 1: a crowd workgroup stages
+ * per workgroup in instanced morph-free frames, 9 = the register-resident form), "pose_prefetch" (-1 auto / 1: the first frame of a zero-copy world pose carries a helper workgroup that stages the
+ * NEXT pose into device memory when the host has already written it — a per-frame loop whose host runs ahead of the GPU then never
+ * pays the PCIe round trip; 0: off; rz_get_tuning("pose_staged") tells whether the current pose was staged that way),
+ * "inst_subsets" (-1 auto / 1: a crowd workgroup stages
  * only the bones its vertex run names when that list is shorter than the skeleton — same bits, a fraction of the LDS and of the
  * per-workgroup front; 0: always the whole palette), "inst_block" (0 auto, 256 / 512 / 1024 threads per
  * workgroup of the instanced kernel; for crowds "fast" -1 / 1 = palettes formed inside the skin kernel, one launch per frame, 0 =

@@ -96,6 +96,24 @@ struct RzDeformParams {
     // this pose. null = the pose is already resident and `world` / `morph_w` are device pointers.
     float *world_copy;          // [B][16] device destination, or null
     float *morph_w_copy;        // [M]     device destination (MODE 2), or null
+    // Pose PREFETCH of zero-copy frames (FAST, one character). A frame whose pose still sits in its pinned slot
+    // pays one PCIe round trip (2-3 us) that a 16 us shard frame cannot hide. So the frame of pose u also carries ONE helper
+    // workgroup (blockIdx.x == 0; the workers shift by one) that looks at the ring slot the NEXT upload will use: if the host
+    // has already written pose u + 1 there — it runs several frames ahead of the GPU in a per-frame loop — the helper copies
+    // it into the device pose block that upload will name and tags it with the upload's sequence number. The frame of pose
+    // u + 1 checks the tag (one scalar load): staged -> it reads HBM like a resident pose; not staged (the host was late, the
+    // slot was not written yet, another pose kind came) -> it reads the pinned slot exactly as before. No event, no wait,
+    // nothing on the host; a miss costs nothing but the helper's slot.
+    const float *pf_src;            // pinned slot of the next upload (device-mapped), or null = no helper in this launch
+    const uint64_t *pf_src_seq;     // its header: the sequence number of the pose it holds, written by the host AFTER the pose
+    float *pf_dst;                  // device pose block the next upload will name ([world | weights], the slot's layout)
+    uint64_t *pf_tag;               // device: sequence number of the pose staged in pf_dst
+    uint64_t pf_expect;             // header value of the completely written next pose
+    uint32_t pf_bytes;              // bytes to stage (multiple of 16)
+    const uint64_t *st_tag;         // THIS frame's pose: staged in the device block when *st_tag == st_expect, else in the pinned slot
+    uint64_t st_expect;
+    const float *st_world;          // [B][16] staged copy
+    const float *st_morph_w;        // [M]     staged copy (MODE 2)
     // FUSED single-character frame (fk_on): every workgroup of the (!FAST) kernel first solves the bone hierarchy itself —
     // motion sampling included when the pose is sampled — straight into its LDS palette, and compacts the morph weights
     // into its LDS list: no rz_fk_kernel, no rz_prep_kernel, ONE launch per device-animated frame. Workgroup 0 also

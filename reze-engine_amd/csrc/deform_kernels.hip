@@ -598,6 +598,46 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     const int inst = blockIdx.y;
     const int lane = tid & 63, wave = tid >> 6;
 
+    // Zero-copy pose prefetch (see RzDeformParams): workgroup 0 of such a launch is the helper, the workers shift by one.
+    const bool pf_on = FAST && p.pf_src != nullptr;
+    if (pf_on && blockIdx.x == 0) {
+        // seqlock read of the next upload's pinned slot: header == the expected sequence number -> the host has finished
+        // writing that pose (it writes the header last); copy; header again; only then the tag. The ring protocol already
+        // keeps the host from re-using the slot while this kernel runs, the second look is belt and braces.
+        const uint64_t h1 = __builtin_nontemporal_load(p.pf_src_seq);
+        if (h1 != p.pf_expect) return;                                   // workgroup-uniform
+        const float4 *src = reinterpret_cast<const float4 *>(p.pf_src);
+        float4 *dst = reinterpret_cast<float4 *>(p.pf_dst);
+        const uint32_t n4 = p.pf_bytes / 16;
+        // eight independent host loads in flight per thread (a 16.6 KB pose is one pass); indices past the end are clamped,
+        // so the tail threads re-copy the last cell instead of branching
+        const uint32_t last = n4 - 1;
+        for (uint32_t i = tid; i < n4; i += kBlock * 8) {
+            const uint32_t i0 = min(i, last), i1 = min(i + kBlock, last), i2 = min(i + 2 * kBlock, last), i3 = min(i + 3 * kBlock, last);
+            const uint32_t i4 = min(i + 4 * kBlock, last), i5 = min(i + 5 * kBlock, last), i6 = min(i + 6 * kBlock, last), i7 = min(i + 7 * kBlock, last);
+            const float4 a0 = src[i0], a1 = src[i1], a2 = src[i2], a3 = src[i3], a4 = src[i4], a5 = src[i5], a6 = src[i6], a7 = src[i7];
+            dst[i0] = a0; dst[i1] = a1; dst[i2] = a2; dst[i3] = a3; dst[i4] = a4; dst[i5] = a5; dst[i6] = a6; dst[i7] = a7;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const uint64_t h2 = __builtin_nontemporal_load(p.pf_src_seq);
+            if (h2 == p.pf_expect) *p.pf_tag = p.pf_expect;               // consumed by the NEXT kernel on this stream
+        }
+        return;
+    }
+    const uint32_t wid = blockIdx.x - (pf_on ? 1u : 0u);                 // worker index of this workgroup
+    // THIS frame's pose: staged in device memory by the previous frame's helper, or still in its pinned slot. The answer is one
+    // tag away, and waiting for it before asking for the matrices would put two memory latencies in a row in front of the
+    // palette. So a frame that MAY find its pose staged (spec) asks for the tag and, at once, for the matrices of the staged
+    // copy (the device pose block: valid memory whatever it holds); the tag is looked at when the palette is formed, and
+    // only a miss then fetches the matrices from the pinned slot. Sparse weights are needed at once: that mode waits for the tag.
+    const bool spec = FAST && p.st_tag != nullptr;
+    const uint64_t st_tagv = spec ? *p.st_tag : 0ull;                   // requested here, compared later (workgroup-uniform)
+    const bool staged_now = MODE == 2 && spec && st_tagv == p.st_expect;
+    const float *world_in = spec ? p.st_world : p.world;                // (re-pointed at the pinned slot on a miss)
+    const float *morph_w_in = (staged_now && p.st_morph_w) ? p.st_morph_w : p.morph_w;
+    const bool from_host = p.world_copy != nullptr && !spec;            // the matrices are asked for over the host link up front
+
     // FAST: this thread's bone (tid < B covers the first 256 bones) — its world and inverse-bind matrices are
     // requested FIRST, as plain loads into registers, so they are the oldest entries of the vmcnt queue: the palette
     // math below only has to wait for them (a counted wait) while the morph loads issued after them stay in flight.
@@ -606,10 +646,10 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     // Zero-copy frame (world_copy != null: `world` is pinned HOST memory, a few microseconds away) with a dense morph stream:
     // vmcnt retires in order, so host loads at the head of the queue would hold back the first morph FMAs; there the world
     // matrices are requested BEHIND the first morph group instead, and the palette is formed after the last group.
-    const bool late_world = FAST && MODE == 1 && p.world_copy != nullptr;
+    const bool late_world = FAST && MODE == 1 && from_host;
     bool world_pending = early && late_world;
     auto load_world = [&]() {
-        const float4 *gw = reinterpret_cast<const float4 *>(p.world) + tid * 4;
+        const float4 *gw = reinterpret_cast<const float4 *>(world_in) + tid * 4;
         ew0 = gw[0]; ew1 = gw[1]; ew2 = gw[2]; ew3 = gw[3];
         world_pending = false;
     };
@@ -629,7 +669,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         if ((MODE != 0 || p.fk.bm_off) && !sampled) {
             for (int i = tid; i < p.M; i += kBlock) lds_mw[i] = p.morph_w[i];       // uploaded weights (pinned slot or device block)
         }
-        fk_solve<true>(p.fk, 0, pal, fscr, lds_mw, blockIdx.x == 0);             // ends with a barrier: pal and lds_mw are complete
+        fk_solve<true>(p.fk, 0, pal, fscr, lds_mw, wid == 0);             // ends with a barrier: pal and lds_mw are complete
         if (MODE == 1) fused_count = compact_active(lds_mw, p.M, p.Mpad, s_idx, s_w, fz_cnt);
         if (MODE == 2)
             for (int i = tid; i < p.M; i += kBlock) s_w[i] = lds_mw[i];
@@ -649,9 +689,9 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     }
 
     if (FAST && MODE == 2) {
-        const bool keep_w = blockIdx.x == 0 && p.morph_w_copy != nullptr;     // zero-copy first frame, as for `world`
+        const bool keep_w = wid == 0 && p.morph_w_copy != nullptr && !(staged_now && p.st_morph_w);     // zero-copy first frame, as for `world`
         for (int i = tid; i < p.M; i += kBlock) {
-            const float w = p.morph_w[i];
+            const float w = morph_w_in[i];
             s_w[i] = w;
             if (keep_w) p.morph_w_copy[i] = w;
         }
@@ -684,22 +724,28 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         const float4 q0 = make_float4(r0[0], r0[1], r0[2], r0[3]), q1 = make_float4(r1[0], r1[1], r1[2], r1[3]),
                      q2 = make_float4(r2[0], r2[1], r2[2], r2[3]);
         pal[b * 3 + 0] = q0; pal[b * 3 + 1] = q1; pal[b * 3 + 2] = q2;
-        if (blockIdx.x == 0 && p.palette) {      // keep the skinMatrixBuffer observable (rz_read_palette)
+        if (wid == 0 && p.palette) {      // keep the skinMatrixBuffer observable (rz_read_palette)
             float4 *gp = p.palette + (size_t)b * 3;
             gp[0] = q0; gp[1] = q1; gp[2] = q2;
         }
     };
     // executed once per wave, wherever the first step has its loads in flight; no barrier here
     // zero-copy first frame: `world` is pinned host memory; workgroup 0 leaves the matrices in device memory for the replays
-    const bool keep_world = FAST && blockIdx.x == 0 && p.world_copy != nullptr;
+    bool keep_world = FAST && wid == 0 && from_host;     // (a staged pose already sits where world_copy points)
     auto form_palette = [&]() {
         if (world_pending) load_world();          // no morph group ran in front of us
+        if (spec && st_tagv != p.st_expect) {
+            // miss: the previous frame's helper did not stage this pose (the host was not ahead): it is in its pinned slot
+            world_in = p.world;
+            keep_world = wid == 0 && p.world_copy != nullptr;
+            if (early) load_world();
+        }
         if (early) {
             palette_rows(tid, ew0, ew1, ew2, ew3, ei0, ei1, ei2, ei3);
             if (keep_world) { float4 *d = reinterpret_cast<float4 *>(p.world_copy) + tid * 4; d[0] = ew0; d[1] = ew1; d[2] = ew2; d[3] = ew3; }
         }
         for (int b = tid + kBlock; b < p.B; b += kBlock) {      // skeletons beyond 256 bones: plain loads, late
-            const float4 *gw = reinterpret_cast<const float4 *>(p.world) + b * 4;
+            const float4 *gw = reinterpret_cast<const float4 *>(world_in) + b * 4;
             const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + b * 4;
             const float4 w0 = gw[0], w1 = gw[1], w2 = gw[2], w3 = gw[3];
             palette_rows(b, w0, w1, w2, w3, gi[0], gi[1], gi[2], gi[3]);
@@ -711,7 +757,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
 
     // persistent, evenly balanced partition: every wave of the grid owns one contiguous run of quads
     // (a multiple of 8 quads = 128 B per plane) and walks it QPW quads at a time; the last step is masked.
-    const uint32_t wave_global = blockIdx.x * (kBlock / 64) + wave;
+    const uint32_t wave_global = wid * (kBlock / 64) + wave;
     const size_t q_begin = (size_t)wave_global * p.quads_per_wave;
     const size_t q_end = min((size_t)p.n_quads, q_begin + p.quads_per_wave);
 
@@ -806,7 +852,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
                 // first group of the first step: the palette math overlaps the 3*U loads just issued. On a zero-copy frame the
                 // matrices come over the host link (a few microseconds): there the palette waits until the LAST group has
                 // issued its loads, so the whole morph stream of the step is in flight under that latency.
-                if (FAST && FIRST && need_palette && (!p.world_copy || a0 + 2 * U * S > count)) form_palette();
+                if (FAST && FIRST && need_palette && (!from_host || a0 + 2 * U * S > count)) form_palette();
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     ax.x = fmaf(w[u], dx[u].x, ax.x); ax.y = fmaf(w[u], dx[u].y, ax.y);
@@ -956,7 +1002,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
             const uint32_t key = bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);
             if (lane < 3) atomicMin(slot + lane, key); else atomicMax(slot + lane, key);
         }
-        if (blockIdx.x == 0 && tid < 6) {
+        if (wid == 0 && tid < 6) {
             uint32_t *next = p.aabb + ((size_t)inst * 2 + ((p.aabb_slot + 1) & 1)) * 6;
             next[tid] = tid < 3 ? 0xffffffffu : 0u;
         }

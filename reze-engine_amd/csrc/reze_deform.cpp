@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -238,6 +239,14 @@ struct rz_ctx {
     uint64_t zc_uploads = 0;
     hipEvent_t zc_ev[2] = {nullptr, nullptr};
     uint64_t zc_ev_seq[2] = {~0ull, ~0ull};
+    // Pose prefetch (deform_kernels.h: pf_*): every slot carries a header behind its payload — the sequence number of the pose
+    // it holds, written LAST — and the device keeps one tag per pose block: the sequence number a frame's helper workgroup
+    // staged there. Sequence numbers are (ring epoch << 32 | upload index + 1): a re-allocated ring never matches old tags.
+    size_t zc_hdr_off = 0;              // byte offset of the header inside a slot
+    uint32_t zc_epoch = 0;
+    uint64_t zc_seq_cur = 0;            // sequence number of the current pose (0 = not prefetchable)
+    uint64_t *zc_tag = nullptr;         // device: [2], one per pose block
+    int t_prefetch = -1;                // "pose_prefetch": -1 / 1 on, 0 off
     int zc_cur = -1;                    // slot of the current pose, -1 = the current pose came down as a copy
     bool zc_local = false;              // layout of that slot: [weights | rotations | translations] or [world | weights]
     size_t zc_total = 0, zc_mw_off = 0, zc_lq_off = 0;     // bytes in the slot, and where the weights / rotations sit in it
@@ -421,6 +430,10 @@ int ensure_pose_buffers(rz_ctx *c)
         HIP_TRY(hipMemsetAsync(c->act_count_ring[k], 0, I * sizeof(int), c->stream));
     }
     set_ring(c, 0);
+    if (!c->zc_tag) HIP_TRY(hipMalloc(&c->zc_tag, 2 * sizeof(uint64_t)));
+    HIP_TRY(hipMemsetAsync(c->zc_tag, 0, 2 * sizeof(uint64_t), c->stream));
+    c->zc_epoch++;                      // poses staged under the old layout must never match again
+    c->zc_seq_cur = 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->pose_alloc_I = I; c->pose_alloc_B = B; c->pose_alloc_M = Mq;
     c->pose_set = false;
@@ -468,6 +481,7 @@ void free_morphs(rz_ctx *c)
     dfree(c->dense); dfree(c->sp_ptr); dfree(c->sp_entries);
     free_bone_morphs(c);                  // their entries name morphs of the old set
     c->morph_mode = 0; c->M = 0; c->Mpad = 12; c->sp_count = 0;
+    c->zc_epoch++; c->zc_seq_cur = 0;     // ... and so does a pose staged ahead of its frame
     c->pose_set = false;                  // morph weights belong to the old target set
 }
 
@@ -484,7 +498,7 @@ int auto_split(const rz_ctx *c)
     return S;
 }
 
-struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; int inst_block; bool fuse_fk; bool subsets; uint32_t sub_bones; uint64_t inst_lds; };
+struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; int inst_block; bool fuse_fk; bool subsets; uint32_t sub_bones; uint64_t inst_lds; bool pf; };
 
 // Where the kernels read the current pose from: the device pose block, or (zero-copy, not yet resident) the pinned slot.
 const float *src_world(const rz_ctx *c)
@@ -525,6 +539,19 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     if (pl.v.fast && c->zc_cur >= 0) {            // the one-launch kernel's workgroup 0 makes the pose resident
         if (!c->world_resident && !c->zc_local) p.world_copy = c->world;
         if (!c->mw_resident && pl.v.mode == 2) p.morph_w_copy = c->morph_w;
+        // Pose prefetch, first frame of a zero-copy world pose only. This frame: was the pose staged by the previous frame's
+        // helper? Next frame: a helper workgroup looks at the slot the next upload will use (deform_kernels.h: pf_*).
+        if (pl.pf && p.world_copy && c->zc_tag && c->zc_seq_cur) {
+            p.st_tag = c->zc_tag + c->pose_slot; p.st_expect = c->zc_seq_cur;
+            p.st_world = c->world; p.st_morph_w = (pl.v.mode == 2 && c->M > 0) ? c->morph_w : nullptr;
+            const int nxt = (c->zc_cur + 1) % rz_ctx::kZcSlots;
+            p.pf_src = static_cast<const float *>(c->zc_dev[nxt]);
+            p.pf_src_seq = reinterpret_cast<const uint64_t *>(static_cast<const char *>(c->zc_dev[nxt]) + c->zc_hdr_off);
+            p.pf_dst = c->pose_blk[c->pose_slot ^ 1];
+            p.pf_tag = c->zc_tag + (c->pose_slot ^ 1);
+            p.pf_expect = ((uint64_t)c->zc_epoch << 32) | (uint64_t)(uint32_t)(c->zc_uploads + 1);
+            p.pf_bytes = (uint32_t)((c->zc_total + 15) / 16 * 16);
+        }
     }
     p.sp_ptr = c->sp_ptr; p.sp_entries = c->sp_entries;
     p.out_pos = c->ext_pos ? c->ext_pos : c->out_pos; p.out_nrm = c->ext_nrm ? c->ext_nrm : c->out_nrm;
@@ -620,6 +647,10 @@ Plan make_plan(const rz_ctx *c)
     const uint32_t waves_per_wg = 4, qpw_step = 64 / (uint32_t)v.S;
     // measured (profiles/r1_*sweep*): 2 workgroups per CU for one big mesh, 8 per instance when instanced
     uint32_t cap = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : std::max(2u * (uint32_t)c->n_cu, 8u * c->I);
+    // Pose prefetch: the first frame of a zero-copy world pose carries one helper workgroup that stages the NEXT pose (if the
+    // host has written it already) — it takes one of the grid's slots, the workers share the mesh among cap - 1.
+    pl.pf = v.fast && c->I == 1 && c->t_prefetch != 0 && c->zc_cur >= 0 && !c->zc_local && !c->world_resident && c->zc_seq_cur != 0 && c->zc_tag;
+    if (pl.pf && cap > 1) cap -= 1;
     uint32_t gx = std::max<uint32_t>(1, cap / std::max<uint32_t>(1, c->I));
     const uint32_t max_useful = (pl.n_quads + waves_per_wg * qpw_step - 1) / (waves_per_wg * qpw_step);
     gx = std::max<uint32_t>(1, std::min(gx, max_useful));
@@ -830,7 +861,7 @@ int launch_deform(rz_ctx *c, const Plan &pl)
     }
     size_t lds = rz_deform_lds_bytes(p, pl.v);
     if (lds > 160 * 1024) return fail(RZ_ERR_UNSUPPORTED, "skeleton too large for the LDS palette (%zu B)", lds);
-    HIP_TRY(rz_launch_deform(p, c->ml, pl.v, pl.grid_x, c->I, c->stream));
+    HIP_TRY(rz_launch_deform(p, c->ml, pl.v, pl.grid_x + (p.pf_src ? 1u : 0u), c->I, c->stream));
     if (p.world_copy) c->world_resident = true;        // workgroup 0 of that launch left the pose in the device block
     if (p.morph_w_copy) c->mw_resident = true;
     if (c->aabb_on) c->aabb_slot ^= 1;     // this launch re-armed the other slot for the next frame
@@ -1031,7 +1062,7 @@ int rz_destroy(rz_ctx *c)
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->inv_bind);
-    dfree(c->rj01); dfree(c->rj23); dfree(c->sub_list); dfree(c->sub_count);
+    dfree(c->rj01); dfree(c->rj23); dfree(c->sub_list); dfree(c->sub_count); dfree(c->zc_tag);
     dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind);
     free_animation(c); dfree(c->an_frames);
     dfree(c->fk_append_ratio); dfree(c->fk_append_move); dfree(c->pose_blk[0]); dfree(c->pose_blk[1]);
@@ -1093,7 +1124,7 @@ int rz_fork(rz_ctx *parent, rz_ctx **out)
     c->t_split = parent->t_split; c->t_unroll = parent->t_unroll; c->t_grid_cap = parent->t_grid_cap; c->t_nt = parent->t_nt; c->t_nts = parent->t_nts;
     c->t_geo = parent->t_geo; c->t_fast = parent->t_fast; c->t_instloop = parent->t_instloop; c->t_outcap = parent->t_outcap; c->t_instblock = parent->t_instblock;
     c->t_instorder = parent->t_instorder; c->t_overlap = parent->t_overlap; c->t_zerocopy = parent->t_zerocopy; c->t_fusefk = parent->t_fusefk;
-    c->t_graph = parent->t_graph; c->tuned_by_search = parent->tuned_by_search; c->t_subsets = parent->t_subsets;
+    c->t_graph = parent->t_graph; c->tuned_by_search = parent->tuned_by_search; c->t_subsets = parent->t_subsets; c->t_prefetch = parent->t_prefetch;
     c->lender = parent;
     parent->n_forks++;
     int rc = ensure_pose_buffers(c);
@@ -1168,6 +1199,7 @@ int rz_upload_skeleton(rz_ctx *c, uint32_t B, const float *inverse_bind16)
     HIP_TRY(hipMalloc(&c->inv_bind, (size_t)B * 16 * sizeof(float)));
     HIP_TRY(hipMemcpy(c->inv_bind, inverse_bind16, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice));
     c->B = B;
+    c->zc_epoch++; c->zc_seq_cur = 0;   // a pose staged for the old skeleton must never match
     c->sub_valid = false;               // joints are clamped to the bone count when the run lists are built
     c->palette_stale = false;
     c->pose_set = false;
@@ -1268,6 +1300,7 @@ int rz_set_instances(rz_ctx *c, uint32_t I)
         // A crowd larger than the one the resident pose was uploaded for has no pose for its new members (and a
         // single-character pose may still sit in its pinned slot, which holds exactly one instance): ask for a new one.
         if (I > c->pose_I) c->pose_set = false;
+        c->zc_epoch++; c->zc_seq_cur = 0;
     }
     c->I = I;
     if (int r = ensure_pose_buffers(c)) return r;
@@ -1305,10 +1338,11 @@ static int zc_acquire(rz_ctx *c, size_t need, int *slot_out)
         HIP_TRY(hipStreamSynchronize(c->up_stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         drop_graph(c);
+        const size_t hdr_off = (need + 63) / 64 * 64;
         for (int i = 0; i < rz_ctx::kZcSlots; ++i) {
             if (c->zc_host[i]) { (void)hipHostFree(c->zc_host[i]); c->zc_host[i] = nullptr; c->zc_dev[i] = nullptr; }
             // no pinned, device-mapped memory to be had (locked-memory limits ...): not an error, the caller copies instead
-            if (hipHostMalloc(&c->zc_host[i], need, hipHostMallocMapped) != hipSuccess ||
+            if (hipHostMalloc(&c->zc_host[i], hdr_off + 64, hipHostMallocMapped) != hipSuccess ||
                 hipHostGetDevicePointer(&c->zc_dev[i], c->zc_host[i], 0) != hipSuccess) {
                 (void)hipGetLastError();
                 for (int j = 0; j <= i; ++j)
@@ -1317,7 +1351,11 @@ static int zc_acquire(rz_ctx *c, size_t need, int *slot_out)
                 return RZ_ERR_UNSUPPORTED;
             }
         }
+        for (int i = 0; i < rz_ctx::kZcSlots; ++i) memset(static_cast<char *>(c->zc_host[i]) + hdr_off, 0, 64);
         c->zc_bytes = need;
+        c->zc_hdr_off = hdr_off;
+        c->zc_epoch++;
+        c->zc_seq_cur = 0;
         c->zc_uploads = 0;
         c->zc_ev_seq[0] = c->zc_ev_seq[1] = ~0ull;
         c->zc_cur = -1;
@@ -1370,7 +1408,18 @@ static int upload_pose_zero_copy(rz_ctx *c, const PoseParts &pp)
 {
     int zs = 0;
     if (int r = zc_acquire(c, std::max<size_t>(std::max<size_t>((size_t)c->B * 64 + pp.mwb, pp.mwb + (size_t)c->B * 28), 4096), &zs)) return r;
-    lay_out_pose(c, pp, static_cast<char *>(c->zc_host[zs]));
+    // header protocol of the pose prefetch: invalid while the pose is being written, its sequence number once it is complete
+    // (x86 stores retire in program order; the fences keep the compiler from moving them). Only world-matrix poses are
+    // prefetched (the hierarchy solve reads local poses in its own kernel / prologue).
+    char *slot = static_cast<char *>(c->zc_host[zs]);
+    volatile uint64_t *hdr = reinterpret_cast<volatile uint64_t *>(slot + c->zc_hdr_off);
+    *hdr = 0;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    lay_out_pose(c, pp, slot);
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    const uint64_t seq = pp.local ? 0 : (((uint64_t)c->zc_epoch << 32) | (uint64_t)(uint32_t)c->zc_uploads);   // zc_uploads is already this upload's index + 1
+    *hdr = seq;
+    c->zc_seq_cur = seq;
     point_pose_slot(c, c->pose_slot ^ 1);   // where the pose will live once something makes it resident
     c->free_recorded[c->pose_slot] = false;
     c->zc_cur = zs; c->zc_local = pp.local; c->zc_total = pp.total;
@@ -1386,6 +1435,7 @@ static int upload_pose_zero_copy(rz_ctx *c, const PoseParts &pp)
 static int upload_pose_copy(rz_ctx *c, const PoseParts &pp)
 {
     c->zc_cur = -1;
+    c->zc_seq_cur = 0;
     c->world_resident = c->mw_resident = c->local_resident = true;
     int slot = 0;
     if (int r = stage_acquire(c, std::max<size_t>((size_t)c->I * c->B * 64 + pp.mwb, pp.mwb + (size_t)c->I * c->B * 28), &slot)) return r;
@@ -1679,6 +1729,7 @@ int rz_set_pose_sampled(rz_ctx *c, const float *frames)
     c->pose_local_t = true;
     if (int r = set_overlap(c, want_overlap(c, make_plan(c)))) return r;
     c->zc_cur = -1;                         // the pose is produced on the device: nothing of it sits in a pinned slot
+    c->zc_seq_cur = 0;
     c->world_resident = c->mw_resident = c->local_resident = true;
     c->frames_inline = c->I == 1 && !c->overlap_on && c->t_zerocopy != 0;
     if (c->frames_inline) {
@@ -2180,6 +2231,9 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
     } else if (!strcmp(key, "inst_loop")) {
         if (value < -1 || value == 1 || value > 64) return fail(RZ_ERR_INVALID, "inst_loop must be -1 (auto), 0 (off), 2..8 / 10..64 (poses per workgroup, LDS form) or 9 (register form)");
         c->t_instloop = value;
+    } else if (!strcmp(key, "pose_prefetch")) {
+        if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "pose_prefetch must be -1 (auto = on), 0 (a zero-copy frame never stages the next pose) or 1");
+        c->t_prefetch = value;
     } else if (!strcmp(key, "inst_subsets")) {
         if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "inst_subsets must be -1 (auto = on), 0 (crowd frames always stage the whole palette) or 1");
         c->t_subsets = value;
@@ -2247,6 +2301,18 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "effective_grid")) *value = (int)make_plan(c).grid_x;
     else if (!strcmp(key, "inst_subsets")) *value = c->t_subsets;
     else if (!strcmp(key, "all_variants")) *value = rz_has_all_variants() ? 1 : 0;
+    else if (!strcmp(key, "pose_prefetch")) *value = c->t_prefetch;
+    else if (!strcmp(key, "pose_staged")) {
+        // did the helper of an earlier frame stage the CURRENT pose in device memory? (synchronises; for tests and tools)
+        *value = 0;
+        if (c->zc_tag && c->zc_seq_cur) {
+            uint64_t tags[2] = {0, 0};
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemcpy(tags, c->zc_tag, sizeof tags, hipMemcpyDeviceToHost));
+            *value = tags[c->pose_slot] == c->zc_seq_cur ? 1 : 0;
+        }
+    }
     else if (!strcmp(key, "effective_subsets")) *value = make_plan(c).subsets ? 1 : 0;
     else if (!strcmp(key, "effective_subset_bones")) *value = (int)make_plan(c).sub_bones;
     else if (!strcmp(key, "effective_inst_lds")) *value = (int)make_plan(c).inst_lds;

@@ -188,3 +188,95 @@ def test_gpu_sits_inside_the_envelope_of_legal_wgsl_evaluations(rz, oracle, pose
         assert ep <= 1e-5 and en <= 1e-5, "GPU vs '%s': %.3e / %.3e" % (name, ep, en)
         worst[name] = (ep, en)
     print("GPU distance to each legal evaluation (%s): %s" % (pose, {k: "%.2e / %.2e" % v for k, v in worst.items()}))
+
+
+@pytest.mark.parametrize("morphs", ["dense", "sparse", "none"])
+def test_pose_prefetch_stages_the_next_pose_and_never_a_wrong_one(rz, oracle, morphs):
+    """Zero-copy frames (one character, rz_set_pose: the per-frame writeBuffer of engine.ts:2383-2389): the frame of pose u
+    carries a helper workgroup that stages pose u + 1 into device memory when the host has ALREADY written it into its
+    pinned slot, so that frame u + 1 need not read over the host link. A hit needs the host to run ahead of the GPU, a miss
+    falls back to the pinned slot; either way every frame must hold exactly the bits of its own pose run in isolation.
+      * forced hits: the GPU is kept busy with a long replay while the host uploads the next poses -> pose_staged == 1;
+      * forced misses: a sync after every frame (the host is never ahead) -> pose_staged == 0;
+      * 300 frames in a free-running loop with replays, other pose kinds and consumerless uploads mixed in;
+      * pose_prefetch = 0 gives the same bits."""
+    V, B = 60000, 120
+    mesh = synth.make_mesh(V, B, seed=21)
+    rng = np.random.default_rng(22)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    M, deltas = 0, None
+    if morphs == "dense":
+        M = 24
+        deltas, _ = synth.make_morphs_dense(V, M, seed=23)
+        c.upload_morphs_dense(deltas)
+    elif morphs == "sparse":
+        M = 20
+        off, vi, d3, _ = synth.make_morphs_sparse(V, M, seed=23)
+        c.upload_morphs_sparse(off, vi, d3)
+        deltas = synth.sparse_to_dense(V, off, vi, d3)
+    c.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+    P = 6
+    worlds = [synth.make_pose(mesh["parents"], mesh["bind"], B, seed=700 + k) for k in range(P)]
+    mws = [(rng.random(M).astype(np.float32) * (rng.random(M) < 0.8)).astype(np.float32) if M else None for _ in range(P)]
+    quats = rng.normal(size=(B, 4)).astype(np.float32)
+    quats /= np.linalg.norm(quats, axis=1, keepdims=True)
+    c.set_tuning(pose_prefetch=0)
+    iso = []
+    for k in range(P):
+        c.set_pose(worlds[k], mws[k]); c.deform(); iso.append(c.read())
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[2], mesh["inv_bind"], deltas, mws[2])
+    assert_parity(iso[2][0], iso[2][1], pr, nr, "isolated pose (%s)" % morphs)
+    c.set_tuning(pose_prefetch=-1)
+
+    def same(k, what):
+        p, n = c.read()
+        assert np.array_equal(p, iso[k][0]) and np.array_equal(n, iso[k][1]), "%s: pose %d (%s)" % (what, k, morphs)
+
+    # forced hits: while the GPU chews on a long replay the host uploads pose a, launches its frame, uploads pose b ...
+    hits = 0
+    for a, b in ((0, 1), (3, 4), (5, 2)):
+        c.set_pose(worlds[a], mws[a])
+        c.deform_n(3000)                        # tens of milliseconds of GPU work in the queue
+        c.set_pose(worlds[a], mws[a]); c.deform()       # frame of pose a: its helper looks at the slot pose b is about to land in
+        c.set_pose(worlds[b], mws[b])                   # written long before that frame's kernel starts
+        staged_before = c.get_tuning("pose_staged")     # (synchronises) the helper of frame a has run by now
+        c.deform()
+        same(b, "staged pose")
+        hits += staged_before
+    assert hits == 3, "the helper workgroup must have staged the next pose in every forced-hit round (%d / 3)" % hits
+    # forced misses: the host is never ahead
+    for k in (1, 4, 0):
+        c.sync()
+        c.set_pose(worlds[k], mws[k])
+        assert c.get_tuning("pose_staged") == 0
+        c.deform(); c.sync()
+        same(k, "pinned-slot pose")
+    # free-running loop: whatever mixture of hits and misses the timing produces, the bits are the pose's own
+    checks = 0
+    for f in range(300):
+        k = int(rng.integers(0, P))
+        r = rng.random()
+        if r < 0.08:
+            c.set_pose(worlds[(k + 1) % P], mws[(k + 1) % P])         # an upload no frame consumes
+        if r > 0.9:
+            c.set_pose_local(quats, mws[k]); c.deform()                # another pose kind in between (never prefetched)
+        c.set_pose(worlds[k], mws[k])
+        c.deform()
+        if rng.random() < 0.3:
+            c.deform_n(int(rng.integers(1, 4)))                        # replays of the resident pose
+        if f % 7 == 0:
+            same(k, "free-running frame %d" % f); checks += 1
+    assert checks > 30
+    # a new skeleton / morph set invalidates whatever was staged ahead (sequence epochs)
+    c.set_pose(worlds[0], mws[0]); c.deform_n(2000); c.set_pose(worlds[0], mws[0]); c.deform(); c.set_pose(worlds[1], mws[1])
+    c.upload_morphs_dense(None)
+    w2 = synth.make_pose(mesh["parents"], mesh["bind"], B, seed=999)
+    c.set_pose(w2)
+    assert c.get_tuning("pose_staged") == 0
+    c.deform()
+    pg, ng = c.read()
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], w2, mesh["inv_bind"])
+    assert_parity(pg, ng, pr, nr, "after the morph set was dropped")
+    c.close()

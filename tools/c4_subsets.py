@@ -16,17 +16,17 @@ worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], 200, seed=1000
 ctx.set_pose(worlds)
 for _ in range(20):
     ctx.deform_n(200); ctx.sync()          # clocks
-quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+quick = len(sys.argv) > 1 and sys.argv[1] in ("quick", "order")
 rows = []
 
 
-def run(sub, blk, il, cap, fast=-1):
-    ctx.set_tuning(inst_subsets=sub, inst_block=blk, inst_loop=il, grid_cap=cap, fast=fast)
+def run(sub, blk, il, cap, fast=-1, order=1):
+    ctx.set_tuning(inst_subsets=sub, inst_block=blk, inst_loop=il, grid_cap=cap, fast=fast, inst_order=order)
     ts = [ctx.time_frames(300) for _ in range(3)]
     t = sorted(ts, key=lambda t: t["frame_ms"])[1]        # median of three
     rows.append((t["frame_ms"], sub, blk, il, cap, fast, t["deform_kernel_ms"]))
-    print("subsets=%d block=%4d G=%2d(eff %2d) cap=%4d grid=%3d fast=%2d bones=%3d lds=%6d : kernel %.2f us frame %.2f us (%.1f %% of 8 TB/s at frame level)" % (
-        ctx.get_tuning("effective_subsets"), blk, il, ctx.get_tuning("effective_inst_group"), cap, ctx.get_tuning("effective_grid"), fast,
+    print("order=%d subsets=%d block=%4d G=%2d(eff %2d) cap=%4d grid=%3d fast=%2d bones=%3d lds=%6d : kernel %.2f us frame %.2f us (%.1f %% of 8 TB/s at frame level)" % (
+        order, ctx.get_tuning("effective_subsets"), blk, il, ctx.get_tuning("effective_inst_group"), cap, ctx.get_tuning("effective_grid"), fast,
         ctx.get_tuning("effective_subset_bones"), ctx.get_tuning("effective_inst_lds"),
         t["deform_kernel_ms"] * 1e3, t["frame_ms"] * 1e3, 188.69e6 / (t["frame_ms"] * 1e-3) / 8e12 * 100), flush=True)
 
@@ -34,8 +34,14 @@ def run(sub, blk, il, cap, fast=-1):
 run(0, 512, 8, 256)                         # round 2's default
 for blk in (512, 256) if not quick else (512,):
     for il in (8, 16, 32, 4) if not quick else (8, 4):
-        for cap in (256, 512, 768, 1024, 1536, 2048):
+        for cap in (256, 512, 768, 1024, 1536, 2048) if not (len(sys.argv) > 1 and sys.argv[1] == "order") else ():
             run(1, blk, il, cap)
+if len(sys.argv) > 1 and sys.argv[1] == "order":
+    rows.clear()
+    for order in (1, 0):
+        for il in (8, 4):
+            for cap in (256, 512, 1024, 2048):
+                run(1, 512, il, cap, order=order)
 if not quick:
     run(1, 1024, 16, 256); run(1, 1024, 32, 256)
     run(1, 512, 8, 256, fast=0); run(1, 256, 8, 512, fast=0)      # rz_prep_kernel in front: finished rows staged

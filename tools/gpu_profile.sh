@@ -12,7 +12,8 @@ CFG[c5]="--steps 40 --warmup 5"
 CFG[shard]="--verts 125952 --steps 200 --warmup 20"
 CFG[c4]="--config c4 --steps 100 --warmup 10"
 CFG[c3]="--config c3 --steps 200 --warmup 20"
-for c in c5 shard c4 c3; do
+CFG[demo]="--config demo --steps 300 --warmup 20"
+for c in c5 shard c4 c3 demo; do
   B="python $R/bench.py ${CFG[$c]} --no-cpu-baseline --no-sampled-loop --frames-in-flight 1 --no-pair-loop"
   echo "== $c: kernel trace + stats"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$c -o bench -- $B > $O/trace_$c.log 2>&1 || echo "FAILED trace $c"

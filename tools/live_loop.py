@@ -22,9 +22,17 @@ for V in (1000000, 125952):
     wp, mp = w32.ctypes.data_as(fp), m32.ctypes.data_as(fp)
     for rep in range(3):
         ctx.sync(); t0 = time.perf_counter(); ctx.deform_n(n); ctx.sync(); replay = (time.perf_counter() - t0) / n
-        t0 = time.perf_counter()
+        ctx.set_tuning(pose_prefetch=0)
+        for _ in range(200): L.rz_set_pose(h, wp, mp); L.rz_deform(h)
+        ctx.sync(); t0 = time.perf_counter()
+        for _ in range(n): L.rz_set_pose(h, wp, mp); L.rz_deform(h)
+        ctx.sync(); live_nopf = (time.perf_counter() - t0) / n
+        ctx.set_tuning(pose_prefetch=-1)
+        for _ in range(200): L.rz_set_pose(h, wp, mp); L.rz_deform(h)
+        ctx.sync(); t0 = time.perf_counter()
         for _ in range(n): L.rz_set_pose(h, wp, mp); L.rz_deform(h)        # raw C ABI calls: no numpy conversions in the loop
         ctx.sync(); live = (time.perf_counter() - t0) / n
+        staged = ctx.get_tuning("pose_staged")
         t0 = time.perf_counter()
         for _ in range(n): L.rz_set_pose(h, wp, mp)
         ctx.sync(); up_only = (time.perf_counter() - t0) / n
@@ -34,7 +42,7 @@ for V in (1000000, 125952):
         t0 = time.perf_counter()
         for _ in range(n): L.rz_deform(h)
         host_only = (time.perf_counter() - t0) / n; ctx.sync()
-        res.append((replay, live, up_only, single, host_only))
+        res.append((replay, live, up_only, single, host_only, live_nopf, staged))
     r = min(res)
-    print("V=%7d: replay (deform_n) %.2f us/frame | rz_deform per frame %.2f us (host side of the call %.2f us) | set_pose + deform %.2f us/frame (+%.2f over replay, +%.2f over per-frame deform) | set_pose alone %.2f us"
-          % (V, r[0] * 1e6, r[3] * 1e6, r[4] * 1e6, r[1] * 1e6, (r[1] - r[0]) * 1e6, (r[1] - r[3]) * 1e6, r[2] * 1e6), flush=True)
+    print("V=%7d: replay (deform_n) %.2f us/frame | rz_deform per frame %.2f us (host side of the call %.2f us) | set_pose + deform %.2f us/frame (+%.2f over replay, +%.2f over per-frame deform; last pose staged by the previous frame: %d) | the same with pose_prefetch = 0: %.2f us/frame | set_pose alone %.2f us"
+          % (V, r[0] * 1e6, r[3] * 1e6, r[4] * 1e6, r[1] * 1e6, (r[1] - r[0]) * 1e6, (r[1] - r[3]) * 1e6, r[6], r[5] * 1e6, r[2] * 1e6), flush=True)

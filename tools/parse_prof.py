@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/prof/ (rocprofv3 CSVs written by tools/gpu_profile.sh) into the tracked summaries under profiles/:
-kernel-trace stats tables per workload and the PMC-derived HBM traffic per launch (profiles/pmc_traffic.json, which
-bench.py looks `roofline.traffic` up in — it says so in `roofline.traffic_source`).
+kernel-trace stats tables per workload and the PMC-derived HBM traffic per launch (profiles/pmc_traffic.json, keyed "<shape>|<kernel>";
+bench.py looks `roofline.traffic` up by the kernel its plan actually launches — and carries no traffic figure when that
+kernel was never measured; it says which in `roofline.traffic_source`).
 
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are collected in separate passes, are
 in KiB, and on gfx950 FETCH_SIZE counts exactly half of a wide coalesced read stream — the factor is re-derived here from
@@ -15,13 +16,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 
 WORK = {   # name -> (title, V per GPU, B, M, I)
     "c5": ("python bench.py --steps 40 --warmup 5 (C5: 1M verts / 256 bones / 64 morphs, 1 GPU)", 1000000, 256, 64, 1),
     "shard": ("python bench.py --verts 125952 (one 1/8 shard of C5)", 125952, 256, 64, 1),
     "c4": ("python bench.py --config c4 (256 x 30000 verts / 200 bones, instanced)", 30000, 200, 0, 256),
     "c3": ("python bench.py --config c3 (30000 verts / 200 bones / 64 morphs)", 30000, 200, 64, 1),
+    "demo": ("python bench.py --config demo (28842 verts / 349 bones / 60 sparse morphs, the demo model's statistics)", 28842, 349, 60, 1),
 }
 
 
@@ -83,32 +85,44 @@ for name, (title, V, B, M, I) in WORK.items():
         print("no PMC passes for", name)
         continue
     fe, wr = counters(fp), counters(wp)
-    kf, kw = dominant(fe, "FETCH_SIZE"), dominant(wr, "WRITE_SIZE")
-    fetch_kib, write_kib = fe[kf]["FETCH_SIZE"][0], wr[kw]["WRITE_SIZE"][0]
-    nts = "true" in kf.split("<")[1].split(",")[4] if "rz_deform_kernel" in kf else False
-    read_b = fetch_kib * 1024 * f_read
-    write_b = write_kib * 1024 * (f_write3 if nts else f_write3_plain)
-    if I > 1:
-        alg_read = V * 36 + I * B * 64 + B * 64  # mesh once, world matrices per instance, inverse bind
-        alg_write = I * V * 24
-    else:
-        alg_read = V * (36 + 12 * M) + B * 128 + M * 4
-        alg_write = V * 24
-    rec["V%d_B%d_M%d_I%d" % (V, B, M, I)] = {
-        "kernel": kf.split("(")[0] if "(anonymous namespace)::" not in kf else kf.replace("void (anonymous namespace)::", "").split("(")[0],
-        "launches_counted": fe[kf]["FETCH_SIZE"][1],
-        "hbm_bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_bytes": write_b,
-        "raw_FETCH_SIZE_KiB": fetch_kib, "raw_WRITE_SIZE_KiB": write_kib,
-        "algorithmic_read_bytes": alg_read, "algorithmic_write_bytes": alg_write,
-        "traffic_over_algorithmic": (read_b + write_b) / (alg_read + alg_write),
-        "note": ("one-launch frame: the kernel reads the mesh and the world + inverse-bind matrices and writes the output plus the palette copy "
-                 "that keeps the skinMatrixBuffer observable (rz_read_palette). Its reads are 4-byte loads + LDS-DMA served mostly from L2 / "
-                 "Infinity Cache (whose hits FETCH_SIZE counts); the x2 factor calibrated on 16 B/lane streams is applied as an UPPER bound "
-                 "(traffic_over_algorithmic), the raw counter gives traffic_over_algorithmic_raw_fetch") if I > 1 else "",
-        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- " + title.split(" (")[0] + " --no-cpu-baseline --no-sampled-loop --frames-in-flight 1 --no-pair-loop",
-    }
-    if I > 1:
-        rec["V%d_B%d_M%d_I%d" % (V, B, M, I)]["traffic_over_algorithmic_raw_fetch"] = (fetch_kib * 1024 + write_b) / (alg_read + alg_write)
+    # one record per (workload shape, kernel): every deform / skin kernel variant the run launched often enough to average
+    # (the launch-shape search tries several; bench.py looks up the one its plan ends up with, and only that one)
+    shape = "V%d_B%d_M%d_I%d%s" % (V, B, M, I, "_demo" if name == "demo" else "")
+    for kf in sorted(fe):
+        if not ("rz_deform_kernel" in kf or "rz_skin_instances" in kf) or "FETCH_SIZE" not in fe[kf] or kf not in wr or "WRITE_SIZE" not in wr[kf]:
+            continue
+        if fe[kf]["FETCH_SIZE"][1] < 30:
+            continue
+        fetch_kib, write_kib = fe[kf]["FETCH_SIZE"][0], wr[kf]["WRITE_SIZE"][0]
+        kname = kf.replace("void (anonymous namespace)::", "").split("(")[0]
+        nts = "true" in kname.split("<")[1].split(",")[4] if "rz_deform_kernel" in kname else ("true" in kname.split("<")[1].split(",")[1])
+        read_b = fetch_kib * 1024 * f_read
+        write_b = write_kib * 1024 * (f_write3 if nts else f_write3_plain)
+        if I > 1:
+            alg_read = V * 36 + I * B * 64 + B * 64  # mesh once, world matrices per instance, inverse bind
+            alg_write = I * V * 24
+        elif name == "demo":
+            alg_read = None                          # sparse: the entry count is the workload's (bench.py's algorithmic_bytes_per_launch carries it)
+            alg_write = V * 24
+        else:
+            alg_read = V * (36 + 12 * M) + B * 128 + M * 4
+            alg_write = V * 24
+        r = {
+            "kernel": kname,
+            "launches_counted": fe[kf]["FETCH_SIZE"][1],
+            "hbm_bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_bytes": write_b,
+            "raw_FETCH_SIZE_KiB": fetch_kib, "raw_WRITE_SIZE_KiB": write_kib,
+            "algorithmic_read_bytes": alg_read, "algorithmic_write_bytes": alg_write,
+            "traffic_over_algorithmic": None if alg_read is None else (read_b + write_b) / (alg_read + alg_write),
+            "note": ("crowd frame: the kernel reads the mesh and the world + inverse-bind matrices and writes the output (the whole-palette form also "
+                     "writes the palette copy that keeps the skinMatrixBuffer observable; the bone-subset form does not). Its reads are 4-byte loads + "
+                     "LDS-DMA served mostly from L2 / Infinity Cache (whose hits FETCH_SIZE counts); the x2 factor calibrated on 16 B/lane streams is applied "
+                     "as an UPPER bound (traffic_over_algorithmic), the raw counter gives traffic_over_algorithmic_raw_fetch") if I > 1 else "",
+            "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- " + title.split(" (")[0] + " --no-cpu-baseline --no-sampled-loop --frames-in-flight 1 --no-pair-loop",
+        }
+        if I > 1:
+            r["traffic_over_algorithmic_raw_fetch"] = (fetch_kib * 1024 + write_b) / (alg_read + alg_write)
+        rec[shape + "|" + kname] = r
 rec["_calibration"] = {"FETCH_SIZE_factor_nt_16B_reads": f_read, "FETCH_SIZE_factor_plain_16B_reads": f_read_plain,
                        "WRITE_SIZE_factor_nt_12B_stores": f_write3, "WRITE_SIZE_factor_plain_12B_stores": f_write3_plain,
                        "WRITE_SIZE_factor_16B_stores": f_write4, "known_bytes": "tools/membench quick: 828 MiB read / filled per launch"}
