@@ -200,7 +200,7 @@ def test_pose_prefetch_stages_the_next_pose_and_never_a_wrong_one(rz, oracle, mo
       * forced misses: a sync after every frame (the host is never ahead) -> pose_staged == 0;
       * 300 frames in a free-running loop with replays, other pose kinds and consumerless uploads mixed in;
       * pose_prefetch = 0 gives the same bits."""
-    V, B = 60000, 120
+    V, B = 200000, 120
     mesh = synth.make_mesh(V, B, seed=21)
     rng = np.random.default_rng(22)
     c = rz.DeformContext(0)
@@ -238,7 +238,8 @@ def test_pose_prefetch_stages_the_next_pose_and_never_a_wrong_one(rz, oracle, mo
     hits = 0
     for a, b in ((0, 1), (3, 4), (5, 2)):
         c.set_pose(worlds[a], mws[a])
-        c.deform_n(3000)                        # tens of milliseconds of GPU work in the queue
+        c.deform(); c.sync()
+        c.deform_n(6000)                        # tens of milliseconds of GPU work in the queue (a frame here is 8-15 us, enqueueing one ~3 us)
         c.set_pose(worlds[a], mws[a]); c.deform()       # frame of pose a: its helper looks at the slot pose b is about to land in
         c.set_pose(worlds[b], mws[b])                   # written long before that frame's kernel starts
         staged_before = c.get_tuning("pose_staged")     # (synchronises) the helper of frame a has run by now
@@ -270,7 +271,7 @@ def test_pose_prefetch_stages_the_next_pose_and_never_a_wrong_one(rz, oracle, mo
             same(k, "free-running frame %d" % f); checks += 1
     assert checks > 30
     # a new skeleton / morph set invalidates whatever was staged ahead (sequence epochs)
-    c.set_pose(worlds[0], mws[0]); c.deform_n(2000); c.set_pose(worlds[0], mws[0]); c.deform(); c.set_pose(worlds[1], mws[1])
+    c.set_pose(worlds[0], mws[0]); c.deform_n(4000); c.set_pose(worlds[0], mws[0]); c.deform(); c.set_pose(worlds[1], mws[1])
     c.upload_morphs_dense(None)
     w2 = synth.make_pose(mesh["parents"], mesh["bind"], B, seed=999)
     c.set_pose(w2)

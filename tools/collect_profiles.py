@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Copies what tools/gpu_full.sh left under gpurun_out/full/ (scratch) into profiles/ (tracked) under the round's names, builds
+profiles/r3_autotune_stability.json from the consecutive runs, and regenerates DESIGN.md's tables (tools/design_tables.py)."""
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC, DST, TAG = os.path.join(ROOT, "gpurun_out", "full"), os.path.join(ROOT, "profiles"), "r3"
+n = 0
+for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))):
+    try:
+        json.load(open(f))
+    except Exception:       # noqa: BLE001
+        print("skipping unreadable", f)
+        continue
+    shutil.copy(f, os.path.join(DST, "%s_%s" % (TAG, os.path.basename(f))))
+    n += 1
+stab = {}
+for name in ("c5", "c4"):
+    runs = []
+    for f in sorted(glob.glob(os.path.join(SRC, "stab_%s_*.json" % name))):
+        try:
+            d = json.load(open(f))
+        except Exception:   # noqa: BLE001
+            continue
+        tab = d["config"].get("autotune_table") or []
+        runs.append({"pick": d["config"].get("autotune_pick"), "kernel": d["roofline"]["kernel"], "grid": d["config"]["grid"], "morph_split": d["config"]["morph_split"],
+                     "inst_group": d["config"].get("inst_group"), "ms_per_step": d["ms_per_step"], "kernel_ms": d["roofline"]["kernel_ms"],
+                     "heuristic_ms": tab[0]["ms"] if tab else None, "best_candidate_ms": min(e["ms"] for e in tab) if tab else None})
+    if runs:
+        stab[{"c5": "C5 (python bench.py)", "c4": "C4 (--config c4)"}[name]] = runs
+if stab:
+    json.dump(stab, open(os.path.join(DST, "%s_autotune_stability.json" % TAG), "w"), indent=1)
+for t in ("shard_scaling", "live_loop", "node_frame_bench", "pytest_gpu", "smoke"):
+    p = os.path.join(SRC, t + ".txt")
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+        shutil.copy(p, os.path.join(DST, "%s_%s.txt" % (TAG, t)))
+print("copied %d bench lines" % n)
+sys.exit(subprocess.call([sys.executable, os.path.join(ROOT, "tools", "design_tables.py")]))

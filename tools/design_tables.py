@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Regenerates the result tables of DESIGN.md from the tracked evidence under profiles/ — so that no number in them is typed.
+
+    python tools/design_tables.py            rewrite the block between the GENERATED markers of DESIGN.md
+    python tools/design_tables.py --check    exit 1 when DESIGN.md's block differs from what profiles/ says (tests/test_docs.py)
+
+Sources (all written on the GPU box by tools/gpu_full.sh / tools/gpu_profile.sh -> tools/parse_prof.py, then copied to profiles/):
+    profiles/r3_bench_*.json          bench.py lines (the driver contract), one per workload
+    profiles/r3_kernel_stats_*.txt    rocprofv3 --kernel-trace --stats of the same bench commands
+    profiles/pmc_traffic.json         HBM bytes per launch from the PMC passes, keyed "<shape>|<kernel>"
+    profiles/r3_autotune_stability.json   what the launch-shape search picked in consecutive runs
+"""
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+TAG = "r3"
+BEGIN = "<!-- BEGIN GENERATED (tools/design_tables.py — do not edit by hand) -->"
+END = "<!-- END GENERATED -->"
+
+# file suffix -> what the line is (order = table order)
+LINES = [
+    ("c5", "C5: 1 M verts / 256 bones / 64 dense morphs, 1 GPU — `python bench.py` (the driver's line)"),
+    ("shard8", "one 1/8 shard of C5 (125 952 verts), one stream — `--verts 125952 --frames-in-flight 1`"),
+    ("shard8_auto", "the same shard, default `--frames-in-flight auto`"),
+    ("c4", "C4: 256 instances x 30 000 verts / 200 bones — `--config c4`"),
+    ("c4_devicefk", "C4 with the hierarchy solved on the GPU — `--config c4 --device-fk`"),
+    ("c4_sampled", "C4 with motion sampling + hierarchy on the GPU — `--config c4 --device-fk --device-sampling`"),
+    ("c3", "C3: 30 000 verts / 200 bones / 64 dense morphs — `--config c3`"),
+    ("c2", "C2: 30 000 verts / 200 bones / no morphs — `--config c2`"),
+    ("demo", "demo-shaped: 28 842 verts / 349 bones / 60 sparse morphs, 36 397 offsets on one face region — `--config demo`"),
+    ("sparse2", "the same mesh, sparse morphs spread at 2 % density — `--config sparse2`"),
+    ("c5_allgather1", "C5 through torch.distributed with one rank + the RCCL all-gather — `--allgather`"),
+    ("rehearse8", "8 ranks sharing ONE GPU over gloo (plumbing rehearsal, not a scaling number) — `--gpus 8 --share-gpu --dist-backend gloo`"),
+]
+STATS = {"c5": "c5", "shard8": "shard", "c4": "c4", "c3": "c3", "demo": "demo"}
+
+
+def load(suffix):
+    p = os.path.join(PROF, "%s_bench_%s.json" % (TAG, suffix))
+    if not os.path.exists(p):
+        return None
+    try:
+        return json.load(open(p))
+    except Exception:       # noqa: BLE001
+        return None
+
+
+def rocprof_row(stats_name, kernel):
+    """(calls, avg_us, min_us, max_us) of `kernel` in profiles/r3_kernel_stats_<name>.txt"""
+    p = os.path.join(PROF, "%s_kernel_stats_%s.txt" % (TAG, stats_name))
+    if not os.path.exists(p):
+        return None
+    for ln in open(p):
+        if kernel in ln:
+            m = re.search(r"\)?\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s*$", ln)
+            if m:
+                return int(m.group(1)), float(m.group(3)), float(m.group(4)), float(m.group(5))
+    return None
+
+
+def us(ms):
+    return "—" if ms is None else "%.2f" % (ms * 1e3)
+
+
+def build():
+    out = [BEGIN, ""]
+    out.append("**Tracked bench lines** (`profiles/%s_bench_*.json`; times in µs; `frac` = algorithmic bytes ÷ event-timed kernel ÷ 8 TB/s, "
+               "`frame` = the same over the whole frame; rocprof = average of that kernel in `profiles/%s_kernel_stats_*.txt`):" % (TAG, TAG))
+    out.append("")
+    out.append("| line | N | step | verts/s | in flight | kernel the plan launches | kernel (events) | rocprof avg | frac | frame | traffic ÷ algorithmic | + pose upload | sampled on GPU |")
+    out.append("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    have = []
+    for suffix, what in LINES:
+        d = load(suffix)
+        if d is None:
+            continue
+        have.append(suffix)
+        c, r = d["config"], d["roofline"]
+        rp = rocprof_row(STATS[suffix], r["kernel"]) if suffix in STATS else None
+        tr = "—" if not r.get("traffic") else "%.4f" % (r["traffic"] / r["algorithmic_bytes_per_launch"])
+        out.append("| %s | %d | %s | %.4g | %s | `%s` | %s | %s | %.3f | %.3f | %s | %s | %s |" % (
+            what, d["n_gpus"], us(d["ms_per_step"]), d["value"], c.get("frames_in_flight", 1), r["kernel"], us(r["kernel_ms"]),
+            "—" if rp is None else "%.2f" % rp[1], r["frac"], r["frame_frac"], tr, us(c.get("frame_ms_with_pose_upload")), us(c.get("frame_ms_device_sampled_pose"))))
+    out.append("")
+    # one stream vs two frames in flight, and what the search did
+    out.append("**Both frame modes of every line** (the scaling ratio must be read mode for mode) **and the launch-shape search:**")
+    out.append("")
+    out.append("| line | one stream | two frames in flight | chosen | search: heuristic plan | picked entry | its time | + pose upload, two in flight |")
+    out.append("|---|---|---|---|---|---|---|---|")
+    for suffix in have:
+        d = load(suffix)
+        c = d["config"]
+        tab, pick = c.get("autotune_table"), c.get("autotune_pick")
+        h = "—" if not tab else "%.2f" % (tab[0]["ms"] * 1e3)
+        pk = "—" if not tab else ("entry %d%s" % (pick, " (the heuristics)" if pick == 0 else " (split %d, cap %d, poses %d)" % (tab[pick]["morph_split"], tab[pick]["grid_cap"], tab[pick]["inst_loop"])))
+        pt = "—" if not tab else "%.2f" % (tab[pick]["ms"] * 1e3)
+        out.append("| %s | %s | %s | %d | %s | %s | %s | %s |" % (suffix, us(c.get("ms_per_step_one_stream")), us(c.get("ms_per_step_two_frames_in_flight")),
+                                                           c.get("frames_in_flight", 1), h, pk, pt, us(c.get("frame_ms_with_pose_upload_two_in_flight"))))
+    out.append("")
+    # CPU baseline + RCCL evidence
+    d = load("c5")
+    if d and d.get("cpu_baseline"):
+        cb = d["cpu_baseline"]
+        out.append("**CPU baseline of the driver line** (`cpu_baseline`, reported, not a target): %.3g %s on %d threads — %s." % (cb["value"], cb["unit"], cb["cores"], cb["sample"]))
+        out.append("")
+    d = load("c5_allgather1")
+    if d:
+        rc = d["config"]["ranks"][0].get("rccl") or {}
+        out.append("**RCCL evidence at N = 1** (`%s_bench_c5_allgather1.json`): communicator count %s, user rank %s, `%s` version %s (reused from the process: %s); all-gather %s µs per call, outside `value`." % (
+            TAG, rc.get("comm_count"), rc.get("comm_user_rank"), rc.get("path"), rc.get("version"), rc.get("reused"), us(d["config"].get("allgather_ms"))))
+        out.append("")
+    d = load("rehearse8")
+    if d:
+        ranks = d["config"]["ranks"]
+        plans = sorted({(r["kernel"], r["morph_split"]) for r in ranks})
+        out.append("**8-rank rehearsal on one GPU** (`%s_bench_rehearse8.json`; launched by: %s): %d ranks, %d distinct plan(s) %s, kernel %.2f–%.2f µs over the ranks "
+                   "(all eight shards take turns on the one GPU, so the step time says nothing about scaling)." % (
+                       TAG, d["config"].get("launched_by"), len(ranks), len(plans), ", ".join("`%s`" % p[0] for p in plans),
+                       d["config"]["kernel_ms_min_over_ranks"] * 1e3, d["config"]["kernel_ms_max_over_ranks"] * 1e3))
+        out.append("")
+    # PMC traffic
+    tj = os.path.join(PROF, "pmc_traffic.json")
+    if os.path.exists(tj):
+        rec = json.load(open(tj))
+        out.append("**HBM traffic per launch from the PMC counters** (`profiles/pmc_traffic.json`: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, "
+                   "calibrated in the same run on `tools/membench`'s known-byte kernels):")
+        out.append("")
+        out.append("| workload shape | kernel | launches averaged | measured bytes | algorithmic bytes | ratio |")
+        out.append("|---|---|---|---|---|---|")
+        for k in sorted(rec):
+            if k.startswith("_") or "|" not in k:
+                continue
+            r = rec[k]
+            alg = None if r.get("algorithmic_read_bytes") is None else r["algorithmic_read_bytes"] + r["algorithmic_write_bytes"]
+            out.append("| %s | `%s` | %d | %.4g | %s | %s |" % (k.split("|")[0], r["kernel"], r["launches_counted"], r["hbm_bytes_per_launch"],
+                                                            "—" if alg is None else "%.4g" % alg, "—" if r.get("traffic_over_algorithmic") is None else "%.4f" % r["traffic_over_algorithmic"]))
+        cal = rec.get("_calibration", {})
+        if cal:
+            out.append("")
+            out.append("Calibration factors of that run: FETCH_SIZE × %.5f (16 B/lane nontemporal reads), WRITE_SIZE × %.4f (nontemporal 12 B/lane stores) / × %.4f (plain)." % (
+                cal.get("FETCH_SIZE_factor_nt_16B_reads", float("nan")), cal.get("WRITE_SIZE_factor_nt_12B_stores", float("nan")), cal.get("WRITE_SIZE_factor_plain_12B_stores", float("nan"))))
+        out.append("")
+    sj = os.path.join(PROF, "%s_autotune_stability.json" % TAG)
+    if os.path.exists(sj):
+        st = json.load(open(sj))
+        out.append("**Stability of the launch-shape search** (`profiles/%s_autotune_stability.json`: consecutive `python bench.py` runs on one box):" % TAG)
+        out.append("")
+        out.append("| workload | picks (entry index per run) | kernels | ms per step per run (µs) |")
+        out.append("|---|---|---|---|")
+        for name, runs in st.items():
+            out.append("| %s | %s | %s | %s |" % (name, " ".join(str(r["pick"]) for r in runs), ", ".join(sorted({"`%s`" % r["kernel"] for r in runs})),
+                                              " ".join("%.2f" % (r["ms_per_step"] * 1e3) for r in runs)))
+        out.append("")
+    out.append(END)
+    return "\n".join(out)
+
+
+def main():
+    path = os.path.join(ROOT, "DESIGN.md")
+    text = open(path).read()
+    if BEGIN not in text or END not in text:
+        sys.stderr.write("DESIGN.md has no GENERATED block\n")
+        return 2
+    a, b = text.index(BEGIN), text.index(END) + len(END)
+    new = build()
+    if "--check" in sys.argv:
+        if text[a:b] != new:
+            import difflib
+            sys.stderr.write("DESIGN.md's generated tables differ from profiles/ — run python tools/design_tables.py\n")
+            sys.stderr.write("".join(list(difflib.unified_diff(text[a:b].splitlines(True), new.splitlines(True), "DESIGN.md", "profiles/"))[:60]))
+            return 1
+        return 0
+    open(path, "w").write(text[:a] + new + text[b:])
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,38 +1,45 @@
 #!/bin/bash
-# Full confirmation run of a round: GPU tests, smoke, the tracked bench lines (C5 default + C4 / C3 / C2 / one 1/8 shard /
-# device-animated C4), shard scaling, the Node frame loop, the per-frame upload loop, the C4 sweeps. Output: gpurun_out/full/.
+# Full confirmation run of a round: GPU tests, smoke, the tracked bench lines (C5 default + C4 / C3 / C2 / one 1/8 shard / sparse
+# real-shape lines / device-animated C4 / RCCL at N = 1 / 8-rank rehearsal), search stability (consecutive runs), shard scaling,
+# the per-frame upload loop, the Node frame loop, the C4 sweep. Output: gpurun_out/full/ (tools/collect_profiles.py copies it to profiles/).
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 O=gpurun_out/full; rm -rf $O; mkdir -p $O
+if [ "$1" != "nobench" ]; then
 echo "== pytest gpu"
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee $O/pytest_gpu.txt; echo "pytest rc=${PIPESTATUS[0]}" | tee -a $O/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6 | tee $O/pytest_gpu.txt; echo "pytest rc=${PIPESTATUS[0]}" | tee -a $O/pytest_gpu.txt
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/smoke.txt
+fi
 echo "== bench"
 timeout 600 python bench.py 2>$O/bench.err | tail -1 > $O/bench_c5.json
 for c in c4 c3 c2; do timeout 600 python bench.py --config $c --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_$c.json; done
+for c in demo sparse2; do timeout 600 python bench.py --config $c 2>>$O/bench.err | tail -1 > $O/bench_$c.json; done
 timeout 600 python bench.py --verts 125952 --no-cpu-baseline --frames-in-flight 1 2>>$O/bench.err | tail -1 > $O/bench_shard8.json
 timeout 600 python bench.py --verts 125952 --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_shard8_auto.json
-timeout 600 python bench.py --verts 125952 --no-cpu-baseline --frames-in-flight 2 2>>$O/bench.err | tail -1 > $O/bench_shard8_inflight2.json
 timeout 600 python bench.py --config c4 --device-fk --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c4_devicefk.json
 timeout 600 python bench.py --config c4 --device-fk --device-sampling --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c4_sampled.json
 REZE_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --allgather --steps 100 --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c5_allgather1.json
+echo "== 8 ranks on the one GPU (plumbing rehearsal; plain invocation: bench.py launches itself)"
+timeout 900 python bench.py --gpus 8 --share-gpu --dist-backend gloo --steps 50 --warmup 5 --no-cpu-baseline --no-sampled-loop --clock-warm-seconds 0.5 2>>$O/bench.err | grep '^{' | tail -1 > $O/bench_rehearse8.json
+echo "== search stability: consecutive runs"
+for i in 1 2 3 4; do timeout 600 python bench.py --no-cpu-baseline --no-sampled-loop --no-pair-loop --frames-in-flight 1 2>>$O/bench.err | tail -1 > $O/stab_c5_$i.json; done
+for i in 1 2 3 4 5; do timeout 600 python bench.py --config c4 --no-cpu-baseline --no-sampled-loop --no-pair-loop --frames-in-flight 1 2>>$O/bench.err | tail -1 > $O/stab_c4_$i.json; done
 python - <<'P'
 import json, glob
-for f in sorted(glob.glob('gpurun_out/full/bench_*.json')):
+for f in sorted(glob.glob('gpurun_out/full/bench_*.json')) + sorted(glob.glob('gpurun_out/full/stab_*.json')):
     try:
         d = json.load(open(f)); c = d['config']; r = d['roofline']
-        print('%-30s value %.4g verts/s  ms/step %.5f (in flight %d; two in flight %s)  kernel %s %.5f ms frac %.3f frame_frac %.3f | upload loop %s sampled loop %s' % (
-            f.split('/')[-1], d['value'], d['ms_per_step'], c.get('frames_in_flight', 1), c.get('ms_per_step_two_frames_in_flight'), r['kernel'], r['kernel_ms'], r['frac'], r['frame_frac'], c['frame_ms_with_pose_upload'], c['frame_ms_device_sampled_pose']))
+        print('%-30s value %.4g verts/s  ms/step %.5f (in flight %d; one %s two %s) pick %s kernel %s %.5f ms frac %.3f frame_frac %.3f | upload loop %s (pair %s) sampled loop %s' % (
+            f.split('/')[-1], d['value'], d['ms_per_step'], c.get('frames_in_flight', 1), c.get('ms_per_step_one_stream'), c.get('ms_per_step_two_frames_in_flight'), c.get('autotune_pick'), r['kernel'], r['kernel_ms'], r['frac'], r['frame_frac'], c['frame_ms_with_pose_upload'], c.get('frame_ms_with_pose_upload_two_in_flight'), c['frame_ms_device_sampled_pose']))
     except Exception as e:
         print(f, 'unreadable', e)
 P
+if [ "$1" != "nobench" ]; then
 echo "== shard scaling"
 timeout 600 python tools/shard_scaling.py 2>&1 | tee $O/shard_scaling.txt
 echo "== live loop"
 timeout 300 python tools/live_loop.py 2>&1 | tee $O/live_loop.txt
 echo "== node frame loop"
 timeout 300 python tools/node_frame_bench.py 2>&1 | tail -8 | tee $O/node_frame_bench.txt
-echo "== c4 sweep / overlap"
-timeout 400 python tools/c4_sweep.py 2>&1 | tee $O/c4_sweep.txt | tail -4
-timeout 300 python tools/c4_overlap.py 2>&1 | tee $O/c4_overlap.txt
+fi
 tail -3 $O/bench.err
