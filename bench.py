@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--cpu-sample-verts", type=int, default=200000)
     ap.add_argument("--allgather", action="store_true", help="time the RCCL all-gather of positions at N = 1 too (at N > 1 it always is, outside `value`)")
     ap.add_argument("--no-allgather", action="store_true", help="N > 1: skip the RCCL communicator + all-gather timing")
+    ap.add_argument("--rccl-timeout", type=float, default=120.0, help="watchdog of the RCCL phase (communicator + all-gather), seconds")
     ap.add_argument("--device-fk", action="store_true",
                     help="solve the bone hierarchy on the GPU: frames start from local rotations (rz_set_pose_local)")
     ap.add_argument("--device-sampling", action="store_true",
@@ -306,7 +307,18 @@ def main():
     # Every rank measures the same candidate list on its own shard; the tables are reduced with MAX over the ranks (the frame
     # time of a sharded mesh is its slowest GPU's) and every rank adopts the SAME entry: the heuristic plan unless a
     # candidate beats it by >= 2 % (rz_autotune_pick). config.autotune_table carries the reduced table.
+    def clock_warm(seconds):
+        # Setup, untimed: bring the GPU to its sustained clock / power state. Measured on MI355X: the first ~2 s of work after
+        # idle run 7-8 % slower (C4 one-launch frame 38.5 us cold, 35.8 us after 3 s of frames), and the driver may ask for as
+        # few as 20 timed steps. A long-running job lives in the warm state; this is the same kind of step as rz_autotune.
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            ctx.deform_n(200)
+            ctx.sync()
+
     tuned, tune_table, tune_pick = None, None, None
+    if args.clock_warm_seconds > 0:
+        clock_warm(args.clock_warm_seconds)          # BEFORE the search: a cold first candidate would lose to a warm last one
     if not args.no_autotune and not args.tune:
         try:
             mine_tab = ctx.autotune_measure()
@@ -332,14 +344,8 @@ def main():
     if args.graph:
         ctx.set_tuning(graph=1)
 
-    # Setup, untimed: bring the GPU to its sustained clock / power state. Measured on MI355X: the first ~2 s of work after
-    # idle run 7-8 % slower (C4 one-launch frame 38.5 us cold, 35.8 us after 3 s of frames), and the driver may ask for as
-    # few as 20 timed steps. A long-running job lives in the warm state; this is the same kind of step as rz_autotune.
     if args.clock_warm_seconds > 0:
-        t_end = time.perf_counter() + args.clock_warm_seconds
-        while time.perf_counter() < t_end:
-            ctx.deform_n(200)
-            ctx.sync()
+        clock_warm(min(0.5, args.clock_warm_seconds))      # the adopted plan, warm
 
     def barrier():
         ctx.sync()
@@ -567,38 +573,65 @@ def main():
             sampled_ms = per_frame_loop(*sampled_call)
         put_pose()                      # back to the primary pose kind
 
+    # one record per rank, so a slow or oddly planned GPU is visible in the scaling file — gathered BEFORE the RCCL phase below,
+    # so that the line has them whatever happens there
+    eff = {k: ctx.get_tuning(k) for k in ("effective_split", "effective_grid", "effective_inst_group", "effective_subsets", "effective_subset_bones", "effective_inst_lds")}
+    mine = {"rank": rank, "device": local_rank, "verts": n, "kernel_ms": timing["deform_kernel_ms"], "frame_ms": timing["frame_ms"],
+            "kernel": kernel_name, "grid": eff["effective_grid"], "morph_split": eff["effective_split"], "autotuned": tuned is not None, "rccl": None}
+    per_rank = gather(mine)
+
     # ---- RCCL: at N > 1 every rank joins a communicator made by the library's own entry points, says what the
-    # communicator reports about itself, and the all-gather of deformed positions is timed — OUTSIDE `value` ----
-    ag_ms, rccl = None, None
+    # communicator reports about itself, and the all-gather of deformed positions is timed — OUTSIDE `value`.
+    # It runs LAST and under a watchdog: a multi-GPU collective is the one thing a 1-GPU box cannot rehearse, and a hang in it
+    # must cost the line its RCCL fields, not the line itself. ----
+    ag_ms, hard_exit = None, False
     want_comm = I == 1 and ((world_size > 1 and not args.no_allgather and not args.share_gpu) or args.allgather)
     if want_comm:
-        try:
-            uid = [rz.capi.comm_unique_id() if rank == 0 else None]
-            if dist is not None:
-                dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(world_size, rank, uid[0], V_total)
-            rccl = rz.capi.rccl_info()
-            rccl.update(ctx.comm_info())
-            rccl["expected_count"] = world_size
-            for _ in range(5):
-                ctx.allgather()
-            barrier()
-            ta = time.perf_counter()
-            for _ in range(50):
-                ctx.allgather()
-            barrier()
-            ag_ms = rank_max((time.perf_counter() - ta) * 1e3 / 50)
-        except Exception as e:          # noqa: BLE001
-            sys.stderr.write("[bench] RCCL communicator / all-gather failed on rank %d: %r\n" % (rank, e))
-            rccl = {"error": repr(e)}
-    elif world_size > 1:
-        rccl = {"skipped": "--share-gpu: ranks share a GPU, RCCL needs one GPU per rank" if args.share_gpu else "--no-allgather"}
+        import threading
+        box = {"done": False, "ranks": None, "ag_ms": None}
 
-    # one record per rank, so a slow or oddly planned GPU is visible in the scaling file
-    mine = {"rank": rank, "device": local_rank, "verts": n, "kernel_ms": timing["deform_kernel_ms"], "frame_ms": timing["frame_ms"],
-            "kernel": kernel_name, "grid": ctx.get_tuning("effective_grid"), "morph_split": ctx.get_tuning("effective_split"),
-            "autotuned": tuned is not None, "rccl": rccl}
-    per_rank = gather(mine)
+        def rccl_phase():
+            rec, ms = None, None
+            try:
+                uid = [rz.capi.comm_unique_id() if rank == 0 else None]
+                if dist is not None:
+                    dist.broadcast_object_list(uid, src=0)
+                ctx.comm_init(world_size, rank, uid[0], V_total)
+                rec = rz.capi.rccl_info()
+                rec.update(ctx.comm_info())
+                rec["expected_count"] = world_size
+                for _ in range(5):
+                    ctx.allgather()
+                barrier()
+                ta = time.perf_counter()
+                for _ in range(50):
+                    ctx.allgather()
+                barrier()
+                ms = (time.perf_counter() - ta) * 1e3 / 50
+            except Exception as e:          # noqa: BLE001
+                sys.stderr.write("[bench] RCCL communicator / all-gather failed on rank %d: %r\n" % (rank, e))
+                rec = {"error": repr(e)}
+            got = gather((rec, ms))
+            box["ranks"] = [g[0] for g in got]
+            times = [g[1] for g in got]
+            box["ag_ms"] = None if any(t is None for t in times) else max(times)
+            box["done"] = True
+        th = threading.Thread(target=rccl_phase, daemon=True)
+        th.start()
+        th.join(timeout=args.rccl_timeout)
+        if box["done"]:
+            ag_ms = box["ag_ms"]
+            for r, rec in zip(per_rank, box["ranks"]):
+                r["rccl"] = rec
+        else:
+            sys.stderr.write("[bench] rank %d: the RCCL phase did not finish within %g s — reporting the line without it\n" % (rank, args.rccl_timeout))
+            for r in per_rank:
+                r["rccl"] = {"error": "RCCL communicator / all-gather did not finish within %g s (watchdog)" % args.rccl_timeout}
+            hard_exit = True            # a collective is stuck: no orderly shutdown is possible
+    elif world_size > 1:
+        why = "--share-gpu: ranks share a GPU, RCCL needs one GPU per rank" if args.share_gpu else "--no-allgather"
+        for r in per_rank:
+            r["rccl"] = {"skipped": why}
 
     cpu = None
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
@@ -642,16 +675,16 @@ def main():
                                else ("external launcher (WORLD_SIZE in the environment)" if "WORLD_SIZE" in os.environ else "single process"),
                 "bone_hierarchy_solve": ("device (motion sampling + hierarchy solve in rz_fk_kernel)" if args.device_sampling else "device (rz_fk_kernel)") if args.device_fk else "host",
                 "autotune": tuned is not None,
-                "autotune_rule": "heuristic plan (entry 0) unless a candidate's median-of-3-rounds time, MAX over ranks, is >= 2 % faster; every rank adopts the same entry",
+                "autotune_rule": "heuristic plan (entry 0) unless a candidate's median-of-5-rounds time, MAX over ranks, is >= 2 % faster; every rank adopts the same entry",
                 "autotune_pick": tune_pick,
                 "autotune_table": None if tune_table is None else [{k: (round(e[k], 6) if isinstance(e[k], float) else e[k]) for k in e} for e in tune_table],
                 "graph_replay": bool(args.graph),
-                "morph_split": ctx.get_tuning("effective_split"),
-                "grid": ctx.get_tuning("effective_grid"),
-                "inst_group": ctx.get_tuning("effective_inst_group"),
-                "inst_subsets": ctx.get_tuning("effective_subsets"),
-                "inst_subset_bones": ctx.get_tuning("effective_subset_bones"),
-                "inst_lds_bytes": ctx.get_tuning("effective_inst_lds"),
+                "morph_split": eff["effective_split"],
+                "grid": eff["effective_grid"],
+                "inst_group": eff["effective_inst_group"],
+                "inst_subsets": eff["effective_subsets"],
+                "inst_subset_bones": eff["effective_subset_bones"],
+                "inst_lds_bytes": eff["effective_inst_lds"],
                 "frame_ms_events": timing["frame_ms"],
                 "prep_kernel_ms": timing["prep_kernel_ms"],
                 "frame_ms_with_pose_upload": with_upload_ms,
@@ -692,9 +725,10 @@ def main():
         }
     else:
         out = None
-    ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if not hard_exit:
+        ctx.close()
+        if dist is not None:
+            dist.destroy_process_group()
     if out is not None:
         # The JSON line must be the LAST thing on stdout: RCCL writes its version banner through C stdio, which sits in a
         # buffer until exit when stdout is a pipe — flush that first, then print.
@@ -705,6 +739,8 @@ def main():
             pass
         sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()
+    if hard_exit:
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -259,7 +259,7 @@ int rz_get_tuning(rz_ctx *ctx, const char *key, int *value);
 /* Setup-time search over launch shapes (like a GEMM library's "find" mode; no reference counterpart — WebGPU hides
  * the dispatch shape, engine.ts:2393-2402). Candidates: the built-in heuristic plan (entry 0) and every distinct plan among morph
  * split {1,2,4,8} x {1,2,4} workgroups per CU (instanced frames: poses per workgroup x workgroups per CU), timed with the
- * CURRENT mesh / morphs / pose on this GPU: `frames` frames per round (0 = 100, at most 1000), >= 3 rounds dealt round-robin over
+ * CURRENT mesh / morphs / pose on this GPU: `frames` frames per round (0 = 100, at most 1000) after ~0.25 s of untimed frames (clocks), 5 rounds dealt round-robin over
  * the candidates (so clock / thermal drift hits all of them alike), the MEDIAN round of each is its time.
  *   rz_autotune_measure  fills `table` (at most `cap` entries, *count = how many) and changes nothing;
  *   rz_autotune_apply    adopts one entry as the "morph_split" / "grid_cap" / "inst_loop" tuning values;

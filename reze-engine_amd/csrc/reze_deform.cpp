@@ -488,11 +488,14 @@ void free_morphs(rz_ctx *c)
 int auto_split(const rz_ctx *c)
 {
     if (c->morph_mode != 1) return 1;
-    // S lanes share a quad, so waves = quads * S / 64. Measured on MI355X (profiles/r1_a_sweep*):
-    // 1 M verts -> S=1..2, 126 k -> S=4, 30 k -> S=8; i.e. aim for ~1500 waves, never beyond 8.
+    // S lanes share a quad, so waves = quads * S / 64. Measured on MI355X (profiles/r1_a_sweep*, and the search tables of
+    // profiles/r3_bench_*.json): 126 k verts -> S = 4, 30 k -> S = 8, i.e. aim for ~1500 waves, never beyond 8; and even
+    // the 1 M-vertex mesh (3 906 waves at S = 1) streams 3 % faster with two lanes per quad (122.8 vs 127.0 us; S = 4 is
+    // within 0.4 % of S = 2), so a dense frame never runs below S = 2 — which also keeps rz_autotune's pick on the
+    // heuristic plan instead of flipping between two near-equal candidates from run to run.
     const uint64_t quads = (uint64_t)c->Vp / 4 * c->I;
     const uint64_t want = 1500;
-    int S = 1;
+    int S = 2;
     while (S < 8 && quads * S / 64 < want) S <<= 1;
     while (S > 1 && (uint32_t)S > c->M) S >>= 1;
     return S;
@@ -2116,9 +2119,19 @@ int rz_autotune_measure(rz_ctx *c, uint32_t frames, rz_tune_entry *table, int ca
                 plans[k].inst_block == pl.inst_block)
                 cands[i].same_as = cands[k].same_as >= 0 ? cands[k].same_as : k;
     }
-    constexpr int kRounds = 3;
+    constexpr int kRounds = 5;
     std::vector<float> t((size_t)n * kRounds, 0.f);
     int rc = RZ_OK;
+    {
+        // the GPU reaches its sustained clocks only after a while of work (measured: the first timed round of the first
+        // candidate came out 15-20 % slow on a cold device, which is enough to move a median of three): run the heuristic
+        // plan for ~0.25 s first, untimed
+        const auto t0 = std::chrono::steady_clock::now();
+        while (rc == RZ_OK && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(250)) {
+            for (uint32_t f = 0; f < 64 && rc == RZ_OK; ++f) rc = run_frame(c, plans[0]);
+            if (rc == RZ_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(RZ_ERR_HIP, "rz_autotune_measure: warm-up failed");
+        }
+    }
     for (int round = -1; round < kRounds && rc == RZ_OK; ++round) {          // round -1 warms every variant up, untimed
         for (int i = 0; i < n && rc == RZ_OK; ++i) {
             if (cands[i].same_as >= 0) continue;

@@ -436,7 +436,7 @@ def test_growing_the_crowd_needs_a_new_pose(rz, oracle):
 
 @pytest.mark.parametrize("pose", ["pose0", "tween150", "tween500"])
 def test_wide_sample_of_the_real_model_against_reference_execution(rz, oracle, pose):
-    """4 121 real vertices (every 7th of the demo model: all body parts, 234 bones, the model's own 40 / 52 / 8 % influence mix)
+    """1 031 real vertices (every 28th of the demo model: all body parts, 166 bones, the model's own 40 / 53 / 7 % influence mix)
     under three reference-produced poses, deformed on the GPU and compared DIRECTLY with vs() as the reference run evaluated
     it with math.ts primitives (tests/golden, tools/ref_erased_run.py), then replicated as a small crowd: the instanced kernel
     on real skinning data (its wave-uniform influence skipping takes all three paths here) must give the same bits."""

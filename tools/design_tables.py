@@ -51,10 +51,20 @@ def load(suffix):
 
 
 def rocprof_row(stats_name, kernel):
-    """(calls, avg_us, min_us, max_us) of `kernel` in profiles/r3_kernel_stats_<name>.txt"""
+    """(calls, avg_us, min_us, max_us[, workgroups]) of `kernel` in profiles/r3_kernel_stats_<name>.txt: its most-launched launch
+    shape when the file has the per-shape section (the plan the bench loops ran), else the all-shapes row of the stats"""
     p = os.path.join(PROF, "%s_kernel_stats_%s.txt" % (TAG, stats_name))
     if not os.path.exists(p):
         return None
+    best = None
+    for ln in open(p):
+        if ln.startswith("SHAPE ") and kernel in ln:
+            f = ln[len("SHAPE "):].rsplit(None, 7)
+            row = (int(f[4]), float(f[5]), float(f[6]), float(f[7]), int(f[1]))
+            if best is None or row[0] > best[0]:
+                best = row
+    if best is not None:
+        return best
     for ln in open(p):
         if kernel in ln:
             m = re.search(r"\)?\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s*$", ln)
@@ -87,6 +97,29 @@ def build():
             what, d["n_gpus"], us(d["ms_per_step"]), d["value"], c.get("frames_in_flight", 1), r["kernel"], us(r["kernel_ms"]),
             "—" if rp is None else "%.2f" % rp[1], r["frac"], r["frame_frac"], tr, us(c.get("frame_ms_with_pose_upload")), us(c.get("frame_ms_device_sampled_pose"))))
     out.append("")
+    # the profiled runs themselves: events vs rocprof in the SAME run
+    rows = []
+    for name in ("c5", "shard", "c4", "c3", "demo"):
+        pj = os.path.join(PROF, "%s_bench_under_rocprof_%s.json" % (TAG, name))
+        if not os.path.exists(pj):
+            continue
+        try:
+            d = json.load(open(pj))
+        except Exception:       # noqa: BLE001
+            continue
+        rp = rocprof_row(name, d["roofline"]["kernel"])
+        if rp is None:
+            continue
+        rows.append("| %s | `%s` | %s | %s | %.2f | %.2f | %d | %.3f |" % (name, d["roofline"]["kernel"], us(d["ms_per_step"]), us(d["roofline"]["kernel_ms"]), rp[1], rp[2], rp[0],
+                                                                  rp[1] / (d["roofline"]["kernel_ms"] * 1e3)))
+    if rows:
+        out.append("**The same numbers inside ONE run** (`profiles/%s_bench_under_rocprof_*.json` = the bench line printed under rocprofv3, against the rocprofv3 average of "
+                   "the most-launched shape of that kernel in the same run, `profiles/%s_kernel_stats_*.txt`; profiled runs clock lower than un-profiled ones):" % (TAG, TAG))
+        out.append("")
+        out.append("| workload | kernel | step (µs) | kernel by events (µs) | rocprof avg (µs) | rocprof min (µs) | launches | rocprof ÷ events |")
+        out.append("|---|---|---|---|---|---|---|---|")
+        out += rows
+        out.append("")
     # one stream vs two frames in flight, and what the search did
     out.append("**Both frame modes of every line** (the scaling ratio must be read mode for mode) **and the launch-shape search:**")
     out.append("")
@@ -160,23 +193,43 @@ def build():
     return "\n".join(out)
 
 
+def build_readme():
+    """the short headline table of README.md"""
+    out = [BEGIN, "", "| Config (BASELINE.json) | frame (µs) | verts/s | kernel: algorithmic GB/s | % of 8 TB/s (kernel / frame) |", "|---|---|---|---|---|"]
+    for suffix, what in LINES:
+        if suffix in ("c5_allgather1", "rehearse8", "shard8_auto"):
+            continue
+        d = load(suffix)
+        if d is None:
+            continue
+        r = d["roofline"]
+        out.append("| %s | %s | %.3g | %.0f | %.1f / %.1f |" % (what.split(" — ")[0], us(d["ms_per_step"]), d["value"], r["achieved"], 100 * r["frac"], 100 * r["frame_frac"]))
+    d = load("c5")
+    if d and d.get("cpu_baseline"):
+        out.append("| CPU baseline of the C5 line (%s, %d threads) | — | %.3g | — | — |" % (d["cpu_baseline"]["kind"], d["cpu_baseline"]["cores"], d["cpu_baseline"]["value"]))
+    out += ["", "(generated from `profiles/%s_bench_*.json` by `tools/design_tables.py`; full tables, rocprof averages and PMC traffic: DESIGN.md §7)" % TAG, END]
+    return "\n".join(out)
+
+
 def main():
-    path = os.path.join(ROOT, "DESIGN.md")
-    text = open(path).read()
-    if BEGIN not in text or END not in text:
-        sys.stderr.write("DESIGN.md has no GENERATED block\n")
-        return 2
-    a, b = text.index(BEGIN), text.index(END) + len(END)
-    new = build()
-    if "--check" in sys.argv:
-        if text[a:b] != new:
-            import difflib
-            sys.stderr.write("DESIGN.md's generated tables differ from profiles/ — run python tools/design_tables.py\n")
-            sys.stderr.write("".join(list(difflib.unified_diff(text[a:b].splitlines(True), new.splitlines(True), "DESIGN.md", "profiles/"))[:60]))
-            return 1
-        return 0
-    open(path, "w").write(text[:a] + new + text[b:])
-    return 0
+    rc = 0
+    for fname, builder in (("DESIGN.md", build), ("README.md", build_readme)):
+        path = os.path.join(ROOT, fname)
+        text = open(path).read()
+        if BEGIN not in text or END not in text:
+            sys.stderr.write("%s has no GENERATED block\n" % fname)
+            return 2
+        a, b = text.index(BEGIN), text.index(END) + len(END)
+        new = builder()
+        if "--check" in sys.argv:
+            if text[a:b] != new:
+                import difflib
+                sys.stderr.write("%s's generated tables differ from profiles/ — run python tools/design_tables.py\n" % fname)
+                sys.stderr.write("".join(list(difflib.unified_diff(text[a:b].splitlines(True), new.splitlines(True), fname, "profiles/"))[:60]))
+                rc = 1
+        else:
+            open(path, "w").write(text[:a] + new + text[b:])
+    return rc
 
 
 if __name__ == "__main__":

@@ -51,7 +51,7 @@ def find(agg, name_part, counter):
     return None
 
 
-def stats_table(path, title, out):
+def stats_table(path, title, out, trace=None):
     rows = list(csv.DictReader(open(path)))
     with open(out, "w") as f:
         f.write("# %s\n# rocprofv3 --kernel-trace --stats --output-format csv (MI355X, gfx950); times in us\n" % title)
@@ -60,6 +60,22 @@ def stats_table(path, title, out):
             f.write("%-100s %7s %12.1f %10.3f %10.3f %10.3f %6s\n" % (
                 r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3,
                 float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+        if trace and os.path.exists(trace):
+            # The stats above average a kernel NAME over every launch shape the run used (the launch-shape search times a dozen);
+            # the kernel trace tells them apart: one row per (kernel, workgroups, threads, LDS bytes). The shape with the most
+            # launches is the plan the bench loops ran.
+            shapes = collections.defaultdict(list)
+            for r in csv.DictReader(open(trace)):
+                k = r["Kernel_Name"]
+                if "rz_deform_kernel" not in k and "rz_skin_instances" not in k:
+                    continue
+                wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+                grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(wg, 1)
+                name = k.replace("void (anonymous namespace)::", "").split("(")[0]
+                shapes[(name, grid, wg, int(r["LDS_Block_Size"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            f.write("# by launch shape (kernel trace of the same run): kernel | workgroups | threads | LDS bytes | calls | avg_us | min_us | max_us\n")
+            for (name, grid, wg, lds), d in sorted(shapes.items(), key=lambda kv: -len(kv[1])):
+                f.write("SHAPE %-70s %6d %5d %7d %7d %10.3f %10.3f %10.3f\n" % (name, grid, wg, lds, len(d), sum(d) / len(d), min(d), max(d)))
     return rows
 
 
@@ -76,7 +92,7 @@ rec = {}
 for name, (title, V, B, M, I) in WORK.items():
     st = os.path.join(P, "trace_" + name, "bench_kernel_stats.csv")
     if os.path.exists(st):
-        stats_table(st, title, os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.txt" % (tag, name)))
+        stats_table(st, title, os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.txt" % (tag, name)), os.path.join(P, "trace_" + name, "bench_kernel_trace.csv"))
     line = os.path.join(P, "line_%s.json" % name)
     if os.path.exists(line) and os.path.getsize(line) > 2:
         open(os.path.join(ROOT, "profiles", "%s_bench_under_rocprof_%s.json" % (tag, name)), "w").write(open(line).read())

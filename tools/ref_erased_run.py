@@ -213,9 +213,9 @@ function pinHotPath(m, tag) {
     out.set([P.x, P.y, P.z, N.x, N.y, N.z], k * 6)
   })
   dump('m2_skinned_' + tag + '.f64', out)
-  // a WIDE sample: every 7th vertex of the model (4 121 vertices over every body part, all three influence types)
+  // a WIDE sample: every 28th vertex of the model (1 031 vertices over every body part, all three influence types)
   const wide = []
-  for (let i = 0; i < V; i += 7) wide.push(i)
+  for (let i = 0; i < V; i += 28) wide.push(i)
   const wout = new Float64Array(wide.length * 6)
   wide.forEach((vi, k) => {
     const w = [0, 1, 2, 3].map((i) => sk.weights[vi * 4 + i] / 255)
@@ -328,7 +328,8 @@ def main():
     d = info["m2"]
     v = rd("m2_vertices.f32", np.float32).reshape(-1, 8)
     sl = np.r_[0:128, 14000:14064, len(v) - 64:len(v)]       # 256-vertex slices (numbers, not the model)
-    wide = np.arange(0, len(v), 7)                           # every 7th vertex: a thin sample of every body part
+    wide = np.arange(0, len(v), 28)                          # every 28th vertex (1 031 of 28 842): a thin sample of every body part
+    v = v.copy(); v[:, 6:8] = 0.0                           # texture coordinates never pass through the deformation: not stored
     np.savez_compressed(
         os.path.join(gold, "ref_c1_pose0.npz"),
         world_pose0=rd("m2_world_pose0.f32", np.float32).reshape(-1, 16),

@@ -9,7 +9,7 @@
 Both are read out of /root/reference/engine/src/engine.ts at run time and interpreted by tools/wgsl_eval.py (binary32 per
 operation, the association documented there). Inputs: the reference-produced world matrices / inverse bind / vertex, joint and
 weight slices already held in tests/golden/ref_c1_pose0.npz (tools/ref_erased_run.py). Output: tests/golden/ref_wgsl.npz —
-palettes [349,16] and deformed (position, normal) [N,6] for the 256-vertex slices and for every 7th vertex of the model, under
+palettes [349,16] and deformed (position, normal) [N,6] for the 256-vertex slices and for every 28th vertex of the model, under
 three poses, plus the SHA-256 of the two shader bodies they came from. No shader text is stored, only numbers.
 """
 import hashlib
