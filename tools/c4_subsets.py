@@ -31,6 +31,11 @@ def run(sub, blk, il, cap, fast=-1, order=1):
         t["deform_kernel_ms"] * 1e3, t["frame_ms"] * 1e3, 188.69e6 / (t["frame_ms"] * 1e-3) / 8e12 * 100), flush=True)
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "mini":
+    for cap in (256, 1024):
+        run(1, 512, 8, cap)
+    run(1, 512, 4, 1024); run(0, 512, 8, 256)
+    sys.exit(0)
 run(0, 512, 8, 256)                         # round 2's default
 for blk in (512, 256) if not quick else (512,):
     for il in (8, 16, 32, 4) if not quick else (8, 4):
