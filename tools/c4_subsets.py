@@ -43,9 +43,11 @@ for blk in (512, 256) if not quick else (512,):
             run(1, blk, il, cap)
 if len(sys.argv) > 1 and sys.argv[1] == "order":
     rows.clear()
-    for order in (1, 0):
+    for order in (1, 0, 1):
         for il in (8, 4):
             for cap in (256, 512, 1024, 2048):
+                if order == 0 and il == 4:
+                    continue
                 run(1, 512, il, cap, order=order)
 if not quick:
     run(1, 1024, 16, 256); run(1, 1024, 32, 256)
