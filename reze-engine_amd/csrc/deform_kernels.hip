@@ -925,12 +925,13 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
                     // step is only 64 vertices, so such a region spreads over many waves.
                     const uint32_t b0 = p.sp_ptr[v], b1 = p.sp_ptr[v + 1];
                     float sx = 0.f, sy = 0.f, sz = 0.f;
-                    for (uint32_t e = b0; e < b1; e += 4) {
-                        float4 ent[4];
+                    constexpr int SPU = RZ_SPARSE_INFLIGHT;      // entry loads in flight per lane and round
+                    for (uint32_t e = b0; e < b1; e += SPU) {
+                        float4 ent[SPU];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) ent[u] = e + u < b1 ? p.sp_entries[e + u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int u = 0; u < SPU; ++u) ent[u] = e + u < b1 ? p.sp_entries[e + u] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < SPU; ++u) {
                             const float w = e + u < b1 ? s_w[__float_as_uint(ent[u].w)] : 0.0f;
                             sx = fmaf(w, ent[u].x, sx); sy = fmaf(w, ent[u].y, sy); sz = fmaf(w, ent[u].z, sz);
                         }
@@ -1037,6 +1038,9 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 // in-place rounds. The palette rows a vertex gathers hold the same bits wherever they sit in LDS: outputs do not change.
 #ifndef RZ_SUB_WAVES
 #define RZ_SUB_WAVES 1
+#endif
+#ifndef RZ_SPARSE_INFLIGHT
+#define RZ_SPARSE_INFLIGHT 4
 #endif
 // Lanes past the end of a vertex run (last step only): 0 (default) = they are masked off; 1 = they re-do the run's LAST vertex
 // (clamped index: same values to the same address as the lane that owns it, in the same store instruction), so that the pose loop
