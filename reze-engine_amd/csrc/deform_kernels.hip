@@ -38,6 +38,11 @@ constexpr int kBlock = 256;
 // Ablation switches for profiling experiments exist only in the tools-only build (make ablate ->
 // tools/ablate/libreze_deform_ablate.so, -DRZ_ABLATE). In the shipped library RZ_DBG is the constant 0, the branches
 // fold away, and rz_set_tuning("dbg", ...) is rejected: no key can make rz_deform emit anything but the deformed mesh.
+// sparse morph rows: 16-byte entry loads a lane keeps in flight per round (8 / 16 measured no faster: NOTEBOOK.md R3.6)
+#ifndef RZ_SPARSE_INFLIGHT
+#define RZ_SPARSE_INFLIGHT 4
+#endif
+
 #ifdef RZ_ABLATE
 #define RZ_DBG(p) ((p).dbg)
 #else
@@ -1039,9 +1044,7 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 #ifndef RZ_SUB_WAVES
 #define RZ_SUB_WAVES 1
 #endif
-#ifndef RZ_SPARSE_INFLIGHT
-#define RZ_SPARSE_INFLIGHT 4
-#endif
+
 // Lanes past the end of a vertex run (last step only): 0 (default) = they are masked off; 1 = they re-do the run's LAST vertex
 // (clamped index: same values to the same address as the lane that owns it, in the same store instruction), so that the pose loop
 // carries no exec-masked region and the compiler interleaves the unrolled poses. Measured on C4 (tools/c4_subsets.py mini,

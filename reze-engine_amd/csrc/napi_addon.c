@@ -728,6 +728,97 @@ static napi_value fn_autotune(napi_env env, napi_callback_info info)
     return rc ? throw_rz(env, rc) : undef(env);
 }
 
+/* rz_autotune_measure -> array of { morphSplit, gridCap, instLoop, effSplit, effGrid, effInstGroup, sameAs, ms, msMin, msMax };
+ * entry 0 is the heuristic plan. rz_autotune_pick / rz_autotune_apply take such an array / one such object. */
+static const char *const kTuneInts[7] = { "morphSplit", "gridCap", "instLoop", "effSplit", "effGrid", "effInstGroup", "sameAs" };
+static const char *const kTuneFloats[3] = { "ms", "msMin", "msMax" };
+
+static int entry_from_js(napi_env env, napi_value o, rz_tune_entry *e)
+{
+    int *ints[7] = { &e->morph_split, &e->grid_cap, &e->inst_loop, &e->eff_split, &e->eff_grid, &e->eff_inst_group, &e->same_as };
+    float *floats[3] = { &e->ms, &e->ms_min, &e->ms_max };
+    napi_valuetype t;
+    if (napi_typeof(env, o, &t) != napi_ok || t != napi_object) return 0;
+    for (int k = 0; k < 7; ++k) {
+        napi_value v;
+        int32_t x;
+        if (napi_get_named_property(env, o, kTuneInts[k], &v) != napi_ok || !get_i32(env, v, &x)) return 0;
+        *ints[k] = x;
+    }
+    for (int k = 0; k < 3; ++k) {
+        napi_value v;
+        double d;
+        if (napi_get_named_property(env, o, kTuneFloats[k], &v) != napi_ok || napi_get_value_double(env, v, &d) != napi_ok) return 0;
+        *floats[k] = (float)d;
+    }
+    return 1;
+}
+
+static napi_value fn_autotune_measure(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    CTX(0);
+    uint32_t frames = 0;
+    if (argc > 1 && !get_u32(env, argv[1], &frames)) return throw_msg(env, "autotuneMeasure(ctx, frames?)");
+    rz_tune_entry tab[32];
+    int n = 0;
+    int rc = rz_autotune_measure(ctx, frames, tab, 32, &n);
+    if (rc) return throw_rz(env, rc);
+    napi_value arr;
+    if (napi_create_array_with_length(env, (size_t)n, &arr) != napi_ok) return throw_msg(env, "array alloc failed");
+    for (int i = 0; i < n; ++i) {
+        const int ints[7] = { tab[i].morph_split, tab[i].grid_cap, tab[i].inst_loop, tab[i].eff_split, tab[i].eff_grid, tab[i].eff_inst_group, tab[i].same_as };
+        const float floats[3] = { tab[i].ms, tab[i].ms_min, tab[i].ms_max };
+        napi_value o, v;
+        if (napi_create_object(env, &o) != napi_ok) return throw_msg(env, "object alloc failed");
+        for (int k = 0; k < 7; ++k) { napi_create_int32(env, ints[k], &v); napi_set_named_property(env, o, kTuneInts[k], v); }
+        for (int k = 0; k < 3; ++k) { napi_create_double(env, (double)floats[k], &v); napi_set_named_property(env, o, kTuneFloats[k], v); }
+        napi_set_element(env, arr, (uint32_t)i, o);
+    }
+    return arr;
+}
+
+static napi_value fn_autotune_pick(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    bool is_arr = false;
+    uint32_t len = 0;
+    if (napi_is_array(env, argv[0], &is_arr) != napi_ok || !is_arr || napi_get_array_length(env, argv[0], &len) != napi_ok || len < 1 || len > 32)
+        return throw_msg(env, "autotunePick(table: entry[1..32])");
+    rz_tune_entry tab[32];
+    for (uint32_t i = 0; i < len; ++i) {
+        napi_value o;
+        if (napi_get_element(env, argv[0], i, &o) != napi_ok || !entry_from_js(env, o, &tab[i])) return throw_msg(env, "autotunePick: malformed entry");
+    }
+    napi_value v;
+    napi_create_int32(env, rz_autotune_pick(tab, (int)len), &v);
+    return v;
+}
+
+static napi_value fn_autotune_apply(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    CTX(0);
+    rz_tune_entry e;
+    if (!entry_from_js(env, argv[1], &e)) return throw_msg(env, "autotuneApply(ctx, entry)");
+    int rc = rz_autotune_apply(ctx, &e);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_comm_info(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    CTX(0);
+    int n = 0, u = -1;
+    int rc = rz_comm_info(ctx, &n, &u);
+    if (rc) return throw_rz(env, rc);
+    napi_value o, v;
+    if (napi_create_object(env, &o) != napi_ok) return throw_msg(env, "object alloc failed");
+    napi_create_int32(env, n, &v); napi_set_named_property(env, o, "commCount", v);
+    napi_create_int32(env, u, &v); napi_set_named_property(env, o, "commUserRank", v);
+    return o;
+}
+
 static napi_value fn_gather_direct(napi_env env, napi_callback_info info)
 {
     ARGS(3);
@@ -777,7 +868,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "timeFrames", fn_time_frames }, { "setTuning", fn_set_tuning }, { "getTuning", fn_get_tuning },
         { "commUniqueId", fn_comm_unique_id }, { "rcclInfo", fn_rccl_info }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },
         { "readGathered", fn_read_gathered }, { "commInitAll", fn_comm_init_all }, { "allgatherAll", fn_allgather_all },
-        { "autotune", fn_autotune }, { "uploadAnimation", fn_upload_animation }, { "setPoseSampled", fn_set_pose_sampled }, { "overrideWorld", fn_override_world }, { "uploadBoneMorphs", fn_upload_bone_morphs }, { "fork", fn_fork }, { "deformPair", fn_deform_pair }, { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
+        { "autotune", fn_autotune }, { "autotuneMeasure", fn_autotune_measure }, { "autotunePick", fn_autotune_pick }, { "autotuneApply", fn_autotune_apply }, { "commInfo", fn_comm_info }, { "uploadAnimation", fn_upload_animation }, { "setPoseSampled", fn_set_pose_sampled }, { "overrideWorld", fn_override_world }, { "uploadBoneMorphs", fn_upload_bone_morphs }, { "fork", fn_fork }, { "deformPair", fn_deform_pair }, { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value f;

@@ -69,6 +69,17 @@ if (process.argv[2] === '--live') { // on a GPU box: the same with a LIVE contex
   a.destroy(fk)
   a.uploadSkeleton(ctx, ib)                          // the lender owns its data again
   a.setPose(ctx, ib, null); a.deform(ctx)           // still usable
+  // the launch-shape search as a table (rz_autotune_measure / _pick / _apply), and the communicator query without a communicator
+  const tab = a.autotuneMeasure(ctx, 5)
+  if (!Array.isArray(tab) || tab.length < 2 || !(tab[0].ms > 0) || tab[0].sameAs !== -1) throw new Error('autotuneMeasure: bad table ' + JSON.stringify(tab && tab[0]))
+  const pk = a.autotunePick(tab)
+  if (!(pk >= 0 && pk < tab.length)) throw new Error('autotunePick out of range')
+  a.autotuneApply(ctx, tab[pk]); a.deform(ctx)
+  let bad = 0
+  try { a.autotuneApply(ctx, { morphSplit: 3 }) } catch (e) { bad += e instanceof Error ? 1 : 0 }
+  try { a.autotunePick([]) } catch (e) { bad += e instanceof Error ? 1 : 0 }
+  try { a.commInfo(ctx) } catch (e) { bad += e instanceof Error ? 1 : 0 }
+  if (bad !== 3) throw new Error('malformed autotune entries / commInfo without a communicator must throw (' + bad + '/3)')
   const pos = new Float32Array(V * 3), nrm = new Float32Array(V * 3)
   a.read(ctx, 0, 0, V, pos, nrm)
   if (!pos.every(Number.isFinite)) throw new Error('context damaged by the misuse')

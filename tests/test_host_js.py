@@ -452,7 +452,8 @@ def test_addon_exports_and_loud_failure_without_gpu():
     for k in ("create", "destroy", "uploadMesh", "uploadSkeleton", "uploadMorphsDense", "uploadMorphsSparse", "setInstances",
               "setPose", "deform", "sync", "read", "timeFrames", "commUniqueId", "commInit", "allgather", "shardRange",
               "uploadSkeletonTopology", "setPoseLocal", "readWorld", "autotune", "gatherDirect", "gatherFence", "readGathered",
-              "overrideWorld", "rcclInfo", "uploadAnimation", "setPoseSampled", "uploadBoneMorphs", "fork", "deformPair"):
+              "overrideWorld", "rcclInfo", "uploadAnimation", "setPoseSampled", "uploadBoneMorphs", "fork", "deformPair",
+              "autotuneMeasure", "autotunePick", "autotuneApply", "commInfo"):
         assert k in r["keys"], k
     import re
     header = open(os.path.join(ROOT, "include", "reze_deform.h")).read()
