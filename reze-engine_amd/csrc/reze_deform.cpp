@@ -574,7 +574,7 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
 
 // Launch shape of an instanced, morph-free crowd frame (rz_skin_instances_kernel): G poses per workgroup share one decode of each
 // vertex; the grid is (vertex runs, pose groups), `total` workgroups in all.
-struct InstShape { int G, blk; bool want_in_kernel; uint32_t per, runs; };
+struct InstShape { int G, blk, blk_full; bool want_in_kernel; uint32_t per, runs; };
 
 void inst_runs(const rz_ctx *c, int G, int blk, bool for_subsets, uint32_t *per, uint32_t *runs)
 {
@@ -600,7 +600,13 @@ bool inst_shape(const rz_ctx *c, InstShape *s)
     const bool epilogues = c->edge != nullptr || c->aabb_on;   // only the generic kernel carries the fused consumers
     if (!(c->morph_mode == 0 && c->I > 1 && c->t_instloop != 0 && c->t_instloop != 9 && !epilogues) || c->B == 0 || c->V == 0) return false;
     s->want_in_kernel = c->t_fast != 0 && !c->pose_local;
-    s->blk = c->t_instblock == 256 || c->t_instblock == 512 || c->t_instblock == 1024 ? c->t_instblock : (s->want_in_kernel ? 512 : 256);
+    // workgroup size. Whole palettes: 512 threads for the one-launch frame (one workgroup of 8 waves per CU shares the 102 KB
+    // group), 256 behind rz_prep_kernel / rz_fk_kernel (two workgroups of 80 KB each: measured best in round 2). Bone subsets
+    // (30 KB): 512 threads in both forms — with finished rows staged the 512-thread kernel runs C4 in 32.1 us against 34.5 us
+    // for 256 threads (tools/c4_subsets.py, fast = 0 rows of profiles/r3_c4_subsets.txt).
+    const bool forced = c->t_instblock == 256 || c->t_instblock == 512 || c->t_instblock == 1024;
+    s->blk_full = forced ? c->t_instblock : (s->want_in_kernel ? 512 : 256);
+    s->blk = forced ? c->t_instblock : (c->t_subsets != 0 ? 512 : s->blk_full);
     s->G = (int)std::min<uint32_t>(c->t_instloop > 0 ? (uint32_t)c->t_instloop : 8u, c->I);
     if (s->G < 2) return false;
     inst_runs(c, s->G, s->blk, c->t_subsets != 0, &s->per, &s->runs);
@@ -704,6 +710,8 @@ Plan make_plan(const rz_ctx *c)
             }
         }
         if (!sub) {
+            const int blk = is.blk_full;
+            const uint32_t lds_budget = (blk == 256 ? 80u : 156u) * 1024u;
             const bool in_kernel = is.want_in_kernel && c->B <= (uint32_t)blk;     // the in-place product gives every bone its own thread
             const uint32_t g_lds = lds_budget / (c->B * (in_kernel ? 64u : 48u));
             int G = (int)std::min<uint32_t>((uint32_t)is.G, g_lds);
