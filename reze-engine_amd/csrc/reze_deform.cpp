@@ -2134,9 +2134,13 @@ int rz_autotune_measure(rz_ctx *c, uint32_t frames, rz_tune_entry *table, int ca
         // the GPU reaches its sustained clocks only after a while of work (measured: the first timed round of the first
         // candidate came out 15-20 % slow on a cold device, which is enough to move a median of three): run the heuristic
         // plan for ~0.25 s first, untimed
+        c->t_split = cands[0].morph_split; c->t_grid_cap = cands[0].grid_cap; c->t_instloop = instanced ? cands[0].inst_loop : keep_loop;
+        Plan warm;
+        rc = frame_plan(c, &warm);      // (a crowd's run lists belong to ONE launch shape: bring them back to entry 0's)
+        if (rc == RZ_OK) rc = set_overlap(c, want_overlap(c, warm));
         const auto t0 = std::chrono::steady_clock::now();
         while (rc == RZ_OK && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(250)) {
-            for (uint32_t f = 0; f < 64 && rc == RZ_OK; ++f) rc = run_frame(c, plans[0]);
+            for (uint32_t f = 0; f < 64 && rc == RZ_OK; ++f) rc = run_frame(c, warm);
             if (rc == RZ_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(RZ_ERR_HIP, "rz_autotune_measure: warm-up failed");
         }
     }
