@@ -61,3 +61,21 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"\boracle[/.]|from oracle|import oracle|rzo_|librz_oracle", src):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_bench_refuses_a_mismatched_world_size_and_never_prints_a_line_without_gpus():
+    """bench.py's launcher logic runs before anything touches a GPU, so it is testable here: a world size that is not --gpus
+    is refused (exit 3); `--gpus 2` run plainly launches its own two ranks, which — on a box without GPUs — fail loudly:
+    non-zero status and NO JSON line (never a quiet N = 1)."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 3 and b"refusing" in p.stderr and not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    import torch
+    if not torch.cuda.is_available():
+        env2 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        p = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--no-cpu-baseline"], env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode != 0 and b"re-executing as 2 ranks" in p.stderr
+        assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
