@@ -1038,7 +1038,7 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 // SUB = bone-subset form. A vertex run names only a few of the skeleton's bones (PMX meshes are bone-local: the synthetic C4
 // mesh's 3 750-vertex runs touch ~34 of 200), and rz_run_subsets_kernel has listed them per run and rewritten the joints as
 // slots of that list. The workgroup stages ONLY those bones of its G poses: 8 x 34 matrices instead of 8 x 200 — the front of
-// every workgroup (LDS-DMA + palette product, during which the CU stores nothing) shrinks from 4.3 us to under 1 us, and the
+// every workgroup (LDS-DMA + palette product, during which the CU stores nothing) shrinks from 2.9 us to 1.3 us (profiles/r3_c4_front.txt), and the
 // group's LDS footprint from 102 KB to 30 KB. World matrices are staged behind the palette region, so the product needs no
 // in-place rounds. The palette rows a vertex gathers hold the same bits wherever they sit in LDS: outputs do not change.
 #ifndef RZ_SUB_WAVES
@@ -1082,7 +1082,7 @@ __global__ void __launch_bounds__(BLOCK, (SUB && BLOCK == 512) ? RZ_SUB_WAVES : 
         // one-launch frame: the listed bones' world matrices, 4 float4 per bone, into the staging region.
         // Either way element e of the linear LDS image is (pose g, slot s, cell k): a per-lane global address, a linear LDS one.
         const int epb = p.dma ? 3 : 4;
-        const int n = ng * ns * epb;
+        const int n = RZ_DBG(p) == 8 ? 0 : ng * ns * epb;           // dbg 8 (tools-only build): neither staging nor product
         const float4 *src = p.dma ? p.palette + (size_t)inst0 * rows : reinterpret_cast<const float4 *>(p.world) + (size_t)inst0 * p.B * 4;
         float4 *dst = p.dma ? pal : stage;
         for (int c = wave * 64; c < n; c += BLOCK) {
@@ -1148,7 +1148,7 @@ __global__ void __launch_bounds__(BLOCK, (SUB && BLOCK == 512) ? RZ_SUB_WAVES : 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // palettes / world matrices (and the first vertex) have landed
     __syncthreads();
     if constexpr (SUB) {
-        if (!p.dma) {
+        if (!p.dma && RZ_DBG(p) != 8) {
             // palette rows of the listed bones: slot (g, s) = rows 0..2 of world * inverseBind (engine.ts:926-928), the same
             // packed FMA chain as below and as rz_prep_kernel — out of the staging region, into the palette region: no hazard,
             // one barrier. With ns ~ 34 and 512 threads every (pose, bone) pair has a thread of its own.

@@ -690,7 +690,7 @@ Plan make_plan(const rz_ctx *c)
         // frame (fast = 0 forces rz_prep_kernel in front). Device-solved poses: rz_fk_kernel has written the palettes already,
         // the skin kernel copies them in (48-byte rows, LDS-DMA).
         // What is staged: by default only the bones the workgroup's vertex run names (bone-subset form) — on C4
-        // ~34 of 200 bones, 30 KB of LDS instead of 102 KB and a front of < 1 us instead of 4.3 us per workgroup. It needs the
+        // ~34 of 200 bones, 30 KB of LDS instead of 102 KB and a front of 1.3 us instead of 2.9 us per workgroup. It needs the
         // run lists of exactly this launch shape (ensure_run_subsets, called by every entry point that launches frames) and
         // is a gain only when the largest list is shorter than the skeleton; otherwise the whole palette is staged: 64-byte
         // slots re-packed in place for the one-launch frame, which wants B <= block threads and, at 8 poses x 200 bones =
