@@ -675,6 +675,13 @@ Plan make_plan(const rz_ctx *c)
         const uint32_t run = round_up(pl.quads_per_wave * 4, 64);
         if (c->t_outcap > 0) pl.out_cap = std::max(std::min<uint32_t>(round_up((uint32_t)c->t_outcap, 64), 640), step);
         else if (c->t_outcap < 0 && run <= 640) pl.out_cap = std::max(run, step);
+        // a skeleton near the LDS limit (3 242 bones = 152 KB of palette) leaves no room for the write-batching buffer: do without
+        if (pl.out_cap) {
+            RzDeformParams q;
+            memset(&q, 0, sizeof q);
+            q.B = (int)c->B; q.M = (int)c->M; q.Mpad = (int)c->Mpad; q.out_cap = pl.out_cap; q.fk_on = pl.fuse_fk ? 1 : 0;
+            if (rz_deform_lds_bytes(q, v) > 160 * 1024) pl.out_cap = 0;
+        }
     }
     // instanced, morph-free frames: G poses per workgroup share one decode of each vertex, their palettes live in LDS.
     // Where the palettes come from (measured on C4, tools/ablate_c4.py, frame = everything a frame launches):

@@ -281,3 +281,79 @@ def test_pose_prefetch_stages_the_next_pose_and_never_a_wrong_one(rz, oracle, mo
     pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], w2, mesh["inv_bind"])
     assert_parity(pg, ng, pr, nr, "after the morph set was dropped")
     c.close()
+
+
+def test_largest_skeleton_the_lds_palette_holds(rz, oracle):
+    """Maximum sizes: 3 242 bones is what rz_upload_skeleton admits (48 B per bone + 8 KB of work area in 160 KB of LDS); a frame
+    of such a skeleton must RUN — single character (with and without dense morphs) and as a crowd (bone subsets are what makes a
+    crowd of it fit at all) — and one bone more must be refused at upload, not at the first frame."""
+    B, V = 3242, 40000
+    mesh = synth.make_mesh(V, B, seed=31)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    c.set_pose(mesh["world"])
+    c.deform()
+    pg, ng = c.read()
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"], threads=4)
+    assert_parity(pg, ng, pr, nr, "3242 bones")
+    deltas, mw = synth.make_morphs_dense(V, 6, seed=32)
+    c.upload_morphs_dense(deltas)
+    c.set_pose(mesh["world"], mw)
+    c.deform()
+    pg, ng = c.read()
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"], deltas, mw, threads=4)
+    assert_parity(pg, ng, pr, nr, "3242 bones + dense morphs")
+    c.upload_morphs_dense(None)
+    worlds = _poses(mesh, B, 3, seed=33)
+    c.set_instances(3)
+    c.set_pose(worlds)
+    c.deform()
+    for k in range(3):
+        pg, ng = c.read(instance=k)
+        pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[k], mesh["inv_bind"], threads=4)
+        assert_parity(pg, ng, pr, nr, "3242-bone crowd, instance %d" % k)
+    with pytest.raises(rz.capi.RzError):
+        c.upload_skeleton(np.tile(np.eye(4, dtype=np.float32).reshape(1, 16), (3243, 1)))
+    c.close()
+
+
+def test_sixteen_million_vertices_index_arithmetic(rz, oracle):
+    """Maximum sizes: a mesh beyond 2^24 vertices (ragged count) — byte offsets of the planes, of the morph targets and of the
+    packed outputs pass 2^32; checked against the oracle on the head, the tail and a strided sample, with and without dense
+    morphs, plus the identity-pose property over the WHOLE mesh (size-independent)."""
+    V, B = (1 << 24) + 43, 64
+    rng = np.random.default_rng(41)
+    small = synth.make_mesh(4096, B, seed=42)
+    pos = rng.random((V, 3), dtype=np.float32) * 10 - 5
+    nrm = rng.standard_normal((V, 3), dtype=np.float32)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-12)
+    reps = V // 4096 + 1
+    joints = np.tile(small["joints"], (reps, 1))[:V]
+    weights = np.tile(small["weights"], (reps, 1))[:V]
+    c = rz.DeformContext(0)
+    c.upload_mesh(pos, nrm, joints, weights)
+    c.upload_skeleton(small["inv_bind"])
+    pick = np.unique(np.concatenate([np.arange(0, 3000), np.arange(V - 3000, V), np.arange(0, V, 9973)]))
+
+    def check(deltas, mw, what):
+        c.set_pose(small["world"], mw)
+        c.deform()
+        pg, ng = c.read()
+        d = None if deltas is None else np.ascontiguousarray(deltas[:, pick])
+        pr, nr = oracle.deform(pos[pick], nrm[pick], joints[pick], weights[pick], small["world"], small["inv_bind"], d, mw, threads=8)
+        assert_parity(pg[pick], ng[pick], pr, nr, what)
+        assert np.isfinite(pg).all() and np.isfinite(ng).all()
+        return pg
+
+    check(None, None, "16 M vertices")
+    q = np.zeros((B, 4), np.float32)
+    q[:, 3] = 1
+    c.set_pose(synth.fk_world(small["parents"], small["bind"], q))
+    c.deform()
+    pg, ng = c.read()
+    assert np.abs(pg - pos).max() <= 2e-5 and np.abs(ng - nrm).max() <= 1e-6, "identity pose over the whole 16 M-vertex mesh"
+    deltas = (rng.random((2, V, 3), dtype=np.float32) - 0.5) * 0.1
+    c.upload_morphs_dense(deltas)
+    check(deltas, np.array([0.75, 0.5], np.float32), "16 M vertices + 2 dense morphs")
+    c.close()
