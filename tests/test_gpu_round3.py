@@ -357,3 +357,28 @@ def test_sixteen_million_vertices_index_arithmetic(rz, oracle):
     c.upload_morphs_dense(deltas)
     check(deltas, np.array([0.75, 0.5], np.float32), "16 M vertices + 2 dense morphs")
     c.close()
+
+
+def test_thousands_of_instances_of_a_tiny_mesh(rz, oracle):
+    """Maximum sizes on the instance axis: 4 099 poses (a prime: the last pose group is partial) of a 257-vertex mesh — more pose
+    groups than workgroup slots, runs shorter than a workgroup; both crowd forms, oracle parity on a sample, bit-identity between
+    the forms on every instance."""
+    V, B, I = 257, 10, 4099
+    mesh = synth.make_mesh(V, B, seed=51)
+    rng = np.random.default_rng(52)
+    base = _poses(mesh, B, 16, seed=53)
+    worlds = base[rng.integers(0, 16, size=I)]
+    c = _crowd(rz, mesh, worlds)
+    c.deform()
+    first = c.get_tuning("effective_subsets")
+    a = [c.read(instance=k) for k in range(0, I, 97)] + [c.read(instance=I - 1)]
+    c.set_tuning(inst_subsets=0 if first else 1)
+    c.deform()
+    b = [c.read(instance=k) for k in range(0, I, 97)] + [c.read(instance=I - 1)]
+    for (pa, na), (pb, nb) in zip(a, b):
+        assert np.array_equal(pa, pb) and np.array_equal(na, nb)
+    for k in (0, 1234, I - 1):
+        pg, ng = c.read(instance=k)
+        pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], worlds[k], mesh["inv_bind"])
+        assert_parity(pg, ng, pr, nr, "instance %d of %d" % (k, I))
+    c.close()
