@@ -1056,6 +1056,10 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 #ifndef RZ_POSE_UNROLL
 #define RZ_POSE_UNROLL 2
 #endif
+// experiment switch: raise the wave's issue priority around its two output stores (NOTEBOOK.md R3.9)
+#ifndef RZ_CROWD_STOREPRIO
+#define RZ_CROWD_STOREPRIO 0
+#endif
 template <int BLOCK, bool NTS, bool SUB>
 __global__ void __launch_bounds__(BLOCK, (SUB && BLOCK == 512) ? RZ_SUB_WAVES : 1) rz_skin_instances_kernel(const RzDeformParams p, int G, int n_inst,
                                                                   uint32_t verts_per_wg)
@@ -1301,8 +1305,14 @@ __global__ void __launch_bounds__(BLOCK, (SUB && BLOCK == 512) ? RZ_SUB_WAVES : 
                 const bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
                 const float rl = __builtin_amdgcn_rsqf(good ? l2 : 1.0f);
                 if (live && (RZ_DBG(p) != 1 || l2 == 1234.5f)) {   // dbg 1 (tools-only build): compute without the output stream
+#if RZ_CROWD_STOREPRIO
+                    __builtin_amdgcn_s_setprio(3);
+#endif
                     st3<NTS>(dp, q[0].x, q[1].x, q[2].x);
                     st3<NTS>(dn, good ? tx * rl : nx, good ? ty * rl : ny, good ? tz * rl : nz);
+#if RZ_CROWD_STOREPRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                 }
                 pg += lrows;
                 dp += Vp * 3;
