@@ -190,7 +190,12 @@ def main():
         sys.exit(3)
 
     import torch
-    if world_size > 1 and not args.share_gpu and torch.cuda.device_count() < world_size:
+    # a launcher may hand every rank ITS OWN GPU through *_VISIBLE_DEVICES (each rank then sees exactly one device, index 0)
+    isolated = (world_size > 1 and torch.cuda.device_count() == 1 and
+                any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")))
+    if isolated:
+        local_rank = 0
+    elif world_size > 1 and not args.share_gpu and torch.cuda.device_count() < world_size:
         if rank == 0:
             sys.stderr.write("[bench] %d ranks but only %d GPU(s) visible: one process per GPU (--share-gpu rehearses N > 1 on fewer GPUs)\n"
                              % (world_size, torch.cuda.device_count()))
