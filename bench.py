@@ -213,6 +213,18 @@ def main():
             dist.init_process_group(backend="gloo")
     elif torch.cuda.is_available():
         torch.cuda.set_device(0)
+    if dist is not None and world_size > 1 and not args.share_gpu:
+        # one PHYSICAL GPU per rank: two ranks that resolve to the same device (a global *_VISIBLE_DEVICES = 0 on a one-GPU box
+        # looks like per-rank isolation from inside one rank) would quietly halve each other's numbers
+        pr = torch.cuda.get_device_properties(local_rank)
+        me = (str(getattr(pr, "uuid", "")), getattr(pr, "pci_domain_id", None), getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", None))
+        ids = [None] * world_size
+        dist.all_gather_object(ids, me)
+        if len(set(ids)) != world_size:
+            if rank == 0:
+                sys.stderr.write("[bench] %d ranks but they resolve to %d distinct GPU(s): one process per GPU (--share-gpu rehearses N > 1 on fewer GPUs)\n"
+                                 % (world_size, len(set(ids))))
+            sys.exit(4)
 
     import reze_engine_amd as rz
     from reze_engine_amd import synth
