@@ -111,6 +111,13 @@ int rccl_bind()
 
 }  // namespace
 
+// Slots of the zero-copy pose ring. One hipEventRecord per RZ_ZC_SLOTS / 2 uploads guards slot reuse, and a record costs ~1.4 us of
+// stream time: measured on a 1/8 shard of C5 (tools/live_shard.py, per-frame-pose loop over the resident replay): 8 slots +0.86 us
+// per frame, 16 slots +0.50 us, 32 slots +0.37 us. 32 x <= 256 KB of pinned memory per context.
+#ifndef RZ_ZC_SLOTS
+#define RZ_ZC_SLOTS 32
+#endif
+
 struct rz_ctx {
     int device = 0;
     int n_cu = 256;
@@ -230,9 +237,9 @@ struct rz_ctx {
     // pose block for the frames that replay the pose); anything that needs a device-resident pose first (rz_prep_kernel)
     // gets it through make_resident(). Measured on MI355X (tools/uploadbench): a 16.6 KB hipMemcpyAsync in front of a
     // frame costs 18 us, two of <= 16 KB 9.5 us, reading the pinned slot from the kernel 7 us with the loads fully exposed.
-    // A slot is reused 8 uploads later; one event per FOUR uploads (recorded on the compute stream at upload time) proves
+    // A slot is reused kZcSlots (32) uploads later; one event per kZcSlots / 2 uploads (recorded on the compute stream at upload time) proves
     // its readers are done, so there is no per-frame marker either.
-    static constexpr int kZcSlots = 8;
+    static constexpr int kZcSlots = RZ_ZC_SLOTS;    // a slot is reused kZcSlots uploads later; one event per kZcSlots / 2 uploads guards the reuse
     void *zc_host[kZcSlots] = {};
     void *zc_dev[kZcSlots] = {};
     size_t zc_bytes = 0;
@@ -1379,17 +1386,19 @@ static int zc_acquire(rz_ctx *c, size_t need, int *slot_out)
         c->zc_cur = -1;
     }
     const uint64_t u = c->zc_uploads;
-    if (u % 4 == 0) {
-        const int e = (int)((u / 4) & 1);
+    constexpr uint64_t P = rz_ctx::kZcSlots / 2;        // event period
+    if (u % P == 0) {
+        const int e = (int)((u / P) & 1);
         if (!c->zc_ev[e]) HIP_TRY(hipEventCreateWithFlags(&c->zc_ev[e], hipEventDisableTiming));
         HIP_TRY(hipEventRecord(c->zc_ev[e], c->stream));      // everything launched before upload u, i.e. every reader of uploads < u
         c->zc_ev_seq[e] = u;
     }
     if (u >= (uint64_t)rz_ctx::kZcSlots) {
-        // previous tenant = upload u - 8, read by frames launched before upload u - 7: covered by the event of the first
-        // multiple of 4 that is >= u - 7 (it is <= u - 4, so it was recorded at least four uploads ago)
-        const uint64_t cand = (u - 7 + 3) / 4 * 4;
-        const int e = (int)((cand / 4) & 1);
+        // previous tenant = upload u - 2P, read by frames launched before upload u - 2P + 1 (and, speculatively, by the helper
+        // workgroup of the frame before it): covered by the event of the first multiple of P that is >= u - 2P + 1 — it is
+        // <= u - P, so it was recorded at least P uploads ago, and it is the older of the two events kept
+        const uint64_t cand = (u - (2 * P - 1) + (P - 1)) / P * P;
+        const int e = (int)((cand / P) & 1);
         if (c->zc_ev_seq[e] != cand) return fail(RZ_ERR_HIP, "zero-copy ring bookkeeping is inconsistent (upload %llu)", (unsigned long long)u);
         if (int r = poll_event(c->zc_ev[e], "zero-copy pose ring")) return r;
     }
