@@ -1041,27 +1041,10 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 // every workgroup (LDS-DMA + palette product, during which the CU stores nothing) shrinks from 2.9 us to 1.3 us (profiles/r3_c4_front.txt), and the
 // group's LDS footprint from 102 KB to 30 KB. World matrices are staged behind the palette region, so the product needs no
 // in-place rounds. The palette rows a vertex gathers hold the same bits wherever they sit in LDS: outputs do not change.
-#ifndef RZ_SUB_WAVES
-#define RZ_SUB_WAVES 1
-#endif
-
-// Lanes past the end of a vertex run (last step only): 0 (default) = they are masked off; 1 = they re-do the run's LAST vertex
-// (clamped index: same values to the same address as the lane that owns it, in the same store instruction), so that the pose loop
-// carries no exec-masked region and the compiler interleaves the unrolled poses. Measured on C4 (tools/c4_subsets.py mini,
-// NOTEBOOK.md R3.4): the branch-free form is SLOWER (33.6 vs 33.2 us; four poses unrolled: 35.0 us) — the kernel is bound by its
-// output stream, and interleaving the math of several poses bunches their stores. Kept as a build-time experiment switch.
-#ifndef RZ_CROWD_CLAMP
-#define RZ_CROWD_CLAMP 0
-#endif
-#ifndef RZ_POSE_UNROLL
-#define RZ_POSE_UNROLL 2
-#endif
-// experiment switch: raise the wave's issue priority around its two output stores (NOTEBOOK.md R3.9)
-#ifndef RZ_CROWD_STOREPRIO
-#define RZ_CROWD_STOREPRIO 0
-#endif
+// (Tried and measured slower or without effect, then removed again — NOTEBOOK.md R3.1 / R3.4 / R3.9: forcing three workgroups per CU
+// (80 VGPRs spill), a branch-free pose loop with clamped tail lanes, four poses unrolled, raised wave priority around the stores.)
 template <int BLOCK, bool NTS, bool SUB>
-__global__ void __launch_bounds__(BLOCK, (SUB && BLOCK == 512) ? RZ_SUB_WAVES : 1) rz_skin_instances_kernel(const RzDeformParams p, int G, int n_inst,
+__global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeformParams p, int G, int n_inst,
                                                                   uint32_t verts_per_wg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1138,16 +1121,13 @@ __global__ void __launch_bounds__(BLOCK, (SUB && BLOCK == 512) ? RZ_SUB_WAVES : 
     // software-pipelined vertex loop: the next vertex's nine attribute loads are issued before the current
     // vertex's pose loop, so their L2 latency hides behind the poses' LDS gathers + FMA
     uint32_t v = v_begin + tid;
-    constexpr bool CLAMP = RZ_CROWD_CLAMP != 0;
-    const uint32_t v_last = v_end - 1;              // (a run is never empty)
     float x = 0, y = 0, z = 0, nx = 0, ny = 0, nz = 0;
     uint32_t j01 = 0, j23 = 0, wq = 0;
     const uint32_t *jp01 = SUB ? p.rj01 : p.joints01, *jp23 = SUB ? p.rj23 : p.joints23;     // SUB: joints as slots of the run's list
-    if (CLAMP || v < v_end) {
-        const uint32_t vl = CLAMP ? min(v, v_last) : v;
-        x = p.geom[0 * Vp + vl]; y = p.geom[1 * Vp + vl]; z = p.geom[2 * Vp + vl];
-        nx = p.geom[3 * Vp + vl]; ny = p.geom[4 * Vp + vl]; nz = p.geom[5 * Vp + vl];
-        j01 = jp01[vl]; j23 = jp23[vl]; wq = p.weights[vl];
+    if (v < v_end) {
+        x = p.geom[0 * Vp + v]; y = p.geom[1 * Vp + v]; z = p.geom[2 * Vp + v];
+        nx = p.geom[3 * Vp + v]; ny = p.geom[4 * Vp + v]; nz = p.geom[5 * Vp + v];
+        j01 = jp01[v]; j23 = jp23[v]; wq = p.weights[v];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // palettes / world matrices (and the first vertex) have landed
     __syncthreads();
@@ -1232,15 +1212,12 @@ __global__ void __launch_bounds__(BLOCK, (SUB && BLOCK == 512) ? RZ_SUB_WAVES : 
         const uint32_t vn = v + BLOCK;
         float xn = 0, yn = 0, zn = 0, nxn = 0, nyn = 0, nzn = 0;
         uint32_t j01n = 0, j23n = 0, wqn = 0;
-        if (CLAMP ? (vb + BLOCK < v_end) : (vn < v_end)) {       // CLAMP: workgroup-uniform — is there a next step at all
-            const uint32_t vl = CLAMP ? min(vn, v_last) : vn;
-            xn = p.geom[0 * Vp + vl]; yn = p.geom[1 * Vp + vl]; zn = p.geom[2 * Vp + vl];
-            nxn = p.geom[3 * Vp + vl]; nyn = p.geom[4 * Vp + vl]; nzn = p.geom[5 * Vp + vl];
-            j01n = jp01[vl]; j23n = jp23[vl]; wqn = p.weights[vl];
+        if (vn < v_end) {
+            xn = p.geom[0 * Vp + vn]; yn = p.geom[1 * Vp + vn]; zn = p.geom[2 * Vp + vn];
+            nxn = p.geom[3 * Vp + vn]; nyn = p.geom[4 * Vp + vn]; nzn = p.geom[5 * Vp + vn];
+            j01n = jp01[vn]; j23n = jp23[vn]; wqn = p.weights[vn];
         }
-        const bool live_real = v < v_end;
-        const bool live = CLAMP || live_real;
-        const uint32_t vs = CLAMP ? min(v, v_last) : v;     // where this lane's results go
+        const bool live = v < v_end;
         // decode once per vertex (engine.ts:255-258)
         const uint32_t b0 = wq & 255u, b1 = (wq >> 8) & 255u, b2 = (wq >> 16) & 255u, b3 = wq >> 24;
         const uint32_t isum = b0 + b1 + b2 + b3;
@@ -1250,8 +1227,8 @@ __global__ void __launch_bounds__(BLOCK, (SUB && BLOCK == 512) ? RZ_SUB_WAVES : 
         const uint32_t jmax = SUB ? 0xffffu : bmax;     // SUB: slots are in range by construction
         const uint32_t o0 = min(j01 & 0xffffu, jmax) * rstride, o1 = min(j01 >> 16, jmax) * rstride,
                        o2 = min(j23 & 0xffffu, jmax) * rstride, o3 = min(j23 >> 16, jmax) * rstride;
-        float *dp = p.out_pos + ((size_t)inst0 * Vp + vs) * 3;
-        float *dn = p.out_nrm + ((size_t)inst0 * Vp + vs) * 3;
+        float *dp = p.out_pos + ((size_t)inst0 * Vp + v) * 3;
+        float *dn = p.out_nrm + ((size_t)inst0 * Vp + v) * 3;
         // Packed-math form (v_pk_fma_f32 = two f32 FMAs per lane per instruction): palette rows are blended as
         // (xy),(zw) register pairs straight out of ds_read_b128, and position + normal are transformed together
         // as the pairs (x,nx),(y,ny),(z,nz), so one FMA chain yields (p_r, n_r) for row r. Every chain is spelled out
@@ -1274,7 +1251,7 @@ __global__ void __launch_bounds__(BLOCK, (SUB && BLOCK == 512) ? RZ_SUB_WAVES : 
         auto pose_loop = [&](auto nb_tag) {
             constexpr int NB = decltype(nb_tag)::value;
             const float4 *pg = pal;
-#pragma unroll RZ_POSE_UNROLL
+#pragma unroll 2
             for (int g = 0; g < ng; ++g) {
                 f2 r[3][2];
 #pragma unroll
@@ -1305,14 +1282,8 @@ __global__ void __launch_bounds__(BLOCK, (SUB && BLOCK == 512) ? RZ_SUB_WAVES : 
                 const bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
                 const float rl = __builtin_amdgcn_rsqf(good ? l2 : 1.0f);
                 if (live && (RZ_DBG(p) != 1 || l2 == 1234.5f)) {   // dbg 1 (tools-only build): compute without the output stream
-#if RZ_CROWD_STOREPRIO
-                    __builtin_amdgcn_s_setprio(3);
-#endif
                     st3<NTS>(dp, q[0].x, q[1].x, q[2].x);
                     st3<NTS>(dn, good ? tx * rl : nx, good ? ty * rl : ny, good ? tz * rl : nz);
-#if RZ_CROWD_STOREPRIO
-                    __builtin_amdgcn_s_setprio(0);
-#endif
                 }
                 pg += lrows;
                 dp += Vp * 3;
@@ -1321,7 +1292,7 @@ __global__ void __launch_bounds__(BLOCK, (SUB && BLOCK == 512) ? RZ_SUB_WAVES : 
         };
         const bool any34 = __ballot((wq >> 16) != 0u) != 0ull;
         const bool any2 = __ballot(((wq >> 8) & 255u) != 0u) != 0ull;
-        if (__ballot(live_real) == 0ull) {}                // a wave past the end of the run (last step only)
+        if (__ballot(live) == 0ull) {}                     // a wave past the end of the run (last step only)
         else if (any34) pose_loop(std::integral_constant<int, 4>{});
         else if (any2) pose_loop(std::integral_constant<int, 2>{});
         else pose_loop(std::integral_constant<int, 1>{});
