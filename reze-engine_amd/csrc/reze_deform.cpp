@@ -724,15 +724,15 @@ Plan make_plan(const rz_ctx *c)
             }
         }
         if (!sub) {
-            const int blk = is.blk_full;
-            const uint32_t lds_budget = (blk == 256 ? 80u : 156u) * 1024u;
-            const bool in_kernel = is.want_in_kernel && c->B <= (uint32_t)blk;     // the in-place product gives every bone its own thread
-            const uint32_t g_lds = lds_budget / (c->B * (in_kernel ? 64u : 48u));
+            const int blk_f = is.blk_full;
+            const uint32_t budget_f = (blk_f == 256 ? 80u : 156u) * 1024u;
+            const bool in_kernel = is.want_in_kernel && c->B <= (uint32_t)blk_f;   // the in-place product gives every bone its own thread
+            const uint32_t g_lds = budget_f / (c->B * (in_kernel ? 64u : 48u));
             int G = (int)std::min<uint32_t>((uint32_t)is.G, g_lds);
             if (G >= 2) {
                 uint32_t per = 0, runs = 0;
-                inst_runs(c, G, blk, false, &per, &runs);
-                pl.inst_group = G; pl.inst_block = blk; pl.verts_per_wg = per; pl.grid_x = runs;
+                inst_runs(c, G, blk_f, false, &per, &runs);
+                pl.inst_group = G; pl.inst_block = blk_f; pl.verts_per_wg = per; pl.grid_x = runs;
                 pl.prep = !in_kernel; pl.dma = !in_kernel;
                 pl.inst_lds = rz_skin_instances_lds_bytes(G, c->B, !in_kernel, false);
             }
