@@ -323,7 +323,7 @@ def main():
     # ---- launch-shape search (untimed setup, like a GEMM library's find mode) ----
     # Every rank measures the same candidate list on its own shard; the tables are reduced with MAX over the ranks (the frame
     # time of a sharded mesh is its slowest GPU's) and every rank adopts the SAME entry: the heuristic plan unless a
-    # candidate beats it by >= 2 % (rz_autotune_pick). config.autotune_table carries the reduced table.
+    # candidate beats it by >= 2 % with non-overlapping round ranges (rz_autotune_pick). config.autotune_table carries the reduced table.
     def clock_warm(seconds):
         # Setup, untimed: bring the GPU to its sustained clock / power state. Measured on MI355X: the first ~2 s of work after
         # idle run 7-8 % slower (C4 one-launch frame 38.5 us cold, 35.8 us after 3 s of frames), and the driver may ask for as
@@ -692,7 +692,7 @@ def main():
                                else ("external launcher (WORLD_SIZE in the environment)" if "WORLD_SIZE" in os.environ else "single process"),
                 "bone_hierarchy_solve": ("device (motion sampling + hierarchy solve in rz_fk_kernel)" if args.device_sampling else "device (rz_fk_kernel)") if args.device_fk else "host",
                 "autotune": tuned is not None,
-                "autotune_rule": "heuristic plan (entry 0) unless a candidate's median-of-5-rounds time, MAX over ranks, is >= 2 % faster; every rank adopts the same entry",
+                "autotune_rule": "heuristic plan (entry 0) unless a candidate's median-of-5-rounds time, MAX over ranks, is >= 2 % faster and its slowest round beats the heuristic's fastest; every rank adopts the same entry",
                 "autotune_pick": tune_pick,
                 "autotune_table": None if tune_table is None else [{k: (round(e[k], 6) if isinstance(e[k], float) else e[k]) for k in e} for e in tune_table],
                 "graph_replay": bool(args.graph),

@@ -263,8 +263,9 @@ int rz_get_tuning(rz_ctx *ctx, const char *key, int *value);
  * the candidates (so clock / thermal drift hits all of them alike), the MEDIAN round of each is its time.
  *   rz_autotune_measure  fills `table` (at most `cap` entries, *count = how many) and changes nothing;
  *   rz_autotune_apply    adopts one entry as the "morph_split" / "grid_cap" / "inst_loop" tuning values;
- *   rz_autotune          = measure + rz_autotune_pick + apply. The heuristic plan is KEPT unless a candidate beats it by >= 2 %: the
- *                        landscape is flat near the optimum and a search that follows noise returns a different plan on every run.
+ *   rz_autotune          = measure + rz_autotune_pick + apply. The heuristic plan is KEPT unless a candidate is clearly faster — median
+ *                        >= 2 % lower and its slowest round under the heuristic's fastest round: the landscape is flat near the
+ *                        optimum and a search that follows noise returns a different plan on every run.
  * Several GPUs deforming shards of one mesh (one process per GPU) take the element-wise MAX of their tables' `ms` over the
  * ranks, then every rank picks from that one table with rz_autotune_pick and applies the same entry — one plan on all ranks,
  * judged by the slowest GPU, which is what the frame time is (bench.py does this over torch.distributed).
@@ -279,7 +280,8 @@ typedef struct rz_tune_entry {
     float ms_min, ms_max;                   /* fastest / slowest round */
 } rz_tune_entry;
 int rz_autotune_measure(rz_ctx *ctx, uint32_t frames, rz_tune_entry *table, int cap, int *count);
-/* index of the entry to adopt under the stability rule above (entry 0 unless some entry's ms < 0.98 x entry 0's) */
+/* index of the entry to adopt under the stability rule above (entry 0 unless some entry's ms < 0.98 x entry 0's and, when the
+ * spreads are filled in, its ms_max < entry 0's ms_min; ranks that MAX-reduce `ms` reduce ms_max by MAX and ms_min by MIN) */
 int rz_autotune_pick(const rz_tune_entry *table, int count);
 int rz_autotune_apply(rz_ctx *ctx, const rz_tune_entry *entry);
 int rz_autotune(rz_ctx *ctx, uint32_t frames);

@@ -509,7 +509,7 @@ class DeformContext:
         return [{k: getattr(tab[i], k) for k in self._TUNE_FIELDS} for i in range(n.value)]
 
     def autotune_pick(self, table):
-        """rz_autotune_pick on a (possibly rank-reduced) table: entry 0 unless something beats it by >= 2 %."""
+        """rz_autotune_pick on a (possibly rank-reduced) table: entry 0 unless something beats it by >= 2 % with its slowest round under entry 0's fastest."""
         tab = (RzTuneEntry * len(table))()
         for i, e in enumerate(table):
             for k in self._TUNE_FIELDS:

@@ -2198,11 +2198,17 @@ int rz_autotune_measure(rz_ctx *c, uint32_t frames, rz_tune_entry *table, int ca
 int rz_autotune_pick(const rz_tune_entry *table, int count)
 {
     if (!table || count < 1) return 0;
-    // entry 0 (the heuristics) stays unless something is >= 2 % faster; among those, the fastest
+    // entry 0 (the heuristics) stays unless something is clearly faster: median >= 2 % lower AND, when the table carries the
+    // per-round spread, its slowest round still under the heuristic's fastest one (overlapping ranges are box noise, and a pick that
+    // follows noise differs from run to run); among the qualifying entries, the lowest median
     int best = 0;
     float best_ms = table[0].ms * 0.98f;
-    for (int i = 1; i < count; ++i)
-        if (table[i].same_as != 0 && table[i].ms > 0.f && table[i].ms < best_ms) { best = i; best_ms = table[i].ms; }
+    const bool spread = table[0].ms_min > 0.f;
+    for (int i = 1; i < count; ++i) {
+        if (table[i].same_as == 0 || !(table[i].ms > 0.f) || !(table[i].ms < best_ms)) continue;
+        if (spread && table[i].ms_max > 0.f && !(table[i].ms_max < table[0].ms_min)) continue;
+        best = i; best_ms = table[i].ms;
+    }
     return best;
 }
 

@@ -79,3 +79,22 @@ def test_bench_refuses_a_mismatched_world_size_and_never_prints_a_line_without_g
         p = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--no-cpu-baseline"], env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert p.returncode != 0 and b"re-executing as 2 ranks" in p.stderr
         assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+def test_autotune_pick_keeps_the_heuristic_unless_a_candidate_is_clearly_faster(rz):
+    """rz_autotune_pick is pure host logic (include/reze_deform.h): entry 0 unless a candidate's median is >= 2 % lower AND its
+    slowest round is under entry 0's fastest round; tables without spreads (ms_min = 0) are judged on the median alone."""
+    capi, L = rz.capi, rz.capi.load()
+
+    def pick(rows):
+        tab = (capi.RzTuneEntry * len(rows))()
+        for i, (ms, lo, hi, same) in enumerate(rows):
+            tab[i].ms, tab[i].ms_min, tab[i].ms_max, tab[i].same_as = ms, lo, hi, same
+        return L.rz_autotune_pick(tab, len(rows))
+
+    assert pick([(33.3, 33.0, 33.7, -1), (32.5, 32.2, 32.7, -1)]) == 1          # 2.4 % and ranges apart
+    assert pick([(33.3, 33.0, 33.7, -1), (32.5, 32.2, 33.1, -1)]) == 0          # 2.4 % but the ranges overlap: noise
+    assert pick([(33.3, 33.0, 33.7, -1), (32.9, 32.8, 32.95, -1)]) == 0         # apart, but only 1.2 %
+    assert pick([(33.3, 0.0, 0.0, -1), (32.5, 0.0, 0.0, -1)]) == 1              # no spreads recorded: the median rule alone
+    assert pick([(33.3, 33.0, 33.7, -1), (30.0, 29.9, 30.1, 0)]) == 0           # an alias of entry 0 is never "another plan"
+    assert pick([(33.3, 33.0, 33.7, -1), (32.5, 32.2, 32.7, -1), (31.9, 31.8, 32.0, -1)]) == 2     # the fastest qualifying entry

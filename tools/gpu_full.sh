@@ -22,7 +22,7 @@ REZE_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZ
 echo "== 8 ranks on the one GPU (plumbing rehearsal; plain invocation: bench.py launches itself)"
 timeout 900 python bench.py --gpus 8 --share-gpu --dist-backend gloo --steps 50 --warmup 5 --no-cpu-baseline --no-sampled-loop --clock-warm-seconds 0.5 2>>$O/bench.err | grep '^{' | tail -1 > $O/bench_rehearse8.json
 echo "== search stability: consecutive runs"
-for i in 1 2 3 4; do timeout 600 python bench.py --no-cpu-baseline --no-sampled-loop --no-pair-loop --frames-in-flight 1 2>>$O/bench.err | tail -1 > $O/stab_c5_$i.json; done
+for i in 1 2 3 4 5; do timeout 600 python bench.py --no-cpu-baseline --no-sampled-loop --no-pair-loop --frames-in-flight 1 2>>$O/bench.err | tail -1 > $O/stab_c5_$i.json; done
 for i in 1 2 3 4 5; do timeout 600 python bench.py --config c4 --no-cpu-baseline --no-sampled-loop --no-pair-loop --frames-in-flight 1 2>>$O/bench.err | tail -1 > $O/stab_c4_$i.json; done
 python - <<'P'
 import json, glob
