@@ -220,7 +220,12 @@ def main():
         me = (str(getattr(pr, "uuid", "")), getattr(pr, "pci_domain_id", None), getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", None))
         ids = [None] * world_size
         dist.all_gather_object(ids, me)
-        if len(set(ids)) != world_size:
+        # an identity that says nothing (no uuid, PCI address all zero — some virtualised nodes) cannot prove a collision: ranks that
+        # index distinct devices of one visible list are distinct GPUs by construction, so only an INFORMATIVE identity seen twice refuses
+        def informative(t):
+            u = "".join(ch for ch in t[0] if ch.isalnum()).strip("0")
+            return bool(u) or any(x not in (None, 0) for x in t[1:])
+        if len(set(ids)) != world_size and (isolated or all(informative(t) for t in ids)):
             if rank == 0:
                 sys.stderr.write("[bench] %d ranks but they resolve to %d distinct GPU(s): one process per GPU (--share-gpu rehearses N > 1 on fewer GPUs)\n"
                                  % (world_size, len(set(ids))))
