@@ -46,18 +46,16 @@ struct RzSampleParams {
 struct RzFkParams {
     const float4 *local_q;      // [I][B] local rotations (x,y,z,w)
     const float *local_t;       // [I][B][3] local translations (SkeletonRuntime.localTranslations) or nullptr = all zero
-    const unsigned char *append_move;   // [B] 1 = the append parent's local translation * ratio is appended too (model.ts:388-393)
-    const int *parents;         // [B] -1 = root
-    const float *bind;          // [B][3] parent-relative bind translations
-    const int *append_parent;   // [B] -1 = no append rotation
-    const float *append_ratio;  // [B]
-    const int *order;           // [B] bones sorted by hierarchy level
-    const int *level_off;       // [n_levels + 1]
+    // static topology, one 32-byte record per bone (two 16-byte loads):
+    //   word 0: parent (-1 = root) | append parent (-1 = no append rotation) | bits(append ratio) | flags (bit 0: append-move —
+    //           the append parent's local translation * ratio is appended too, model.ts:388-393)
+    //   word 1: bits of the parent-relative bind translation x y z | 0
+    const uint4 *bone_rec;      // [B][2]
     const float *inv_bind;      // [B][16]
     float *world;               // [I][B][16] out
     float4 *palette;            // [I][B][3] out
     int B;
-    int n_levels;
+    int n_levels;               // depth of the hierarchy (1 = roots only): the solve runs ceil(log2(n_levels)) doubling rounds
     // physics hand-off (engine.ts:2379-2381, physics.ts:715-751): world matrices that replace the solved ones AFTER the
     // hierarchy solve — children keep the matrices solved from the un-overridden parent, exactly like the reference's
     // in-place boneWorldMatrices.set(). Entries sorted by instance; ovr_off[i]..ovr_off[i+1] are instance i's.
@@ -75,6 +73,12 @@ struct RzFkParams {
     const float *bm_w;          // [I][bm_M] morph weights of an uploaded (not sampled) pose
     int bm_M;
     RzSampleParams sample;      // sample.frames != nullptr: local_q / local_t are ignored, the pose is sampled in the kernel
+    // FUSED frame of a zero-copy local pose (one character; RzDeformParams: pf_* / st_tag): `local_q` / `local_t` name the pinned slot.
+    float4 *copy_q;             // device pose block: workgroup 0 leaves the pose there for the frames that replay it, or null
+    float *copy_t;
+    const float4 *st_local_q;   // where the previous frame's helper staged this pose if RzDeformParams::st_tag holds st_expect, or null
+    const float *st_local_t;
+    uint64_t st_expect;
 };
 
 // rz_deform_kernel: fused morph + 4-bone LBS (engine/src/engine.ts:253-272).
@@ -113,7 +117,7 @@ struct RzDeformParams {
     const uint64_t *st_tag;         // THIS frame's pose: staged in the device block when *st_tag == st_expect, else in the pinned slot
     uint64_t st_expect;
     const float *st_world;          // [B][16] staged copy
-    const float *st_morph_w;        // [M]     staged copy (MODE 2)
+    const float *st_morph_w;        // [M]     staged copy (MODE 2; fused-hierarchy frames: every mode)
     // FUSED single-character frame (fk_on): every workgroup of the (!FAST) kernel first solves the bone hierarchy itself —
     // motion sampling included when the pose is sampled — straight into its LDS palette, and compacts the morph weights
     // into its LDS list: no rz_fk_kernel, no rz_prep_kernel, ONE launch per device-animated frame. Workgroup 0 also
@@ -172,6 +176,10 @@ struct RzVariant {
     bool geo;    // rest geometry through LDS
     bool fast;   // fused palette + kernarg morph list (single instance)
 };
+
+// LDS the hierarchy solve needs behind the palette rows: per bone 48 B (local rotation | record | bind translation, then the
+// second matrix buffer of the doubling rounds) + 8 B (two ancestor indices) + 12 B (local translation), 16-byte rounded
+__host__ __device__ inline size_t rz_fk_scratch_bytes(int B) { return ((size_t)B * 68 + 15) & ~(size_t)15; }
 
 hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t st);
 hipError_t rz_launch_fk(const RzFkParams &p, uint32_t instances, hipStream_t st);

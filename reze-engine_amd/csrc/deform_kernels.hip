@@ -38,11 +38,6 @@ constexpr int kBlock = 256;
 // Ablation switches for profiling experiments exist only in the tools-only build (make ablate ->
 // tools/ablate/libreze_deform_ablate.so, -DRZ_ABLATE). In the shipped library RZ_DBG is the constant 0, the branches
 // fold away, and rz_set_tuning("dbg", ...) is rejected: no key can make rz_deform emit anything but the deformed mesh.
-// sparse morph rows: 16-byte entry loads a lane keeps in flight per round (8 / 16 measured no faster: NOTEBOOK.md R3.6)
-#ifndef RZ_SPARSE_INFLIGHT
-#define RZ_SPARSE_INFLIGHT 4
-#endif
-
 #ifdef RZ_ABLATE
 #define RZ_DBG(p) ((p).dbg)
 #else
@@ -300,21 +295,46 @@ __device__ __forceinline__ float4 slerp_from_identity(float4 a, const float t)
     return make_float4(sx, sy, sz, sw);
 }
 
+// W = P * L for 3x4 affine rows (bottom rows 0 0 0 1): the product a child's world matrix is made of (model.ts:405-414)
+__device__ __forceinline__ void affine_mul(const float4 p0, const float4 p1, const float4 p2, const float4 l0, const float4 l1, const float4 l2,
+                                           float4 &w0, float4 &w1, float4 &w2)
+{
+    const float P[12] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w };
+    float W[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        W[i * 4 + 0] = P[i * 4] * l0.x + P[i * 4 + 1] * l1.x + P[i * 4 + 2] * l2.x;
+        W[i * 4 + 1] = P[i * 4] * l0.y + P[i * 4 + 1] * l1.y + P[i * 4 + 2] * l2.y;
+        W[i * 4 + 2] = P[i * 4] * l0.z + P[i * 4 + 1] * l1.z + P[i * 4 + 2] * l2.z;
+        W[i * 4 + 3] = P[i * 4] * l0.w + P[i * 4 + 1] * l1.w + P[i * 4 + 2] * l2.w + P[i * 4 + 3];
+    }
+    w0 = make_float4(W[0], W[1], W[2], W[3]); w1 = make_float4(W[4], W[5], W[6], W[7]); w2 = make_float4(W[8], W[9], W[10], W[11]);
+}
+
 // The body of the hierarchy solve, shared by rz_fk_kernel (one workgroup per pose, results to global memory) and by the
 // FUSED single-character frame, where every workgroup of rz_deform_kernel runs it as its prologue: `wl` is then the deform
 // kernel's LDS palette (it ends up holding rows 0..2 of W * inverseBind), `scr` aliases its wave scratch, the sampled morph
 // weights go to `lds_mw`, and only workgroup 0 (`to_global`) also leaves world matrices / palette / weights in memory.
-// LDS behind `scr`: B x (16 + 3*4 + 4 + 12 + 12) = 56 bytes per bone. Ends with a barrier.
+//
+// Shape of the solve (round 4): the topology comes as ONE 32-byte record per bone (two 16-byte loads instead of seven scalar
+// arrays), and the parent chain is resolved by POINTER DOUBLING instead of level by level: every bone holds the product M of
+// the local matrices of a run of its ancestors ending at itself and the index A of the bone above that run; a round does
+// M[b] = M[A[b]] * M[b], A[b] = A[A[b]] for all bones at once (ping-pong buffers, one barrier), so ceil(log2(depth)) rounds
+// — 4 for a 12-level tree — replace depth - 1 barrier-separated levels. The products are associated differently from the
+// reference's parent-first recursion ((L0 L1)(L2 L3) instead of ((L0 L1) L2) L3): same f32 error class, ~1e-7 per product.
+// LDS behind `scr`: rz_fk_scratch_bytes(B) = B x (48 + 8 + 12) bytes. Ends with a barrier.
 template <bool FUSED>
-__device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, float4 *wl, unsigned char *scr, float *lds_mw, const bool to_global)
+__device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, float4 *wl, unsigned char *scr, float *lds_mw, const bool to_global,
+                                         const uint64_t st_tagv = 0ull)
 {
-    float4 *sq = reinterpret_cast<float4 *>(scr);        // local rotations of this pose
-    int *s_par = reinterpret_cast<int *>(sq + p.B);
-    int *s_ap = s_par + p.B;
-    int *s_order = s_ap + p.B;
-    float *s_ratio = reinterpret_cast<float *>(s_order + p.B);
-    float *s_bind = s_ratio + p.B;
-    float *s_lt = s_bind + (size_t)p.B * 3;               // local translations of this pose
+    // region X, 48 B per bone: local rotation | record word 0 | bind translation while the local matrices are formed, then the
+    // second matrix buffer of the doubling rounds
+    float4 *sq = reinterpret_cast<float4 *>(scr);                    // [B] local rotations of this pose
+    uint4 *s_rec = reinterpret_cast<uint4 *>(sq + p.B);              // [B] (parent, append parent, bits(append ratio), flags)
+    float4 *s_bind = reinterpret_cast<float4 *>(s_rec + p.B);        // [B] parent-relative bind translation
+    float4 *m2 = reinterpret_cast<float4 *>(scr);                    // [B][3] aliases the three arrays above
+    int *s_anc = reinterpret_cast<int *>(scr + (size_t)p.B * 48);    // [2][B] ping-pong ancestor indices
+    float *s_lt = reinterpret_cast<float *>(s_anc + 2 * (size_t)p.B);   // [B][3] local translations of this pose
     const int tid = threadIdx.x;
     const float4 *lq = p.local_q + (size_t)inst * p.B;
     const float *glt = p.local_t ? p.local_t + (size_t)inst * p.B * 3 : nullptr;
@@ -325,28 +345,45 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
     const float frame = sampled ? (p.sample.frames_inline ? p.sample.frame0 : p.sample.frames[inst]) : 0.0f;
     float *world = p.world + (size_t)inst * p.B * 16;
     float4 *pal = p.palette + (size_t)inst * p.B * 3;
-    // this thread's inverse bind matrix (consumed after the level loop) is requested first, so its latency hides
-    // behind the staging pass and the level loop instead of sitting in front of the output pass
+    // this thread's inverse bind matrix (consumed after the rounds) is requested first, so its latency hides behind the
+    // staging pass and the rounds instead of sitting in front of the output pass
     float4 pib0 = make_float4(0.f, 0.f, 0.f, 0.f), pib1 = pib0, pib2 = pib0, pib3 = pib0;
     if (tid < p.B) {
         const float4 *Im = reinterpret_cast<const float4 *>(p.inv_bind + (size_t)tid * 16);
         pib0 = Im[0]; pib1 = Im[1]; pib2 = Im[2]; pib3 = Im[3];
     }
-    // one cooperative pass stages everything the level loop touches, so each level costs LDS latency + a barrier
-    // instead of two dependent global round trips
+    // one cooperative pass stages everything the later passes touch: the record loads are issued in front of the pose
+    // (sampled: the track record, then its keys), so the static topology rides under the pose's own latency
     for (int i = tid; i < p.B; i += kBlock) {
-        s_par[i] = p.parents[i]; s_ap[i] = p.append_parent[i]; s_order[i] = p.order[i]; s_ratio[i] = p.append_ratio[i];
-        s_bind[i * 3] = p.bind[i * 3]; s_bind[i * 3 + 1] = p.bind[i * 3 + 1]; s_bind[i * 3 + 2] = p.bind[i * 3 + 2];
+        const uint4 r0 = p.bone_rec[2 * i], r1 = p.bone_rec[2 * i + 1];
+        float4 q;
+        float tx = 0.0f, ty = 0.0f, tz = 0.0f;
         if (sampled) {
-            float4 q;
-            float tx, ty, tz;
             sample_bone(p.sample, frame, i, q, tx, ty, tz);
-            sq[i] = q; s_lt[i * 3] = tx; s_lt[i * 3 + 1] = ty; s_lt[i * 3 + 2] = tz;
+        } else if (FUSED && p.st_local_q) {
+            // zero-copy pose that the previous frame's helper may have staged: the staged copy is asked for at once, the tag
+            // (requested by the caller) decides afterwards; a miss re-reads the pinned slot and workgroup 0 keeps the pose
+            q = p.st_local_q[i];
+            if (glt) { tx = p.st_local_t[i * 3]; ty = p.st_local_t[i * 3 + 1]; tz = p.st_local_t[i * 3 + 2]; }
+            if (st_tagv != p.st_expect) {
+                q = lq[i];
+                if (glt) { tx = glt[i * 3]; ty = glt[i * 3 + 1]; tz = glt[i * 3 + 2]; }
+                if (to_global && p.copy_q) {
+                    p.copy_q[i] = q;
+                    if (glt) { p.copy_t[i * 3] = tx; p.copy_t[i * 3 + 1] = ty; p.copy_t[i * 3 + 2] = tz; }
+                }
+            }
         } else {
-            sq[i] = lq[i];
-            if (glt) { s_lt[i * 3] = glt[i * 3]; s_lt[i * 3 + 1] = glt[i * 3 + 1]; s_lt[i * 3 + 2] = glt[i * 3 + 2]; }
-            else if (bone_morphs) { s_lt[i * 3] = 0.0f; s_lt[i * 3 + 1] = 0.0f; s_lt[i * 3 + 2] = 0.0f; }
+            q = lq[i];
+            if (glt) { tx = glt[i * 3]; ty = glt[i * 3 + 1]; tz = glt[i * 3 + 2]; }
+            if (FUSED && to_global && p.copy_q) {        // zero-copy first frame without a prefetch: keep the pose for the replays
+                p.copy_q[i] = q;
+                if (glt) { p.copy_t[i * 3] = tx; p.copy_t[i * 3 + 1] = ty; p.copy_t[i * 3 + 2] = tz; }
+            }
         }
+        sq[i] = q; s_rec[i] = r0;
+        s_bind[i] = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), 0.0f);
+        if (has_t) { s_lt[i * 3] = tx; s_lt[i * 3 + 1] = ty; s_lt[i * 3 + 2] = tz; }
     }
     if (sampled)        // vertex-morph weights of this pose: consumed by the prep / deform kernels that follow (FUSED: by this very workgroup)
         for (int m = tid; m < p.sample.M; m += kBlock) {
@@ -379,29 +416,29 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         }
         __syncthreads();
     }
-    // Pass A, every bone in parallel: its LOCAL matrix L = T(bind + t) * R * T(add) (rows 0..2), parked in the slot that
-    // will hold its world matrix. The level loop below is then only W = W_parent * L — the quaternion / append / slerp
-    // math is off the level-by-level critical path.
+    // Pass A, every bone in parallel: its LOCAL matrix L = T(bind + t) * R * T(add) (rows 0..2) into `wl`, its parent into
+    // the first ancestor buffer. The quaternion / append / slerp math is off the rounds' critical path.
     for (int b = tid; b < p.B; b += kBlock) {
         const float4 q = sq[b];
+        const uint4 rec = s_rec[b];
+        const float4 bind = s_bind[b];
         float R[9];
         quat_to_rows(q.x, q.y, q.z, q.w, R);
-        const int ap = s_ap[b];
+        const int ap = (int)rec.y;
+        const float ratio_raw = __uint_as_float(rec.z);
         float ax = 0.0f, ay = 0.0f, az = 0.0f;       // append-move: T(add) of L = T(bind) * R * T(add)
         if (ap >= 0) {
-            const float ratio = fminf(1.0f, fmaxf(-1.0f, s_ratio[b]));
+            const float ratio = fminf(1.0f, fmaxf(-1.0f, ratio_raw));
             if (fabsf(ratio) > 1e-6f) {
-                if (lt && p.append_move[b]) {            // model.ts:388-393 uses the UNclamped ratio here
-                    const float r = s_ratio[b];
-                    ax = lt[ap * 3] * r; ay = lt[ap * 3 + 1] * r; az = lt[ap * 3 + 2] * r;
+                if (lt && (rec.w & 1u)) {                // model.ts:388-393 uses the UNclamped ratio here
+                    ax = lt[ap * 3] * ratio_raw; ay = lt[ap * 3 + 1] * ratio_raw; az = lt[ap * 3 + 2] * ratio_raw;
                 }
                 float4 a = sq[ap];
                 const float t = fabsf(ratio);
                 if (ratio < 0.0f) { a.x = -a.x; a.y = -a.y; a.z = -a.z; }
                 const float4 sl = slerp_from_identity(a, t);
-                const float sx = sl.x, sy = sl.y, sz = sl.z, sw = sl.w;
                 float A[9], X[9];
-                quat_to_rows(sx, sy, sz, sw, A);
+                quat_to_rows(sl.x, sl.y, sl.z, sl.w, A);
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -411,7 +448,7 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
             }
         }
         // translation column of L = T(bind + local) * R * T(add)  =  bind + local + R * add
-        float tx = s_bind[b * 3], ty = s_bind[b * 3 + 1], tz = s_bind[b * 3 + 2];
+        float tx = bind.x, ty = bind.y, tz = bind.z;
         if (lt) {
             tx += lt[b * 3]; ty += lt[b * 3 + 1]; tz += lt[b * 3 + 2];
             tx += R[0] * ax + R[1] * ay + R[2] * az;
@@ -421,29 +458,29 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         wl[b * 3] = make_float4(R[0], R[1], R[2], tx);
         wl[b * 3 + 1] = make_float4(R[3], R[4], R[5], ty);
         wl[b * 3 + 2] = make_float4(R[6], R[7], R[8], tz);
+        s_anc[b] = (int)rec.x;
     }
-    __syncthreads();
-    for (int l = 1; l < p.n_levels; ++l) {          // level 0 = roots: W = L already
-        const int lo = p.level_off[l], hi = p.level_off[l + 1];
-        for (int idx = lo + tid; idx < hi; idx += kBlock) {
-            const int b = s_order[idx];
-            const int par = s_par[b];
-            const float4 l0 = wl[b * 3], l1 = wl[b * 3 + 1], l2 = wl[b * 3 + 2];
-            const float4 p0 = wl[par * 3], p1 = wl[par * 3 + 1], p2 = wl[par * 3 + 2];
-            const float P[12] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w };
-            float W[12];   // 3 rows x 4:  W = P * L  (bottom rows 0 0 0 1)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                W[i * 4 + 0] = P[i * 4] * l0.x + P[i * 4 + 1] * l1.x + P[i * 4 + 2] * l2.x;
-                W[i * 4 + 1] = P[i * 4] * l0.y + P[i * 4 + 1] * l1.y + P[i * 4 + 2] * l2.y;
-                W[i * 4 + 2] = P[i * 4] * l0.z + P[i * 4 + 1] * l1.z + P[i * 4 + 2] * l2.z;
-                W[i * 4 + 3] = P[i * 4] * l0.w + P[i * 4 + 1] * l1.w + P[i * 4 + 2] * l2.w + P[i * 4 + 3];
+    __syncthreads();          // (also: every read of region X is done, the rounds may write it)
+    // Doubling rounds. Round k reads (M, A) from one buffer pair and writes the other: M'[b] = M[A[b]] * M[b], A'[b] = A[A[b]];
+    // a bone whose run has reached its root (A < 0) is carried over unchanged. After ceil(log2(levels)) rounds every A is -1
+    // and M is the world matrix (roots: W = L from the start).
+    float4 *src = wl, *dst = m2;
+    int *asrc = s_anc, *adst = s_anc + p.B;
+    for (int span = 1; span < p.n_levels; span <<= 1) {
+        for (int b = tid; b < p.B; b += kBlock) {
+            const int a = asrc[b];
+            float4 w0 = src[b * 3], w1 = src[b * 3 + 1], w2 = src[b * 3 + 2];
+            int an = -1;
+            if (a >= 0) {
+                an = asrc[a];
+                affine_mul(src[a * 3], src[a * 3 + 1], src[a * 3 + 2], w0, w1, w2, w0, w1, w2);
             }
-            wl[b * 3] = make_float4(W[0], W[1], W[2], W[3]);
-            wl[b * 3 + 1] = make_float4(W[4], W[5], W[6], W[7]);
-            wl[b * 3 + 2] = make_float4(W[8], W[9], W[10], W[11]);
+            dst[b * 3] = w0; dst[b * 3 + 1] = w1; dst[b * 3 + 2] = w2;
+            adst[b] = an;
         }
         __syncthreads();
+        float4 *t4 = src; src = dst; dst = t4;
+        int *ti = asrc; asrc = adst; adst = ti;
     }
     if (p.ovr_off) {
         // physics-driven bones: the supplied world matrix replaces the solved one (rows 0..2 of the column-major 4x4)
@@ -451,16 +488,15 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
             const int b = p.ovr_bone[k];
             const float4 *m = reinterpret_cast<const float4 *>(p.ovr_world + (size_t)k * 16);
             const float4 c0 = m[0], c1 = m[1], c2 = m[2], c3 = m[3];
-            wl[b * 3] = make_float4(c0.x, c1.x, c2.x, c3.x);
-            wl[b * 3 + 1] = make_float4(c0.y, c1.y, c2.y, c3.y);
-            wl[b * 3 + 2] = make_float4(c0.z, c1.z, c2.z, c3.z);
+            src[b * 3] = make_float4(c0.x, c1.x, c2.x, c3.x);
+            src[b * 3 + 1] = make_float4(c0.y, c1.y, c2.y, c3.y);
+            src[b * 3 + 2] = make_float4(c0.z, c1.z, c2.z, c3.z);
         }
         __syncthreads();
     }
-    // all levels solved: one parallel pass writes the world matrices and the palette (the inverse-bind loads of
-    // every bone are in flight together instead of once per level)
+    // all rounds done: one parallel pass writes the world matrices and the palette
     for (int b = tid; b < p.B; b += kBlock) {
-        const float4 w0 = wl[b * 3], w1 = wl[b * 3 + 1], w2 = wl[b * 3 + 2];
+        const float4 w0 = src[b * 3], w1 = src[b * 3 + 1], w2 = src[b * 3 + 2];
         const float W[12] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w };
         // world, column-major 4x4 (what queue.writeBuffer(worldMatrixBuffer) would have carried)
         if (to_global) {
@@ -485,7 +521,7 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         const float4 q0 = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]), q1 = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]),
                      q2 = make_float4(r[2][0], r[2][1], r[2][2], r[2][3]);
         if (to_global) { pal[b * 3] = q0; pal[b * 3 + 1] = q1; pal[b * 3 + 2] = q2; }
-        if (FUSED) { wl[b * 3] = q0; wl[b * 3 + 1] = q1; wl[b * 3 + 2] = q2; }     // in place: bone b's rows are only ever read by this thread in this pass
+        if (FUSED) { wl[b * 3] = q0; wl[b * 3 + 1] = q1; wl[b * 3 + 2] = q2; }     // bone b's rows (in wl or in the other buffer) are only ever read by this thread in this pass
     }
     if (FUSED) __syncthreads();
 }
@@ -494,7 +530,7 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *scr = smem + (size_t)p.B * 48;
-    fk_solve<false>(p, (int)blockIdx.x, reinterpret_cast<float4 *>(smem), scr, reinterpret_cast<float *>(scr + (((size_t)p.B * 56 + 15) & ~(size_t)15)), true);
+    fk_solve<false>(p, (int)blockIdx.x, reinterpret_cast<float4 *>(smem), scr, reinterpret_cast<float *>(scr + rz_fk_scratch_bytes(p.B)), true);
 }
 
 
@@ -502,6 +538,17 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
 // helpers for the skin phase
 // ------------------------------------------------------------------------------------------------
 struct Skinned { float px, py, pz, nx, ny, nz; };
+
+// Sum over the 8 lanes of an aligned lane octet, left in every lane of it: a fixed butterfly of three DPP adds (lane ^ 1, lane ^ 2,
+// then the octet mirrored: k <-> 7 - k). Both partners of a pair add the same two values, and IEEE addition commutes, so all eight
+// lanes end with the same bits: the tree ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)), whichever lane is asked.
+__device__ __forceinline__ float row8_sum(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    return v;
+}
 
 // vs() lines engine.ts:255-272 for one vertex. `pal` = LDS palette (3 float4 rows per bone).
 //   weights: w_i = (u8_i/255) / sum_k(u8_k/255)  (engine.ts:255-257)  ==  u8_i / isum  up to rounding;
@@ -604,7 +651,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     const int lane = tid & 63, wave = tid >> 6;
 
     // Zero-copy pose prefetch (see RzDeformParams): workgroup 0 of such a launch is the helper, the workers shift by one.
-    const bool pf_on = FAST && p.pf_src != nullptr;
+    const bool pf_on = p.pf_src != nullptr;          // (only one-launch and fused-hierarchy frames ever carry one)
     if (pf_on && blockIdx.x == 0) {
         // seqlock read of the next upload's pinned slot: header == the expected sequence number -> the host has finished
         // writing that pose (it writes the header last); copy; header again; only then the tag. The ring protocol already
@@ -669,12 +716,24 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         // into `pal`; the solve's scratch and the pose's morph weights alias the wave scratch, which nothing uses yet.
         __shared__ int fz_cnt[kBlock / 64];
         unsigned char *fscr = reinterpret_cast<unsigned char *>(scratch_all);
-        float *lds_mw = reinterpret_cast<float *>(fscr + (((size_t)p.B * 56 + 15) & ~(size_t)15));
+        float *lds_mw = reinterpret_cast<float *>(fscr + rz_fk_scratch_bytes(p.B));
         const bool sampled = p.fk.sample.frames != nullptr || p.fk.sample.frames_inline;
+        // zero-copy local pose: staged in the device block by the previous frame's helper when the tag says so (requested here,
+        // compared after the speculative loads of the staged copy have been issued), else still in its pinned slot; on a miss
+        // workgroup 0 leaves the pose in the device block for the frames that replay it
+        const bool fspec = p.st_tag != nullptr;
+        const uint64_t ftag = fspec ? *p.st_tag : 0ull;
         if ((MODE != 0 || p.fk.bm_off) && !sampled) {
-            for (int i = tid; i < p.M; i += kBlock) lds_mw[i] = p.morph_w[i];       // uploaded weights (pinned slot or device block)
+            const float *mw0 = fspec ? p.st_morph_w : p.morph_w;               // uploaded weights (staged copy, pinned slot or device block)
+            for (int i = tid; i < p.M; i += kBlock) {
+                float w = mw0[i];
+                const bool miss = fspec && ftag != p.st_expect;
+                if (miss) w = p.morph_w[i];
+                lds_mw[i] = w;
+                if (wid == 0 && p.morph_w_copy && (!fspec || miss)) p.morph_w_copy[i] = w;
+            }
         }
-        fk_solve<true>(p.fk, 0, pal, fscr, lds_mw, wid == 0);             // ends with a barrier: pal and lds_mw are complete
+        fk_solve<true>(p.fk, 0, pal, fscr, lds_mw, wid == 0, ftag);       // ends with a barrier: pal and lds_mw are complete
         if (MODE == 1) fused_count = compact_active(lds_mw, p.M, p.Mpad, s_idx, s_w, fz_cnt);
         if (MODE == 2)
             for (int i = tid; i < p.M; i += kBlock) s_w[i] = lds_mw[i];
@@ -913,36 +972,79 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // ---- phase 2: one vertex per lane ----
         const size_t vw0 = qw * 4;     // first vertex of this wave's step
         const int v_live = RZ_DBG(p) == 4 ? 0 : (int)min((size_t)VW, (q_end - qw) * 4);   // dbg 4: ablation — morph phase only
+
+        if (MODE == 2) {
+            // ---- sparse morph targets: ROW-COOPERATIVE walk of the vertex-ordered CSR ----
+            // entry = (dx, dy, dz, bits(morph)), a vertex's entries ascending by morph. Eight lanes share a row: lane k of the
+            // eight takes entries k, k + 8, ... (a 128-byte piece of the row per load instruction, and the eight rows of a pass
+            // are neighbours in memory), its partial sums are one FMA chain, and the eight partials are combined by a fixed
+            // DPP butterfly — so a row's sum depends on the row alone, not on the launch shape or on the rows around it.
+            // Eight passes cover the 64 vertices of a round; the passes' loads of one round are all in flight together.
+            // One vertex per lane walking its own row (rounds 1-3) made every load instruction touch 64 different cache lines:
+            // the face of the demo model (60 expression morphs on the same ~1 800 vertices, up to 60 entries per vertex) cost
+            // 2 us more than the same entries spread over the mesh, all of it address processing (NOTEBOOK.md R4.1).
+            constexpr int RL = 8;                       // lanes per row
+            constexpr int RPP = 64 / RL;                // rows per pass
+            constexpr int NP = 64 / RPP;                // passes per round of 64 vertices
+            const int rg = lane / RL, rl = lane % RL;
+#pragma unroll 1
+            for (int r = 0; r < ROUNDS; ++r) {
+                uint32_t cur[NP], end[NP];
+                uint32_t has = 0u;                      // bit ps: this lane's row of pass ps has entries
+#pragma unroll
+                for (int ps = 0; ps < NP; ++ps) {
+                    const int vl = r * 64 + ps * RPP + rg;
+                    uint32_t b0 = 0u, b1 = 0u;
+                    if (vl < v_live) { b0 = p.sp_ptr[vw0 + vl]; b1 = p.sp_ptr[vw0 + vl + 1]; }
+                    cur[ps] = b0 + (uint32_t)rl; end[ps] = b1;
+                    has |= (b1 > b0 ? 1u : 0u) << ps;
+                }
+                if (__ballot(has != 0u) == 0ull) continue;          // no vertex of this round carries an offset
+                float sx[NP], sy[NP], sz[NP];
+#pragma unroll
+                for (int ps = 0; ps < NP; ++ps) { sx[ps] = 0.0f; sy[ps] = 0.0f; sz[ps] = 0.0f; }
+                for (;;) {
+                    bool more = false;
+#pragma unroll
+                    for (int ps = 0; ps < NP; ++ps) more = more || cur[ps] < end[ps];
+                    if (__ballot(more) == 0ull) break;
+                    float4 ent[NP];
+#pragma unroll
+                    for (int ps = 0; ps < NP; ++ps)
+                        ent[ps] = cur[ps] < end[ps] ? p.sp_entries[cur[ps]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int ps = 0; ps < NP; ++ps) {
+                        const bool on = cur[ps] < end[ps];
+                        const float w = s_w[on ? __float_as_uint(ent[ps].w) : 0u];
+                        sx[ps] = on ? fmaf(w, ent[ps].x, sx[ps]) : sx[ps];
+                        sy[ps] = on ? fmaf(w, ent[ps].y, sy[ps]) : sy[ps];
+                        sz[ps] = on ? fmaf(w, ent[ps].z, sz[ps]) : sz[ps];
+                        cur[ps] += RL;
+                    }
+                }
+#pragma unroll
+                for (int ps = 0; ps < NP; ++ps) {
+                    if (__ballot((has >> ps) & 1u) == 0ull) continue;     // wave-uniform: nothing in this pass
+                    const float tx = row8_sum(sx[ps]), ty = row8_sum(sy[ps]), tz = row8_sum(sz[ps]);
+                    if (rl == 0 && ((has >> ps) & 1u)) {
+                        const int vl = r * 64 + ps * RPP + rg;
+                        scr[0 * VW + vl] += tx; scr[1 * VW + vl] += ty; scr[2 * VW + vl] += tz;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---- phase 2: one vertex per lane ----
 #pragma unroll 1
         for (int r = 0; r < ROUNDS; ++r) {
             const int vl = r * 64 + lane;
             if (vl < v_live) {
                 const size_t v = vw0 + vl;
-                float x = scr[0 * VW + vl], y = scr[1 * VW + vl], z = scr[2 * VW + vl];
-                if (MODE == 2) {
-                    // sparse morph targets: this vertex's row of the vertex-ordered CSR, entry = (dx, dy, dz, bits(morph)),
-                    // ascending morph = the oracle's accumulation order. One vertex per lane and four independent entry
-                    // loads in flight, weights from LDS: a vertex carrying dozens of entries (the demo model's face —
-                    // all 60 expression morphs sit on the same ~600 vertices) is a short chain, and with S = 4 a wave
-                    // step is only 64 vertices, so such a region spreads over many waves.
-                    const uint32_t b0 = p.sp_ptr[v], b1 = p.sp_ptr[v + 1];
-                    float sx = 0.f, sy = 0.f, sz = 0.f;
-                    constexpr int SPU = RZ_SPARSE_INFLIGHT;      // entry loads in flight per lane and round
-                    for (uint32_t e = b0; e < b1; e += SPU) {
-                        float4 ent[SPU];
-#pragma unroll
-                        for (int u = 0; u < SPU; ++u) ent[u] = e + u < b1 ? p.sp_entries[e + u] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int u = 0; u < SPU; ++u) {
-                            const float w = e + u < b1 ? s_w[__float_as_uint(ent[u].w)] : 0.0f;
-                            sx = fmaf(w, ent[u].x, sx); sy = fmaf(w, ent[u].y, sy); sz = fmaf(w, ent[u].z, sz);
-                        }
-                    }
-                    x += sx; y += sy; z += sz;
-                }
+                const float x = scr[0 * VW + vl], y = scr[1 * VW + vl], z = scr[2 * VW + vl];
                 float nx, ny, nz;
                 uint32_t j01, j23, wq;
                 if (GEO) {
@@ -1491,7 +1593,7 @@ hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t
 
 hipError_t rz_launch_fk(const RzFkParams &p, uint32_t instances, hipStream_t st)
 {
-    size_t lds = (size_t)p.B * 48 + (((size_t)p.B * (16 + 4 * 4 + 12 + 12) + 15) & ~(size_t)15);
+    size_t lds = (size_t)p.B * 48 + rz_fk_scratch_bytes(p.B);
     if (p.bm_off) lds += (size_t)std::max(std::max(p.bm_M, p.sample.M), 1) * 4;      // the pose's morph weights, for the bone morphs
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rz_fk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1507,7 +1609,7 @@ size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v)
     size_t scratch = (size_t)(kBlock / 64) * (v.geo ? 9 : 3) * vw * 4;
     const size_t list = (v.mode == 2 || (!v.fast && v.mode == 1)) ? (size_t)p.Mpad * 8 : 0;
     size_t work = scratch + (size_t)(kBlock / 64) * p.out_cap * 24;
-    if (p.fk_on) work = std::max(work, (((size_t)p.B * 56 + 15) & ~(size_t)15) + (size_t)std::max(p.M, 1) * 4 + 16);   // the fused solve's scratch aliases it
+    if (p.fk_on) work = std::max(work, rz_fk_scratch_bytes(p.B) + (size_t)std::max(p.M, 1) * 4 + 16);   // the fused solve's scratch aliases it
     return (size_t)p.B * 48 + list + work;
 }
 

@@ -134,8 +134,7 @@ struct rz_ctx {
     float *inv_bind = nullptr;          // B x 16
     // optional topology for on-device FK
     bool has_topology = false;
-    int *fk_parents = nullptr, *fk_append_parent = nullptr, *fk_order = nullptr, *fk_level_off = nullptr;
-    unsigned char *fk_append_move = nullptr;
+    uint4 *fk_rec = nullptr;            // [B][2] one 32-byte record per bone (deform_kernels.h: RzFkParams::bone_rec)
     bool pose_local_t = false;
     // device-side motion sampling (rz_upload_animation / rz_set_pose_sampled)
     bool has_animation = false, pose_sampled = false;
@@ -149,8 +148,7 @@ struct rz_ctx {
     bool frames_inline = false;         // one character: the frame rides in the kernel arguments (frame0), nothing is uploaded
     float frame0 = 0.0f;
     size_t an_frames_alloc = 0;          // the current local pose carries translations (behind the rotations in its slot)
-    float *fk_bind = nullptr, *fk_append_ratio = nullptr;
-    int fk_levels = 0;
+    int fk_levels = 0;                  // depth of the hierarchy
     float4 *local_q = nullptr;          // I x B   (current pose slot)
 
     bool pose_local = false;            // the current pose came from rz_set_pose_local
@@ -256,6 +254,7 @@ struct rz_ctx {
     int t_prefetch = -1;                // "pose_prefetch": -1 / 1 on, 0 off
     int zc_cur = -1;                    // slot of the current pose, -1 = the current pose came down as a copy
     bool zc_local = false;              // layout of that slot: [weights | rotations | translations] or [world | weights]
+    int zc_kind = 0;                    // 0 world, 1 local rotations, 2 local rotations + translations (part of the sequence number)
     size_t zc_total = 0, zc_mw_off = 0, zc_lq_off = 0;     // bytes in the slot, and where the weights / rotations sit in it
     bool world_resident = true, mw_resident = true, local_resident = true;   // which parts the device pose block holds
 
@@ -420,7 +419,7 @@ int ensure_pose_buffers(rz_ctx *c)
     c->palette = nullptr; c->act_idx = nullptr; c->act_w = nullptr; c->act_count = nullptr;
     const size_t I = c->I, B = c->B;
     const size_t Mpad = round_up(Mq + 8, 4);
-    const size_t blk_floats = I * B * 16 + ((I * Mq + 3) / 4 * 4) + I * B * 7;
+    const size_t blk_floats = I * B * 16 + ((I * Mq + 3) / 4 * 4) + I * B * 7 + 4;      // + 4: the prefetch helper copies whole 16-byte cells
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipMalloc(&c->pose_blk[k], blk_floats * sizeof(float)));
         HIP_TRY(hipMemsetAsync(c->pose_blk[k], 0, blk_floats * sizeof(float), c->stream));
@@ -539,6 +538,16 @@ int make_resident(rz_ctx *c)
 
 RzFkParams fk_params(const rz_ctx *c);
 
+// Sequence number of a zero-copy pose, the value its slot header and — once staged — its device tag hold:
+// ring epoch << 32 | pose kind << 30 | upload index (1-based, 30 bits). The KIND (0 world matrices, 1 local rotations, 2 local
+// rotations + translations) is part of the number because a helper workgroup stages the next slot assuming the next pose has the
+// layout and size of its own frame's: a pose of another kind can then never match what the helper expected. Sizes inside a kind
+// only change with the skeleton / morph set / instance count, which start a new epoch.
+uint64_t zc_seq(const rz_ctx *c, uint64_t upload_index_1, int kind)
+{
+    return ((uint64_t)c->zc_epoch << 32) | ((uint64_t)(kind & 3) << 30) | (upload_index_1 & 0x3fffffffull);
+}
+
 RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
 {
     RzDeformParams p;
@@ -559,7 +568,7 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
             p.pf_src_seq = reinterpret_cast<const uint64_t *>(static_cast<const char *>(c->zc_dev[nxt]) + c->zc_hdr_off);
             p.pf_dst = c->pose_blk[c->pose_slot ^ 1];
             p.pf_tag = c->zc_tag + (c->pose_slot ^ 1);
-            p.pf_expect = ((uint64_t)c->zc_epoch << 32) | (uint64_t)(uint32_t)(c->zc_uploads + 1);
+            p.pf_expect = zc_seq(c, c->zc_uploads + 1, c->zc_kind);
             p.pf_bytes = (uint32_t)((c->zc_total + 15) / 16 * 16);
         }
     }
@@ -575,7 +584,28 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
 #endif
     p.out_cap = pl.out_cap;
     if (pl.subsets) { p.rj01 = c->rj01; p.rj23 = c->rj23; p.sub_list = c->sub_list; p.sub_count = c->sub_count; p.sub_stride = (int)c->sub_B; }
-    if (pl.fuse_fk) { p.fk = fk_params(c); p.fk_on = 1; }
+    if (pl.fuse_fk) {
+        p.fk = fk_params(c); p.fk_on = 1;
+        if (c->zc_cur >= 0 && c->zc_local && !c->pose_sampled && (!c->local_resident || !c->mw_resident)) {
+            // zero-copy local pose, first frame: workgroup 0 makes it resident (every later frame of this pose reads the device
+            // block instead of pulling the pose over the host link in every workgroup), and — like the one-launch frame of a
+            // world pose — the frame looks for a copy the previous frame's helper staged and carries a helper for the next upload
+            float *blk_t = c->pose_local_t ? reinterpret_cast<float *>(c->local_q + c->B) : nullptr;
+            p.fk.copy_q = c->local_q; p.fk.copy_t = blk_t;
+            if (c->M > 0) p.morph_w_copy = c->morph_w;
+            if (pl.pf && c->zc_tag && c->zc_seq_cur) {
+                p.st_tag = c->zc_tag + c->pose_slot; p.st_expect = c->zc_seq_cur; p.fk.st_expect = c->zc_seq_cur;
+                p.fk.st_local_q = c->local_q; p.fk.st_local_t = blk_t; p.st_morph_w = c->morph_w;
+                const int nxt = (c->zc_cur + 1) % rz_ctx::kZcSlots;
+                p.pf_src = static_cast<const float *>(c->zc_dev[nxt]);
+                p.pf_src_seq = reinterpret_cast<const uint64_t *>(static_cast<const char *>(c->zc_dev[nxt]) + c->zc_hdr_off);
+                p.pf_dst = c->pose_blk[c->pose_slot ^ 1] + (c->morph_w - c->pose_blk[c->pose_slot]);     // the local range of the other block
+                p.pf_tag = c->zc_tag + (c->pose_slot ^ 1);
+                p.pf_expect = zc_seq(c, c->zc_uploads + 1, c->zc_kind);
+                p.pf_bytes = (uint32_t)((c->zc_total + 15) / 16 * 16);
+            }
+        }
+    }
     return p;
 }
 
@@ -646,7 +676,7 @@ Plan make_plan(const rz_ctx *c)
     // mode (and 27.7 -> 24.5 us on a 1/8 shard of C5); local poses 12.7-14.4 -> 9.8-12.8 us without dense morphs, no gain
     // with them (there the three-kernel frame keeps its kernel-argument morph list and streams from its first instruction).
     // Automatic mode follows that; "fuse_fk" = 0 / 1 forces it.
-    pl.fuse_fk = c->I == 1 && c->pose_local && c->has_topology && (size_t)c->B * 104 + (size_t)c->M * 12 + 4096 <= 160 * 1024 &&
+    pl.fuse_fk = c->I == 1 && c->pose_local && c->has_topology && (size_t)c->B * 48 + rz_fk_scratch_bytes((int)c->B) + (size_t)c->M * 12 + 4096 <= 160 * 1024 &&
                  (c->t_fusefk == 1 || (c->t_fusefk < 0 && (c->pose_sampled || c->morph_mode != 1)));
     const bool can_fast = c->I == 1 && !pl.fuse_fk && (v.mode != 1 || c->ml.count >= 0);
     v.fast = can_fast && c->t_fast != 0;
@@ -665,7 +695,9 @@ Plan make_plan(const rz_ctx *c)
     uint32_t cap = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : std::max(2u * (uint32_t)c->n_cu, 8u * c->I);
     // Pose prefetch: the first frame of a zero-copy world pose carries one helper workgroup that stages the NEXT pose (if the
     // host has written it already) — it takes one of the grid's slots, the workers share the mesh among cap - 1.
-    pl.pf = v.fast && c->I == 1 && c->t_prefetch != 0 && c->zc_cur >= 0 && !c->zc_local && !c->world_resident && c->zc_seq_cur != 0 && c->zc_tag;
+    pl.pf = c->I == 1 && c->t_prefetch != 0 && c->zc_cur >= 0 && c->zc_seq_cur != 0 && c->zc_tag &&
+            ((v.fast && !c->zc_local && !c->world_resident) ||
+             (pl.fuse_fk && c->zc_local && !c->pose_sampled && (!c->local_resident || !c->mw_resident)));
     if (pl.pf && cap > 1) cap -= 1;
     uint32_t gx = std::max<uint32_t>(1, cap / std::max<uint32_t>(1, c->I));
     const uint32_t max_useful = (pl.n_quads + waves_per_wg * qpw_step - 1) / (waves_per_wg * qpw_step);
@@ -822,9 +854,7 @@ RzFkParams fk_params(const rz_ctx *c)
     memset(&p, 0, sizeof p);            // padding too: frame_signature() hashes the struct
     p.local_q = src_local_q(c);
     p.local_t = c->pose_local_t ? reinterpret_cast<const float *>(p.local_q + (size_t)c->I * c->B) : nullptr;
-    p.append_move = c->fk_append_move;
-    p.parents = c->fk_parents; p.bind = c->fk_bind; p.append_parent = c->fk_append_parent;
-    p.append_ratio = c->fk_append_ratio; p.order = c->fk_order; p.level_off = c->fk_level_off; p.inv_bind = c->inv_bind;
+    p.bone_rec = c->fk_rec; p.inv_bind = c->inv_bind;
     p.world = c->world; p.palette = c->palette; p.B = (int)c->B; p.n_levels = c->fk_levels;
     if (c->ovr_count) { p.ovr_off = c->ovr_off; p.ovr_bone = c->ovr_bone; p.ovr_world = c->ovr_world; }
     if (c->bm_count && c->M) {
@@ -887,8 +917,10 @@ int launch_deform(rz_ctx *c, const Plan &pl)
     size_t lds = rz_deform_lds_bytes(p, pl.v);
     if (lds > 160 * 1024) return fail(RZ_ERR_UNSUPPORTED, "skeleton too large for the LDS palette (%zu B)", lds);
     HIP_TRY(rz_launch_deform(p, c->ml, pl.v, pl.grid_x + (p.pf_src ? 1u : 0u), c->I, c->stream));
+    c->palette_stale = false;                          // this frame's palette is in memory: written by its front kernels or by workgroup 0
     if (p.world_copy) c->world_resident = true;        // workgroup 0 of that launch left the pose in the device block
     if (p.morph_w_copy) c->mw_resident = true;
+    if (p.fk.copy_q) c->local_resident = c->mw_resident = true;
     if (c->aabb_on) c->aabb_slot ^= 1;     // this launch re-armed the other slot for the next frame
     return RZ_OK;
 }
@@ -1074,7 +1106,7 @@ int rz_destroy(rz_ctx *c)
     if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
     if (c->lender) {                      // a fork frees nothing it borrowed
         c->geom = nullptr; c->j01 = c->j23 = c->wq = nullptr; c->inv_bind = nullptr;
-        c->fk_parents = c->fk_append_parent = c->fk_order = c->fk_level_off = nullptr; c->fk_bind = c->fk_append_ratio = nullptr; c->fk_append_move = nullptr;
+        c->fk_rec = nullptr;
         c->an_bone_range = c->an_feed_range = nullptr; c->an_feed_off = nullptr;
         c->an_key_frame = c->an_key_pos = c->an_mkey_frame = c->an_mkey_weight = c->an_feed_ratio = nullptr; c->an_key_rot = nullptr; c->an_key_interp = nullptr;
         c->bm_off = c->bm_morph = nullptr; c->bm_rot = c->bm_tr = nullptr;
@@ -1088,9 +1120,9 @@ int rz_destroy(rz_ctx *c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->inv_bind);
     dfree(c->rj01); dfree(c->rj23); dfree(c->sub_list); dfree(c->sub_count); dfree(c->zc_tag);
-    dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind);
+    dfree(c->fk_rec);
     free_animation(c); dfree(c->an_frames);
-    dfree(c->fk_append_ratio); dfree(c->fk_append_move); dfree(c->pose_blk[0]); dfree(c->pose_blk[1]);
+    dfree(c->pose_blk[0]); dfree(c->pose_blk[1]);
     dfree(c->ovr_off); dfree(c->ovr_bone); dfree(c->ovr_world);
     free_bone_morphs(c);
     free_morphs(c);
@@ -1134,9 +1166,7 @@ int rz_fork(rz_ctx *parent, rz_ctx **out)
     if (int r = rz_create(parent->device, &c)) return r;
     c->V = parent->V; c->Vp = parent->Vp; c->geom = parent->geom; c->j01 = parent->j01; c->j23 = parent->j23; c->wq = parent->wq;
     c->B = parent->B; c->inv_bind = parent->inv_bind;
-    c->has_topology = parent->has_topology; c->fk_parents = parent->fk_parents; c->fk_append_parent = parent->fk_append_parent;
-    c->fk_order = parent->fk_order; c->fk_level_off = parent->fk_level_off; c->fk_append_move = parent->fk_append_move;
-    c->fk_bind = parent->fk_bind; c->fk_append_ratio = parent->fk_append_ratio; c->fk_levels = parent->fk_levels;
+    c->has_topology = parent->has_topology; c->fk_rec = parent->fk_rec; c->fk_levels = parent->fk_levels;
     c->has_animation = parent->has_animation; c->an_bone_range = parent->an_bone_range; c->an_feed_range = parent->an_feed_range;
     c->an_feed_off = parent->an_feed_off; c->an_key_frame = parent->an_key_frame; c->an_key_pos = parent->an_key_pos;
     c->an_mkey_frame = parent->an_mkey_frame; c->an_mkey_weight = parent->an_mkey_weight; c->an_feed_ratio = parent->an_feed_ratio;
@@ -1436,20 +1466,21 @@ static int upload_pose_zero_copy(rz_ctx *c, const PoseParts &pp)
     int zs = 0;
     if (int r = zc_acquire(c, std::max<size_t>(std::max<size_t>((size_t)c->B * 64 + pp.mwb, pp.mwb + (size_t)c->B * 28), 4096), &zs)) return r;
     // header protocol of the pose prefetch: invalid while the pose is being written, its sequence number once it is complete
-    // (x86 stores retire in program order; the fences keep the compiler from moving them). Only world-matrix poses are
-    // prefetched (the hierarchy solve reads local poses in its own kernel / prologue).
+    // (x86 stores retire in program order; the fences keep the compiler from moving them). World-matrix poses are prefetched
+    // by the one-launch frame's helper, local poses by the fused-hierarchy frame's (zc_seq: the kind is part of the number).
     char *slot = static_cast<char *>(c->zc_host[zs]);
     volatile uint64_t *hdr = reinterpret_cast<volatile uint64_t *>(slot + c->zc_hdr_off);
     *hdr = 0;
     std::atomic_thread_fence(std::memory_order_seq_cst);
     lay_out_pose(c, pp, slot);
     std::atomic_thread_fence(std::memory_order_seq_cst);
-    const uint64_t seq = pp.local ? 0 : (((uint64_t)c->zc_epoch << 32) | (uint64_t)(uint32_t)c->zc_uploads);   // zc_uploads is already this upload's index + 1
+    const int kind = pp.local ? (pp.sbytes ? 2 : 1) : 0;
+    const uint64_t seq = zc_seq(c, c->zc_uploads, kind);       // zc_uploads is already this upload's index + 1
     *hdr = seq;
     c->zc_seq_cur = seq;
     point_pose_slot(c, c->pose_slot ^ 1);   // where the pose will live once something makes it resident
     c->free_recorded[c->pose_slot] = false;
-    c->zc_cur = zs; c->zc_local = pp.local; c->zc_total = pp.total;
+    c->zc_cur = zs; c->zc_local = pp.local; c->zc_kind = kind; c->zc_total = pp.total;
     c->zc_mw_off = pp.local ? 0 : pp.pbytes; c->zc_lq_off = pp.mwb;
     c->world_resident = pp.local;           // a local pose has no world matrices to bring over: rz_fk_kernel writes them
     c->mw_resident = false;
@@ -1463,6 +1494,7 @@ static int upload_pose_copy(rz_ctx *c, const PoseParts &pp)
 {
     c->zc_cur = -1;
     c->zc_seq_cur = 0;
+    c->zc_epoch++;        // this copy overwrites a pose block a helper may have staged and tagged: no later zero-copy pose may match that tag
     c->world_resident = c->mw_resident = c->local_resident = true;
     int slot = 0;
     if (int r = stage_acquire(c, std::max<size_t>((size_t)c->I * c->B * 64 + pp.mwb, pp.mwb + (size_t)c->I * c->B * 28), &slot)) return r;
@@ -1512,7 +1544,9 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
     c->pose_set = false;
     c->pose_local = local;
     c->pose_sampled = false;
-    if (int r = set_overlap(c, want_overlap(c, make_plan(c)))) return r;
+    Plan upl;
+    if (int r = frame_plan(c, &upl)) return r;          // the plan frames will use (run lists first), not the whole-palette fallback
+    if (int r = set_overlap(c, want_overlap(c, upl))) return r;
     PoseParts pp;
     pp.primary = primary; pp.pbytes = pbytes; pp.secondary = secondary; pp.sbytes = sbytes; pp.morph_weights = morph_weights; pp.local = local;
     pp.mb = (size_t)c->I * c->M * sizeof(float);
@@ -1574,37 +1608,22 @@ int rz_upload_skeleton_topology(rz_ctx *c, uint32_t B, const int32_t *parents, c
     }
     int n_levels = 0;
     for (uint32_t b = 0; b < B; ++b) n_levels = std::max(n_levels, level[b] + 1);
-    std::vector<int> off(n_levels + 1, 0), order(B), ap(B, -1);
-    std::vector<float> ratio(B, 1.0f);
-    std::vector<unsigned char> mv(B, 0);
-    for (uint32_t b = 0; b < B; ++b) off[level[b] + 1]++;
-    for (int l = 0; l < n_levels; ++l) off[l + 1] += off[l];
-    std::vector<int> cur(off.begin(), off.end() - 1);
-    for (uint32_t b = 0; b < B; ++b) order[cur[level[b]]++] = (int)b;
+    // one 32-byte record per bone: (parent, append parent, bits(append ratio), flags) (bits(bind x y z), 0)
+    std::vector<uint4> rec((size_t)B * 2);
     for (uint32_t b = 0; b < B; ++b) {
-        if (append_parent && append_parent[b] >= 0 && append_parent[b] < (int32_t)B) ap[b] = append_parent[b];
-        if (append_ratio) ratio[b] = append_ratio[b];
-        if (append_move) mv[b] = append_move[b] ? 1 : 0;
+        const int32_t ap = (append_parent && append_parent[b] >= 0 && append_parent[b] < (int32_t)B) ? append_parent[b] : -1;
+        const float ratio = append_ratio ? append_ratio[b] : 1.0f;
+        uint32_t rb, bx, by, bz;
+        memcpy(&rb, &ratio, 4);
+        memcpy(&bx, bind_translation3 + (size_t)b * 3, 4); memcpy(&by, bind_translation3 + (size_t)b * 3 + 1, 4); memcpy(&bz, bind_translation3 + (size_t)b * 3 + 2, 4);
+        rec[2 * b] = make_uint4((uint32_t)(parents[b] < 0 ? -1 : parents[b]), (uint32_t)ap, rb, (append_move && append_move[b]) ? 1u : 0u);
+        rec[2 * b + 1] = make_uint4(bx, by, bz, 0u);
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     drop_graph(c);
     c->ovr_count = 0;
-    dfree(c->fk_parents); dfree(c->fk_append_parent); dfree(c->fk_order); dfree(c->fk_level_off); dfree(c->fk_bind); dfree(c->fk_append_ratio);
-    dfree(c->fk_append_move);
-    HIP_TRY(hipMalloc(&c->fk_append_move, B));
-    HIP_TRY(hipMemcpy(c->fk_append_move, mv.data(), B, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&c->fk_parents, B * sizeof(int)));
-    HIP_TRY(hipMalloc(&c->fk_append_parent, B * sizeof(int)));
-    HIP_TRY(hipMalloc(&c->fk_order, B * sizeof(int)));
-    HIP_TRY(hipMalloc(&c->fk_level_off, (n_levels + 1) * sizeof(int)));
-    HIP_TRY(hipMalloc(&c->fk_bind, (size_t)B * 3 * sizeof(float)));
-    HIP_TRY(hipMalloc(&c->fk_append_ratio, B * sizeof(float)));
-    HIP_TRY(hipMemcpy(c->fk_parents, parents, B * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->fk_append_parent, ap.data(), B * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->fk_order, order.data(), B * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->fk_level_off, off.data(), (n_levels + 1) * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->fk_bind, bind_translation3, (size_t)B * 3 * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->fk_append_ratio, ratio.data(), B * sizeof(float), hipMemcpyHostToDevice));
+    dfree(c->fk_rec);
+    if (int r = to_device(&c->fk_rec, rec.data(), rec.size())) return r;
     c->fk_levels = n_levels;
     c->has_topology = true;
     return RZ_OK;
@@ -1754,9 +1773,12 @@ int rz_set_pose_sampled(rz_ctx *c, const float *frames)
     c->pose_sampled = true;
     c->pose_local = true;
     c->pose_local_t = true;
-    if (int r = set_overlap(c, want_overlap(c, make_plan(c)))) return r;
+    Plan upl;
+    if (int r = frame_plan(c, &upl)) return r;
+    if (int r = set_overlap(c, want_overlap(c, upl))) return r;
     c->zc_cur = -1;                         // the pose is produced on the device: nothing of it sits in a pinned slot
     c->zc_seq_cur = 0;
+    c->zc_epoch++;                          // its frame writes world matrices / weights into the pose block: tags staged before never match again
     c->world_resident = c->mw_resident = c->local_resident = true;
     c->frames_inline = c->I == 1 && !c->overlap_on && c->t_zerocopy != 0;
     if (c->frames_inline) {
@@ -2115,8 +2137,8 @@ int rz_autotune_measure(rz_ctx *c, uint32_t frames, rz_tune_entry *table, int ca
     const int keep_split = c->t_split, keep_cap = c->t_grid_cap, keep_loop = c->t_instloop;
     const bool keep_tuned = c->tuned_by_search;
     InstShape is;
-    c->t_split = 0; c->t_grid_cap = 0; c->t_instloop = -1;
-    const bool instanced = inst_shape(c, &is);
+    const bool instanced = inst_shape(c, &is);      // with the caller's inst_loop: 0 (crowd kernel off) and 9 (register form) are not searched over
+    c->t_split = 0; c->t_grid_cap = 0; if (instanced) c->t_instloop = -1;
     add(0, 0, -1);
     if (instanced) {
         // total workgroups: one or two rounds of what the CUs hold at once (two 256-thread workgroups or one larger one);
@@ -2219,12 +2241,14 @@ int rz_autotune_apply(rz_ctx *c, const rz_tune_entry *e)
     const int sp = e->morph_split;
     if (sp != 0 && sp != 1 && sp != 2 && sp != 4 && sp != 8) return fail(RZ_ERR_INVALID, "rz_autotune_apply: morph_split %d", sp);
     if (e->grid_cap < 0 || e->inst_loop < -1 || e->inst_loop == 1 || e->inst_loop > 64) return fail(RZ_ERR_INVALID, "rz_autotune_apply: bad entry");
+    if (e->inst_loop == 9 && !rz_has_all_variants())
+        return fail(RZ_ERR_UNSUPPORTED, "rz_autotune_apply: inst_loop = 9 selects the register-resident crowd kernel, which the product library does not carry");
+    // a caller who switched the crowd kernel off (inst_loop = 0) or chose the register form (9) keeps that choice: the entry's
+    // pose-group size only applies where the search itself would have used one
     InstShape is;
-    c->t_split = sp; c->t_grid_cap = e->grid_cap;
-    const int keep_loop = c->t_instloop;
-    c->t_instloop = -1;
     const bool instanced = inst_shape(c, &is);
-    c->t_instloop = instanced ? e->inst_loop : keep_loop;
+    c->t_split = sp; c->t_grid_cap = e->grid_cap;
+    if (instanced) c->t_instloop = e->inst_loop;
     c->tuned_by_search = true;
     return RZ_OK;
 }
@@ -2241,11 +2265,11 @@ int rz_autotune(rz_ctx *c, uint32_t frames)
 int rz_set_tuning(rz_ctx *c, const char *key, int value)
 {
     if (!c || !key) return fail(RZ_ERR_INVALID, "null argument");
-    if (!strcmp(key, "morph_split") || !strcmp(key, "grid_cap") || !strcmp(key, "inst_loop")) c->tuned_by_search = false;   // the caller owns the shape now
     // variants that were measured slower everywhere are compiled into the tools-only build (make variants), not the product
     if (!rz_has_all_variants() && ((!strcmp(key, "unroll") && value == 4) || (!strcmp(key, "geo_lds") && value != 0) ||
                                    (!strcmp(key, "nontemporal") && value == 0) || (!strcmp(key, "inst_loop") && value == 9)))
         return fail(RZ_ERR_UNSUPPORTED, "%s = %d selects a kernel variant the product library does not carry (tools-only build: make -C reze-engine_amd/csrc variants)", key, value);
+    if (!strcmp(key, "morph_split") || !strcmp(key, "grid_cap") || !strcmp(key, "inst_loop")) c->tuned_by_search = false;   // the caller owns the shape now
     if (!strcmp(key, "morph_split")) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
             return fail(RZ_ERR_INVALID, "morph_split must be 0 (auto),1,2,4,8");
@@ -2311,6 +2335,12 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
 int rz_get_tuning(rz_ctx *c, const char *key, int *value)
 {
     if (!c || !key || !value) return fail(RZ_ERR_INVALID, "null argument");
+    if (!strncmp(key, "effective_", 10)) {
+        // what the NEXT frame will launch: a crowd's plan depends on the run lists of its launch shape, so bring them up to
+        // date first (as every entry point that launches frames does) instead of describing the whole-palette fallback
+        if (int r = use(c)) return r;
+        if (c->V && c->B) if (int r = ensure_run_subsets(c)) return r;
+    }
     if (!strcmp(key, "morph_split")) *value = c->t_split;
     else if (!strcmp(key, "unroll")) *value = c->t_unroll;
     else if (!strcmp(key, "grid_cap")) *value = c->t_grid_cap;

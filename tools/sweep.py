@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel-variant sweep on one MI355X (run through gpurun). Times the fused morph+skin kernel
+"""Kernel-variant sweep on one MI355X (run through gpurun; needs `make -C reze-engine_amd/csrc variants`). Times the fused morph+skin kernel
 alone with HIP events (rz_time_frames) for every tuning combination on the BASELINE configs and
 prints achieved algorithmic GB/s. Output: a table on stdout + gpurun_out/sweep.json."""
 import itertools
@@ -74,7 +74,8 @@ def run(ctx, name, frames, grid):
 
 def main():
     which = sys.argv[1:] or ["c5", "c5shard", "c4", "c3", "c2", "real"]
-    ctx = rz.DeformContext(0)
+    # the sweep covers variants the product does not carry (unroll = 4, geo_lds = 1, ...): it runs on the all-variants build
+    ctx = rz.DeformContext(0, lib=rz.capi.load(rz.capi.VARIANTS_LIB_PATH))
     out = []
     t0 = time.time()
     base = dict(morph_split=[0], unroll=[0], nontemporal=[1], nt_store=[-1], geo_lds=[0], grid_cap=[0], fast=[-1], inst_loop=[-1])
