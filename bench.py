@@ -52,7 +52,9 @@ def parse_args():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong: --verts is the whole mesh, sharded over ranks; weak: --verts per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-verts", type=int, default=200000)
+    ap.add_argument("--cpu-sample-verts", type=int, default=0,
+                    help="cpu_baseline: vertices of the mesh the CPU skin runs on; 0 (default) = the WHOLE mesh the GPU line deforms "
+                         "(BASELINE north star: 'CPU skin of the same mesh'), timed for ~10 s of frames")
     ap.add_argument("--allgather", action="store_true", help="time the RCCL all-gather of positions at N = 1 too (at N > 1 it always is, outside `value`)")
     ap.add_argument("--no-allgather", action="store_true", help="N > 1: skip the RCCL communicator + all-gather timing")
     ap.add_argument("--rccl-timeout", type=float, default=120.0, help="watchdog of the RCCL phase (communicator + all-gather), seconds")
@@ -77,7 +79,8 @@ def parse_args():
 
 
 def cpu_baseline(args, mesh, deltas, mw, sparse=None):
-    """Bounded CPU sample of the same workload: first `cpu_sample_verts` vertices, all morphs.
+    """CPU baseline on the same workload: the whole mesh (or, with --cpu-sample-verts, its first vertices), all morphs, a bounded
+    number of frames (~10 s).
     Preferred: the all-core JavaScript f32 skin (oracle/js/cpu_baseline.js, worker_threads).
     Fallback: the threaded C oracle, labelled as a stand-in. Sparse-morph workloads use the C oracle's sparse accumulate
     (the JavaScript baseline only knows dense targets) followed by its threaded skin."""
@@ -97,7 +100,7 @@ def cpu_baseline(args, mesh, deltas, mw, sparse=None):
         return {"value": V * frames / el, "unit": "verts/s", "cores": cores, "kind": "port",
                 "sample": "%d verts x %d sparse morphs (%d offsets), %d frames, C oracle: sparse morph accumulate on one thread + skin on %d threads "
                           "(C stand-in for the TypeScript baseline)" % (V, len(sparse[0]) - 1, int(sparse[0][-1]), frames, cores)}
-    n = min(args.cpu_sample_verts, len(mesh["pos"]))     # rank 0's shard = the head of the mesh
+    n = len(mesh["pos"]) if args.cpu_sample_verts <= 0 else min(args.cpu_sample_verts, len(mesh["pos"]))     # rank 0's shard = the head of the mesh
     sub = {k: np.ascontiguousarray(mesh[k][:n]) for k in ("pos", "nrm", "joints", "weights")}
     d = None if deltas is None else np.ascontiguousarray(deltas[:, :n])
     cores = os.cpu_count() or 1
@@ -124,12 +127,12 @@ def cpu_baseline(args, mesh, deltas, mw, sparse=None):
                     mw.astype(np.float32).tofile(os.path.join(td, "mw.f32"))
                 out = subprocess.check_output(
                     [node, js, td, str(n), str(len(mesh["world"])),
-                     str(0 if d is None else d.shape[0]), str(cores), "15"],
-                    stderr=subprocess.STDOUT, timeout=180).decode()
+                     str(0 if d is None else d.shape[0]), str(cores), "10"],
+                    stderr=subprocess.STDOUT, timeout=300).decode()
             r = json.loads(out.strip().splitlines()[-1])
             return {"value": r["verts_per_s"], "unit": "verts/s", "cores": r["threads"], "kind": "port",
-                    "sample": "%d verts x %d morphs, %d frames, JavaScript f32 skin (oracle/js) on %d worker_threads; "
-                              "single-thread %.3g verts/s" % (n, 0 if d is None else d.shape[0], r["frames"],
+                    "sample": "%d of the mesh's %d verts x %d morphs, %d timed frames, JavaScript f32 skin (oracle/js) on %d worker_threads; "
+                              "single-thread %.3g verts/s" % (n, len(mesh["pos"]), 0 if d is None else d.shape[0], r["frames"],
                                                                r["threads"], r["single_thread_verts_per_s"])}
         except Exception as e:   # fall through to the C port, say why
             sys.stderr.write("node cpu baseline failed (%s); using the C oracle\n" % e)

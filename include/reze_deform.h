@@ -68,7 +68,7 @@ int rz_create(int device, rz_ctx **out);
 int rz_destroy(rz_ctx *ctx);
 
 /* Pure helper: contiguous shard of rank `rank` of `nranks` over v_total vertices.
- * Shards are equal-sized (a multiple of 1024 vertices) except the last; *count may be 0. */
+ * Shards are equal-sized (a multiple of 256 vertices) except the last; *count may be 0. */
 int rz_shard_range(uint32_t v_total, int nranks, int rank, uint32_t *begin, uint32_t *count);
 
 /* setupModelBuffers()  engine/src/engine.ts:1734-1765: vertex buffer in the reference's

@@ -710,6 +710,68 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         if (!late_world) load_world();
         ei0 = gi[0]; ei1 = gi[1]; ei2 = gi[2]; ei3 = gi[3];
     }
+    const int s = lane / QPW;                // morph slice of this lane
+    const int qi = lane % QPW;
+    const size_t Vp = p.Vp;
+    const size_t plane4 = Vp / 4;            // float4 per plane
+    // persistent, evenly balanced partition: every wave of the grid owns one contiguous run of quads
+    // (a multiple of 8 quads = 128 B per plane) and walks it QPW quads at a time; the last step is masked.
+    const uint32_t wave_global = wid * (kBlock / 64) + wave;
+    const size_t q_begin = (size_t)wave_global * p.quads_per_wave;
+    const size_t q_end = min((size_t)p.n_quads, q_begin + p.quads_per_wave);
+
+    // Everything a step reads from the static mesh. Frames WITHOUT a dense morph stream (MODE 0 / 2: one character, small
+    // crowds, sparse targets) are latency-bound — a 30 k-vertex frame is two or three dependent memory round trips and a
+    // launch — so their steps ask for ALL of it at once: the quad's rest position, the skin phase's normal / joints / weights
+    // (vertex per lane) and, for sparse targets, the row bounds of the cooperative walk; and the FIRST step asks right here,
+    // in front of whatever the workgroup does first (the hierarchy solve, the staging of the morph weights, the palette), so
+    // the mesh arrives under that prologue instead of behind it (NOTEBOOK.md R4.1: one round trip is ~1.1 us of a 4-7 us
+    // frame). Dense frames keep the skin phase's loads behind the morph phase: there the kernel lives at 245 VGPRs.
+    constexpr bool PRE = MODE != 1 && !GEO;
+    constexpr int SP_RL = 8;                    // sparse rows: lanes per row ...
+    constexpr int SP_RPP = 64 / SP_RL;          // ... rows per pass ...
+    constexpr int SP_NP = 64 / SP_RPP;          // ... passes per round of 64 vertices
+    constexpr bool PRE_SP = PRE && MODE == 2 && ROUNDS == 1;      // (S = 1 steps are 4 rounds: their bounds are loaded round by round)
+    float4 gx, gy, gz, gnx, gny, gnz;
+    uint4 gj01, gj23, gw;
+    float pnx[PRE ? ROUNDS : 1], pny[PRE ? ROUNDS : 1], pnz[PRE ? ROUNDS : 1];
+    uint32_t pj01[PRE ? ROUNDS : 1], pj23[PRE ? ROUNDS : 1], pwq[PRE ? ROUNDS : 1];
+    uint32_t sb0[PRE_SP ? SP_NP : 1], sb1[PRE_SP ? SP_NP : 1];
+    auto issue = [&](const size_t qw) {
+        const size_t q = qw + qi;
+        if (s == 0 && q < q_end) {
+            const float4 *G = reinterpret_cast<const float4 *>(p.geom) + q;
+            gx = G[0]; gy = G[plane4]; gz = G[2 * plane4];
+            if (GEO) {
+                gnx = G[3 * plane4]; gny = G[4 * plane4]; gnz = G[5 * plane4];
+                gj01 = reinterpret_cast<const uint4 *>(p.joints01)[q];
+                gj23 = reinterpret_cast<const uint4 *>(p.joints23)[q];
+                gw = reinterpret_cast<const uint4 *>(p.weights)[q];
+            }
+        }
+        if constexpr (PRE) {
+            const int v_live = (int)min((size_t)VW, (q_end - qw) * 4);
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const int vl = r * 64 + lane;
+                if (vl < v_live) {
+                    const size_t v = qw * 4 + vl;
+                    pnx[r] = p.geom[3 * Vp + v]; pny[r] = p.geom[4 * Vp + v]; pnz[r] = p.geom[5 * Vp + v];
+                    pj01[r] = p.joints01[v]; pj23[r] = p.joints23[v]; pwq[r] = p.weights[v];
+                }
+            }
+            if constexpr (PRE_SP) {
+#pragma unroll
+                for (int ps = 0; ps < SP_NP; ++ps) {
+                    const int vl = ps * SP_RPP + lane / SP_RL;
+                    sb0[ps] = 0u; sb1[ps] = 0u;
+                    if (vl < v_live) { sb0[ps] = p.sp_ptr[qw * 4 + vl]; sb1[ps] = p.sp_ptr[qw * 4 + vl + 1]; }
+                }
+            }
+        }
+    };
+    if (PRE && q_begin < q_end) issue(q_begin);
+
     int fused_count = 0;
     if (!FAST && p.fk_on) {
         // FUSED single-character frame: hierarchy solve (and motion sampling) as this workgroup's prologue, palette straight
@@ -762,11 +824,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         __syncthreads();
     }
 
-    const int s = lane / QPW;                // morph slice of this lane
-    const int qi = lane % QPW;
     const int count = (MODE == 1) ? (FAST ? ml.count : (p.fk_on ? fused_count : p.act_count[inst])) : 0;
-    const size_t Vp = p.Vp;
-    const size_t plane4 = Vp / 4;            // float4 per plane
     float *scr = scratch_all + (size_t)wave * NPL * VW;
     const uint32_t bmax = (uint32_t)(p.B - 1);
     float *opos = p.out_pos + (size_t)inst * Vp * 3;
@@ -819,12 +877,6 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     };
     bool need_sync = FAST && RZ_DBG(p) != 3;          // one workgroup barrier publishes the palette before the first phase 2
 
-    // persistent, evenly balanced partition: every wave of the grid owns one contiguous run of quads
-    // (a multiple of 8 quads = 128 B per plane) and walks it QPW quads at a time; the last step is masked.
-    const uint32_t wave_global = wid * (kBlock / 64) + wave;
-    const size_t q_begin = (size_t)wave_global * p.quads_per_wave;
-    const size_t q_end = min((size_t)p.n_quads, q_begin + p.quads_per_wave);
-
     // Write batching (p.out_cap > 0): deformed vertices are parked in a per-wave LDS buffer of out_cap vertices and
     // flushed as 16-byte-per-lane stores when it fills and at the end of the run. Interleaving 24 B of stores per
     // vertex with the read stream cost 10.7 us of a 130 us C5 frame (ablation dbg 5) although the bytes are only
@@ -865,19 +917,9 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         const bool live = q < q_end;
         float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), ay = ax, az = ax;
 
-        // rest geometry of the quad (slice 0 only); issued first so it overlaps the morph stream
-        float4 gx, gy, gz, gnx, gny, gnz;
-        uint4 gj01, gj23, gw;
-        if (s == 0 && live) {
-            const float4 *G = reinterpret_cast<const float4 *>(p.geom) + q;
-            gx = G[0]; gy = G[plane4]; gz = G[2 * plane4];
-            if (GEO) {
-                gnx = G[3 * plane4]; gny = G[4 * plane4]; gnz = G[5 * plane4];
-                gj01 = reinterpret_cast<const uint4 *>(p.joints01)[q];
-                gj23 = reinterpret_cast<const uint4 *>(p.joints23)[q];
-                gw = reinterpret_cast<const uint4 *>(p.weights)[q];
-            }
-        }
+        // rest geometry of the quad (slice 0 only), issued first so it overlaps the morph stream; without a dense stream: the
+        // whole step's loads, and the run's first step has asked at the top of the kernel already
+        if (!PRE || !FIRST) issue(qw);
 
         if (MODE == 1 && live) {
             const float4 *D = reinterpret_cast<const float4 *>(p.dense) + q;
@@ -975,7 +1017,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         const size_t vw0 = qw * 4;     // first vertex of this wave's step
         const int v_live = RZ_DBG(p) == 4 ? 0 : (int)min((size_t)VW, (q_end - qw) * 4);   // dbg 4: ablation — morph phase only
 
-        if (MODE == 2) {
+        if constexpr (MODE == 2) {
             // ---- sparse morph targets: ROW-COOPERATIVE walk of the vertex-ordered CSR ----
             // entry = (dx, dy, dz, bits(morph)), a vertex's entries ascending by morph. Eight lanes share a row: lane k of the
             // eight takes entries k, k + 8, ... (a 128-byte piece of the row per load instruction, and the eight rows of a pass
@@ -985,19 +1027,18 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
             // One vertex per lane walking its own row (rounds 1-3) made every load instruction touch 64 different cache lines:
             // the face of the demo model (60 expression morphs on the same ~1 800 vertices, up to 60 entries per vertex) cost
             // 2 us more than the same entries spread over the mesh, all of it address processing (NOTEBOOK.md R4.1).
-            constexpr int RL = 8;                       // lanes per row
-            constexpr int RPP = 64 / RL;                // rows per pass
-            constexpr int NP = 64 / RPP;                // passes per round of 64 vertices
+            constexpr int RL = SP_RL, RPP = SP_RPP, NP = SP_NP;       // lanes per row, rows per pass, passes per round of 64 vertices
             const int rg = lane / RL, rl = lane % RL;
 #pragma unroll 1
-            for (int r = 0; r < ROUNDS; ++r) {
+            for (int r = 0; r < ROUNDS; ++r) {      // (PRE_SP: ROUNDS == 1)
                 uint32_t cur[NP], end[NP];
                 uint32_t has = 0u;                      // bit ps: this lane's row of pass ps has entries
 #pragma unroll
                 for (int ps = 0; ps < NP; ++ps) {
                     const int vl = r * 64 + ps * RPP + rg;
                     uint32_t b0 = 0u, b1 = 0u;
-                    if (vl < v_live) { b0 = p.sp_ptr[vw0 + vl]; b1 = p.sp_ptr[vw0 + vl + 1]; }
+                    if constexpr (PRE_SP) { b0 = sb0[ps]; b1 = sb1[ps]; }
+                    else if (vl < v_live) { b0 = p.sp_ptr[vw0 + vl]; b1 = p.sp_ptr[vw0 + vl + 1]; }
                     cur[ps] = b0 + (uint32_t)rl; end[ps] = b1;
                     has |= (b1 > b0 ? 1u : 0u) << ps;
                 }
@@ -1039,15 +1080,14 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         }
 
         // ---- phase 2: one vertex per lane ----
-#pragma unroll 1
-        for (int r = 0; r < ROUNDS; ++r) {
+        auto skin_round = [&](const int r, float nx, float ny, float nz, uint32_t j01, uint32_t j23, uint32_t wq) {
             const int vl = r * 64 + lane;
             if (vl < v_live) {
                 const size_t v = vw0 + vl;
                 const float x = scr[0 * VW + vl], y = scr[1 * VW + vl], z = scr[2 * VW + vl];
-                float nx, ny, nz;
-                uint32_t j01, j23, wq;
-                if (GEO) {
+                if constexpr (PRE) {
+                    // (asked for at the top of the step)
+                } else if (GEO) {
                     nx = scr[3 * VW + vl]; ny = scr[4 * VW + vl]; nz = scr[5 * VW + vl];
                     const uint32_t *su = reinterpret_cast<const uint32_t *>(scr);
                     j01 = su[6 * VW + vl]; j23 = su[7 * VW + vl]; wq = su[8 * VW + vl];
@@ -1076,6 +1116,13 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
                     bb[3] = fmaxf(bb[3], o.px); bb[4] = fmaxf(bb[4], o.py); bb[5] = fmaxf(bb[5], o.pz);
                 }
             }
+        };
+        if constexpr (PRE) {
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) skin_round(r, pnx[r], pny[r], pnz[r], pj01[r], pj23[r], pwq[r]);
+        } else {
+#pragma unroll 1
+            for (int r = 0; r < ROUNDS; ++r) skin_round(r, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u);
         }
         __builtin_amdgcn_wave_barrier();
         if (cap) {

@@ -48,6 +48,10 @@ int fail(int code, const char *fmt, ...)
 uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
 constexpr uint32_t kVertPad = 1024;   // planes are padded to a whole S=1 tile (256 quads)
+// Shards of one mesh are equal-sized except the last; their size is a multiple of 256 vertices (whole quads, whole S = 1 wave
+// steps, 16-byte aligned float3 boundaries in the gathered buffer). 1024 (rounds 1-3) made the ranks of a 1 M-vertex mesh over
+// 8 GPUs carry 125 952 vertices and the last 118 336; now 125 184 / 123 712: the slowest rank has 0.6 % less to do.
+constexpr uint32_t kShardGrain = 256;
 constexpr int kStageSlots = 8;
 
 // ---- lazily bound RCCL (librccl.so.1 is only needed by the multi-GPU entry points) ----
@@ -1194,7 +1198,7 @@ int rz_shard_range(uint32_t v_total, int nranks, int rank, uint32_t *begin, uint
     if (nranks < 1 || rank < 0 || rank >= nranks || !begin || !count)
         return fail(RZ_ERR_INVALID, "bad shard query (nranks=%d rank=%d)", nranks, rank);
     const uint64_t per = ((uint64_t)v_total + nranks - 1) / nranks;
-    const uint64_t chunk = (per + kVertPad - 1) / kVertPad * kVertPad;
+    const uint64_t chunk = (per + kShardGrain - 1) / kShardGrain * kShardGrain;
     uint64_t b = std::min<uint64_t>(v_total, chunk * (uint64_t)rank);
     uint64_t n = std::min<uint64_t>(chunk, v_total - b);
     *begin = (uint32_t)b;
@@ -2479,7 +2483,7 @@ static int comm_buffers(rz_ctx *c, int nranks, int rank, uint32_t v_total)
     c->nranks = nranks; c->rank = rank; c->v_total = v_total;
     uint32_t b0 = 0, n0 = 0;
     rz_shard_range(v_total, nranks, 0, &b0, &n0);
-    c->chunk = round_up(n0, kVertPad);
+    c->chunk = round_up(n0, kShardGrain);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     dfree(c->g_pos); dfree(c->g_nrm);
@@ -2552,7 +2556,7 @@ static int gather_direct_attach(rz_ctx **ctxs, int n, uint32_t v_total, int root
     rt->nranks = n; rt->rank = root; rt->v_total = v_total;
     uint32_t b0 = 0, n0 = 0;
     rz_shard_range(v_total, n, 0, &b0, &n0);
-    const uint32_t chunk = round_up(n0, kVertPad);
+    const uint32_t chunk = round_up(n0, kShardGrain);
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipStreamSynchronize(rt->stream));
     dfree(rt->g_pos); dfree(rt->g_nrm);

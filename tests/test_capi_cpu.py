@@ -36,7 +36,7 @@ def test_shard_ranges_tile_the_mesh(rz):
                 assert b1 == b0 + c0 or (c0 == 0 and b1 == v_total) or b1 == v_total
             full = [c for _, c in spans if c and c != spans[0][1]]
             assert len(full) <= 1                      # only the last non-empty shard may be short
-            assert spans[0][1] % 1024 == 0 or n == 1 or spans[0][1] == v_total
+            assert spans[0][1] % 256 == 0 or n == 1 or spans[0][1] == v_total
     with pytest.raises(rz.RzError):
         rz.shard_range(10, 0, 0)
 

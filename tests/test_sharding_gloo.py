@@ -79,7 +79,7 @@ def _check(res, v_total):
     for rank, ok, ranges, chunk in res:
         assert ok, "rank %d: gathered mesh differs from the unsharded result" % rank
         assert ranges[0][0] == 0 and ranges[0][1] + ranges[1][1] == v_total and (ranges[1][0] == ranges[0][1] or ranges[1][1] == 0)
-        assert chunk % 1024 == 0
+        assert chunk % 256 == 0
 
 
 def _free_port():

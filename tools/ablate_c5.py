@@ -8,7 +8,7 @@ import reze_engine_amd as rz
 rz.capi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ablate", "libreze_deform_ablate.so")
 from reze_engine_amd import synth
 ctx = rz.DeformContext(0)
-for V in (1000000, 125952):
+for V in (1000000, 125184):
     mesh = synth.make_mesh(V, 256); deltas, mw = synth.make_morphs_dense(V, 64)
     ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); ctx.upload_skeleton(mesh["inv_bind"])
     ctx.upload_morphs_dense(deltas); ctx.set_pose(mesh["world"], mw)

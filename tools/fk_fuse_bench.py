@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth
-for V, B, M, kind in ((30000, 200, 30, "sparse"), (30000, 200, 0, "none"), (30000, 200, 64, "dense"), (125952, 256, 64, "dense"), (1000000, 256, 64, "dense")):
+for V, B, M, kind in ((30000, 200, 30, "sparse"), (30000, 200, 0, "none"), (30000, 200, 64, "dense"), (125184, 256, 64, "dense"), (1000000, 256, 64, "dense")):
     ctx = rz.DeformContext(0)
     mesh = synth.make_mesh_range(max(V, 30000), B, 0, V)
     ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); ctx.upload_skeleton(mesh["inv_bind"])

@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth
-V, B, M = int(sys.argv[1]) if len(sys.argv) > 1 else 125952, 256, 64
+V, B, M = int(sys.argv[1]) if len(sys.argv) > 1 else 125184, 256, 64
 mesh = synth.make_mesh(V, B); deltas, w = synth.make_morphs_dense(V, M)
 world = synth.make_pose(mesh["parents"], mesh["bind"], B, seed=3)
 a = rz.DeformContext(0)

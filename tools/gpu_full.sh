@@ -14,8 +14,8 @@ echo "== bench"
 timeout 600 python bench.py 2>$O/bench.err | tail -1 > $O/bench_c5.json
 for c in c4 c3 c2; do timeout 600 python bench.py --config $c --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_$c.json; done
 for c in demo sparse2; do timeout 600 python bench.py --config $c 2>>$O/bench.err | tail -1 > $O/bench_$c.json; done
-timeout 600 python bench.py --verts 125952 --no-cpu-baseline --frames-in-flight 1 2>>$O/bench.err | tail -1 > $O/bench_shard8.json
-timeout 600 python bench.py --verts 125952 --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_shard8_auto.json
+timeout 600 python bench.py --verts 125184 --no-cpu-baseline --frames-in-flight 1 2>>$O/bench.err | tail -1 > $O/bench_shard8.json
+timeout 600 python bench.py --verts 125184 --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_shard8_auto.json
 timeout 600 python bench.py --config c4 --device-fk --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c4_devicefk.json
 timeout 600 python bench.py --config c4 --device-fk --device-sampling --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c4_sampled.json
 REZE_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --allgather --steps 100 --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c5_allgather1.json

@@ -6,7 +6,7 @@ rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 declare -A CFG
 CFG[c5]="--steps 20 --warmup 3 --no-cpu-baseline"
-CFG[shard]="--verts 125952 --steps 50 --warmup 5 --no-cpu-baseline"
+CFG[shard]="--verts 125184 --steps 50 --warmup 5 --no-cpu-baseline"
 CFG[c4]="--verts 30000 --bones 200 --morphs 0 --instances 256 --steps 30 --warmup 3 --no-cpu-baseline"
 G1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 G2="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"

@@ -9,7 +9,7 @@ rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 declare -A CFG
 CFG[c5]="--steps 40 --warmup 5"
-CFG[shard]="--verts 125952 --steps 200 --warmup 20"
+CFG[shard]="--verts 125184 --steps 200 --warmup 20"
 CFG[c4]="--config c4 --steps 100 --warmup 10"
 CFG[c3]="--config c3 --steps 200 --warmup 20"
 CFG[demo]="--config demo --steps 300 --warmup 20"

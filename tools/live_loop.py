@@ -6,7 +6,7 @@ import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth
 ctx = rz.DeformContext(0)
-for V in (1000000, 125952):
+for V in (1000000, 125184):
     mesh = synth.make_mesh_range(1000000, 256, 0, V); deltas, mw = synth.make_morphs_dense_range(1000000, 64, 0, V)
     ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); ctx.upload_skeleton(mesh["inv_bind"])
     ctx.upload_morphs_dense(deltas); ctx.set_pose(mesh["world"], mw)

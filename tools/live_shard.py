@@ -7,7 +7,7 @@ from reze_engine_amd import synth
 if os.environ.get("REZE_LIB"):
     rz.capi.LIB_PATH = os.environ["REZE_LIB"]
 ctx = rz.DeformContext(0)
-V = 125952
+V = 125184
 mesh = synth.make_mesh_range(1000000, 256, 0, V); deltas, mw = synth.make_morphs_dense_range(1000000, 64, 0, V)
 ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); ctx.upload_skeleton(mesh["inv_bind"])
 ctx.upload_morphs_dense(deltas); ctx.set_pose(mesh["world"], mw)
