@@ -137,8 +137,10 @@ struct RzDeformParams {
     uint32_t n_quads;           // ceil(V / 4)
     uint32_t quads_per_wave;    // contiguous run owned by each wave of the grid (multiple of 8)
     uint32_t out_cap;           // vertices buffered in LDS per wave before a 16-B/lane flush (0 = store directly)
+    uint32_t sp_cap;            // MODE 2: CSR entries a wave stages in LDS at a time (multiple of 64 = whole 1 KiB bursts)
 #ifdef RZ_ABLATE
     int dbg;                    // ablation switch — tools-only build (see RZ_DBG in deform_kernels.hip); absent from the product
+    unsigned long long *tl;     // tools-only build, dbg = 100: per-wave timeline, 8 x u64 per wave (RZ_STAMP in deform_kernels.hip)
 #endif
     int inst_order;             // instanced skin: 0 = an XCD takes one vertex run of every pose group, 1 = every vertex run of its pose groups
     // Instanced skin, BONE-SUBSET form: a vertex run only references a few of the skeleton's bones (PMX meshes are bone-local),

@@ -40,8 +40,27 @@ constexpr int kBlock = 256;
 // fold away, and rz_set_tuning("dbg", ...) is rejected: no key can make rz_deform emit anything but the deformed mesh.
 #ifdef RZ_ABLATE
 #define RZ_DBG(p) ((p).dbg)
+// Per-wave TIMELINE (tools-only build, rz_set_tuning dbg = 100; tools/timeline.py): a wave keeps up to seven readings of the
+// chip-wide 100 MHz counter (s_memrealtime: 10 ns steps, the same clock on every XCD) in scalar registers and writes them out
+// when it ends, with the XCC / CU / SIMD it ran on (16 x u64 per wave: 0..6 stamps, 7 where, 8..12 stamps inside the fused
+// hierarchy solve). Slot 6 is taken after every store of the wave has been acknowledged.
+#define RZ_TL_DECL unsigned long long tl_t[7] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, tl_f[5] = {0ull, 0ull, 0ull, 0ull, 0ull}
+#define RZ_STAMP(k) do { if (p.tl) tl_t[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RZ_TL_FLUSH(wave_index) do { if (p.tl) { \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+        tl_t[6] = __builtin_amdgcn_s_memrealtime(); \
+        if ((threadIdx.x & 63) == 0) { \
+            unsigned long long *o_ = p.tl + (size_t)(wave_index) * 16; \
+            for (int k_ = 0; k_ < 7; ++k_) o_[k_] = tl_t[k_]; \
+            for (int k_ = 0; k_ < 5; ++k_) o_[8 + k_] = tl_f[k_]; \
+            o_[7] = (unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) | \
+                    ((unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) << 8); \
+        } } } while (0)
 #else
 #define RZ_DBG(p) 0
+#define RZ_TL_DECL do {} while (0)
+#define RZ_STAMP(k) do {} while (0)
+#define RZ_TL_FLUSH(wave_index) do {} while (0)
 #endif
 
 __device__ __forceinline__ float4 ld_stream(const float4 *p, bool nt)
@@ -325,8 +344,13 @@ __device__ __forceinline__ void affine_mul(const float4 p0, const float4 p1, con
 // LDS behind `scr`: rz_fk_scratch_bytes(B) = B x (48 + 8 + 12) bytes. Ends with a barrier.
 template <bool FUSED>
 __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, float4 *wl, unsigned char *scr, float *lds_mw, const bool to_global,
-                                         const uint64_t st_tagv = 0ull)
+                                         const uint64_t st_tagv = 0ull, unsigned long long *fs = nullptr)
 {
+#ifdef RZ_ABLATE
+#define RZ_FSTAMP(k) do { if (fs) fs[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RZ_FSTAMP(k) do { (void)fs; } while (0)
+#endif
     // region X, 48 B per bone: local rotation | record word 0 | bind translation while the local matrices are formed, then the
     // second matrix buffer of the doubling rounds
     float4 *sq = reinterpret_cast<float4 *>(scr);                    // [B] local rotations of this pose
@@ -393,7 +417,9 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         }
     else if (bone_morphs && !FUSED)         // (FUSED: the caller has staged the uploaded weights already)
         for (int m = tid; m < p.bm_M; m += kBlock) lds_mw[m] = p.bm_w[(size_t)inst * p.bm_M + m];
+    RZ_FSTAMP(0);             // pose staged (sampled), before the barrier
     __syncthreads();
+    RZ_FSTAMP(1);
     if (bone_morphs) {
         // PMX bone morphs on the staged local pose: every bone folds its own entries, ascending morph index
         for (int b = tid; b < p.B; b += kBlock) {
@@ -460,6 +486,7 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         wl[b * 3 + 2] = make_float4(R[6], R[7], R[8], tz);
         s_anc[b] = (int)rec.x;
     }
+    RZ_FSTAMP(2);             // local matrices formed
     __syncthreads();          // (also: every read of region X is done, the rounds may write it)
     // Doubling rounds. Round k reads (M, A) from one buffer pair and writes the other: M'[b] = M[A[b]] * M[b], A'[b] = A[A[b]];
     // a bone whose run has reached its root (A < 0) is carried over unchanged. After ceil(log2(levels)) rounds every A is -1
@@ -482,6 +509,7 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         float4 *t4 = src; src = dst; dst = t4;
         int *ti = asrc; asrc = adst; adst = ti;
     }
+    RZ_FSTAMP(3);             // doubling rounds done
     if (p.ovr_off) {
         // physics-driven bones: the supplied world matrix replaces the solved one (rows 0..2 of the column-major 4x4)
         for (int k = p.ovr_off[inst] + tid; k < p.ovr_off[inst + 1]; k += kBlock) {
@@ -523,7 +551,9 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         if (to_global) { pal[b * 3] = q0; pal[b * 3 + 1] = q1; pal[b * 3 + 2] = q2; }
         if (FUSED) { wl[b * 3] = q0; wl[b * 3 + 1] = q1; wl[b * 3 + 2] = q2; }     // bone b's rows (in wl or in the other buffer) are only ever read by this thread in this pass
     }
+    RZ_FSTAMP(4);             // palette rows written
     if (FUSED) __syncthreads();
+#undef RZ_FSTAMP
 }
 
 __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
@@ -538,17 +568,6 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
 // helpers for the skin phase
 // ------------------------------------------------------------------------------------------------
 struct Skinned { float px, py, pz, nx, ny, nz; };
-
-// Sum over the 8 lanes of an aligned lane octet, left in every lane of it: a fixed butterfly of three DPP adds (lane ^ 1, lane ^ 2,
-// then the octet mirrored: k <-> 7 - k). Both partners of a pair add the same two values, and IEEE addition commutes, so all eight
-// lanes end with the same bits: the tree ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)), whichever lane is asked.
-__device__ __forceinline__ float row8_sum(float v)
-{
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    return v;
-}
 
 // vs() lines engine.ts:255-272 for one vertex. `pal` = LDS palette (3 float4 rows per bone).
 //   weights: w_i = (u8_i/255) / sum_k(u8_k/255)  (engine.ts:255-257)  ==  u8_i / isum  up to rounding;
@@ -649,6 +668,8 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     const int tid = threadIdx.x;
     const int inst = blockIdx.y;
     const int lane = tid & 63, wave = tid >> 6;
+    RZ_TL_DECL;
+    RZ_STAMP(0);                 // entry
 
     // Zero-copy pose prefetch (see RzDeformParams): workgroup 0 of such a launch is the helper, the workers shift by one.
     const bool pf_on = p.pf_src != nullptr;          // (only one-launch and fused-hierarchy frames ever carry one)
@@ -710,33 +731,53 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         if (!late_world) load_world();
         ei0 = gi[0]; ei1 = gi[1]; ei2 = gi[2]; ei3 = gi[3];
     }
+    // Skeletons of 257..512 bones (the demo model has 349): without a dense stream there are registers to spare, so the thread's
+    // SECOND bone is asked for up front as well — left to form_palette()'s late loop it was one more memory round trip in front
+    // of the first skin phase of every workgroup (dense frames keep the late loop: it hides under their morph stream).
+    constexpr bool EARLY2 = FAST && MODE != 1;
+    float4 fw0, fw1, fw2, fw3, fi0, fi1, fi2, fi3;
+    const bool early2 = EARLY2 && early && tid + kBlock < p.B;
+    auto load_world2 = [&]() {
+        const float4 *gw = reinterpret_cast<const float4 *>(world_in) + (tid + kBlock) * 4;
+        fw0 = gw[0]; fw1 = gw[1]; fw2 = gw[2]; fw3 = gw[3];
+    };
+    if (early2) {
+        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + (tid + kBlock) * 4;
+        load_world2();
+        fi0 = gi[0]; fi1 = gi[1]; fi2 = gi[2]; fi3 = gi[3];
+    }
     const int s = lane / QPW;                // morph slice of this lane
     const int qi = lane % QPW;
     const size_t Vp = p.Vp;
     const size_t plane4 = Vp / 4;            // float4 per plane
     // persistent, evenly balanced partition: every wave of the grid owns one contiguous run of quads
     // (a multiple of 8 quads = 128 B per plane) and walks it QPW quads at a time; the last step is masked.
-    const uint32_t wave_global = wid * (kBlock / 64) + wave;
+    // Without a dense stream the four waves of a workgroup take runs that lie a quarter of the mesh apart instead of next to
+    // each other: work on such frames is uneven — the demo model's 60 expression morphs all sit on one 1 800-vertex face region,
+    // 28 consecutive 64-vertex steps — and four neighbouring heavy steps on ONE CU share its LDS and its texture path
+    // (profiles/r4_timeline_demo.txt: 2.7 us in the row walk with four face waves per CU). Dense frames stream evenly: unchanged.
+    const uint32_t n_workers = gridDim.x - (pf_on ? 1u : 0u);
+    const uint32_t wave_global = MODE != 1 ? (uint32_t)wave * n_workers + wid : wid * (kBlock / 64) + wave;
     const size_t q_begin = (size_t)wave_global * p.quads_per_wave;
     const size_t q_end = min((size_t)p.n_quads, q_begin + p.quads_per_wave);
 
     // Everything a step reads from the static mesh. Frames WITHOUT a dense morph stream (MODE 0 / 2: one character, small
     // crowds, sparse targets) are latency-bound — a 30 k-vertex frame is two or three dependent memory round trips and a
     // launch — so their steps ask for ALL of it at once: the quad's rest position, the skin phase's normal / joints / weights
-    // (vertex per lane) and, for sparse targets, the row bounds of the cooperative walk; and the FIRST step asks right here,
+    // (vertex per lane) and, for sparse targets, the bounds of the vertex's row; and the FIRST step asks right here,
     // in front of whatever the workgroup does first (the hierarchy solve, the staging of the morph weights, the palette), so
     // the mesh arrives under that prologue instead of behind it (NOTEBOOK.md R4.1: one round trip is ~1.1 us of a 4-7 us
     // frame). Dense frames keep the skin phase's loads behind the morph phase: there the kernel lives at 245 VGPRs.
     constexpr bool PRE = MODE != 1 && !GEO;
-    constexpr int SP_RL = 8;                    // sparse rows: lanes per row ...
-    constexpr int SP_RPP = 64 / SP_RL;          // ... rows per pass ...
-    constexpr int SP_NP = 64 / SP_RPP;          // ... passes per round of 64 vertices
+    // (Dense frames keep the skin phase's attribute loads behind the morph phase. Round 4 tried to bring them in by LDS-DMA at the
+    // top of the step — 6 x 4 bytes per vertex straight into LDS, no VGPR held — so that the skin phase would not start with a
+    // memory round trip: C5 123.2 -> 128.5 us, a 1/8 shard 16.52 -> 16.75 us, only C3 gained (7.4 -> 7.0): NOTEBOOK.md R4.4. Removed.)
     constexpr bool PRE_SP = PRE && MODE == 2 && ROUNDS == 1;      // (S = 1 steps are 4 rounds: their bounds are loaded round by round)
     float4 gx, gy, gz, gnx, gny, gnz;
     uint4 gj01, gj23, gw;
     float pnx[PRE ? ROUNDS : 1], pny[PRE ? ROUNDS : 1], pnz[PRE ? ROUNDS : 1];
     uint32_t pj01[PRE ? ROUNDS : 1], pj23[PRE ? ROUNDS : 1], pwq[PRE ? ROUNDS : 1];
-    uint32_t sb0[PRE_SP ? SP_NP : 1], sb1[PRE_SP ? SP_NP : 1];
+    uint32_t sb0[1], sb1[1];                    // PRE_SP: row bounds of this lane's vertex
     auto issue = [&](const size_t qw) {
         const size_t q = qw + qi;
         if (s == 0 && q < q_end) {
@@ -761,12 +802,8 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
                 }
             }
             if constexpr (PRE_SP) {
-#pragma unroll
-                for (int ps = 0; ps < SP_NP; ++ps) {
-                    const int vl = ps * SP_RPP + lane / SP_RL;
-                    sb0[ps] = 0u; sb1[ps] = 0u;
-                    if (vl < v_live) { sb0[ps] = p.sp_ptr[qw * 4 + vl]; sb1[ps] = p.sp_ptr[qw * 4 + vl + 1]; }
-                }
+                sb0[0] = 0u; sb1[0] = 0u;
+                if (lane < v_live) { sb0[0] = p.sp_ptr[qw * 4 + lane]; sb1[0] = p.sp_ptr[qw * 4 + lane + 1]; }
             }
         }
     };
@@ -795,7 +832,11 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
                 if (wid == 0 && p.morph_w_copy && (!fspec || miss)) p.morph_w_copy[i] = w;
             }
         }
+#ifdef RZ_ABLATE
+        fk_solve<true>(p.fk, 0, pal, fscr, lds_mw, wid == 0, ftag, p.tl ? tl_f : nullptr);
+#else
         fk_solve<true>(p.fk, 0, pal, fscr, lds_mw, wid == 0, ftag);       // ends with a barrier: pal and lds_mw are complete
+#endif
         if (MODE == 1) fused_count = compact_active(lds_mw, p.M, p.Mpad, s_idx, s_w, fz_cnt);
         if (MODE == 2)
             for (int i = tid; i < p.M; i += kBlock) s_w[i] = lds_mw[i];
@@ -814,8 +855,21 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         __syncthreads();
     }
 
-    if (FAST && MODE == 2) {
-        const bool keep_w = wid == 0 && p.morph_w_copy != nullptr && !(staged_now && p.st_morph_w);     // zero-copy first frame, as for `world`
+    // Sparse targets, one-launch frame: the pose's morph weights go to LDS. Up to 256 morphs (one per thread) the weight is only
+    // REQUESTED here — it travels with the matrices and the first step's mesh loads — and is parked in LDS in front of the barrier
+    // that publishes the palette (publish_weights): one wait and one barrier for everything the first skin phase needs, where
+    // rounds 1-3 had a load -> LDS -> barrier sequence of their own in front of the palette (0.8 us of every such frame).
+    const bool keep_w = FAST && MODE == 2 && wid == 0 && p.morph_w_copy != nullptr && !(staged_now && p.st_morph_w);     // zero-copy first frame, as for `world`
+    bool w_pending = FAST && MODE == 2 && p.M <= kBlock;
+    float w_early = 0.0f;
+    if (w_pending && tid < p.M) w_early = morph_w_in[tid];
+    auto publish_weights = [&]() {
+        if (w_pending) {
+            if (tid < p.M) { s_w[tid] = w_early; if (keep_w) p.morph_w_copy[tid] = w_early; }
+            w_pending = false;
+        }
+    };
+    if (FAST && MODE == 2 && !w_pending) {
         for (int i = tid; i < p.M; i += kBlock) {
             const float w = morph_w_in[i];
             s_w[i] = w;
@@ -824,6 +878,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         __syncthreads();
     }
 
+    RZ_STAMP(1);                 // prologue done (hierarchy solve / staged palette + morph list / sparse weights)
     const int count = (MODE == 1) ? (FAST ? ml.count : (p.fk_on ? fused_count : p.act_count[inst])) : 0;
     float *scr = scratch_all + (size_t)wave * NPL * VW;
     const uint32_t bmax = (uint32_t)(p.B - 1);
@@ -861,12 +916,17 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
             world_in = p.world;
             keep_world = wid == 0 && p.world_copy != nullptr;
             if (early) load_world();
+            if (early2) load_world2();
         }
         if (early) {
             palette_rows(tid, ew0, ew1, ew2, ew3, ei0, ei1, ei2, ei3);
             if (keep_world) { float4 *d = reinterpret_cast<float4 *>(p.world_copy) + tid * 4; d[0] = ew0; d[1] = ew1; d[2] = ew2; d[3] = ew3; }
         }
-        for (int b = tid + kBlock; b < p.B; b += kBlock) {      // skeletons beyond 256 bones: plain loads, late
+        if (early2) {
+            palette_rows(tid + kBlock, fw0, fw1, fw2, fw3, fi0, fi1, fi2, fi3);
+            if (keep_world) { float4 *d = reinterpret_cast<float4 *>(p.world_copy) + (tid + kBlock) * 4; d[0] = fw0; d[1] = fw1; d[2] = fw2; d[3] = fw3; }
+        }
+        for (int b = tid + (EARLY2 ? 2 : 1) * kBlock; b < p.B; b += kBlock) {      // bones beyond what was asked for up front: plain loads, late
             const float4 *gw = reinterpret_cast<const float4 *>(world_in) + b * 4;
             const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + b * 4;
             const float4 w0 = gw[0], w1 = gw[1], w2 = gw[2], w3 = gw[3];
@@ -884,6 +944,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     const uint32_t cap = p.out_cap;
     float *ob_pos = scratch_all + (size_t)(kBlock / 64) * NPL * VW + (size_t)wave * cap * 6;
     float *ob_nrm = ob_pos + (size_t)cap * 3;
+    float *sp_all = scratch_all + (size_t)(kBlock / 64) * NPL * VW + (size_t)(kBlock / 64) * cap * 6;      // MODE 2: 4 x sp_cap staged CSR entries (16-byte aligned: every term is a multiple of 4 floats)
     uint32_t ob_fill = 0;               // vertices parked
     size_t ob_v0 = q_begin * 4;         // global vertex index of the first parked vertex
     auto flush_out = [&]() {
@@ -909,6 +970,41 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         ob_fill = 0;
     };
 
+    // ---- sparse morph targets (MODE 2): the step's piece of the vertex-ordered CSR goes through LDS ----
+    // entry = (dx, dy, dz, bits(morph)), a vertex's entries ascending by morph, the entries of a step's vertices one contiguous
+    // range [E0, E1). The wave copies that range into its LDS buffer by LDS-DMA — consecutive lanes, 16-byte entries: every
+    // instruction is one 1 KiB burst, no register is held and ALL of them are in flight at once — and only then does each lane
+    // (= one vertex) walk its own row, out of LDS: acc = acc + w * d, one rounding per operation, ascending entries: the CPU
+    // oracle's sparse accumulate bit for bit, whatever the launch shape. Ranges larger than the buffer go through it in pieces; a
+    // row that straddles two pieces keeps its running sum. A 64-vertex step asks for its first piece at the TOP of the step, as
+    // soon as its row bounds are there: it lands while the palette is formed and the quad is parked.
+    // Rounds 1-3 let every lane walk its row in global memory, 4 entries at a time: a load instruction then touches 64 different
+    // cache lines and every four entries cost a memory round trip — the face of the demo model (60 expression morphs on the same
+    // ~1 800 vertices, up to 60 entries per vertex) kept its waves 4.3 us in that loop (profiles/r4_timeline_*.txt, NOTEBOOK.md R4.1).
+    // LDS slots are XOR-swizzled (bits 0..3 with bits 4..7 of the entry's index in the piece): lanes read rows whose starts are
+    // a row length apart, and with rows of 16 / 32 / 48 entries — or the demo shape's 20 — plain slots put a whole wave on the same
+    // few banks. The DMA cannot scatter, so the swizzle is applied on the way IN: lane L of a burst fetches the entry whose slot L is
+    // (an involution inside aligned 16-entry groups: the burst still reads the same 256-byte segments).
+    float4 *sp_buf = reinterpret_cast<float4 *>(sp_all) + (size_t)wave * p.sp_cap;
+    const uint32_t sp_cap = p.sp_cap;
+    auto sp_slot = [](uint32_t i) { return i ^ ((i >> 4) & 15u); };
+    // Four bursts share one LDS base (M0); the instruction offset — added to the global AND the LDS address — steps through
+    // them. Rewriting M0 for every burst doubled the time a wave needs to issue a 20 KB piece (tools/dmabench: 2 155 vs 995 cycles).
+    auto sp_stage = [&](const uint32_t c0, const uint32_t c1) {
+        typedef const __attribute__((address_space(1))) void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
+        for (uint32_t i = 0; c0 + i < c1; i += 256) {
+            const lptr_t l = (lptr_t)(uint32_t)(uintptr_t)(sp_buf + i);
+            const uint32_t e0 = c0 + sp_slot(i + (uint32_t)lane), e1 = c0 + sp_slot(i + 64 + (uint32_t)lane);
+            const uint32_t e2 = c0 + sp_slot(i + 128 + (uint32_t)lane), e3 = c0 + sp_slot(i + 192 + (uint32_t)lane);
+            if (e0 < c1) __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(p.sp_entries + e0), l, 16, 0, 0);
+            if (e1 < c1) __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(p.sp_entries + e1 - 64), l, 16, 1024, 0);
+            if (e2 < c1) __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(p.sp_entries + e2 - 128), l, 16, 2048, 0);
+            if (e3 < c1) __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(p.sp_entries + e3 - 192), l, 16, 3072, 0);
+        }
+    };
+    uint32_t spE0 = 0u, spE1 = 0u;          // PRE_SP: the step's entry range
+
     // One step = QPW quads. The body is instantiated twice: FIRST (the run's first step, which also forms the
     // palette from the early-loaded matrices) and the steady-state form, where those 32 registers are dead.
     auto step = [&](const size_t qw, auto first_tag) {
@@ -920,6 +1016,14 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         // rest geometry of the quad (slice 0 only), issued first so it overlaps the morph stream; without a dense stream: the
         // whole step's loads, and the run's first step has asked at the top of the kernel already
         if (!PRE || !FIRST) issue(qw);
+        if constexpr (PRE_SP) {
+            // the row bounds are the oldest loads in flight (the first step's were asked for at the top of the kernel): the first
+            // piece of the step's entries is requested before anything else the step does
+            const int n_live = (int)min((size_t)64, (q_end - qw) * 4);
+            spE0 = __builtin_amdgcn_readfirstlane(sb0[0]);
+            spE1 = __builtin_amdgcn_readlane(sb1[0], n_live - 1);
+            if (spE0 < spE1) sp_stage(spE0, min(spE1, spE0 + sp_cap));
+        }
 
         if (MODE == 1 && live) {
             const float4 *D = reinterpret_cast<const float4 *>(p.dense) + q;
@@ -996,8 +1100,11 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
             }
         }
 
+        if (FIRST) RZ_STAMP(2);       // first step: morph phase done (its loads have landed)
         if (FAST && FIRST && need_palette) form_palette();            // no morph group ran (MODE 0/2, or nothing active)
-        if (FAST && FIRST && need_sync) { __syncthreads(); need_sync = false; }   // palette of every wave is in LDS
+        if (FAST && MODE == 2 && FIRST) publish_weights();
+        if (FAST && FIRST && need_sync) { __syncthreads(); need_sync = false; }   // palette (and sparse weights) of every wave are in LDS
+        if (FIRST) RZ_STAMP(3);       // first step: palette published
 
         // ---- park the quad in the wave's scratch: plane-major [NPL][VW] dwords ----
         if (s == 0 && live) {
@@ -1017,66 +1124,48 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         const size_t vw0 = qw * 4;     // first vertex of this wave's step
         const int v_live = RZ_DBG(p) == 4 ? 0 : (int)min((size_t)VW, (q_end - qw) * 4);   // dbg 4: ablation — morph phase only
 
+        float spx[ROUNDS], spy[ROUNDS], spz[ROUNDS];        // MODE 2: this lane's vertex's morph offset, per round
         if constexpr (MODE == 2) {
-            // ---- sparse morph targets: ROW-COOPERATIVE walk of the vertex-ordered CSR ----
-            // entry = (dx, dy, dz, bits(morph)), a vertex's entries ascending by morph. Eight lanes share a row: lane k of the
-            // eight takes entries k, k + 8, ... (a 128-byte piece of the row per load instruction, and the eight rows of a pass
-            // are neighbours in memory), its partial sums are one FMA chain, and the eight partials are combined by a fixed
-            // DPP butterfly — so a row's sum depends on the row alone, not on the launch shape or on the rows around it.
-            // Eight passes cover the 64 vertices of a round; the passes' loads of one round are all in flight together.
-            // One vertex per lane walking its own row (rounds 1-3) made every load instruction touch 64 different cache lines:
-            // the face of the demo model (60 expression morphs on the same ~1 800 vertices, up to 60 entries per vertex) cost
-            // 2 us more than the same entries spread over the mesh, all of it address processing (NOTEBOOK.md R4.1).
-            constexpr int RL = SP_RL, RPP = SP_RPP, NP = SP_NP;       // lanes per row, rows per pass, passes per round of 64 vertices
-            const int rg = lane / RL, rl = lane % RL;
-#pragma unroll 1
-            for (int r = 0; r < ROUNDS; ++r) {      // (PRE_SP: ROUNDS == 1)
-                uint32_t cur[NP], end[NP];
-                uint32_t has = 0u;                      // bit ps: this lane's row of pass ps has entries
 #pragma unroll
-                for (int ps = 0; ps < NP; ++ps) {
-                    const int vl = r * 64 + ps * RPP + rg;
-                    uint32_t b0 = 0u, b1 = 0u;
-                    if constexpr (PRE_SP) { b0 = sb0[ps]; b1 = sb1[ps]; }
-                    else if (vl < v_live) { b0 = p.sp_ptr[vw0 + vl]; b1 = p.sp_ptr[vw0 + vl + 1]; }
-                    cur[ps] = b0 + (uint32_t)rl; end[ps] = b1;
-                    has |= (b1 > b0 ? 1u : 0u) << ps;
+            for (int r = 0; r < ROUNDS; ++r) {
+                const int vl = r * 64 + lane;
+                const int n_live = min(64, v_live - r * 64);        // lanes of this round that own a vertex (wave-uniform)
+                spx[r] = 0.0f; spy[r] = 0.0f; spz[r] = 0.0f;
+                if (n_live <= 0) continue;
+                uint32_t b0, b1, E0, E1;
+                if constexpr (PRE_SP) { b0 = sb0[0]; b1 = sb1[0]; E0 = spE0; E1 = spE1; }        // (the first piece is on its way)
+                else {
+                    b0 = 0u; b1 = 0u;
+                    if (vl < v_live) { b0 = p.sp_ptr[vw0 + vl]; b1 = p.sp_ptr[vw0 + vl + 1]; }
+                    E0 = __builtin_amdgcn_readfirstlane(b0);
+                    E1 = __builtin_amdgcn_readlane(b1, n_live - 1);
                 }
-                if (__ballot(has != 0u) == 0ull) continue;          // no vertex of this round carries an offset
-                float sx[NP], sy[NP], sz[NP];
+                for (uint32_t c0 = E0; c0 < E1; c0 += sp_cap) {             // wave-uniform; no iteration at all for a step without offsets
+                    const uint32_t c1 = min(E1, c0 + sp_cap);
+                    if (!PRE_SP || c0 != E0) sp_stage(c0, c1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t lo = max(b0, c0), hi = min(b1, c1);
+                    constexpr int SU = 8;                                   // LDS reads in flight per lane (entry, then its weight)
+                    for (uint32_t j = lo; j < hi; j += SU) {
+                        float4 ent[SU];
+                        float w[SU];
 #pragma unroll
-                for (int ps = 0; ps < NP; ++ps) { sx[ps] = 0.0f; sy[ps] = 0.0f; sz[ps] = 0.0f; }
-                for (;;) {
-                    bool more = false;
+                        for (int u = 0; u < SU; ++u) ent[u] = sp_buf[sp_slot(min(j + u, hi - 1) - c0)];
 #pragma unroll
-                    for (int ps = 0; ps < NP; ++ps) more = more || cur[ps] < end[ps];
-                    if (__ballot(more) == 0ull) break;
-                    float4 ent[NP];
+                        for (int u = 0; u < SU; ++u) w[u] = s_w[__float_as_uint(ent[u].w)];
 #pragma unroll
-                    for (int ps = 0; ps < NP; ++ps)
-                        ent[ps] = cur[ps] < end[ps] ? p.sp_entries[cur[ps]] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int ps = 0; ps < NP; ++ps) {
-                        const bool on = cur[ps] < end[ps];
-                        const float w = s_w[on ? __float_as_uint(ent[ps].w) : 0u];
-                        sx[ps] = on ? fmaf(w, ent[ps].x, sx[ps]) : sx[ps];
-                        sy[ps] = on ? fmaf(w, ent[ps].y, sy[ps]) : sy[ps];
-                        sz[ps] = on ? fmaf(w, ent[ps].z, sz[ps]) : sz[ps];
-                        cur[ps] += RL;
+                        for (int u = 0; u < SU; ++u)
+                            if (j + u < hi) {
+                                spx[r] = __fadd_rn(spx[r], __fmul_rn(w[u], ent[u].x));
+                                spy[r] = __fadd_rn(spy[r], __fmul_rn(w[u], ent[u].y));
+                                spz[r] = __fadd_rn(spz[r], __fmul_rn(w[u], ent[u].z));
+                            }
                     }
-                }
-#pragma unroll
-                for (int ps = 0; ps < NP; ++ps) {
-                    if (__ballot((has >> ps) & 1u) == 0ull) continue;     // wave-uniform: nothing in this pass
-                    const float tx = row8_sum(sx[ps]), ty = row8_sum(sy[ps]), tz = row8_sum(sz[ps]);
-                    if (rl == 0 && ((has >> ps) & 1u)) {
-                        const int vl = r * 64 + ps * RPP + rg;
-                        scr[0 * VW + vl] += tx; scr[1 * VW + vl] += ty; scr[2 * VW + vl] += tz;
-                    }
+                    __builtin_amdgcn_wave_barrier();                        // every lane is done with this piece before the next one lands
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
 
         // ---- phase 2: one vertex per lane ----
@@ -1084,7 +1173,8 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
             const int vl = r * 64 + lane;
             if (vl < v_live) {
                 const size_t v = vw0 + vl;
-                const float x = scr[0 * VW + vl], y = scr[1 * VW + vl], z = scr[2 * VW + vl];
+                float x = scr[0 * VW + vl], y = scr[1 * VW + vl], z = scr[2 * VW + vl];
+                if constexpr (MODE == 2) { x = __fadd_rn(x, spx[r]); y = __fadd_rn(y, spy[r]); z = __fadd_rn(z, spz[r]); }
                 if constexpr (PRE) {
                     // (asked for at the top of the step)
                 } else if (GEO) {
@@ -1120,11 +1210,15 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         if constexpr (PRE) {
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) skin_round(r, pnx[r], pny[r], pnz[r], pj01[r], pj23[r], pwq[r]);
+        } else if constexpr (MODE == 2) {      // (GEO form of the sparse kernel, tools-only build: spx[r] wants a constant index)
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) skin_round(r, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u);
         } else {
 #pragma unroll 1
             for (int r = 0; r < ROUNDS; ++r) skin_round(r, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u);
         }
         __builtin_amdgcn_wave_barrier();
+        if (FIRST) RZ_STAMP(4);       // first step: skin phase issued
         if (cap) {
             ob_fill += (uint32_t)v_live;
             if (ob_fill + VW > cap) flush_out();      // the next step might not fit
@@ -1135,8 +1229,10 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
         if (qw < q_end) { step(qw, std::true_type{}); qw += QPW; }
         for (; qw < q_end; qw += QPW) step(qw, std::false_type{});
     }
+    RZ_STAMP(5);                 // last step done
     if (cap && ob_fill) flush_out();
     if (FAST && need_palette) form_palette();    // a wave with an empty run still owes the workgroup its bones ...
+    if (FAST && MODE == 2) publish_weights();    // ... its morph weights ...
     if (FAST && need_sync) __syncthreads();      // ... and its barrier
     if (p.aabb) {
         // fused per-frame bounding box: per-lane running min/max -> wave butterfly -> one atomic per wave and
@@ -1162,6 +1258,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
             next[tid] = tid < 3 ? 0xffffffffu : 0u;
         }
     }
+    RZ_TL_FLUSH(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + wave);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1199,6 +1296,8 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *pal = reinterpret_cast<float4 *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    RZ_TL_DECL;
+    RZ_STAMP(0);                 // entry
     // Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest). inst_order 0: x = vertex run — an XCD sees every
     // pose group and one eighth of the mesh; 1: consecutive workgroups take consecutive pose groups — an XCD sees one eighth of
     // the poses' matrices and the whole mesh.
@@ -1279,6 +1378,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         j01 = jp01[v]; j23 = jp23[v]; wq = p.weights[v];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // palettes / world matrices (and the first vertex) have landed
+    RZ_STAMP(1);                 // staged matrices have landed
     __syncthreads();
     if constexpr (SUB) {
         if (!p.dma && RZ_DBG(p) != 8) {
@@ -1357,7 +1457,9 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
             for (int i = lo + tid; i < hi; i += BLOCK) gp[i] = pal[i];
         }
     }
+    RZ_STAMP(2);                 // palettes formed and published: the front is over
     for (uint32_t vb = v_begin; vb < v_end; vb += BLOCK, v += BLOCK) {   // workgroup-uniform trip count (the ballots below need whole waves)
+        if (vb == v_begin + BLOCK) RZ_STAMP(3);      // first vertex step done (8 poses written)
         const uint32_t vn = v + BLOCK;
         float xn = 0, yn = 0, zn = 0, nxn = 0, nyn = 0, nzn = 0;
         uint32_t j01n = 0, j23n = 0, wqn = 0;
@@ -1447,6 +1549,8 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         else pose_loop(std::integral_constant<int, 1>{});
         x = xn; y = yn; z = zn; nx = nxn; ny = nyn; nz = nzn; j01 = j01n; j23 = j23n; wq = wqn;
     }
+    RZ_STAMP(5);                 // last vertex step issued
+    RZ_TL_FLUSH(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (BLOCK / 64) + wave);
 }
 
 #ifdef RZ_ALL_VARIANTS
@@ -1655,7 +1759,7 @@ size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v)
     const size_t vw = 256 / v.S;   // vertices per wave per tile
     size_t scratch = (size_t)(kBlock / 64) * (v.geo ? 9 : 3) * vw * 4;
     const size_t list = (v.mode == 2 || (!v.fast && v.mode == 1)) ? (size_t)p.Mpad * 8 : 0;
-    size_t work = scratch + (size_t)(kBlock / 64) * p.out_cap * 24;
+    size_t work = scratch + (size_t)(kBlock / 64) * p.out_cap * 24 + (v.mode == 2 ? (size_t)(kBlock / 64) * p.sp_cap * 16 : 0);     // sparse: staged CSR pieces
     if (p.fk_on) work = std::max(work, rz_fk_scratch_bytes(p.B) + (size_t)std::max(p.M, 1) * 4 + 16);   // the fused solve's scratch aliases it
     return (size_t)p.B * 48 + list + work;
 }

@@ -297,6 +297,10 @@ struct rz_ctx {
     // side may replace static data.
     rz_ctx *lender = nullptr;
     int n_forks = 0;
+#ifdef RZ_ABLATE
+    unsigned long long *tl = nullptr;           // tools-only build: per-wave timeline of the last frame (dbg = 100)
+    size_t tl_waves = 0;
+#endif
     std::vector<rz_ctx *> contributors;         // set on the root
     hipEvent_t ev_done = nullptr;               // "my last frame has been enqueued up to here" for rz_gather_fence
 };
@@ -511,7 +515,7 @@ int auto_split(const rz_ctx *c)
     return S;
 }
 
-struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; int inst_block; bool fuse_fk; bool subsets; uint32_t sub_bones; uint64_t inst_lds; bool pf; };
+struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; int inst_block; bool fuse_fk; bool subsets; uint32_t sub_bones; uint64_t inst_lds; bool pf; uint32_t sp_cap; };
 
 // Where the kernels read the current pose from: the device pose block, or (zero-copy, not yet resident) the pinned slot.
 const float *src_world(const rz_ctx *c)
@@ -584,9 +588,11 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     p.B = (int)c->B; p.M = (int)c->M; p.Mpad = (int)c->Mpad;
     p.inst_order = c->t_instorder;
 #ifdef RZ_ABLATE
-    p.dbg = c->t_dbg;
+    p.dbg = c->t_dbg == 100 ? 0 : c->t_dbg;
+    p.tl = c->t_dbg == 100 ? c->tl : nullptr;      // (allocated by rz_debug_timeline_arm)
 #endif
     p.out_cap = pl.out_cap;
+    p.sp_cap = pl.sp_cap;
     if (pl.subsets) { p.rj01 = c->rj01; p.rj23 = c->rj23; p.sub_list = c->sub_list; p.sub_count = c->sub_count; p.sub_stride = (int)c->sub_B; }
     if (pl.fuse_fk) {
         p.fk = fk_params(c); p.fk_on = 1;
@@ -725,6 +731,20 @@ Plan make_plan(const rz_ctx *c)
             q.B = (int)c->B; q.M = (int)c->M; q.Mpad = (int)c->Mpad; q.out_cap = pl.out_cap; q.fk_on = pl.fuse_fk ? 1 : 0;
             if (rz_deform_lds_bytes(q, v) > 160 * 1024) pl.out_cap = 0;
         }
+    }
+    // Sparse targets: every wave stages its step's piece of the CSR in LDS (deform_kernels.hip, MODE 2). The buffer takes what the
+    // launch leaves of the LDS — a frame of at most one workgroup per CU (a single character: the demo model is 113 workgroups)
+    // has the CU's 160 KB to itself, larger frames plan for two workgroups per CU — up to a whole step of M-entry rows or 2 048
+    // entries (32 KB per wave); longer ranges go through it in pieces.
+    if (v.mode == 2) {
+        RzDeformParams q;
+        memset(&q, 0, sizeof q);
+        q.B = (int)c->B; q.M = (int)c->M; q.Mpad = (int)c->Mpad; q.out_cap = pl.out_cap; q.fk_on = pl.fuse_fk ? 1 : 0;
+        const size_t base = rz_deform_lds_bytes(q, v);
+        const size_t budget = ((uint64_t)pl.grid_x * c->I <= (uint64_t)c->n_cu ? 160u : 80u) * 1024u;
+        const size_t avail = budget > base + 4096 ? (budget - base - 1024) / (waves_per_wg * 16) : 64;
+        const uint32_t want = std::min<uint32_t>(2048u, (256u / (uint32_t)v.S) * std::max<uint32_t>(c->M, 1u));
+        pl.sp_cap = std::max<uint32_t>(64u, std::min<uint32_t>(round_up(want, 256), (uint32_t)(avail / 64 * 64)));         // whole 1 KiB bursts (the kernel issues them in groups of four)
     }
     // instanced, morph-free frames: G poses per workgroup share one decode of each vertex, their palettes live in LDS.
     // Where the palettes come from (measured on C4, tools/ablate_c4.py, frame = everything a frame launches):
@@ -1140,6 +1160,9 @@ int rz_destroy(rz_ctx *c)
         if (c->ev_skin[k]) (void)hipEventDestroy(c->ev_skin[k]);
     }
     dfree(c->out_pos); dfree(c->out_nrm); dfree(c->g_pos); dfree(c->g_nrm);
+#ifdef RZ_ABLATE
+    dfree(c->tl);
+#endif
     dfree(c->edge); dfree(c->out_hull); dfree(c->aabb);
     for (int i = 0; i < kStageSlots; ++i) {
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
@@ -2400,6 +2423,34 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else return fail(RZ_ERR_INVALID, "unknown tuning key '%s'", key);
     return RZ_OK;
 }
+
+#ifdef RZ_ABLATE
+// tools-only build (make ablate): per-wave timeline of the frames that follow (tools/timeline.py). Not part of the C ABI.
+__attribute__((visibility("default"))) int rz_debug_timeline_arm(rz_ctx *c, uint32_t *waves)
+{
+    if (int r = use(c)) return r;
+    Plan pl;
+    if (int r = frame_plan(c, &pl)) return r;
+    const size_t wpw = pl.inst_group > 0 ? (size_t)pl.inst_block / 64 : 4;
+    const size_t groups = pl.inst_group > 0 ? (c->I + pl.inst_group - 1) / pl.inst_group : c->I;
+    const size_t n = ((size_t)pl.grid_x + 1) * groups * wpw;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n > c->tl_waves) { dfree(c->tl); HIP_TRY(hipMalloc(&c->tl, n * 128)); c->tl_waves = n; }
+    HIP_TRY(hipMemset(c->tl, 0, c->tl_waves * 128));
+    c->t_dbg = 100;
+    drop_graph(c);
+    if (waves) *waves = (uint32_t)n;
+    return RZ_OK;
+}
+__attribute__((visibility("default"))) int rz_debug_timeline_read(rz_ctx *c, unsigned long long *out, uint32_t waves)
+{
+    if (int r = use(c)) return r;
+    if (!c->tl || waves > c->tl_waves || !out) return fail(RZ_ERR_INVALID, "no timeline armed");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->tl, (size_t)waves * 128, hipMemcpyDeviceToHost));
+    return RZ_OK;
+}
+#endif
 
 int rz_output_ptrs(rz_ctx *c, void **pos, void **nrm, uint32_t *v_padded)
 {

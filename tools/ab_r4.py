@@ -29,6 +29,19 @@ if "small" in which:
         out.append("%s %.3f" % (name, ts[3] * 1e3))
     print(tag, "kernel us (median of 7 x 1000 frames):", " | ".join(out), flush=True)
     ctx.close()
+if "dense" in which:
+    for name, V, B, M in (("c3", 30000, 200, 64), ("shard", 125184, 256, 64), ("c5", 1000000, 256, 64)):
+        ctx = rz.DeformContext(0)
+        mesh = synth.make_mesh_range(max(V, 30000), B, 0, V)
+        ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); ctx.upload_skeleton(mesh["inv_bind"])
+        d, mw = synth.make_morphs_dense_range(max(V, 30000), M, 0, V); ctx.upload_morphs_dense(d); del d
+        ctx.set_pose(mesh["world"], mw)
+        for _ in range(6):
+            ctx.deform_n(300 if V < 500000 else 60); ctx.sync()
+        n = 1000 if V < 500000 else 200
+        ts = sorted((t["deform_kernel_ms"], t["frame_ms"]) for t in (ctx.time_frames(n) for _ in range(7)))
+        print(tag, "%s kernel / frame us (median of 7 x %d frames): %.3f / %.3f" % (name, n, ts[3][0] * 1e3, ts[3][1] * 1e3), flush=True)
+        ctx.close()
 if "anim" in which:
     for V, B, M, kind in ((30000, 200, 0, "none"), (28842, 349, 60, "sparse")):
         ctx = rz.DeformContext(0)

@@ -2,7 +2,7 @@
 # Round 4, first contact: parity of the row-cooperative sparse walk / pointer-doubling hierarchy solve / local-pose prefetch,
 # then A/B against the round-3 library (tools/_tmp/old/libreze_deform_old.so, built from the previous commit).
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
-O=gpurun_out/r4b; rm -rf $O; mkdir -p $O
+O=gpurun_out/r4c; rm -rf $O; mkdir -p $O
 echo "== pytest (sparse, device FK, prefetch, fuzz)"
 timeout 900 python -m pytest tests -m gpu -q -x -k "sparse or fk or FK or prefetch or fuzz or bone_morph or sampled or local or smoke or physics or override" 2>&1 | tail -15 | tee $O/pytest_subset.txt
 echo "== A/B"
@@ -15,7 +15,7 @@ for c in demo sparse2 c2; do timeout 300 python bench.py --config $c --no-cpu-ba
 timeout 300 python bench.py --config c4 --device-fk --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/bench_c4_devicefk.json
 python - <<'P'
 import json, glob
-for f in sorted(glob.glob('gpurun_out/r4b/bench_*.json')):
+for f in sorted(glob.glob('gpurun_out/r4c/bench_*.json')):
     try:
         d = json.load(open(f)); c = d['config']; r = d['roofline']
         print('%-26s ms/step %.5f (one %s two %s) kernel %s %.5f ms frac %.3f traffic %s | upload loop %s sampled loop %s' % (
