@@ -201,6 +201,9 @@ hipError_t rz_launch_run_subsets(const uint32_t *j01, const uint32_t *j23, uint3
                                  uint16_t *list, uint32_t *count, uint32_t *rj01, uint32_t *rj23, hipStream_t st);
 uint32_t rz_quads_per_tile(int S);
 bool rz_has_all_variants();      // false in the product: only the variants a plan can select by default are compiled in
+#ifdef RZ_ALL_VARIANTS
+hipError_t rz_launch_gate(const uint32_t *flag, hipStream_t st);     // test hook (tools-only build): the stream waits until *flag != 0
+#endif
 hipError_t rz_launch_deinterleave(const float *src, int stride, int offset, uint32_t n, float *px, float *py,
                                   float *pz, hipStream_t st);
 hipError_t rz_launch_pack_skinning(const uint16_t *joints4, const uint8_t *weights4, uint32_t n, uint32_t *j01,

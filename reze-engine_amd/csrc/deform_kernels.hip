@@ -974,9 +974,9 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     // entry = (dx, dy, dz, bits(morph)), a vertex's entries ascending by morph, the entries of a step's vertices one contiguous
     // range [E0, E1). The wave copies that range into its LDS buffer by LDS-DMA — consecutive lanes, 16-byte entries: every
     // instruction is one 1 KiB burst, no register is held and ALL of them are in flight at once — and only then does each lane
-    // (= one vertex) walk its own row, out of LDS: acc = acc + w * d, one rounding per operation, ascending entries: the CPU
-    // oracle's sparse accumulate bit for bit, whatever the launch shape. Ranges larger than the buffer go through it in pieces; a
-    // row that straddles two pieces keeps its running sum. A 64-vertex step asks for its first piece at the TOP of the step, as
+    // (= one vertex) walk its own row, out of LDS: acc = fma(w, d, acc) over ascending entries — the order of the CPU oracle's
+    // sparse accumulate, whatever the launch shape. Ranges larger than the buffer go through it in pieces; a row that straddles
+    // two pieces keeps its running sum. A 64-vertex step asks for its first piece at the TOP of the step, as
     // soon as its row bounds are there: it lands while the palette is formed and the quad is parked.
     // Rounds 1-3 let every lane walk its row in global memory, 4 entries at a time: a load instruction then touches 64 different
     // cache lines and every four entries cost a memory round trip — the face of the demo model (60 expression morphs on the same
@@ -1156,12 +1156,10 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
 #pragma unroll
                         for (int u = 0; u < SU; ++u) w[u] = s_w[__float_as_uint(ent[u].w)];
 #pragma unroll
-                        for (int u = 0; u < SU; ++u)
-                            if (j + u < hi) {
-                                spx[r] = __fadd_rn(spx[r], __fmul_rn(w[u], ent[u].x));
-                                spy[r] = __fadd_rn(spy[r], __fmul_rn(w[u], ent[u].y));
-                                spz[r] = __fadd_rn(spz[r], __fmul_rn(w[u], ent[u].z));
-                            }
+                        for (int u = 0; u < SU; ++u) {
+                            const float wu = j + u < hi ? w[u] : 0.0f;       // (past the row's end the clamped index re-read its last entry)
+                            spx[r] = fmaf(wu, ent[u].x, spx[r]); spy[r] = fmaf(wu, ent[u].y, spy[r]); spz[r] = fmaf(wu, ent[u].z, spz[r]);
+                        }
                     }
                     __builtin_amdgcn_wave_barrier();                        // every lane is done with this piece before the next one lands
                 }
@@ -1174,7 +1172,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
             if (vl < v_live) {
                 const size_t v = vw0 + vl;
                 float x = scr[0 * VW + vl], y = scr[1 * VW + vl], z = scr[2 * VW + vl];
-                if constexpr (MODE == 2) { x = __fadd_rn(x, spx[r]); y = __fadd_rn(y, spy[r]); z = __fadd_rn(z, spz[r]); }
+                if constexpr (MODE == 2) { x += spx[r]; y += spy[r]; z += spz[r]; }
                 if constexpr (PRE) {
                     // (asked for at the top of the step)
                 } else if (GEO) {
@@ -1660,6 +1658,19 @@ __global__ void __launch_bounds__(kBlock) rz_skin_instances_reg_kernel(const RzD
     }
 }
 
+// Test hook of the tools-only build (tests/conftest.py: rzv): a one-thread kernel that holds its stream until the host opens
+// the gate (a word in pinned memory) — so a test can put frames BEHIND it, write the next pose, and only then let them run:
+// the pose-prefetch helper then finds the next pose complete by construction, not because the host happened to be ahead.
+// Gives up after two seconds of the 100 MHz counter: a test that dies with the gate closed must not take the GPU with it.
+__global__ void rz_gate_kernel(const uint32_t *flag)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_nontemporal_load(flag) == 0u) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
 #endif  // RZ_ALL_VARIANTS
 
 // ------------------------------------------------------------------------------------------------
@@ -1907,6 +1918,14 @@ hipError_t rz_launch_skin_instances_reg(const RzDeformParams &p, int n_inst, int
     return hipErrorInvalidValue;       // the register-resident crowd kernel (measured slower, inst_loop = 9) is a tools-only variant
 #endif
 }
+
+#ifdef RZ_ALL_VARIANTS
+hipError_t rz_launch_gate(const uint32_t *flag, hipStream_t st)
+{
+    hipLaunchKernelGGL(rz_gate_kernel, dim3(1), dim3(1), 0, st, flag);
+    return hipGetLastError();
+}
+#endif
 
 hipError_t rz_launch_deinterleave(const float *src, int stride, int offset, uint32_t n, float *px, float *py,
                                   float *pz, hipStream_t st)

@@ -301,6 +301,9 @@ struct rz_ctx {
     unsigned long long *tl = nullptr;           // tools-only build: per-wave timeline of the last frame (dbg = 100)
     size_t tl_waves = 0;
 #endif
+#ifdef RZ_ALL_VARIANTS
+    uint32_t *gate_host = nullptr, *gate_dev = nullptr;     // tools-only build: rz_debug_gate
+#endif
     std::vector<rz_ctx *> contributors;         // set on the root
     hipEvent_t ev_done = nullptr;               // "my last frame has been enqueued up to here" for rz_gather_fence
 };
@@ -1162,6 +1165,9 @@ int rz_destroy(rz_ctx *c)
     dfree(c->out_pos); dfree(c->out_nrm); dfree(c->g_pos); dfree(c->g_nrm);
 #ifdef RZ_ABLATE
     dfree(c->tl);
+#endif
+#ifdef RZ_ALL_VARIANTS
+    if (c->gate_host) { *c->gate_host = 1u; (void)hipHostFree(c->gate_host); c->gate_host = nullptr; }
 #endif
     dfree(c->edge); dfree(c->out_hull); dfree(c->aabb);
     for (int i = 0; i < kStageSlots; ++i) {
@@ -2423,6 +2429,31 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else return fail(RZ_ERR_INVALID, "unknown tuning key '%s'", key);
     return RZ_OK;
 }
+
+#ifdef RZ_ALL_VARIANTS
+// tools-only build (make variants), test hook — not part of the C ABI. close = 1: everything enqueued on the context's stream from
+// here on waits behind a gate kernel; close = 0: the gate opens. (tests: frames are queued behind the gate, the NEXT pose is
+// uploaded, the gate opens — the prefetch helper of the queued frame then finds that pose complete by construction.)
+__attribute__((visibility("default"))) int rz_debug_gate(rz_ctx *c, int close)
+{
+    if (int r = use(c)) return r;
+    if (!c->gate_host) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->gate_host), 64, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->gate_dev), c->gate_host, 0));
+        *c->gate_host = 1u;
+    }
+    if (close) {
+        HIP_TRY(hipStreamSynchronize(c->stream));       // an earlier gate kernel has gone
+        *reinterpret_cast<volatile uint32_t *>(c->gate_host) = 0u;
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        HIP_TRY(rz_launch_gate(c->gate_dev, c->stream));
+    } else {
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        *reinterpret_cast<volatile uint32_t *>(c->gate_host) = 1u;
+    }
+    return RZ_OK;
+}
+#endif
 
 #ifdef RZ_ABLATE
 // tools-only build (make ablate): per-wave timeline of the frames that follow (tools/timeline.py). Not part of the C ABI.

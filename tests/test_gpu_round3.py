@@ -191,12 +191,14 @@ def test_gpu_sits_inside_the_envelope_of_legal_wgsl_evaluations(rz, oracle, pose
 
 
 @pytest.mark.parametrize("morphs", ["dense", "sparse", "none"])
-def test_pose_prefetch_stages_the_next_pose_and_never_a_wrong_one(rz, oracle, morphs):
+def test_pose_prefetch_stages_the_next_pose_and_never_a_wrong_one(rz, rzv, oracle, morphs):
     """Zero-copy frames (one character, rz_set_pose: the per-frame writeBuffer of engine.ts:2383-2389): the frame of pose u
     carries a helper workgroup that stages pose u + 1 into device memory when the host has ALREADY written it into its
     pinned slot, so that frame u + 1 need not read over the host link. A hit needs the host to run ahead of the GPU, a miss
     falls back to the pinned slot; either way every frame must hold exactly the bits of its own pose run in isolation.
-      * forced hits: the GPU is kept busy with a long replay while the host uploads the next poses -> pose_staged == 1;
+      * forced hits, by construction: on the tools-only build the frame of pose a is queued BEHIND A GATE (rz_debug_gate: a
+        kernel that holds the stream until the host opens it), pose b is uploaded, the gate opens -> the helper of frame a finds
+        pose b complete whatever the host's and the GPU's relative speed -> pose_staged == 1 (no race decides the assertion);
       * forced misses: a sync after every frame (the host is never ahead) -> pose_staged == 0;
       * 300 frames in a free-running loop with replays, other pose kinds and consumerless uploads mixed in;
       * pose_prefetch = 0 gives the same bits."""
@@ -234,19 +236,31 @@ def test_pose_prefetch_stages_the_next_pose_and_never_a_wrong_one(rz, oracle, mo
         p, n = c.read()
         assert np.array_equal(p, iso[k][0]) and np.array_equal(n, iso[k][1]), "%s: pose %d (%s)" % (what, k, morphs)
 
-    # forced hits: while the GPU chews on a long replay the host uploads pose a, launches its frame, uploads pose b ...
+    # forced hits, deterministically: the frame of pose a waits behind a gate while the host writes pose b into its slot
+    g = rzv.DeformContext(0)
+    g.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    g.upload_skeleton(mesh["inv_bind"])
+    if morphs == "dense":
+        g.upload_morphs_dense(deltas)
+    elif morphs == "sparse":
+        g.upload_morphs_sparse(off, vi, d3)
     hits = 0
     for a, b in ((0, 1), (3, 4), (5, 2)):
-        c.set_pose(worlds[a], mws[a])
-        c.deform(); c.sync()
-        c.deform_n(6000)                        # tens of milliseconds of GPU work in the queue (a frame here is 8-15 us, enqueueing one ~3 us)
-        c.set_pose(worlds[a], mws[a]); c.deform()       # frame of pose a: its helper looks at the slot pose b is about to land in
-        c.set_pose(worlds[b], mws[b])                   # written long before that frame's kernel starts
-        staged_before = c.get_tuning("pose_staged")     # (synchronises) the helper of frame a has run by now
-        c.deform()
-        same(b, "staged pose")
+        g.set_pose(worlds[a], mws[a])
+        g.deform(); g.sync()
+        try:
+            g._chk(rzv.lib.rz_debug_gate(g._h, 1))
+            g.set_pose(worlds[a], mws[a]); g.deform()   # frame of pose a, held by the gate: its helper will look at the slot pose b lands in
+            g.set_pose(worlds[b], mws[b])               # complete before that frame's kernel can start
+        finally:
+            g._chk(rzv.lib.rz_debug_gate(g._h, 0))
+        staged_before = g.get_tuning("pose_staged")     # (synchronises) the helper of frame a has run
+        g.deform()
+        p, n = g.read()
+        assert np.array_equal(p, iso[b][0]) and np.array_equal(n, iso[b][1]), "staged pose %d (%s)" % (b, morphs)
         hits += staged_before
-    assert hits == 3, "the helper workgroup must have staged the next pose in every forced-hit round (%d / 3)" % hits
+    assert hits == 3, "the helper workgroup must stage the next pose in every gated round (%d / 3)" % hits
+    g.close()
     # forced misses: the host is never ahead
     for k in (1, 4, 0):
         c.sync()
@@ -262,7 +276,7 @@ def test_pose_prefetch_stages_the_next_pose_and_never_a_wrong_one(rz, oracle, mo
         if r < 0.08:
             c.set_pose(worlds[(k + 1) % P], mws[(k + 1) % P])         # an upload no frame consumes
         if r > 0.9:
-            c.set_pose_local(quats, mws[k]); c.deform()                # another pose kind in between (never prefetched)
+            c.set_pose_local(quats, mws[k]); c.deform()                # another pose kind in between (its sequence numbers carry the kind: never mistaken for a world pose)
         c.set_pose(worlds[k], mws[k])
         c.deform()
         if rng.random() < 0.3:
