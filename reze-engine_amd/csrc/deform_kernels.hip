@@ -1366,7 +1366,12 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
     const uint32_t bmax = (uint32_t)(p.B - 1);
     // software-pipelined vertex loop: the next vertex's nine attribute loads are issued before the current
     // vertex's pose loop, so their L2 latency hides behind the poses' LDS gathers + FMA
-    uint32_t v = v_begin + tid;
+    // (Round 4 tried two ways of sharing the run's last, partial step (a 3 750-vertex run is 7 steps of 512 and one of 166) among
+    // all waves — its vertices dealt out in quarter-wave pieces: 33.5 -> 36.3 us; its poses split between the waves that hold the
+    // same piece: 33.0 -> 33.7 us. The waves of a workgroup end up to 5.7 us apart (profiles/r4_timeline_c4.txt), but not because
+    // of that step: NOTEBOOK.md R4.5. Both removed.)
+    auto vert_of = [&](const uint32_t vb) { return vb + (uint32_t)tid; };
+    uint32_t v = vert_of(v_begin);
     float x = 0, y = 0, z = 0, nx = 0, ny = 0, nz = 0;
     uint32_t j01 = 0, j23 = 0, wq = 0;
     const uint32_t *jp01 = SUB ? p.rj01 : p.joints01, *jp23 = SUB ? p.rj23 : p.joints23;     // SUB: joints as slots of the run's list
@@ -1456,9 +1461,9 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         }
     }
     RZ_STAMP(2);                 // palettes formed and published: the front is over
-    for (uint32_t vb = v_begin; vb < v_end; vb += BLOCK, v += BLOCK) {   // workgroup-uniform trip count (the ballots below need whole waves)
+    for (uint32_t vb = v_begin; vb < v_end; vb += BLOCK) {   // workgroup-uniform trip count (the ballots below need whole waves)
         if (vb == v_begin + BLOCK) RZ_STAMP(3);      // first vertex step done (8 poses written)
-        const uint32_t vn = v + BLOCK;
+        const uint32_t vn = vert_of(vb + BLOCK);
         float xn = 0, yn = 0, zn = 0, nxn = 0, nyn = 0, nzn = 0;
         uint32_t j01n = 0, j23n = 0, wqn = 0;
         if (vn < v_end) {
@@ -1494,6 +1499,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
                     dp += Vp * 3; dn += Vp * 3;
                 }
             x = xn; y = yn; z = zn; nx = nxn; ny = nyn; nz = nzn; j01 = j01n; j23 = j23n; wq = wqn;
+            v = vn;
             continue;
         }
 #endif
@@ -1546,6 +1552,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         else if (any2) pose_loop(std::integral_constant<int, 2>{});
         else pose_loop(std::integral_constant<int, 1>{});
         x = xn; y = yn; z = zn; nx = nxn; ny = nyn; nz = nzn; j01 = j01n; j23 = j23n; wq = wqn;
+        v = vn;
     }
     RZ_STAMP(5);                 // last vertex step issued
     RZ_TL_FLUSH(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (BLOCK / 64) + wave);

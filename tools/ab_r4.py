@@ -42,6 +42,18 @@ if "dense" in which:
         ts = sorted((t["deform_kernel_ms"], t["frame_ms"]) for t in (ctx.time_frames(n) for _ in range(7)))
         print(tag, "%s kernel / frame us (median of 7 x %d frames): %.3f / %.3f" % (name, n, ts[3][0] * 1e3, ts[3][1] * 1e3), flush=True)
         ctx.close()
+if "c4" in which:
+    V, B, I = 30000, 200, 256
+    ctx = rz.DeformContext(0)
+    mesh = synth.make_mesh(V, B)
+    ctx.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); ctx.upload_skeleton(mesh["inv_bind"]); ctx.upload_morphs_dense(None)
+    ctx.set_instances(I)
+    ctx.set_pose(np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=1000 + i) for i in range(I)]))
+    for _ in range(8):
+        ctx.deform_n(300); ctx.sync()
+    ts = sorted((t["deform_kernel_ms"], t["frame_ms"]) for t in (ctx.time_frames(500) for _ in range(9)))
+    print(tag, "c4 kernel / frame us (median of 9 x 500 frames): %.3f / %.3f" % (ts[4][0] * 1e3, ts[4][1] * 1e3), flush=True)
+    ctx.close()
 if "anim" in which:
     for V, B, M, kind in ((30000, 200, 0, "none"), (28842, 349, 60, "sparse")):
         ctx = rz.DeformContext(0)

@@ -98,6 +98,14 @@ if (t[:, 8] != 0).any():
     fn = ["pose staged", "barrier passed", "local matrices formed", "doubling rounds done", "palette rows written"]
     print("  inside the hierarchy solve (us after the wave's own entry), median / max: " + " | ".join(
         "%s %.2f / %.2f" % (fn[k], np.median((f[:, 8 + k].astype(np.int64) - f[:, 0].astype(np.int64)) * 0.01), ((f[:, 8 + k].astype(np.int64) - f[:, 0].astype(np.int64)) * 0.01).max()) for k in range(5)))
+wpw = 8 if cfg == "c4" else 4
+nwg = n.value // wpw
+full = buf[: nwg * wpw].reshape(nwg, wpw, 16)
+okwg = (full[:, :, 0] != 0).all(axis=1)
+if okwg.any():
+    e5 = (full[okwg][:, :, 5].astype(np.int64) - t0) * 0.01
+    print("  'last step done' inside a workgroup: spread max - min, median over workgroups %.2f us (max %.2f); across workgroups the slowest wave ends %.2f .. %.2f us" % (
+        np.median(e5.max(axis=1) - e5.min(axis=1)), (e5.max(axis=1) - e5.min(axis=1)).max(), e5.max(axis=1).min(), e5.max(axis=1).max()))
 late = np.argsort(t[:, 6])[-3:]
 for w in late:
     print("  late wave: " + " ".join("%.2f" % v for v in us(t[w, :7])) + "  xcc %d" % (int(t[w, 7]) & 0xff))
