@@ -223,36 +223,66 @@ __device__ __forceinline__ uint32_t span_bisect(const float *kf, const KeyRange 
     return lo;
 }
 
-__device__ __forceinline__ void sample_bone(const RzSampleParams &p, float frame, int bone, float4 &q, float &tx, float &ty, float &tz)
-{
-    const KeyRange kr = key_range(p.bone_range[bone]);
-    q = make_float4(0.f, 0.f, 0.f, 1.f);
-    tx = ty = tz = 0.f;
-    if (kr.e == kr.b) return;
+// A track is sampled in two halves so that a thread can have SEVERAL tracks' loads in flight at once (its bones and its morph):
+// *_issue() turns the track record into the guessed key span and REQUESTS the keys; *_finish() — called after every issue —
+// waits for them, repairs a wrong guess and interpolates. Chain of dependent loads for any number of tracks: records -> keys.
+struct BoneKeys {
+    int mode;                   // 0 = the motion does not key the bone, 1 = clamped to key i0, 2 = interior span (i0, i0 + 1)
     uint32_t i0;
-    if (!span_guess(kr, frame, i0)) {                       // clamped: the key itself
-        const float *pa = p.key_pos + (size_t)i0 * 3;
-        q = p.key_rot[i0]; tx = pa[0]; ty = pa[1]; tz = pa[2];
-        return;
+    KeyRange kr;
+    float f_a, f_b;
+    float4 a, b;
+    float pa0, pa1, pa2, pb0, pb1, pb2;
+    uint4 ip;
+};
+
+__device__ __forceinline__ BoneKeys bone_issue(const RzSampleParams &p, float frame, const uint4 rec)
+{
+    BoneKeys k;
+    k.kr = key_range(rec);
+    k.mode = 0; k.i0 = 0u; k.f_a = k.f_b = 0.0f;
+    k.a = k.b = make_float4(0.f, 0.f, 0.f, 1.f);
+    k.pa0 = k.pa1 = k.pa2 = k.pb0 = k.pb1 = k.pb2 = 0.0f;
+    k.ip = make_uint4(0, 0, 0, 0);
+    if (k.kr.e == k.kr.b) return k;
+    if (!span_guess(k.kr, frame, k.i0)) {                   // clamped: the key itself
+        const float *pa = p.key_pos + (size_t)k.i0 * 3;
+        k.mode = 1; k.a = p.key_rot[k.i0]; k.pa0 = pa[0]; k.pa1 = pa[1]; k.pa2 = pa[2];
+        return k;
     }
     // speculative: everything the guessed span needs, requested together
-    float f_a = p.key_frame[i0], f_b = p.key_frame[i0 + 1];
-    float4 a = p.key_rot[i0], b = p.key_rot[i0 + 1];
+    const uint32_t i0 = k.i0;
+    k.mode = 2;
+    k.f_a = p.key_frame[i0]; k.f_b = p.key_frame[i0 + 1];
+    k.a = p.key_rot[i0]; k.b = p.key_rot[i0 + 1];
     const float *pa = p.key_pos + (size_t)i0 * 3;
-    float pa0 = pa[0], pa1 = pa[1], pa2 = pa[2], pb0 = pa[3], pb1 = pa[4], pb2 = pa[5];
-    uint4 ip = p.key_interp ? p.key_interp[i0 + 1] : make_uint4(0, 0, 0, 0);
-    if (!(f_a <= frame && frame < f_b)) {
-        i0 = span_bisect(p.key_frame, kr, frame, i0, f_a);
+    k.pa0 = pa[0]; k.pa1 = pa[1]; k.pa2 = pa[2]; k.pb0 = pa[3]; k.pb1 = pa[4]; k.pb2 = pa[5];
+    if (p.key_interp) k.ip = p.key_interp[i0 + 1];
+    return k;
+}
+
+__device__ __forceinline__ void bone_finish(const RzSampleParams &p, float frame, BoneKeys &k, float4 &q, float &tx, float &ty, float &tz)
+{
+    q = make_float4(0.f, 0.f, 0.f, 1.f);
+    tx = ty = tz = 0.f;
+    if (k.mode == 0) return;
+    if (k.mode == 1) { q = k.a; tx = k.pa0; ty = k.pa1; tz = k.pa2; return; }
+    float f_a = k.f_a, f_b = k.f_b;
+    float4 a = k.a, b = k.b;
+    float pa0 = k.pa0, pa1 = k.pa1, pa2 = k.pa2, pb0 = k.pb0, pb1 = k.pb1, pb2 = k.pb2;
+    uint4 ip = k.ip;
+    if (!(f_a <= frame && frame < f_b)) {                   // the guess missed (uneven keys, duplicates): bisect what it left
+        const uint32_t i0 = span_bisect(p.key_frame, k.kr, frame, k.i0, f_a);
         f_a = p.key_frame[i0]; f_b = p.key_frame[i0 + 1];
         a = p.key_rot[i0]; b = p.key_rot[i0 + 1];
-        pa = p.key_pos + (size_t)i0 * 3;
+        const float *pa = p.key_pos + (size_t)i0 * 3;
         pa0 = pa[0]; pa1 = pa[1]; pa2 = pa[2]; pb0 = pa[3]; pb1 = pa[4]; pb2 = pa[5];
         if (p.key_interp) ip = p.key_interp[i0 + 1];
     }
     const float x = (frame - f_a) / (f_b - f_a);
     float cx = x, cy = x, cz = x, cr = x;
     if (p.key_interp) {                                     // bytes [X_x1 Y_x1 Z_x1 R_x1 | X_y1 .. | X_x2 .. | X_y2 ..] of the LATER key
-        auto byte = [](uint32_t w, int k) { return (float)((w >> (8 * k)) & 255u) * (1.0f / 127.0f); };
+        auto byte = [](uint32_t w, int n) { return (float)((w >> (8 * n)) & 255u) * (1.0f / 127.0f); };
         cx = bezier_y(x, byte(ip.x, 0), byte(ip.y, 0), byte(ip.z, 0), byte(ip.w, 0));
         cy = bezier_y(x, byte(ip.x, 1), byte(ip.y, 1), byte(ip.z, 1), byte(ip.w, 1));
         cz = bezier_y(x, byte(ip.x, 2), byte(ip.y, 2), byte(ip.z, 2), byte(ip.w, 2));
@@ -273,27 +303,55 @@ __device__ __forceinline__ void sample_bone(const RzSampleParams &p, float frame
     tx = pa0 + (pb0 - pa0) * cx; ty = pa1 + (pb1 - pa1) * cy; tz = pa2 + (pb2 - pa2) * cz;
 }
 
-__device__ __forceinline__ float sample_morph(const RzSampleParams &p, float frame, int m)
+__device__ __forceinline__ void sample_bone(const RzSampleParams &p, float frame, int bone, float4 &q, float &tx, float &ty, float &tz)
 {
-    float w = 0.0f;
-    for (uint32_t f = p.feed_off[m]; f < p.feed_off[m + 1]; ++f) {
-        const KeyRange kr = key_range(p.feed_range[f]);
-        if (kr.e == kr.b) continue;
-        uint32_t i0;
-        float wk;
-        if (!span_guess(kr, frame, i0)) {
-            wk = p.mkey_weight[i0];
-        } else {
-            float f_a = p.mkey_frame[i0], f_b = p.mkey_frame[i0 + 1], w_a = p.mkey_weight[i0], w_b = p.mkey_weight[i0 + 1];
-            if (!(f_a <= frame && frame < f_b)) {
-                i0 = span_bisect(p.mkey_frame, kr, frame, i0, f_a);
-                f_a = p.mkey_frame[i0]; f_b = p.mkey_frame[i0 + 1]; w_a = p.mkey_weight[i0]; w_b = p.mkey_weight[i0 + 1];
-            }
-            wk = w_a + (w_b - w_a) * ((frame - f_a) / (f_b - f_a));
-        }
-        w += wk * p.feed_ratio[f];
+    BoneKeys k = bone_issue(p, frame, p.bone_range[bone]);
+    bone_finish(p, frame, k, q, tx, ty, tz);
+}
+
+struct MorphKeys { int mode; uint32_t i0; KeyRange kr; float f_a, f_b, w_a, w_b; };     // mode as in BoneKeys
+
+__device__ __forceinline__ MorphKeys morph_issue(const RzSampleParams &p, float frame, const uint4 rec)
+{
+    MorphKeys k;
+    k.kr = key_range(rec);
+    k.mode = 0; k.i0 = 0u; k.f_a = k.f_b = k.w_a = k.w_b = 0.0f;
+    if (k.kr.e == k.kr.b) return k;
+    if (!span_guess(k.kr, frame, k.i0)) { k.mode = 1; k.w_a = p.mkey_weight[k.i0]; return k; }
+    k.mode = 2;
+    k.f_a = p.mkey_frame[k.i0]; k.f_b = p.mkey_frame[k.i0 + 1]; k.w_a = p.mkey_weight[k.i0]; k.w_b = p.mkey_weight[k.i0 + 1];
+    return k;
+}
+
+// the track's weight at `frame`; `keyed` = false when the track holds no key (it then contributes nothing at all)
+__device__ __forceinline__ float morph_finish(const RzSampleParams &p, float frame, const MorphKeys &k, bool &keyed)
+{
+    keyed = k.mode != 0;
+    if (k.mode == 0) return 0.0f;
+    if (k.mode == 1) return k.w_a;
+    float f_a = k.f_a, f_b = k.f_b, w_a = k.w_a, w_b = k.w_b;
+    if (!(f_a <= frame && frame < f_b)) {
+        const uint32_t i0 = span_bisect(p.mkey_frame, k.kr, frame, k.i0, f_a);
+        f_a = p.mkey_frame[i0]; f_b = p.mkey_frame[i0 + 1]; w_a = p.mkey_weight[i0]; w_b = p.mkey_weight[i0 + 1];
+    }
+    return w_a + (w_b - w_a) * ((frame - f_a) / (f_b - f_a));
+}
+
+// feeds [f0, f1) of one vertex morph, accumulated in feed order on top of `w`
+__device__ __forceinline__ float sample_feeds(const RzSampleParams &p, float frame, uint32_t f0, uint32_t f1, float w)
+{
+    for (uint32_t f = f0; f < f1; ++f) {
+        const MorphKeys k = morph_issue(p, frame, p.feed_range[f]);
+        bool keyed;
+        const float wk = morph_finish(p, frame, k, keyed);
+        if (keyed) w += wk * p.feed_ratio[f];
     }
     return w;
+}
+
+__device__ __forceinline__ float sample_morph(const RzSampleParams &p, float frame, int m)
+{
+    return sample_feeds(p, frame, p.feed_off[m], p.feed_off[m + 1], 0.0f);
 }
 
 // Quat.slerp(identity, a, t)  (math.ts:156-189): the append rotation (model.ts:367-386) and the bone-morph rotation use it
@@ -376,9 +434,50 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         const float4 *Im = reinterpret_cast<const float4 *>(p.inv_bind + (size_t)tid * 16);
         pib0 = Im[0]; pib1 = Im[1]; pib2 = Im[2]; pib3 = Im[3];
     }
+    // Sampled pose, the common sizes (<= 512 bones: two per thread; <= 256 vertex morphs: one per thread): the track records of
+    // the thread's bones AND the feed list of its morph are requested together, then all their keys, then the morph's keys —
+    // three dependent round trips for the whole pose. Bone loop followed by morph loop (rounds 2-3) was five: records -> keys,
+    // then feed offsets -> feed record -> keys (profiles/r4_timeline_sampled-demo.txt: "pose staged" 4.2 / 6.3 us median / max).
+    const bool inter = sampled;
+    int m_done = 0;                       // vertex morphs [0, m_done) have been sampled by the interleaved pass
+    if (inter) {
+        const int b0 = tid, b1 = tid + kBlock;
+        const bool hb0 = b0 < p.B, hb1 = b1 < p.B, hm = tid < p.sample.M;
+        uint4 ra0, ra1, rb0, rb1;
+        uint4 tr0 = make_uint4(0, 0, 0, 0), tr1 = tr0;
+        if (hb0) { ra0 = p.bone_rec[2 * b0]; ra1 = p.bone_rec[2 * b0 + 1]; tr0 = p.sample.bone_range[b0]; }
+        if (hb1) { rb0 = p.bone_rec[2 * b1]; rb1 = p.bone_rec[2 * b1 + 1]; tr1 = p.sample.bone_range[b1]; }
+        uint32_t f0 = 0u, f1 = 0u;
+        if (hm) { f0 = p.sample.feed_off[tid]; f1 = p.sample.feed_off[tid + 1]; }
+        BoneKeys k0 = bone_issue(p.sample, frame, tr0), k1 = bone_issue(p.sample, frame, tr1);
+        uint4 fr = make_uint4(0, 0, 0, 0);
+        float ratio0 = 0.0f;
+        if (f1 > f0) { fr = p.sample.feed_range[f0]; ratio0 = p.sample.feed_ratio[f0]; }
+        const MorphKeys mk = morph_issue(p.sample, frame, fr);
+        auto park = [&](const int b, BoneKeys &k, const uint4 r0, const uint4 r1) {
+            float4 q;
+            float tx, ty, tz;
+            bone_finish(p.sample, frame, k, q, tx, ty, tz);
+            sq[b] = q; s_rec[b] = r0;
+            s_bind[b] = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), 0.0f);
+            s_lt[b * 3] = tx; s_lt[b * 3 + 1] = ty; s_lt[b * 3 + 2] = tz;
+        };
+        if (hb0) park(b0, k0, ra0, ra1);
+        if (hb1) park(b1, k1, rb0, rb1);
+        if (hm) {
+            bool keyed;
+            const float wk = morph_finish(p.sample, frame, mk, keyed);
+            float w = 0.0f;
+            if (keyed) w += wk * ratio0;
+            if (f1 > f0 + 1u) w = sample_feeds(p.sample, frame, f0 + 1u, f1, w);      // group-morph tracks that feed it too
+            if (FUSED || bone_morphs) lds_mw[tid] = w;
+            if (to_global) p.sample.morph_w[(size_t)inst * p.sample.M + tid] = w;
+        }
+        m_done = min(p.sample.M, kBlock);
+    }
     // one cooperative pass stages everything the later passes touch: the record loads are issued in front of the pose
     // (sampled: the track record, then its keys), so the static topology rides under the pose's own latency
-    for (int i = tid; i < p.B; i += kBlock) {
+    for (int i = inter ? tid + 2 * kBlock : tid; i < p.B; i += kBlock) {
         const uint4 r0 = p.bone_rec[2 * i], r1 = p.bone_rec[2 * i + 1];
         float4 q;
         float tx = 0.0f, ty = 0.0f, tz = 0.0f;
@@ -410,7 +509,7 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         if (has_t) { s_lt[i * 3] = tx; s_lt[i * 3 + 1] = ty; s_lt[i * 3 + 2] = tz; }
     }
     if (sampled)        // vertex-morph weights of this pose: consumed by the prep / deform kernels that follow (FUSED: by this very workgroup)
-        for (int m = tid; m < p.sample.M; m += kBlock) {
+        for (int m = m_done + tid; m < p.sample.M; m += kBlock) {      // (morphs beyond the interleaved pass)
             const float w = sample_morph(p.sample, frame, m);
             if (FUSED || bone_morphs) lds_mw[m] = w;
             if (to_global) p.sample.morph_w[(size_t)inst * p.sample.M + m] = w;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Copies what tools/gpu_full.sh left under gpurun_out/full/ (scratch) into profiles/ (tracked) under the round's names, builds
-profiles/r3_autotune_stability.json from the consecutive runs, and regenerates DESIGN.md's tables (tools/design_tables.py)."""
+profiles/r4_autotune_stability.json from the consecutive runs, and regenerates DESIGN.md's tables (tools/design_tables.py)."""
 import glob
 import json
 import os
@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC, DST, TAG = os.path.join(ROOT, "gpurun_out", "full"), os.path.join(ROOT, "profiles"), "r3"
+SRC, DST, TAG = os.path.join(ROOT, "gpurun_out", "full"), os.path.join(ROOT, "profiles"), "r4"
 n = 0
 for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))):
     try:

@@ -5,10 +5,10 @@
     python tools/design_tables.py --check    exit 1 when DESIGN.md's block differs from what profiles/ says (tests/test_docs.py)
 
 Sources (all written on the GPU box by tools/gpu_full.sh / tools/gpu_profile.sh -> tools/parse_prof.py, then copied to profiles/):
-    profiles/r3_bench_*.json          bench.py lines (the driver contract), one per workload
-    profiles/r3_kernel_stats_*.txt    rocprofv3 --kernel-trace --stats of the same bench commands
+    profiles/r4_bench_*.json          bench.py lines (the driver contract), one per workload
+    profiles/r4_kernel_stats_*.txt    rocprofv3 --kernel-trace --stats of the same bench commands
     profiles/pmc_traffic.json         HBM bytes per launch from the PMC passes, keyed "<shape>|<kernel>"
-    profiles/r3_autotune_stability.json   what the launch-shape search picked in consecutive runs
+    profiles/r4_autotune_stability.json   what the launch-shape search picked in consecutive runs
 """
 import glob
 import json
@@ -18,14 +18,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
-TAG = "r3"
+TAG = "r4"
+PREV = "r3"
 BEGIN = "<!-- BEGIN GENERATED (tools/design_tables.py — do not edit by hand) -->"
 END = "<!-- END GENERATED -->"
 
 # file suffix -> what the line is (order = table order)
 LINES = [
     ("c5", "C5: 1 M verts / 256 bones / 64 dense morphs, 1 GPU — `python bench.py` (the driver's line)"),
-    ("shard8", "one 1/8 shard of C5 (125 952 verts), one stream — `--verts 125952 --frames-in-flight 1`"),
+    ("shard8", "one 1/8 shard of C5 (125 184 verts), one stream — `--verts 125184 --frames-in-flight 1`"),
     ("shard8_auto", "the same shard, default `--frames-in-flight auto`"),
     ("c4", "C4: 256 instances x 30 000 verts / 200 bones — `--config c4`"),
     ("c4_devicefk", "C4 with the hierarchy solved on the GPU — `--config c4 --device-fk`"),
@@ -40,8 +41,8 @@ LINES = [
 STATS = {"c5": "c5", "shard8": "shard", "c4": "c4", "c3": "c3", "demo": "demo"}
 
 
-def load(suffix):
-    p = os.path.join(PROF, "%s_bench_%s.json" % (TAG, suffix))
+def load(suffix, tag=None):
+    p = os.path.join(PROF, "%s_bench_%s.json" % (tag or TAG, suffix))
     if not os.path.exists(p):
         return None
     try:
@@ -51,7 +52,7 @@ def load(suffix):
 
 
 def rocprof_row(stats_name, kernel):
-    """(calls, avg_us, min_us, max_us[, workgroups]) of `kernel` in profiles/r3_kernel_stats_<name>.txt: its most-launched launch
+    """(calls, avg_us, min_us, max_us[, workgroups]) of `kernel` in profiles/r4_kernel_stats_<name>.txt: its most-launched launch
     shape when the file has the per-shape section (the plan the bench loops ran), else the all-shapes row of the stats"""
     p = os.path.join(PROF, "%s_kernel_stats_%s.txt" % (TAG, stats_name))
     if not os.path.exists(p):
@@ -97,6 +98,45 @@ def build():
             what, d["n_gpus"], us(d["ms_per_step"]), d["value"], c.get("frames_in_flight", 1), r["kernel"], us(r["kernel_ms"]),
             "—" if rp is None else "%.2f" % rp[1], r["frac"], r["frame_frac"], tr, us(c.get("frame_ms_with_pose_upload")), us(c.get("frame_ms_device_sampled_pose"))))
     out.append("")
+    # what the round changed: the same lines of the previous round's tracked evidence
+    rows = []
+    for suffix, what in LINES:
+        a, b = load(suffix, PREV), load(suffix)
+        if a is None or b is None or suffix in ("rehearse8", "c5_allgather1"):
+            continue
+        ca, cb = a["config"], b["config"]
+
+        def pair(x, y):
+            return "—" if x is None or y is None else "%.2f → %.2f" % (x * 1e3, y * 1e3)
+        rows.append("| %s | %s | %s | %s | %s |" % (suffix, pair(ca.get("ms_per_step_one_stream"), cb.get("ms_per_step_one_stream")), pair(a["roofline"]["kernel_ms"], b["roofline"]["kernel_ms"]),
+                                                 pair(ca.get("frame_ms_with_pose_upload"), cb.get("frame_ms_with_pose_upload")), pair(ca.get("frame_ms_device_sampled_pose"), cb.get("frame_ms_device_sampled_pose"))))
+    if rows:
+        out.append("**Round %s → round %s, line by line** (`profiles/%s_bench_*.json` against `profiles/%s_bench_*.json`, µs; different boxes: differences under ≈ 3 %% are box noise — "
+                   "the same-session A/B runs are in `profiles/%s_ab_*.txt`; the 1/8 shard is 125 952 vertices in round 3 and 125 184 in round 4):" % (PREV[1:], TAG[1:], PREV, TAG, TAG))
+        out.append("")
+        out.append("| line | frame, one stream | kernel (events) | frame + pose upload | frame, pose sampled on the GPU |")
+        out.append("|---|---|---|---|---|")
+        out += rows
+        out.append("")
+    nb = []
+    for tag in (PREV, TAG):
+        pth = os.path.join(PROF, "%s_node_frame_bench.txt" % tag)
+        if os.path.exists(pth):
+            for ln in open(pth):
+                if ln.startswith("{"):
+                    try:
+                        nb.append((tag, json.loads(ln)))
+                    except Exception:       # noqa: BLE001
+                        pass
+    if len(nb) == 2:
+        out.append("**Through Node** (`profiles/*_node_frame_bench.txt`: Node → N-API → C ABI → MI355X, the same PMX + VMD; `gpuFrameUs` = resident replay of the last frame, `usPerFrame` = the per-frame loop incl. the JavaScript side):")
+        out.append("")
+        out.append("| mode | round %s: µs per frame / GPU frame | round %s: µs per frame / GPU frame |" % (PREV[1:], TAG[1:]))
+        out.append("|---|---|---|")
+        for k in ("host", "deviceFK", "sampled", "deviceFK2", "sampled2"):
+            if k in nb[0][1] and k in nb[1][1]:
+                out.append("| %s | %.2f / %.2f | %.2f / %.2f |" % (k, nb[0][1][k]["usPerFrame"], nb[0][1][k]["gpuFrameUs"], nb[1][1][k]["usPerFrame"], nb[1][1][k]["gpuFrameUs"]))
+        out.append("")
     # the profiled runs themselves: events vs rocprof in the SAME run
     rows = []
     for name in ("c5", "shard", "c4", "c3", "demo"):
