@@ -870,7 +870,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     constexpr bool PRE = MODE != 1 && !GEO;
     // (Dense frames keep the skin phase's attribute loads behind the morph phase. Round 4 tried to bring them in by LDS-DMA at the
     // top of the step — 6 x 4 bytes per vertex straight into LDS, no VGPR held — so that the skin phase would not start with a
-    // memory round trip: C5 123.2 -> 128.5 us, a 1/8 shard 16.52 -> 16.75 us, only C3 gained (7.4 -> 7.0): NOTEBOOK.md R4.4. Removed.)
+    // memory round trip: C5 123.2 -> 128.5 us, a 1/8 shard 16.52 -> 16.75 us, only C3 gained (7.4 -> 7.0): NOTEBOOK.md R4.3. Removed.)
     constexpr bool PRE_SP = PRE && MODE == 2 && ROUNDS == 1;      // (S = 1 steps are 4 rounds: their bounds are loaded round by round)
     float4 gx, gy, gz, gnx, gny, gnz;
     uint4 gj01, gj23, gw;

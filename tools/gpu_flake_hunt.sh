@@ -1,16 +1,14 @@
 #!/bin/bash
-# which GPU test fails one run in ten? the timing-dependent ones, repeated, first failure kept
+# Is the GPU suite flaky? The whole -m gpu suite N times back to back on one box (default 5), counts kept -> gpurun_out/flake/summary.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
+N=${1:-5}
 O=gpurun_out/flake; rm -rf $O; mkdir -p $O
-t0=$(date +%s)
-for i in $(seq 1 12); do
-  [ $(( $(date +%s) - t0 )) -gt 170 ] && break
-  timeout 120 python -m pytest tests/test_gpu_round3.py -k prefetch -x -q -rf > $O/prefetch_$i.txt 2>&1 || { echo "prefetch FAILED in round $i"; grep -v "^RCCL\|^HIP \|^ROCm\|^Hostname\|^Librccl" $O/prefetch_$i.txt | tail -40; break; }
-  echo "prefetch round $i ok ($(( $(date +%s) - t0 )) s)"
-done
-t1=$(date +%s)
-for i in $(seq 1 6); do
-  [ $(( $(date +%s) - t1 )) -gt 110 ] && break
-  timeout 120 python -m pytest tests/test_bench_gpu.py -k two_rank_run -x -q -rf > $O/bench2_$i.txt 2>&1 || { echo "bench2 FAILED in round $i"; grep -v "^RCCL\|^HIP \|^ROCm\|^Hostname\|^Librccl" $O/bench2_$i.txt | tail -30 | cut -c1-1500; break; }
-  echo "bench2 round $i ok ($(( $(date +%s) - t1 )) s)"
+echo "# python -m pytest tests -m gpu -q, $N runs back to back on one MI355X box ($(date -u +%Y-%m-%dT%H:%MZ))" > $O/summary.txt
+for i in $(seq 1 $N); do
+  t0=$(date +%s)
+  timeout 1500 python -m pytest tests -m gpu -q -rf > $O/run_$i.txt 2>&1; rc=$?
+  line=$(grep -E "passed|failed" $O/run_$i.txt | tail -1)
+  echo "run $i: rc=$rc  $line  ($(( $(date +%s) - t0 )) s wall)" | tee -a $O/summary.txt
+  if [ $rc -ne 0 ]; then grep -E "^FAILED|^ERROR" $O/run_$i.txt | head -10 | tee -a $O/summary.txt; fi
+  grep -v "^RCCL\|^HIP \|^ROCm\|^Hostname\|^Librccl" $O/run_$i.txt | tail -30 > $O/run_${i}_tail.txt; rm -f $O/run_$i.txt
 done

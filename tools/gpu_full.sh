@@ -6,7 +6,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 O=gpurun_out/full; rm -rf $O; mkdir -p $O
 if [ "$1" != "nobench" ]; then
 echo "== pytest gpu"
-timeout 1500 python -m pytest tests -m gpu -q -rf 2>&1 | tail -12 | tee $O/pytest_gpu.txt; echo "pytest rc=${PIPESTATUS[0]}" | tee -a $O/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -q -rf > $O/pytest_gpu_full.txt 2>&1; echo "pytest rc=$?" > $O/pytest_rc.txt
+grep -E "passed|failed|^FAILED|^ERROR" $O/pytest_gpu_full.txt | tail -12 | tee $O/pytest_gpu.txt; cat $O/pytest_rc.txt | tee -a $O/pytest_gpu.txt; rm -f $O/pytest_gpu_full.txt
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/smoke.txt
 fi

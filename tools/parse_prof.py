@@ -118,7 +118,7 @@ for name, (title, V, B, M, I) in WORK.items():
             alg_read = V * 36 + I * B * 64 + B * 64  # mesh once, world matrices per instance, inverse bind
             alg_write = I * V * 24
         elif name == "demo":
-            alg_read = None                          # sparse: the entry count is the workload's (bench.py's algorithmic_bytes_per_launch carries it)
+            alg_read = V * (36 + 4) + 36397 * 16 + B * 128 + M * 4      # sparse: + 4 B of row pointer per vertex and the demo shape's 36 397 entries of 16 B
             alg_write = V * 24
         else:
             alg_read = V * (36 + 12 * M) + B * 128 + M * 4
