@@ -112,8 +112,10 @@ int rz_set_pose(rz_ctx *ctx, const float *world, const float *morph_weights);
  * SkeletonRuntime.localTranslations, model.ts:56; NULL = all zero, which is all the reference ever has: nothing
  * writes that array there, VMD bone translations are this build's row f2) instead of world matrices, and the frame
  * computes L = T(bind + t) * R * T(add), W = W_parent * L and the palette on the GPU (f32; the host solves in
- * doubles with f32 stores, so results agree to ~1e-6, not bit for bit). 4x less per-frame upload; hierarchy solve
- * for all instances in one launch. */
+ * doubles with f32 stores, so results agree to ~1e-6, not bit for bit; the device resolves the parent chains by pointer
+ * doubling, so products are associated as (L0 L1)(L2 L3) rather than ((L0 L1) L2) L3). 4x less per-frame upload; hierarchy
+ * solve for all instances in one launch; one character's local pose is zero-copy like a world pose (resident after its first
+ * frame, prefetched by the helper workgroup). */
 int rz_upload_skeleton_topology(rz_ctx *ctx, uint32_t B, const int32_t *parents, const float *bind_translation3,
                                 const int32_t *append_parent, const float *append_ratio, const uint8_t *append_move);
 int rz_set_pose_local(rz_ctx *ctx, const float *local_rotations4, const float *local_translations3, const float *morph_weights);
@@ -234,9 +236,11 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * morph-stream loads), "nt_store" (0/1, output stores), "fast" (-1 auto, 0 always run the
  * separate prep kernel, 1 one-launch frame when possible), "out_cap" (-1 auto, 0 off, else vertices a wave
  * parks in LDS before writing them out in one burst), "inst_loop" (-1 auto, 0 off, 2..8 / 10..64 poses
- * per workgroup in instanced morph-free frames, 9 = the register-resident form), "pose_prefetch" (-1 auto / 1: the first frame of a zero-copy world pose carries a helper workgroup that stages the
+ * per workgroup in instanced morph-free frames, 9 = the register-resident form), "pose_prefetch" (-1 auto / 1: the first frame of a zero-copy pose — world matrices, or local rotations
+ * [+ translations] of a single character whose hierarchy is solved inside the deform kernel — carries a helper workgroup that stages the
  * NEXT pose into device memory when the host has already written it — a per-frame loop whose host runs ahead of the GPU then never
- * pays the PCIe round trip; 0: off; rz_get_tuning("pose_staged") tells whether the current pose was staged that way),
+ * pays the PCIe round trip; a staged pose is only ever taken by a frame of the same pose kind;
+ * 0: off; rz_get_tuning("pose_staged") tells whether the current pose was staged that way),
  * "inst_subsets" (-1 auto / 1: a crowd workgroup stages
  * only the bones its vertex run names when that list is shorter than the skeleton — same bits, a fraction of the LDS and of the
  * per-workgroup front; 0: always the whole palette), "inst_block" (0 auto, 256 / 512 / 1024 threads per

@@ -98,3 +98,15 @@ def test_autotune_pick_keeps_the_heuristic_unless_a_candidate_is_clearly_faster(
     assert pick([(33.3, 0.0, 0.0, -1), (32.5, 0.0, 0.0, -1)]) == 1              # no spreads recorded: the median rule alone
     assert pick([(33.3, 33.0, 33.7, -1), (30.0, 29.9, 30.1, 0)]) == 0           # an alias of entry 0 is never "another plan"
     assert pick([(33.3, 33.0, 33.7, -1), (32.5, 32.2, 32.7, -1), (31.9, 31.8, 32.0, -1)]) == 2     # the fastest qualifying entry
+
+
+def test_sanitized_host_library_cpu_driver():
+    """make asan + tools/asan_run.py cpu: the host library (reze_deform.cpp) under AddressSanitizer + UndefinedBehaviorSanitizer,
+    driven through every C-ABI path that needs no GPU — every export refuses a NULL context with a message, shard arithmetic
+    over edge sizes, the launch-shape pick rule on synthetic tables, rz_create without a device. Any report aborts the child.
+    (The GPU half — misuse script, fuzz walks, ring / fork / graph soak — runs on the GPU box: profiles/r4_asan.txt.)"""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asan_run.py"), "cpu"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "ASAN-CPU-OK" in out, out[-3000:]
