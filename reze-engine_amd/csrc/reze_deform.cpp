@@ -1129,6 +1129,9 @@ int rz_destroy(rz_ctx *c)
     if (!c) return RZ_OK;
     if (c->n_forks) return fail(RZ_ERR_INVALID, "%d fork(s) still borrow this context's static data: destroy them first", c->n_forks);
     (void)hipSetDevice(c->device);
+#ifdef RZ_ALL_VARIANTS
+    if (c->gate_host) *reinterpret_cast<volatile uint32_t *>(c->gate_host) = 1u;      // a test died with the gate closed: open it before draining the stream
+#endif
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
     if (c->lender) {                      // a fork frees nothing it borrowed
@@ -1167,7 +1170,7 @@ int rz_destroy(rz_ctx *c)
     dfree(c->tl);
 #endif
 #ifdef RZ_ALL_VARIANTS
-    if (c->gate_host) { *c->gate_host = 1u; (void)hipHostFree(c->gate_host); c->gate_host = nullptr; }
+    if (c->gate_host) { (void)hipHostFree(c->gate_host); c->gate_host = nullptr; }
 #endif
     dfree(c->edge); dfree(c->out_hull); dfree(c->aabb);
     for (int i = 0; i < kStageSlots; ++i) {
