@@ -437,7 +437,7 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
     // Sampled pose, the common sizes (<= 512 bones: two per thread; <= 256 vertex morphs: one per thread): the track records of
     // the thread's bones AND the feed list of its morph are requested together, then all their keys, then the morph's keys —
     // three dependent round trips for the whole pose. Bone loop followed by morph loop (rounds 2-3) was five: records -> keys,
-    // then feed offsets -> feed record -> keys (profiles/r4_timeline_sampled-demo.txt: "pose staged" 4.2 / 6.3 us median / max).
+    // then feed offsets -> feed record -> keys ("pose staged" 4.2 / 6.3 us median / max after a wave's entry then, 4.2 / 5.7 now: NOTEBOOK.md R4.2, profiles/r4_timeline_sampled-demo.txt).
     const bool inter = sampled;
     int m_done = 0;                       // vertex morphs [0, m_done) have been sampled by the interleaved pass
     if (inter) {
@@ -854,7 +854,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     // Without a dense stream the four waves of a workgroup take runs that lie a quarter of the mesh apart instead of next to
     // each other: work on such frames is uneven — the demo model's 60 expression morphs all sit on one 1 800-vertex face region,
     // 28 consecutive 64-vertex steps — and four neighbouring heavy steps on ONE CU share its LDS and its texture path
-    // (profiles/r4_timeline_demo.txt: 2.7 us in the row walk with four face waves per CU). Dense frames stream evenly: unchanged.
+    // (2.7 us in the row walk with four face waves per CU: NOTEBOOK.md R4.1). Dense frames stream evenly: unchanged.
     const uint32_t n_workers = gridDim.x - (pf_on ? 1u : 0u);
     const uint32_t wave_global = MODE != 1 ? (uint32_t)wave * n_workers + wid : wid * (kBlock / 64) + wave;
     const size_t q_begin = (size_t)wave_global * p.quads_per_wave;
@@ -1079,7 +1079,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     // soon as its row bounds are there: it lands while the palette is formed and the quad is parked.
     // Rounds 1-3 let every lane walk its row in global memory, 4 entries at a time: a load instruction then touches 64 different
     // cache lines and every four entries cost a memory round trip — the face of the demo model (60 expression morphs on the same
-    // ~1 800 vertices, up to 60 entries per vertex) kept its waves 4.3 us in that loop (profiles/r4_timeline_*.txt, NOTEBOOK.md R4.1).
+    // ~1 800 vertices, up to 60 entries per vertex) kept its waves 4.3 us in that loop (NOTEBOOK.md R4.1; now: profiles/r4_timeline_demo.txt).
     // LDS slots are XOR-swizzled (bits 0..3 with bits 4..7 of the entry's index in the piece): lanes read rows whose starts are
     // a row length apart, and with rows of 16 / 32 / 48 entries — or the demo shape's 20 — plain slots put a whole wave on the same
     // few banks. The DMA cannot scatter, so the swizzle is applied on the way IN: lane L of a burst fetches the entry whose slot L is

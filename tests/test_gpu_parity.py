@@ -200,7 +200,7 @@ def test_sparse_morphs_match_oracle_and_dense_path(ctx, oracle):
 
 def test_sparse_morphs_concentrated_on_a_face_region(ctx, oracle):
     """The demo model's shape: every vertex morph is a facial expression over the same few hundred vertices, so some
-    vertices carry dozens of entries and most carry none. The tile-cooperative sparse path must match the oracle there
+    vertices carry dozens of entries and most carry none. The LDS-staged sparse row walk must match the oracle there
     too — on ragged sizes, with a grid cap that gives waves several tiles, with instances that have their own weights,
     and with out_cap on and off."""
     for V, B, M, region in ((28842, 349, 60, (5000, 700)), (1000, 16, 40, (700, 300)), (70003, 64, 33, (69000, 1003))):
