@@ -590,10 +590,36 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
     // Doubling rounds. Round k reads (M, A) from one buffer pair and writes the other: M'[b] = M[A[b]] * M[b], A'[b] = A[A[b]];
     // a bone whose run has reached its root (A < 0) is carried over unchanged. After ceil(log2(levels)) rounds every A is -1
     // and M is the world matrix (roots: W = L from the start).
+    // A thread's first two bones (skeletons up to 512 bones: all of them) keep their matrix and their ancestor index in REGISTERS
+    // across the rounds: a round then reads only the ancestor's matrix and the ancestor's ancestor — both addressed by a value the
+    // thread already holds, so one LDS latency per round instead of two dependent ones — and writes its own for the others.
     float4 *src = wl, *dst = m2;
     int *asrc = s_anc, *adst = s_anc + p.B;
+    constexpr int NBR = 2;
+    float4 rm[NBR][3];
+    int ra[NBR];
+#pragma unroll
+    for (int k = 0; k < NBR; ++k) {
+        const int b = tid + k * kBlock;
+        ra[k] = -1;
+        rm[k][0] = rm[k][1] = rm[k][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < p.B) { ra[k] = asrc[b]; rm[k][0] = src[b * 3]; rm[k][1] = src[b * 3 + 1]; rm[k][2] = src[b * 3 + 2]; }
+    }
     for (int span = 1; span < p.n_levels; span <<= 1) {
-        for (int b = tid; b < p.B; b += kBlock) {
+#pragma unroll
+        for (int k = 0; k < NBR; ++k) {
+            const int b = tid + k * kBlock;
+            if (b < p.B) {
+                const int a = ra[k];
+                if (a >= 0) {
+                    ra[k] = asrc[a];
+                    affine_mul(src[a * 3], src[a * 3 + 1], src[a * 3 + 2], rm[k][0], rm[k][1], rm[k][2], rm[k][0], rm[k][1], rm[k][2]);
+                }
+                dst[b * 3] = rm[k][0]; dst[b * 3 + 1] = rm[k][1]; dst[b * 3 + 2] = rm[k][2];
+                adst[b] = ra[k];
+            }
+        }
+        for (int b = tid + NBR * kBlock; b < p.B; b += kBlock) {       // bones beyond the register slots: through LDS, as before
             const int a = asrc[b];
             float4 w0 = src[b * 3], w1 = src[b * 3 + 1], w2 = src[b * 3 + 2];
             int an = -1;
