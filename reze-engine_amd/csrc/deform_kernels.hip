@@ -776,28 +776,32 @@ template <bool NTS> __device__ __forceinline__ void st3(float *d, float a, float
 // __launch_bounds__(256, 2): the persistent grid is two workgroups per CU (2 waves per SIMD), so the register
 // allocator may use up to 256 VGPRs but not one more (a 257th would halve residency).
 template <int S, int U, int MODE, bool NT, bool NTS, bool GEO, bool FAST>
-__global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformParams p, const RzMorphList ml)
+__global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const float *k_geom, const float *k_world, const float *k_inv_bind, const uint32_t k_bf,
+                                                              const uint32_t k_Vp, const uint32_t k_nq, const uint32_t k_qpw, const uint32_t *k_j01,
+                                                              const uint32_t *k_j23, const uint32_t *k_wq, const RzDeformParams p, const RzMorphList ml)
 {
+    // The leading arguments repeat what the FIRST loads of a wave need: the file is compiled with -amdgpu-kernarg-preload-count=16,
+    // so the command processor hands the first 14 dwords over in SGPRs when the wave starts (16 user SGPRs less the kernel-argument
+    // pointer: everything up to k_j23; k_wq follows by scalar load like `p`) — the matrices, the partition, the mesh planes, and
+    // k_bf = bone count | helper-workgroup flag << 16 | may-be-staged flag << 17 | pose-in-pinned-memory flag << 18 | worker workgroups << 19. Everything else comes out of `p` by scalar loads, which take ~0.9 us to arrive (profiles/r4_timeline_c2.txt:
+    // "entry -> prologue done"): a 3-17 us frame no longer waits for them before asking for its matrices and its mesh.
     constexpr int QPW = 64 / S;              // quads per wave
     constexpr int VW = 4 * QPW;              // vertices per wave per tile
     constexpr int NPL = GEO ? 9 : 3;         // scratch planes per wave
     constexpr int ROUNDS = (VW + 63) / 64;
     constexpr bool LDS_LIST = MODE == 2 || (!FAST && MODE == 1);   // MODE 2 keeps all M weights in LDS on both paths
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4 *pal = reinterpret_cast<float4 *>(smem);                       // B*3 float4
-    uint32_t *s_idx = reinterpret_cast<uint32_t *>(smem + (size_t)p.B * 48);   // Mpad   (LDS_LIST)
-    float *s_w = reinterpret_cast<float *>(s_idx + (LDS_LIST ? p.Mpad : 0));
-    float *scratch_all = s_w + (LDS_LIST ? p.Mpad : 0);                   // 16-B aligned: Mpad % 4 == 0
-
     const int tid = threadIdx.x;
     const int inst = blockIdx.y;
     const int lane = tid & 63, wave = tid >> 6;
+    const int kB = (int)(k_bf & 0xffffu);            // == p.B
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *pal = reinterpret_cast<float4 *>(smem);                       // B*3 float4
     RZ_TL_DECL;
     RZ_STAMP(0);                 // entry
 
     // Zero-copy pose prefetch (see RzDeformParams): workgroup 0 of such a launch is the helper, the workers shift by one.
-    const bool pf_on = p.pf_src != nullptr;          // (only one-launch and fused-hierarchy frames ever carry one)
+    const bool pf_on = (k_bf >> 16) & 1u;            // == p.pf_src != nullptr (only one-launch and fused-hierarchy frames ever carry one)
     if (pf_on && blockIdx.x == 0) {
         // seqlock read of the next upload's pinned slot: header == the expected sequence number -> the host has finished
         // writing that pose (it writes the header last); copy; header again; only then the tag. The ring protocol already
@@ -829,30 +833,31 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     // palette. So a frame that MAY find its pose staged (spec) asks for the tag and, at once, for the matrices of the staged
     // copy (the device pose block: valid memory whatever it holds); the tag is looked at when the palette is formed, and
     // only a miss then fetches the matrices from the pinned slot. Sparse weights are needed at once: that mode waits for the tag.
-    const bool spec = FAST && p.st_tag != nullptr;
-    const uint64_t st_tagv = spec ? *p.st_tag : 0ull;                   // requested here, compared later (workgroup-uniform)
-    const bool staged_now = MODE == 2 && spec && st_tagv == p.st_expect;
-    const float *world_in = spec ? p.st_world : p.world;                // (re-pointed at the pinned slot on a miss)
-    const float *morph_w_in = (staged_now && p.st_morph_w) ? p.st_morph_w : p.morph_w;
-    const bool from_host = p.world_copy != nullptr && !spec;            // the matrices are asked for over the host link up front
+    const bool spec = FAST && ((k_bf >> 17) & 1u);                       // == p.st_tag != nullptr
+    const float *world_in = k_world;                                     // == spec ? p.st_world : p.world (re-pointed at the pinned slot on a miss)
+    const bool from_host = ((k_bf >> 18) & 1u) && !spec;                 // (p.world_copy != nullptr) the matrices are asked for over the host link up front
 
     // FAST: this thread's bone (tid < B covers the first 256 bones) — its world and inverse-bind matrices are
     // requested FIRST, as plain loads into registers, so they are the oldest entries of the vmcnt queue: the palette
     // math below only has to wait for them (a counted wait) while the morph loads issued after them stay in flight.
     float4 ew0, ew1, ew2, ew3, ei0, ei1, ei2, ei3;
-    const bool early = FAST && tid < p.B && RZ_DBG(p) != 3;      // dbg 3: ablation — no palette staging (output is garbage)
+    const bool early = FAST && tid < kB && RZ_DBG(p) != 3;      // dbg 3: ablation — no palette staging (output is garbage)
     // Zero-copy frame (world_copy != null: `world` is pinned HOST memory, a few microseconds away) with a dense morph stream:
     // vmcnt retires in order, so host loads at the head of the queue would hold back the first morph FMAs; there the world
     // matrices are requested BEHIND the first morph group instead, and the palette is formed after the last group.
     const bool late_world = FAST && MODE == 1 && from_host;
     bool world_pending = early && late_world;
+    // (The loads are NOT predicated on `early`: threads past the last bone re-read bone B - 1. Inside a divergent branch the
+    // compiler closed the block by shuffling the loaded registers, which made every wave WAIT for its matrices right here, in front
+    // of the mesh loads that follow — a whole memory round trip at the head of every frame. FAST kernels only: a dead load otherwise.)
+    const int eb = MODE != 1 ? min(tid, kB - 1) : tid;        // (dense kernels keep the predicated form: they have no register to spare)
     auto load_world = [&]() {
-        const float4 *gw = reinterpret_cast<const float4 *>(world_in) + tid * 4;
+        const float4 *gw = reinterpret_cast<const float4 *>(world_in) + eb * 4;
         ew0 = gw[0]; ew1 = gw[1]; ew2 = gw[2]; ew3 = gw[3];
         world_pending = false;
     };
-    if (early) {
-        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + tid * 4;
+    if (FAST && (MODE != 1 || early)) {
+        const float4 *gi = reinterpret_cast<const float4 *>(k_inv_bind) + eb * 4;
         if (!late_world) load_world();
         ei0 = gi[0]; ei1 = gi[1]; ei2 = gi[2]; ei3 = gi[3];
     }
@@ -861,19 +866,20 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     // of the first skin phase of every workgroup (dense frames keep the late loop: it hides under their morph stream).
     constexpr bool EARLY2 = FAST && MODE != 1;
     float4 fw0, fw1, fw2, fw3, fi0, fi1, fi2, fi3;
-    const bool early2 = EARLY2 && early && tid + kBlock < p.B;
+    const bool early2 = EARLY2 && early && tid + kBlock < kB;
+    const int eb2 = min(tid + kBlock, kB - 1);
     auto load_world2 = [&]() {
-        const float4 *gw = reinterpret_cast<const float4 *>(world_in) + (tid + kBlock) * 4;
+        const float4 *gw = reinterpret_cast<const float4 *>(world_in) + eb2 * 4;
         fw0 = gw[0]; fw1 = gw[1]; fw2 = gw[2]; fw3 = gw[3];
     };
-    if (early2) {
-        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + (tid + kBlock) * 4;
+    if constexpr (EARLY2) {                      // (unpredicated like the first bone's: with <= 256 bones every thread re-reads bone B - 1)
+        const float4 *gi = reinterpret_cast<const float4 *>(k_inv_bind) + eb2 * 4;
         load_world2();
         fi0 = gi[0]; fi1 = gi[1]; fi2 = gi[2]; fi3 = gi[3];
     }
     const int s = lane / QPW;                // morph slice of this lane
     const int qi = lane % QPW;
-    const size_t Vp = p.Vp;
+    const size_t Vp = k_Vp;
     const size_t plane4 = Vp / 4;            // float4 per plane
     // persistent, evenly balanced partition: every wave of the grid owns one contiguous run of quads
     // (a multiple of 8 quads = 128 B per plane) and walks it QPW quads at a time; the last step is masked.
@@ -881,10 +887,12 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     // each other: work on such frames is uneven — the demo model's 60 expression morphs all sit on one 1 800-vertex face region,
     // 28 consecutive 64-vertex steps — and four neighbouring heavy steps on ONE CU share its LDS and its texture path
     // (2.7 us in the row walk with four face waves per CU: NOTEBOOK.md R4.1). Dense frames stream evenly: unchanged.
-    const uint32_t n_workers = gridDim.x - (pf_on ? 1u : 0u);
-    const uint32_t wave_global = MODE != 1 ? (uint32_t)wave * n_workers + wid : wid * (kBlock / 64) + wave;
-    const size_t q_begin = (size_t)wave_global * p.quads_per_wave;
-    const size_t q_end = min((size_t)p.n_quads, q_begin + p.quads_per_wave);
+    // (the worker count rides in k_bf's upper bits — gridDim.x is a hidden kernel argument, i.e. one more scalar load; a grid too large
+    // for the 13 bits keeps neighbouring runs)
+    const uint32_t n_workers = k_bf >> 19;
+    const uint32_t wave_global = (MODE != 1 && n_workers) ? (uint32_t)wave * n_workers + wid : wid * (kBlock / 64) + wave;
+    const size_t q_begin = (size_t)wave_global * k_qpw;
+    const size_t q_end = min((size_t)k_nq, q_begin + k_qpw);
 
     // Everything a step reads from the static mesh. Frames WITHOUT a dense morph stream (MODE 0 / 2: one character, small
     // crowds, sparse targets) are latency-bound — a 30 k-vertex frame is two or three dependent memory round trips and a
@@ -906,13 +914,13 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     auto issue = [&](const size_t qw) {
         const size_t q = qw + qi;
         if (s == 0 && q < q_end) {
-            const float4 *G = reinterpret_cast<const float4 *>(p.geom) + q;
+            const float4 *G = reinterpret_cast<const float4 *>(k_geom) + q;
             gx = G[0]; gy = G[plane4]; gz = G[2 * plane4];
             if (GEO) {
                 gnx = G[3 * plane4]; gny = G[4 * plane4]; gnz = G[5 * plane4];
-                gj01 = reinterpret_cast<const uint4 *>(p.joints01)[q];
-                gj23 = reinterpret_cast<const uint4 *>(p.joints23)[q];
-                gw = reinterpret_cast<const uint4 *>(p.weights)[q];
+                gj01 = reinterpret_cast<const uint4 *>(k_j01)[q];
+                gj23 = reinterpret_cast<const uint4 *>(k_j23)[q];
+                gw = reinterpret_cast<const uint4 *>(k_wq)[q];
             }
         }
         if constexpr (PRE) {
@@ -922,10 +930,13 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
                 const int vl = r * 64 + lane;
                 if (vl < v_live) {
                     const size_t v = qw * 4 + vl;
-                    pnx[r] = p.geom[3 * Vp + v]; pny[r] = p.geom[4 * Vp + v]; pnz[r] = p.geom[5 * Vp + v];
-                    pj01[r] = p.joints01[v]; pj23[r] = p.joints23[v]; pwq[r] = p.weights[v];
+                    pnx[r] = k_geom[3 * Vp + v]; pny[r] = k_geom[4 * Vp + v]; pnz[r] = k_geom[5 * Vp + v];
+                    pj01[r] = k_j01[v]; pj23[r] = k_j23[v];
                 }
             }
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r)         // (the weights plane's pointer is not among the preloaded arguments: asked for last)
+                if (r * 64 + lane < v_live) pwq[r] = k_wq[qw * 4 + r * 64 + lane];
             if constexpr (PRE_SP) {
                 sb0[0] = 0u; sb1[0] = 0u;
                 if (lane < v_live) { sb0[0] = p.sp_ptr[qw * 4 + lane]; sb1[0] = p.sp_ptr[qw * 4 + lane + 1]; }
@@ -934,6 +945,13 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const RzDeformPara
     };
     if (PRE && q_begin < q_end) issue(q_begin);
 
+    // ---- from here on the kernel reads `p` (scalar loads of the kernel arguments: the loads above are in flight under them) ----
+    uint32_t *s_idx = reinterpret_cast<uint32_t *>(smem + (size_t)p.B * 48);   // Mpad   (LDS_LIST)
+    float *s_w = reinterpret_cast<float *>(s_idx + (LDS_LIST ? p.Mpad : 0));
+    float *scratch_all = s_w + (LDS_LIST ? p.Mpad : 0);                   // 16-B aligned: Mpad % 4 == 0
+    const uint64_t st_tagv = spec ? *p.st_tag : 0ull;                   // requested here, compared later (workgroup-uniform)
+    const bool staged_now = MODE == 2 && spec && st_tagv == p.st_expect;
+    const float *morph_w_in = (staged_now && p.st_morph_w) ? p.st_morph_w : p.morph_w;
     int fused_count = 0;
     if (!FAST && p.fk_on) {
         // FUSED single-character frame: hierarchy solve (and motion sampling) as this workgroup's prologue, palette straight
@@ -1918,7 +1936,12 @@ static hipError_t launch_one(const RzDeformParams &p, const RzMorphList &ml, dim
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p, ml);
+    // the leading arguments (kernel-argument preload: see the kernel) repeat fields of `p`; k_world is the pose the kernel asks for
+    // FIRST — the copy a helper may have staged when the frame looks for one, else p.world
+    const float *k_world = (FAST && p.st_tag) ? p.st_world : p.world;
+    const uint32_t workers = grid.x - (p.pf_src ? 1u : 0u);
+    const uint32_t k_bf = (uint32_t)p.B | (p.pf_src ? 1u << 16 : 0u) | (p.st_tag ? 1u << 17 : 0u) | (p.world_copy ? 1u << 18 : 0u) | (workers < 8192u ? workers << 19 : 0u);
+    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p.geom, k_world, p.inv_bind, k_bf, p.Vp, p.n_quads, p.quads_per_wave, p.joints01, p.joints23, p.weights, p, ml);
     return hipGetLastError();
 }
 
