@@ -112,7 +112,8 @@ def build():
                                                  pair(ca.get("frame_ms_with_pose_upload"), cb.get("frame_ms_with_pose_upload")), pair(ca.get("frame_ms_device_sampled_pose"), cb.get("frame_ms_device_sampled_pose"))))
     if rows:
         out.append("**Round %s → round %s, line by line** (`profiles/%s_bench_*.json` against `profiles/%s_bench_*.json`, µs; different boxes: differences under ≈ 3 %% are box noise — "
-                   "the same-session A/B runs are in `profiles/%s_ab_*.txt`; the 1/8 shard is 125 952 vertices in round 3 and 125 184 in round 4):" % (PREV[1:], TAG[1:], PREV, TAG, TAG))
+                   "the C5 and C4 kernels are the round-3 kernels, so their rows ARE box noise (`profiles/%s_box_variance.txt`); the same-session A/B runs are in `profiles/%s_ab_*.txt`; "
+                   "the 1/8 shard is 125 952 vertices in round 3 and 125 184 in round 4):" % (PREV[1:], TAG[1:], PREV, TAG, TAG, TAG))
         out.append("")
         out.append("| line | frame, one stream | kernel (events) | frame + pose upload | frame, pose sampled on the GPU |")
         out.append("|---|---|---|---|---|")
