@@ -1431,9 +1431,16 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 // (Tried and measured slower or without effect, then removed again — NOTEBOOK.md R3.1 / R3.4 / R3.9: forcing three workgroups per CU
 // (80 VGPRs spill), a branch-free pose loop with clamped tail lanes, four poses unrolled, raised wave priority around the stores.)
 template <int BLOCK, bool NTS, bool SUB>
-__global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeformParams p, int G, int n_inst,
-                                                                  uint32_t verts_per_wg)
+__global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const uint32_t *k_sub_count, const uint16_t *k_sub_list, const float4 *k_src,
+                                                                  const float *k_inv_bind, const int G, const int n_inst, const uint32_t verts_per_wg,
+                                                                  const uint32_t k_grid, const uint32_t k_bf, const uint32_t k_Vp, const RzDeformParams p)
 {
+    // The leading arguments are preloaded into SGPRs at wave start (14 dwords; see rz_deform_kernel): what the FRONT of a workgroup
+    // needs — the run's bone list, the matrices it stages (k_src = the poses' world matrices, or their finished palettes behind
+    // rz_prep_kernel / rz_fk_kernel), the inverse bind matrices, the launch shape (k_grid = gridDim.x | gridDim.y << 16: the hidden
+    // arguments would be one more scalar load) and k_bf = bone count | inst_order << 16 | dma << 17.
+    const int kB = (int)(k_bf & 0xffffu);
+    const bool k_order = (k_bf >> 16) & 1u, k_dma = (k_bf >> 17) & 1u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *pal = reinterpret_cast<float4 *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1442,31 +1449,31 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
     // Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest). inst_order 0: x = vertex run — an XCD sees every
     // pose group and one eighth of the mesh; 1: consecutive workgroups take consecutive pose groups — an XCD sees one eighth of
     // the poses' matrices and the whole mesh.
-    const uint32_t n_groups = gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
-    const uint32_t wg_group = p.inst_order ? lin % n_groups : blockIdx.y, wg_run = p.inst_order ? lin / n_groups : blockIdx.x;
+    const uint32_t n_groups = k_grid >> 16, lin = blockIdx.x + (k_grid & 0xffffu) * blockIdx.y;
+    const uint32_t wg_group = k_order ? lin % n_groups : blockIdx.y, wg_run = k_order ? lin / n_groups : blockIdx.x;
     const int inst0 = (int)wg_group * G;
     const int ng = min(G, n_inst - inst0);
-    const int rows = p.B * 3;                       // float4 per palette, in global memory and (finished) in LDS
+    const int rows = kB * 3;                       // float4 per palette, in global memory and (finished) in LDS
     constexpr int rstride = 3;                      // float4 per bone of a finished palette
     // SUB: this run's bone list (workgroup-uniform: scalar loads)
-    const int ns = SUB ? (int)p.sub_count[wg_run] : 0;
-    const uint16_t *sub = SUB ? p.sub_list + (size_t)wg_run * p.sub_stride : nullptr;
+    const int ns = SUB ? (int)k_sub_count[wg_run] : 0;
+    const uint16_t *sub = SUB ? k_sub_list + (size_t)wg_run * kB : nullptr;      // (the lists' stride is the bone count)
     const int lrows = SUB ? ns * 3 : rows;          // float4 per pose of the finished LDS palettes
     float4 *stage = pal + (size_t)G * ns * 3;       // SUB, one-launch frame: staged world matrices sit behind the palette region
     if constexpr (SUB) {
         // prep-kernel / device-FK path (dma): the listed bones' finished rows, 3 float4 per bone, straight to their place.
         // one-launch frame: the listed bones' world matrices, 4 float4 per bone, into the staging region.
         // Either way element e of the linear LDS image is (pose g, slot s, cell k): a per-lane global address, a linear LDS one.
-        const int epb = p.dma ? 3 : 4;
+        const int epb = k_dma ? 3 : 4;
         const int n = RZ_DBG(p) == 8 ? 0 : ng * ns * epb;           // dbg 8 (tools-only build): neither staging nor product
-        const float4 *src = p.dma ? p.palette + (size_t)inst0 * rows : reinterpret_cast<const float4 *>(p.world) + (size_t)inst0 * p.B * 4;
-        float4 *dst = p.dma ? pal : stage;
+        const float4 *src = k_src + (size_t)inst0 * kB * (k_dma ? 3 : 4);
+        float4 *dst = k_dma ? pal : stage;
         for (int c = wave * 64; c < n; c += BLOCK) {
             const int e = c + lane;
             if (e < n) {
-                const int gs = p.dma ? e / 3 : e >> 2, k = e - gs * epb;
+                const int gs = k_dma ? e / 3 : e >> 2, k = e - gs * epb;
                 const int g = gs / ns, sl = gs - g * ns;
-                const float4 *a = src + ((size_t)g * p.B + sub[sl]) * epb + k;
+                const float4 *a = src + ((size_t)g * kB + sub[sl]) * epb + k;
                 typedef const __attribute__((address_space(1))) void *gptr_t;
                 typedef __attribute__((address_space(3))) void *lptr_t;
                 __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)a, (lptr_t)(uint32_t)(uintptr_t)(dst + c), 16, 0, 0);
@@ -1478,8 +1485,8 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
         // 16-byte LDS-DMA); the conversion pass below multiplies by the inverse bind matrix and re-packs the rows to the
         // same 48-byte stride. (Leaving them in the 64-byte slots made every fourth bone share its LDS banks: 52 % of the
         // skin loop's LDS cycles were bank conflicts, against 11 % at 48 bytes — profiles/r2_sq_counters_c4.txt.)
-        const float4 *src = p.dma ? p.palette + (size_t)inst0 * rows : reinterpret_cast<const float4 *>(p.world) + (size_t)inst0 * p.B * 4;
-        const int n = (RZ_DBG(p) == 6 || RZ_DBG(p) == 7 || RZ_DBG(p) == 8) ? 0 : (p.dma ? ng * rows : ng * p.B * 4);   // dbg 6 / 7 (tools-only build): no palette staging
+        const float4 *src = k_src + (size_t)inst0 * kB * (k_dma ? 3 : 4);
+        const int n = (RZ_DBG(p) == 6 || RZ_DBG(p) == 7 || RZ_DBG(p) == 8) ? 0 : (k_dma ? ng * rows : ng * kB * 4);   // dbg 6 / 7 (tools-only build): no palette staging
         for (int c = wave * 64; c < n; c += BLOCK) {
             const int e = c + lane;
             if (e < n) {
@@ -1493,17 +1500,17 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const RzDeform
     // B <= BLOCK / 2 the spare threads take a second, third ... stripe of the group's poses (stripe s converts poses s,
     // s + stripes, ...): 200 bones on 512 threads = 2 stripes.
     // SUB: the same mapping over the run's ns listed bones (the host plans the form only for ns <= BLOCK).
-    const int cvB = SUB ? max(ns, 1) : p.B;
-    const int stripes = !p.dma ? max(1, min(ng, BLOCK / cvB)) : 1;
+    const int cvB = SUB ? max(ns, 1) : kB;
+    const int stripes = !k_dma ? max(1, min(ng, BLOCK / cvB)) : 1;
     const int cv_b0 = tid % cvB;
     const int cv_g0 = tid / cvB;
-    const bool cv_on = !p.dma && cv_g0 < stripes && (!SUB || ns > 0);
+    const bool cv_on = !k_dma && cv_g0 < stripes && (!SUB || ns > 0);
     float4 ib0 = {0, 0, 0, 0}, ib1 = ib0, ib2 = ib0, ib3 = ib0;
     if (cv_on) {                                    // requested first: lands while the staging copy is in flight
-        const float4 *gi = reinterpret_cast<const float4 *>(p.inv_bind) + (SUB ? (int)sub[cv_b0] : cv_b0) * 4;
+        const float4 *gi = reinterpret_cast<const float4 *>(k_inv_bind) + (SUB ? (int)sub[cv_b0] : cv_b0) * 4;
         ib0 = gi[0]; ib1 = gi[1]; ib2 = gi[2]; ib3 = gi[3];
     }
-    const size_t Vp = p.Vp;
+    const size_t Vp = k_Vp;
     const uint32_t v_begin = wg_run * verts_per_wg;
     const uint32_t v_end = min(p.n_quads * 4u, v_begin + verts_per_wg);
     const uint32_t bmax = (uint32_t)(p.B - 1);
@@ -2032,7 +2039,11 @@ static hipError_t launch_skin_instances(const RzDeformParams &p, int G, int n_in
         if (e != hipSuccess) return e;
     }
     dim3 grid(grid_x, (n_inst + G - 1) / G);
-    hipLaunchKernelGGL(k, grid, dim3(BLOCK), lds, st, p, G, n_inst, verts_per_wg);
+    if (grid.x > 0xffffu || grid.y > 0xffffu || (sub && p.sub_stride != p.B)) return hipErrorInvalidValue;      // (k_grid packs both; the lists' stride is the bone count)
+    // leading arguments = what the front of a workgroup needs, preloaded into SGPRs (see the kernel)
+    const float4 *k_src = p.dma ? p.palette : reinterpret_cast<const float4 *>(p.world);
+    const uint32_t k_grid = grid.x | (grid.y << 16), k_bf = (uint32_t)p.B | (p.inst_order ? 1u << 16 : 0u) | (p.dma ? 1u << 17 : 0u);
+    hipLaunchKernelGGL(k, grid, dim3(BLOCK), lds, st, p.sub_count, p.sub_list, k_src, p.inv_bind, G, n_inst, verts_per_wg, k_grid, k_bf, p.Vp, p);
     return hipGetLastError();
 }
 
