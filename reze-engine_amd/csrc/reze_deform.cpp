@@ -641,6 +641,10 @@ void inst_runs(const rz_ctx *c, int G, int blk, bool for_subsets, uint32_t *per,
     const uint32_t gxi = std::max<uint32_t>(1, total / groups);
     *per = round_up((c->V + gxi - 1) / gxi, 64);
     *runs = (c->V + *per - 1) / *per;
+    if (*runs > 0xffffu) {                  // the crowd kernel takes its launch shape as two 16-bit fields of one preloaded argument
+        *per = round_up((c->V + 0xfffeu) / 0xffffu, 64);
+        *runs = (c->V + *per - 1) / *per;
+    }
 }
 
 // The shape the caller ASKS for (inst_loop / inst_block / grid_cap or the defaults), before LDS limits the group size; when
