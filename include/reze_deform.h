@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 4
+/* 5 (round 5): shards are cut at 256 vertices (4: 1 024 before round 4's change, which should have bumped this), so the chunk stride of the
+ * gathered buffer changed; rz_gather_chunk exports it instead of making callers re-derive it. */
+#define RZ_ABI_VERSION 5
 
 typedef struct rz_ctx rz_ctx;
 
@@ -70,6 +72,10 @@ int rz_destroy(rz_ctx *ctx);
 /* Pure helper: contiguous shard of rank `rank` of `nranks` over v_total vertices.
  * Shards are equal-sized (a multiple of 256 vertices) except the last; *count may be 0. */
 int rz_shard_range(uint32_t v_total, int nranks, int rank, uint32_t *begin, uint32_t *count);
+/* The uniform stride, in vertices, between two ranks' blocks of the gathered buffers (rz_allgather / rz_gather_direct /
+ * rz_read_gathered): rank r's vertices land at [r * chunk, r * chunk + count_r). It is rank 0's shard size rounded up to the shard
+ * grain — ask for it here rather than re-deriving the rule (the grain changed from 1 024 to 256 vertices with ABI 5). */
+int rz_gather_chunk(uint32_t v_total, int nranks, uint32_t *chunk);
 
 /* setupModelBuffers()  engine/src/engine.ts:1734-1765: vertex buffer in the reference's
  * interleaved layout (8 floats/vertex: pos3 nrm3 uv2, engine.ts:340-347), joints Uint16x4
@@ -256,7 +262,11 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * rz_get_tuning also answers "effective_split" / "effective_unroll" / "effective_grid" / "effective_fast" / "effective_out_cap" /
  * "effective_inst_group" / "effective_inst_block" / "effective_fuse_fk" / "effective_overlap" / "pose_resident" /
  * "effective_subsets" / "effective_subset_bones" / "effective_inst_lds" and the counts
- * "verts" / "bones" / "morphs" / "instances". Unknown keys return RZ_ERR_INVALID. */
+ * "verts" / "bones" / "morphs" / "instances". Unknown keys return RZ_ERR_INVALID.
+ * NOT a pure getter for crowds: an "effective_*" key describes the frame the NEXT rz_deform will launch, and a crowd's plan depends on
+ * the per-run bone lists of its launch shape — when the shape, the mesh or the skeleton changed since the last frame the call brings
+ * them up to date first, exactly as the next frame would (stream drained, one small kernel, one readback, a captured graph dropped).
+ * Poll these keys at setup time or after a frame, not between a shape change and the frame in a latency-critical loop. */
 int rz_set_tuning(rz_ctx *ctx, const char *key, int value);
 int rz_get_tuning(rz_ctx *ctx, const char *key, int *value);
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libreze_deform.so")
 
 # every symbol include/reze_deform.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_destroy", "rz_shard_range",
+    "rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_destroy", "rz_shard_range", "rz_gather_chunk",
     "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
     "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_upload_bone_morphs", "rz_upload_animation", "rz_set_pose_sampled", "rz_override_world", "rz_read_world", "rz_deform", "rz_deform_n", "rz_fork", "rz_deform_pair", "rz_sync", "rz_read",
     "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_autotune", "rz_autotune_measure", "rz_autotune_pick",
@@ -85,6 +85,8 @@ def load(path=None):
     L.rz_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.rz_destroy.argtypes = [vp]
     L.rz_shard_range.argtypes = [u32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    if hasattr(L, "rz_gather_chunk"):          # (absent from libraries older than ABI 5, which tools/ab_inproc.py loads for A/B runs)
+        L.rz_gather_chunk.argtypes = [u32, ctypes.c_int, ctypes.POINTER(u32)]
     L.rz_upload_mesh.argtypes = [vp, u32, fp, ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint8)]
     L.rz_upload_mesh_soa.argtypes = [vp, u32, fp, fp, ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint8)]
     L.rz_upload_skeleton.argtypes = [vp, u32, fp]
@@ -130,7 +132,7 @@ def load(path=None):
     L.rz_gather_direct.argtypes = [ctypes.POINTER(vp), ctypes.c_int, u32, ctypes.c_int]
     L.rz_gather_fence.argtypes = [vp]
     for name in SYMBOLS:
-        if name != "rz_last_error":
+        if name != "rz_last_error" and (name != "rz_gather_chunk" or hasattr(L, name)):
             getattr(L, name).restype = ctypes.c_int
     _libs[path] = L
     if path == os.path.abspath(LIB_PATH):
@@ -163,6 +165,13 @@ def shard_range(v_total, nranks, rank):
     n = ctypes.c_uint32(0)
     _chk(load().rz_shard_range(int(v_total), int(nranks), int(rank), ctypes.byref(b), ctypes.byref(n)))
     return b.value, n.value
+
+
+def gather_chunk(v_total, nranks):
+    """Pure host helper: the stride, in vertices, between two ranks' blocks of the gathered buffers."""
+    c = ctypes.c_uint32(0)
+    _chk(load().rz_gather_chunk(int(v_total), int(nranks), ctypes.byref(c)))
+    return c.value
 
 
 def comm_unique_id():

@@ -185,6 +185,7 @@ __host__ __device__ inline size_t rz_fk_scratch_bytes(int B) { return ((size_t)B
 
 hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t st);
 hipError_t rz_launch_fk(const RzFkParams &p, uint32_t instances, hipStream_t st);
+size_t rz_fk_lds_bytes(const RzFkParams &p);      // dynamic LDS of rz_fk_kernel (palette rows + solve scratch + the pose's morph weights)
 hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, const RzVariant &v, uint32_t grid_x,
                             uint32_t instances, hipStream_t st);
 size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v);

@@ -35,6 +35,12 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// Build-time switch (A/B builds: make flavor): bit log2(S) set = the kernel-argument morph list of the dense one-launch kernel with
+// morph split S is read through SGPRs (readfirstlane) instead of the per-lane indexed load the compiler folds the selects into.
+#ifndef RZ_PIN_ML
+#define RZ_PIN_ML 0
+#endif
+
 // Ablation switches for profiling experiments exist only in the tools-only build (make ablate ->
 // tools/ablate/libreze_deform_ablate.so, -DRZ_ABLATE). In the shipped library RZ_DBG is the constant 0, the branches
 // fold away, and rz_set_tuning("dbg", ...) is rejected: no key can make rz_deform emit anything but the deformed mesh.
@@ -1176,12 +1182,27 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_kernel(const float *k_geo
             // v_cndmask — no vector-memory load sits in front of the morph stream.
             auto entry = [&](int base, uint32_t &m, float &w) {
                 if (FAST) {
-                    m = (uint32_t)ml.idx[base]; w = ml.w[base];
+                    // (PIN: the compiler folds the select chain below into ONE per-lane indexed load ml.idx[base + s] from the
+                    // kernel-argument segment, i.e. a vector-memory load in front of every group's morph loads; readfirstlane
+                    // keeps the entries in SGPRs — scalar loads — and the select a v_cndmask. NOTEBOOK.md R4.10 / R5.2.)
+                    constexpr bool PIN = (RZ_PIN_ML >> (S == 1 ? 0 : S == 2 ? 1 : S == 4 ? 2 : 3)) & 1;
+                    if constexpr (PIN) {
+                        auto sg = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+                        m = sg((uint32_t)ml.idx[base]); w = __uint_as_float(sg(__float_as_uint(ml.w[base])));
 #pragma unroll
-                    for (int k = 1; k < S; ++k) {
-                        const uint32_t mk = (uint32_t)ml.idx[base + k];
-                        const float wk = ml.w[base + k];
-                        m = (s == k) ? mk : m; w = (s == k) ? wk : w;
+                        for (int k = 1; k < S; ++k) {
+                            const uint32_t mk = sg((uint32_t)ml.idx[base + k]);
+                            const float wk = __uint_as_float(sg(__float_as_uint(ml.w[base + k])));
+                            m = (s == k) ? mk : m; w = (s == k) ? wk : w;
+                        }
+                    } else {
+                        m = (uint32_t)ml.idx[base]; w = ml.w[base];
+#pragma unroll
+                        for (int k = 1; k < S; ++k) {
+                            const uint32_t mk = (uint32_t)ml.idx[base + k];
+                            const float wk = ml.w[base + k];
+                            m = (s == k) ? mk : m; w = (s == k) ? wk : w;
+                        }
                     }
                 } else {
                     m = s_idx[base + s]; w = s_w[base + s];
@@ -1910,10 +1931,17 @@ hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t
     return hipGetLastError();
 }
 
-hipError_t rz_launch_fk(const RzFkParams &p, uint32_t instances, hipStream_t st)
+size_t rz_fk_lds_bytes(const RzFkParams &p)
 {
     size_t lds = (size_t)p.B * 48 + rz_fk_scratch_bytes(p.B);
     if (p.bm_off) lds += (size_t)std::max(std::max(p.bm_M, p.sample.M), 1) * 4;      // the pose's morph weights, for the bone morphs
+    return lds;
+}
+
+hipError_t rz_launch_fk(const RzFkParams &p, uint32_t instances, hipStream_t st)
+{
+    const size_t lds = rz_fk_lds_bytes(p);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;      // (the host checks first and says why: launch_fk in reze_deform.cpp)
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rz_fk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1938,6 +1966,7 @@ template <int S, int U, int MODE, bool NT, bool NTS, bool GEO, bool FAST>
 static hipError_t launch_one(const RzDeformParams &p, const RzMorphList &ml, dim3 grid, size_t lds, hipStream_t st)
 {
     auto k = rz_deform_kernel<S, U, MODE, NT, NTS, GEO, FAST>;
+    if (p.B > 0xffff) return hipErrorInvalidValue;      // k_bf carries the bone count in 16 bits (the 48 B per bone LDS palette keeps it far below today)
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2039,7 +2068,7 @@ static hipError_t launch_skin_instances(const RzDeformParams &p, int G, int n_in
         if (e != hipSuccess) return e;
     }
     dim3 grid(grid_x, (n_inst + G - 1) / G);
-    if (grid.x > 0xffffu || grid.y > 0xffffu || (sub && p.sub_stride != p.B)) return hipErrorInvalidValue;      // (k_grid packs both; the lists' stride is the bone count)
+    if (grid.x > 0xffffu || grid.y > 0xffffu || p.B > 0xffff || (sub && p.sub_stride != p.B)) return hipErrorInvalidValue;      // (k_grid packs both; the lists' stride is the bone count)
     // leading arguments = what the front of a workgroup needs, preloaded into SGPRs (see the kernel)
     const float4 *k_src = p.dma ? p.palette : reinterpret_cast<const float4 *>(p.world);
     const uint32_t k_grid = grid.x | (grid.y << 16), k_bf = (uint32_t)p.B | (p.inst_order ? 1u << 16 : 0u) | (p.dma ? 1u << 17 : 0u);

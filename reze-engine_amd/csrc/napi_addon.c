@@ -191,6 +191,19 @@ static napi_value fn_shard_range(napi_env env, napi_callback_info info)
     return arr;
 }
 
+static napi_value fn_gather_chunk(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    uint32_t vt, c = 0;
+    int32_t nr;
+    if (!get_u32(env, argv[0], &vt) || !get_i32(env, argv[1], &nr)) return throw_msg(env, "gatherChunk(vTotal, nranks)");
+    int rc = rz_gather_chunk(vt, nr, &c);
+    if (rc) return throw_rz(env, rc);
+    napi_value v;
+    napi_create_uint32(env, c, &v);
+    return v;
+}
+
 static napi_value fn_upload_mesh(napi_env env, napi_callback_info info)
 {
     ARGS(4);
@@ -858,7 +871,7 @@ static napi_value init(napi_env env, napi_value exports)
 {
     static const struct { const char *name; napi_callback fn; } table[] = {
         { "abiVersion", fn_abi_version }, { "deviceCount", fn_device_count }, { "create", fn_create },
-        { "destroy", fn_destroy }, { "shardRange", fn_shard_range }, { "uploadMesh", fn_upload_mesh },
+        { "destroy", fn_destroy }, { "shardRange", fn_shard_range }, { "gatherChunk", fn_gather_chunk }, { "uploadMesh", fn_upload_mesh },
         { "uploadMeshSoa", fn_upload_mesh_soa }, { "uploadSkeleton", fn_upload_skeleton },
         { "uploadMorphsDense", fn_upload_morphs_dense }, { "uploadMorphsSparse", fn_upload_morphs_sparse },
         { "setInstances", fn_set_instances }, { "setPose", fn_set_pose }, { "uploadSkeletonTopology", fn_upload_topology },

@@ -10,9 +10,7 @@ from . import capi
 def shard_of(v_total, world_size, rank):
     """(begin, count, chunk): this rank's range and the uniform chunk stride of the gathered buffer."""
     begin, count = capi.shard_range(v_total, world_size, rank)
-    _b0, c0 = capi.shard_range(v_total, world_size, 0)
-    chunk = (c0 + 255) // 256 * 256
-    return begin, count, chunk
+    return begin, count, capi.gather_chunk(v_total, world_size)
 
 
 def cut_mesh(mesh, deltas, begin, count):

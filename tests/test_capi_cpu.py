@@ -101,7 +101,7 @@ def test_autotune_pick_keeps_the_heuristic_unless_a_candidate_is_clearly_faster(
 
 
 def test_sanitized_host_library_cpu_driver():
-    """make asan + tools/asan_run.py cpu: the host library (reze_deform.cpp) under AddressSanitizer + UndefinedBehaviorSanitizer,
+    """make asan + tools/asan_run.py cpu: the host library (csrc/*.cpp) under AddressSanitizer + UndefinedBehaviorSanitizer,
     driven through every C-ABI path that needs no GPU — every export refuses a NULL context with a message, shard arithmetic
     over edge sizes, the launch-shape pick rule on synthetic tables, rz_create without a device. Any report aborts the child.
     (The GPU half — misuse script, fuzz walks, ring / fork / graph soak — runs on the GPU box: profiles/r4_asan.txt.)"""
@@ -109,4 +109,6 @@ def test_sanitized_host_library_cpu_driver():
     import sys
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asan_run.py"), "cpu"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode()
+    if p.returncode == 77:          # the toolchain for the sanitized build is not on this machine (tools/asan_run.py says which part)
+        pytest.skip(out.strip().splitlines()[-1] if out.strip() else "sanitized build unavailable")
     assert p.returncode == 0 and "ASAN-CPU-OK" in out, out[-3000:]

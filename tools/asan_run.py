@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Drive the C ABI of the SANITIZED host library (make -C reze-engine_amd/csrc asan: reze_deform.cpp under AddressSanitizer +
+"""Drive the C ABI of the SANITIZED host library (make -C reze-engine_amd/csrc asan: the host sources under AddressSanitizer +
 UndefinedBehaviorSanitizer, device code untouched). Re-executes itself with the sanitizer runtime preloaded.
   python tools/asan_run.py cpu            host paths that need no GPU: argument validation with a NULL context on every export,
                                           shard arithmetic, the launch-shape pick rule, create without a device
@@ -11,9 +11,20 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "tools", "asan", "libreze_deform_asan.so")
 if os.environ.get("REZE_ASAN_CHILD") != "1":
-    if not os.path.exists(LIB):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "reze-engine_amd", "csrc"), "asan"])
+    # (incremental: a no-op when the sanitized build is up to date with the sources; exit code 77 = the toolchain for it is not
+    # here — hipcc for the device objects, g++ with libasan, the ROCm headers — which the CPU test suite reports as a skip)
+    import shutil
+    if not (shutil.which("g++") and shutil.which("make") and os.path.exists("/opt/rocm/bin/hipcc")):
+        print("ASAN-SKIP: no g++ / make / hipcc on this machine")
+        sys.exit(77)
     rt = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()     # gcc's runtime (see the Makefile)
+    if not os.path.isabs(rt) or not os.path.exists(rt):
+        print("ASAN-SKIP: gcc has no libasan.so here")
+        sys.exit(77)
+    mk = subprocess.run(["make", "-j8", "-C", os.path.join(ROOT, "reze-engine_amd", "csrc"), "asan"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if mk.returncode != 0:
+        print("ASAN-SKIP: `make asan` failed:\n" + mk.stdout.decode()[-2000:])
+        sys.exit(77)
     env = dict(os.environ, REZE_ASAN_CHILD="1", LD_PRELOAD=rt + (":" + os.environ["LD_PRELOAD"] if os.environ.get("LD_PRELOAD") else ""),
                # leaks: the interpreter's own; shadow gap: the ROCm runtime maps memory there
                ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=1:protect_shadow_gap=0:detect_odr_violation=0",
@@ -32,7 +43,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "cpu"
 if mode == "cpu":
     n = 0
     for name in rz.capi.SYMBOLS:
-        if name in ("rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_shard_range", "rz_comm_unique_id", "rz_comm_init_all",
+        if name in ("rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_shard_range", "rz_gather_chunk", "rz_comm_unique_id", "rz_comm_init_all",
                     "rz_allgather_all", "rz_gather_direct", "rz_destroy", "rz_rccl_info", "rz_autotune_pick"):
             continue
         f = getattr(L, name)
@@ -45,6 +56,11 @@ if mode == "cpu":
         for nr in (1, 2, 3, 7, 8, 64):
             spans = [rz.shard_range(v_total, nr, r) for r in range(nr)]
             assert sum(c for _, c in spans) == v_total and all(b + c <= v_total for b, c in spans), (v_total, nr, spans)
+            if spans[0][1] > (1 << 32) - 256:      # the rounded-up chunk would not fit 32 bits: refused, not wrapped
+                assert L.rz_gather_chunk(v_total, nr, ctypes.byref(ctypes.c_uint32())) < 0
+                continue
+            ch = rz.capi.gather_chunk(v_total, nr)
+            assert ch % 256 == 0 and ch >= spans[0][1] and all(b == min(v_total, r * ch) for r, (b, _) in enumerate(spans)), (v_total, nr, ch, spans)
     b, c = ctypes.c_uint32(), ctypes.c_uint32()
     assert L.rz_shard_range(10, 0, 0, ctypes.byref(b), ctypes.byref(c)) < 0 and L.rz_shard_range(10, 2, 2, ctypes.byref(b), ctypes.byref(c)) < 0
     assert L.rz_shard_range(10, 2, 0, None, None) < 0
