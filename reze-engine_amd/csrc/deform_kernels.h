@@ -1,4 +1,4 @@
-// deform_kernels.h — parameter blocks and launchers shared by deform_kernels.hip and reze_deform.cpp.
+// deform_kernels.h — parameter blocks and launchers shared by the kernel files (kernels/*.hip) and the host side (ctx.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -168,7 +168,7 @@ struct RzMorphList {
     float w[kKargMorphs + kKargPad];
 };
 
-// Compile-time variant selection of rz_deform_kernel (see deform_kernels.hip).
+// Compile-time variant selection of the single-mesh frame kernels (kernels/deform_dense.hip, kernels/deform_small.hip).
 struct RzVariant {
     int mode;    // 0 none, 1 dense, 2 sparse
     int S;       // morph split 1,2,4,8 (mode 1 only)
@@ -189,6 +189,9 @@ size_t rz_fk_lds_bytes(const RzFkParams &p);      // dynamic LDS of rz_fk_kernel
 hipError_t rz_launch_deform(const RzDeformParams &p, const RzMorphList &ml, const RzVariant &v, uint32_t grid_x,
                             uint32_t instances, hipStream_t st);
 size_t rz_deform_lds_bytes(const RzDeformParams &p, const RzVariant &v);
+// the two single-mesh frame kernels behind rz_launch_deform (kernels/deform_dense.hip: v.mode == 1; kernels/deform_small.hip: modes 0 / 2)
+hipError_t rz_launch_deform_dense(const RzDeformParams &p, const RzMorphList &ml, const RzVariant &v, dim3 grid, size_t lds, hipStream_t st);
+hipError_t rz_launch_deform_small(const RzDeformParams &p, const RzVariant &v, dim3 grid, size_t lds, hipStream_t st);
 // instanced skin (no morphs): G poses per workgroup share one decode of each vertex
 // register-resident form: 2048 vertices per workgroup decoded once, poses streamed through a 2-deep LDS palette ring
 hipError_t rz_launch_skin_instances_reg(const RzDeformParams &p, int n_inst, int poses_per_wg, uint32_t grid_x, bool nts,

@@ -1,0 +1,527 @@
+// kernels/crowd.hip — instanced skin (BASELINE config C4: many poses of one static mesh) and its plan-time bone-subset pass.
+#include "common.hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// instanced skin (MODE 0, I > 1 — BASELINE config C4: many poses of one static mesh).
+// A workgroup owns a run of vertices and a GROUP of G instances whose palettes it stages together in
+// LDS (LDS-DMA from the prep kernel's palette). Each lane decodes a vertex ONCE — rest position/normal,
+// the four joints as palette row offsets, the four weights as floats — and then loops over the G poses:
+// 12 ds_read_b128 + blend + transform + 24 B store per pose. The static mesh is read I/G times instead
+// of I times, and the per-pose body has no global load in front of it (the generic kernel was latency-
+// bound here: 43 % of wave time in s_waitcnt, VALU 30 %, LDS 31 % — profiles/r1_sq_counters.txt).
+// grid = (vertex runs, instance groups); block = 256; dynamic LDS = G * B * 48 bytes.
+// ------------------------------------------------------------------------------------------------
+
+// BLOCK threads per workgroup (256: two workgroups per CU; 512 / 1024: one, with 8 / 16 waves sharing one staged palette
+// group — half / a quarter of the palette traffic per CU). NB = how many influences the pose loop gathers: the host picks
+// nothing here, every wave decides per vertex step from a ballot over its lanes' weights (wave-uniform, so no divergence):
+// a step whose 64 vertices are all BDEF1 / BDEF2 (real PMX models cluster them by mesh part) reads 3 / 6 palette rows per
+// pose instead of 12. Skipped terms are w = 0, i.e. fma(0, row, m) = m: the result bits do not depend on the path taken.
+//
+// SUB = bone-subset form. A vertex run names only a few of the skeleton's bones (PMX meshes are bone-local: the synthetic C4
+// mesh's 3 750-vertex runs touch ~34 of 200), and rz_run_subsets_kernel has listed them per run and rewritten the joints as
+// slots of that list. The workgroup stages ONLY those bones of its G poses: 8 x 34 matrices instead of 8 x 200 — the front of
+// every workgroup (LDS-DMA + palette product, during which the CU stores nothing) shrinks from 2.9 us to 1.3 us (profiles/r3_c4_front.txt), and the
+// group's LDS footprint from 102 KB to 30 KB. World matrices are staged behind the palette region, so the product needs no
+// in-place rounds. The palette rows a vertex gathers hold the same bits wherever they sit in LDS: outputs do not change.
+// (Tried and measured slower or without effect, then removed again — NOTEBOOK.md R3.1 / R3.4 / R3.9: forcing three workgroups per CU
+// (80 VGPRs spill), a branch-free pose loop with clamped tail lanes, four poses unrolled, raised wave priority around the stores.)
+template <int BLOCK, bool NTS, bool SUB>
+__global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const uint32_t *k_sub_count, const uint16_t *k_sub_list, const float4 *k_src,
+                                                                  const float *k_inv_bind, const int G, const int n_inst, const uint32_t verts_per_wg,
+                                                                  const uint32_t k_grid, const uint32_t k_bf, const uint32_t k_Vp, const RzDeformParams p)
+{
+    // The leading arguments are preloaded into SGPRs at wave start (14 dwords; see rz_deform_kernel): what the FRONT of a workgroup
+    // needs — the run's bone list, the matrices it stages (k_src = the poses' world matrices, or their finished palettes behind
+    // rz_prep_kernel / rz_fk_kernel), the inverse bind matrices, the launch shape (k_grid = gridDim.x | gridDim.y << 16: the hidden
+    // arguments would be one more scalar load) and k_bf = bone count | inst_order << 16 | dma << 17.
+    const int kB = (int)(k_bf & 0xffffu);
+    const bool k_order = (k_bf >> 16) & 1u, k_dma = (k_bf >> 17) & 1u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *pal = reinterpret_cast<float4 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    RZ_TL_DECL;
+    RZ_STAMP(0);                 // entry
+    // Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest). inst_order 0: x = vertex run — an XCD sees every
+    // pose group and one eighth of the mesh; 1: consecutive workgroups take consecutive pose groups — an XCD sees one eighth of
+    // the poses' matrices and the whole mesh.
+    const uint32_t n_groups = k_grid >> 16, lin = blockIdx.x + (k_grid & 0xffffu) * blockIdx.y;
+    const uint32_t wg_group = k_order ? lin % n_groups : blockIdx.y, wg_run = k_order ? lin / n_groups : blockIdx.x;
+    const int inst0 = (int)wg_group * G;
+    const int ng = min(G, n_inst - inst0);
+    const int rows = kB * 3;                       // float4 per palette, in global memory and (finished) in LDS
+    constexpr int rstride = 3;                      // float4 per bone of a finished palette
+    // SUB: this run's bone list (workgroup-uniform: scalar loads)
+    const int ns = SUB ? (int)k_sub_count[wg_run] : 0;
+    const uint16_t *sub = SUB ? k_sub_list + (size_t)wg_run * kB : nullptr;      // (the lists' stride is the bone count)
+    const int lrows = SUB ? ns * 3 : rows;          // float4 per pose of the finished LDS palettes
+    float4 *stage = pal + (size_t)G * ns * 3;       // SUB, one-launch frame: staged world matrices sit behind the palette region
+    if constexpr (SUB) {
+        // prep-kernel / device-FK path (dma): the listed bones' finished rows, 3 float4 per bone, straight to their place.
+        // one-launch frame: the listed bones' world matrices, 4 float4 per bone, into the staging region.
+        // Either way element e of the linear LDS image is (pose g, slot s, cell k): a per-lane global address, a linear LDS one.
+        const int epb = k_dma ? 3 : 4;
+        const int n = RZ_DBG(p) == 8 ? 0 : ng * ns * epb;           // dbg 8 (tools-only build): neither staging nor product
+        const float4 *src = k_src + (size_t)inst0 * kB * (k_dma ? 3 : 4);
+        float4 *dst = k_dma ? pal : stage;
+        for (int c = wave * 64; c < n; c += BLOCK) {
+            const int e = c + lane;
+            if (e < n) {
+                const int gs = k_dma ? e / 3 : e >> 2, k = e - gs * epb;
+                const int g = gs / ns, sl = gs - g * ns;
+                const float4 *a = src + ((size_t)g * kB + sub[sl]) * epb + k;
+                typedef const __attribute__((address_space(1))) void *gptr_t;
+                typedef __attribute__((address_space(3))) void *lptr_t;
+                __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)a, (lptr_t)(uint32_t)(uintptr_t)(dst + c), 16, 0, 0);
+            }
+        }
+    } else {
+        // prep-kernel path (dma): the group's finished palettes are contiguous in global memory -> one linear LDS-DMA copy.
+        // one-launch frame (!dma): the group's WORLD matrices are staged instead, whole (64-byte slots, the same linear
+        // 16-byte LDS-DMA); the conversion pass below multiplies by the inverse bind matrix and re-packs the rows to the
+        // same 48-byte stride. (Leaving them in the 64-byte slots made every fourth bone share its LDS banks: 52 % of the
+        // skin loop's LDS cycles were bank conflicts, against 11 % at 48 bytes — profiles/r2_sq_counters_c4.txt.)
+        const float4 *src = k_src + (size_t)inst0 * kB * (k_dma ? 3 : 4);
+        const int n = (RZ_DBG(p) == 6 || RZ_DBG(p) == 7 || RZ_DBG(p) == 8) ? 0 : (k_dma ? ng * rows : ng * kB * 4);   // dbg 6 / 7 (tools-only build): no palette staging
+        for (int c = wave * 64; c < n; c += BLOCK) {
+            const int e = c + lane;
+            if (e < n) {
+                typedef const __attribute__((address_space(1))) void *gptr_t;
+                typedef __attribute__((address_space(3))) void *lptr_t;
+                __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(src + e), (lptr_t)(uint32_t)(uintptr_t)(pal + c), 16, 0, 0);
+            }
+        }
+    }
+    // One-launch frame (the host only plans it for B <= BLOCK): which (bone, pose stripe) this thread converts. With
+    // B <= BLOCK / 2 the spare threads take a second, third ... stripe of the group's poses (stripe s converts poses s,
+    // s + stripes, ...): 200 bones on 512 threads = 2 stripes.
+    // SUB: the same mapping over the run's ns listed bones (the host plans the form only for ns <= BLOCK).
+    const int cvB = SUB ? max(ns, 1) : kB;
+    const int stripes = !k_dma ? max(1, min(ng, BLOCK / cvB)) : 1;
+    const int cv_b0 = tid % cvB;
+    const int cv_g0 = tid / cvB;
+    const bool cv_on = !k_dma && cv_g0 < stripes && (!SUB || ns > 0);
+    float4 ib0 = {0, 0, 0, 0}, ib1 = ib0, ib2 = ib0, ib3 = ib0;
+    if (cv_on) {                                    // requested first: lands while the staging copy is in flight
+        const float4 *gi = reinterpret_cast<const float4 *>(k_inv_bind) + (SUB ? (int)sub[cv_b0] : cv_b0) * 4;
+        ib0 = gi[0]; ib1 = gi[1]; ib2 = gi[2]; ib3 = gi[3];
+    }
+    const size_t Vp = k_Vp;
+    const uint32_t v_begin = wg_run * verts_per_wg;
+    const uint32_t v_end = min(p.n_quads * 4u, v_begin + verts_per_wg);
+    const uint32_t bmax = (uint32_t)(p.B - 1);
+    // software-pipelined vertex loop: the next vertex's nine attribute loads are issued before the current
+    // vertex's pose loop, so their L2 latency hides behind the poses' LDS gathers + FMA
+    // (Round 4 tried two ways of sharing the run's last, partial step (a 3 750-vertex run is 7 steps of 512 and one of 166) among
+    // all waves — its vertices dealt out in quarter-wave pieces: 33.5 -> 36.3 us; its poses split between the waves that hold the
+    // same piece: 33.0 -> 33.7 us. The waves of a workgroup end up to 5.7 us apart (profiles/r4_timeline_c4.txt), but not because
+    // of that step: NOTEBOOK.md R4.5. Both removed.)
+    auto vert_of = [&](const uint32_t vb) { return vb + (uint32_t)tid; };
+    uint32_t v = vert_of(v_begin);
+    float x = 0, y = 0, z = 0, nx = 0, ny = 0, nz = 0;
+    uint32_t j01 = 0, j23 = 0, wq = 0;
+    const uint32_t *jp01 = SUB ? p.rj01 : p.joints01, *jp23 = SUB ? p.rj23 : p.joints23;     // SUB: joints as slots of the run's list
+    if (v < v_end) {
+        x = p.geom[0 * Vp + v]; y = p.geom[1 * Vp + v]; z = p.geom[2 * Vp + v];
+        nx = p.geom[3 * Vp + v]; ny = p.geom[4 * Vp + v]; nz = p.geom[5 * Vp + v];
+        j01 = jp01[v]; j23 = jp23[v]; wq = p.weights[v];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // palettes / world matrices (and the first vertex) have landed
+    RZ_STAMP(1);                 // staged matrices have landed
+    __syncthreads();
+    if constexpr (SUB) {
+        if (!p.dma && RZ_DBG(p) != 8) {
+            // palette rows of the listed bones: slot (g, s) = rows 0..2 of world * inverseBind (engine.ts:926-928), the same
+            // packed FMA chain as below and as rz_prep_kernel — out of the staging region, into the palette region: no hazard,
+            // one barrier. With ns ~ 34 and 512 threads every (pose, bone) pair has a thread of its own.
+            const f2 px01 = {ib0.x, ib1.x}, px23 = {ib2.x, ib3.x}, py01 = {ib0.y, ib1.y}, py23 = {ib2.y, ib3.y};
+            const f2 pz01 = {ib0.z, ib1.z}, pz23 = {ib2.z, ib3.z}, pw01 = {ib0.w, ib1.w}, pw23 = {ib2.w, ib3.w};
+            auto row = [&](float e0, float e1, float e2, float e3, const f2 &bx, const f2 &by, const f2 &bz, const f2 &bw) {
+                return pk_fma(f2{e3, e3}, bw, pk_fma(f2{e2, e2}, bz, pk_fma(f2{e1, e1}, by, f2{e0, e0} * bx)));
+            };
+            if (cv_on)
+                for (int g = cv_g0; g < ng; g += stripes) {
+                    const float4 *slot = stage + ((size_t)g * ns + cv_b0) * 4;
+                    const float4 a0 = slot[0], a1 = slot[1], a2 = slot[2], a3 = slot[3];      // the world matrix's columns
+                    const f2 r0 = row(a0.x, a1.x, a2.x, a3.x, px01, py01, pz01, pw01), r1 = row(a0.x, a1.x, a2.x, a3.x, px23, py23, pz23, pw23);
+                    const f2 r2 = row(a0.y, a1.y, a2.y, a3.y, px01, py01, pz01, pw01), r3 = row(a0.y, a1.y, a2.y, a3.y, px23, py23, pz23, pw23);
+                    const f2 r4 = row(a0.z, a1.z, a2.z, a3.z, px01, py01, pz01, pw01), r5 = row(a0.z, a1.z, a2.z, a3.z, px23, py23, pz23, pw23);
+                    float4 *dst = pal + ((size_t)g * ns + cv_b0) * 3;
+                    dst[0] = make_float4(r0.x, r0.y, r1.x, r1.y);
+                    dst[1] = make_float4(r2.x, r2.y, r3.x, r3.y);
+                    dst[2] = make_float4(r4.x, r4.y, r5.x, r5.y);
+                }
+            __syncthreads();
+            // (the skinMatrixBuffer is not written here: a workgroup only holds its run's bones. rz_read_palette forms it on
+            // demand with rz_prep_kernel — the same chain, the same bits.)
+        }
+    } else
+    if (!p.dma && RZ_DBG(p) != 8) {                  // dbg 8 (tools-only build): neither staging nor conversion
+        // in-place conversion: slot (g, b) = rows 0..2 of world * inverseBind (engine.ts:926-928). Packed math: the
+        // inverse bind matrix is held as column PAIRS (c0,c1),(c2,c3) per k, so each result row is two v_pk_fma
+        // chains (the same chain as rz_prep_kernel: ((a0*b0 + a1*b1) + a2*b2) + a3*b3); the next pose's cells are read
+        // before the current product is formed.
+        // Rounds of up to four poses per thread: read the staged world matrices (64-byte slots) and form the palette rows
+        // in registers (engine.ts:926-928, packed math, the same FMA chain as rz_prep_kernel: ((a0*b0 + a1*b1) + a2*b2) +
+        // a3*b3) -> barrier -> write them back at the 48-byte stride. Poses ascend, and the compact rows of pose g only
+        // ever land on staged matrices of poses <= g, which every thread has read by then.
+        const f2 px01 = {ib0.x, ib1.x}, px23 = {ib2.x, ib3.x}, py01 = {ib0.y, ib1.y}, py23 = {ib2.y, ib3.y};
+        const f2 pz01 = {ib0.z, ib1.z}, pz23 = {ib2.z, ib3.z}, pw01 = {ib0.w, ib1.w}, pw23 = {ib2.w, ib3.w};
+        auto row = [&](float e0, float e1, float e2, float e3, const f2 &bx, const f2 &by, const f2 &bz, const f2 &bw) {
+            return pk_fma(f2{e3, e3}, bw, pk_fma(f2{e2, e2}, bz, pk_fma(f2{e1, e1}, by, f2{e0, e0} * bx)));
+        };
+        constexpr int PR = 4;                               // poses per thread per round
+        for (int g_base = 0; g_base < ng; g_base += PR * stripes) {       // workgroup-uniform trip count
+            f2 res[PR][6];
+#pragma unroll
+            for (int i = 0; i < PR; ++i) {
+                const int g = g_base + cv_g0 + i * stripes;
+                if (cv_on && g < ng) {
+                    const float4 *slot = pal + ((size_t)g * p.B + cv_b0) * 4;
+                    const float4 a0 = slot[0], a1 = slot[1], a2 = slot[2], a3 = slot[3];      // the world matrix's columns
+                    res[i][0] = row(a0.x, a1.x, a2.x, a3.x, px01, py01, pz01, pw01); res[i][1] = row(a0.x, a1.x, a2.x, a3.x, px23, py23, pz23, pw23);
+                    res[i][2] = row(a0.y, a1.y, a2.y, a3.y, px01, py01, pz01, pw01); res[i][3] = row(a0.y, a1.y, a2.y, a3.y, px23, py23, pz23, pw23);
+                    res[i][4] = row(a0.z, a1.z, a2.z, a3.z, px01, py01, pz01, pw01); res[i][5] = row(a0.z, a1.z, a2.z, a3.z, px23, py23, pz23, pw23);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < PR; ++i) {
+                const int g = g_base + cv_g0 + i * stripes;
+                if (cv_on && g < ng) {
+                    float4 *dst = pal + ((size_t)g * p.B + cv_b0) * 3;
+                    dst[0] = make_float4(res[i][0].x, res[i][0].y, res[i][1].x, res[i][1].y);
+                    dst[1] = make_float4(res[i][2].x, res[i][2].y, res[i][3].x, res[i][3].y);
+                    dst[2] = make_float4(res[i][4].x, res[i][4].y, res[i][5].x, res[i][5].y);
+                }
+            }
+        }
+        __syncthreads();
+        if (p.palette) {
+            // keep the skinMatrixBuffer observable (rz_read_palette): the vertex runs of a pose group each copy one
+            // slice of the finished palettes out of LDS, coalesced
+            const int n = ng * rows, per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+            const int lo = (int)wg_run * per, hi = min(n, lo + per);
+            float4 *gp = p.palette + (size_t)inst0 * rows;
+            for (int i = lo + tid; i < hi; i += BLOCK) gp[i] = pal[i];
+        }
+    }
+    RZ_STAMP(2);                 // palettes formed and published: the front is over
+    for (uint32_t vb = v_begin; vb < v_end; vb += BLOCK) {   // workgroup-uniform trip count (the ballots below need whole waves)
+        if (vb == v_begin + BLOCK) RZ_STAMP(3);      // first vertex step done (8 poses written)
+        const uint32_t vn = vert_of(vb + BLOCK);
+        float xn = 0, yn = 0, zn = 0, nxn = 0, nyn = 0, nzn = 0;
+        uint32_t j01n = 0, j23n = 0, wqn = 0;
+        if (vn < v_end) {
+            xn = p.geom[0 * Vp + vn]; yn = p.geom[1 * Vp + vn]; zn = p.geom[2 * Vp + vn];
+            nxn = p.geom[3 * Vp + vn]; nyn = p.geom[4 * Vp + vn]; nzn = p.geom[5 * Vp + vn];
+            j01n = jp01[vn]; j23n = jp23[vn]; wqn = p.weights[vn];
+        }
+        const bool live = v < v_end;
+        // decode once per vertex (engine.ts:255-258)
+        const uint32_t b0 = wq & 255u, b1 = (wq >> 8) & 255u, b2 = (wq >> 16) & 255u, b3 = wq >> 24;
+        const uint32_t isum = b0 + b1 + b2 + b3;
+        const bool ok = isum != 0u;
+        const float inv = __builtin_amdgcn_rcpf((float)(ok ? isum : 1u));
+        const float w0 = ok ? (float)b0 * inv : 1.0f, w1 = (float)b1 * inv, w2 = (float)b2 * inv, w3 = (float)b3 * inv;
+        const uint32_t jmax = SUB ? 0xffffu : bmax;     // SUB: slots are in range by construction
+        const uint32_t o0 = min(j01 & 0xffffu, jmax) * rstride, o1 = min(j01 >> 16, jmax) * rstride,
+                       o2 = min(j23 & 0xffffu, jmax) * rstride, o3 = min(j23 >> 16, jmax) * rstride;
+        float *dp = p.out_pos + ((size_t)inst0 * Vp + v) * 3;
+        float *dn = p.out_nrm + ((size_t)inst0 * Vp + v) * 3;
+        // Packed-math form (v_pk_fma_f32 = two f32 FMAs per lane per instruction): palette rows are blended as
+        // (xy),(zw) register pairs straight out of ds_read_b128, and position + normal are transformed together
+        // as the pairs (x,nx),(y,ny),(z,nz), so one FMA chain yields (p_r, n_r) for row r. Every chain is spelled out
+        // with explicit FMAs in the order of skin_vertex() above — bones ascending from w0 * row, then
+        // fma(m.z, z, fma(m.y, y, fma(m.x, x, m.w))) — so a pose of a crowd has the SAME BITS as that pose run alone
+        // through rz_deform_kernel (tests/test_gpu_round2.py checks it at full C4 size).
+        const f2 vx = {x, nx}, vy = {y, ny}, vz = {z, nz};
+        const f2 W0 = {w0, w0}, W1 = {w1, w1}, W2 = {w2, w2}, W3 = {w3, w3};
+#ifdef RZ_ABLATE
+        if (p.dbg == 2 || p.dbg == 7) {          // dbg 2 / 7: ablation — the output stream without gathers / math
+            if (live)
+                for (int g = 0; g < ng; ++g) {
+                    st3<NTS>(dp, x, y, z); st3<NTS>(dn, nx, ny, nz);
+                    dp += Vp * 3; dn += Vp * 3;
+                }
+            x = xn; y = yn; z = zn; nx = nxn; ny = nyn; nz = nzn; j01 = j01n; j23 = j23n; wq = wqn;
+            v = vn;
+            continue;
+        }
+#endif
+        auto pose_loop = [&](auto nb_tag) {
+            constexpr int NB = decltype(nb_tag)::value;
+            const float4 *pg = pal;
+#pragma unroll 2
+            for (int g = 0; g < ng; ++g) {
+                f2 r[3][2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float4 a = pg[o0 + k];
+                    r[k][0] = W0 * f2{a.x, a.y};
+                    r[k][1] = W0 * f2{a.z, a.w};
+                    if (NB >= 2) {
+                        const float4 c = pg[o1 + k];
+                        r[k][0] = pk_fma(W1, f2{c.x, c.y}, r[k][0]);
+                        r[k][1] = pk_fma(W1, f2{c.z, c.w}, r[k][1]);
+                    }
+                    if (NB >= 4) {
+                        const float4 d = pg[o2 + k], e = pg[o3 + k];
+                        r[k][0] = pk_fma(W3, f2{e.x, e.y}, pk_fma(W2, f2{d.x, d.y}, r[k][0]));
+                        r[k][1] = pk_fma(W3, f2{e.z, e.w}, pk_fma(W2, f2{d.z, d.w}, r[k][1]));
+                    }
+                }
+                // (p_r, t_r) = fma(m_r.z, (z,nz), fma(m_r.y, (y,ny), fma(m_r.x, (x,nx), (m_r.w, 0))))
+                f2 q[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const f2 m_xy = r[k][0], m_zw = r[k][1];
+                    q[k] = pk_fma(f2{m_zw.x, m_zw.x}, vz, pk_fma(f2{m_xy.y, m_xy.y}, vy, pk_fma(f2{m_xy.x, m_xy.x}, vx, f2{m_zw.y, 0.0f})));
+                }
+                const float tx = q[0].y, ty = q[1].y, tz = q[2].y;
+                const float l2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+                const bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
+                const float rl = __builtin_amdgcn_rsqf(good ? l2 : 1.0f);
+                if (live && (RZ_DBG(p) != 1 || l2 == 1234.5f)) {   // dbg 1 (tools-only build): compute without the output stream
+                    st3<NTS>(dp, q[0].x, q[1].x, q[2].x);
+                    st3<NTS>(dn, good ? tx * rl : nx, good ? ty * rl : ny, good ? tz * rl : nz);
+                }
+                pg += lrows;
+                dp += Vp * 3;
+                dn += Vp * 3;
+            }
+        };
+        const bool any34 = __ballot((wq >> 16) != 0u) != 0ull;
+        const bool any2 = __ballot(((wq >> 8) & 255u) != 0u) != 0ull;
+        if (__ballot(live) == 0ull) {}                     // a wave past the end of the run (last step only)
+        else if (any34) pose_loop(std::integral_constant<int, 4>{});
+        else if (any2) pose_loop(std::integral_constant<int, 2>{});
+        else pose_loop(std::integral_constant<int, 1>{});
+        x = xn; y = yn; z = zn; nx = nxn; ny = nyn; nz = nzn; j01 = j01n; j23 = j23n; wq = wqn;
+        v = vn;
+    }
+    RZ_STAMP(5);                 // last vertex step issued
+    RZ_TL_FLUSH(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (BLOCK / 64) + wave);
+}
+
+#ifdef RZ_ALL_VARIANTS
+// ------------------------------------------------------------------------------------------------
+// instanced skin, register-resident form: a workgroup owns a run of KV*256 vertices and a RANGE of poses.
+// Each lane loads and decodes its KV vertices ONCE into registers (the static mesh is read once per
+// (run, pose range) instead of once per pose), then walks the poses: the palette of pose g+1 streams into
+// the other half of a 2-deep LDS ring by LDS-DMA while pose g is skinned, and every pose is written as one
+// contiguous KV*256*12-byte block per output array. LDS is only 2 palettes (19 KB at 200 bones).
+// grid = (vertex runs, pose ranges); block = 256.
+// ------------------------------------------------------------------------------------------------
+template <int KV, bool NTS>
+__global__ void __launch_bounds__(kBlock) rz_skin_instances_reg_kernel(const RzDeformParams p, int n_inst, int poses_per_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *ring = reinterpret_cast<float4 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows = p.B * 3;
+    const int inst0 = blockIdx.y * poses_per_wg;
+    const int ng = min(poses_per_wg, n_inst - inst0);
+    const size_t Vp = p.Vp;
+    const uint32_t v_lim = p.n_quads * 4u;
+    const uint32_t v0 = blockIdx.x * (KV * kBlock) + tid;
+    const uint32_t bmax = (uint32_t)(p.B - 1);
+
+    auto dma_palette = [&](int g) {
+        const float4 *src = p.palette + (size_t)(inst0 + g) * rows;
+        float4 *dst = ring + (size_t)(g & 1) * rows;
+        for (int c = wave * 64; c < rows; c += kBlock) {
+            const int e = c + lane;
+            if (e < rows) {
+                typedef const __attribute__((address_space(1))) void *gptr_t;
+                typedef __attribute__((address_space(3))) void *lptr_t;
+                __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(src + e), (lptr_t)(uint32_t)(uintptr_t)(dst + c), 16, 0, 0);
+            }
+        }
+    };
+    dma_palette(0);
+
+    // ---- decode KV vertices per lane, once ----
+    f2 vx[KV], vy[KV], vz[KV];
+    float w0[KV], w1[KV], w2[KV], w3[KV];
+    uint32_t j01[KV], j23[KV];
+    {
+        float x[KV], y[KV], z[KV], nx[KV], ny[KV], nz[KV];
+        uint32_t wq[KV];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const uint32_t v = v0 + k * kBlock;
+            const bool live = v < v_lim;
+            const size_t vs = live ? v : 0;
+            x[k] = p.geom[0 * Vp + vs]; y[k] = p.geom[1 * Vp + vs]; z[k] = p.geom[2 * Vp + vs];
+            nx[k] = p.geom[3 * Vp + vs]; ny[k] = p.geom[4 * Vp + vs]; nz[k] = p.geom[5 * Vp + vs];
+            j01[k] = p.joints01[vs]; j23[k] = p.joints23[vs]; wq[k] = p.weights[vs];
+        }
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const uint32_t b0 = wq[k] & 255u, b1 = (wq[k] >> 8) & 255u, b2 = (wq[k] >> 16) & 255u, b3 = wq[k] >> 24;
+            const uint32_t isum = b0 + b1 + b2 + b3;
+            const bool ok = isum != 0u;
+            const float inv = __builtin_amdgcn_rcpf((float)(ok ? isum : 1u));
+            w0[k] = ok ? (float)b0 * inv : 1.0f; w1[k] = (float)b1 * inv; w2[k] = (float)b2 * inv; w3[k] = (float)b3 * inv;
+            // joints -> clamped palette row offsets, two 16-bit fields per register (B*3 <= 65535 is checked on the host)
+            const uint32_t o0 = min(j01[k] & 0xffffu, bmax) * 3u, o1 = min(j01[k] >> 16, bmax) * 3u;
+            const uint32_t o2 = min(j23[k] & 0xffffu, bmax) * 3u, o3 = min(j23[k] >> 16, bmax) * 3u;
+            j01[k] = o0 | (o1 << 16); j23[k] = o2 | (o3 << 16);
+            vx[k] = f2{x[k], nx[k]}; vy[k] = f2{y[k], ny[k]}; vz[k] = f2{z[k], nz[k]};
+        }
+    }
+    const f2 vw = {1.0f, 0.0f};
+
+    for (int g = 0; g < ng; ++g) {
+        // pose g's palette has landed (own DMA drained, barrier publishes everyone's part and also retires
+        // every wave's reads of the other ring slot, which pose g+1 may now overwrite)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (g + 1 < ng) dma_palette(g + 1);
+        const float4 *pg = ring + (size_t)(g & 1) * rows;
+        float *op = p.out_pos + (size_t)(inst0 + g) * Vp * 3;
+        float *on = p.out_nrm + (size_t)(inst0 + g) * Vp * 3;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const uint32_t v = v0 + k * kBlock;
+            const uint32_t o0 = j01[k] & 0xffffu, o1 = j01[k] >> 16, o2 = j23[k] & 0xffffu, o3 = j23[k] >> 16;
+            f2 r[3][2];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float4 a = pg[o0 + q], c = pg[o1 + q], d = pg[o2 + q], e = pg[o3 + q];
+                const f2 axy = {a.x, a.y}, azw = {a.z, a.w}, cxy = {c.x, c.y}, czw = {c.z, c.w};
+                const f2 dxy = {d.x, d.y}, dzw = {d.z, d.w}, exy = {e.x, e.y}, ezw = {e.z, e.w};
+                r[q][0] = w3[k] * exy + (w2[k] * dxy + (w1[k] * cxy + w0[k] * axy));
+                r[q][1] = w3[k] * ezw + (w2[k] * dzw + (w1[k] * czw + w0[k] * azw));
+            }
+            const f2 q0 = r[0][0].x * vx[k] + (r[0][0].y * vy[k] + (r[0][1].x * vz[k] + r[0][1].y * vw));
+            const f2 q1 = r[1][0].x * vx[k] + (r[1][0].y * vy[k] + (r[1][1].x * vz[k] + r[1][1].y * vw));
+            const f2 q2 = r[2][0].x * vx[k] + (r[2][0].y * vy[k] + (r[2][1].x * vz[k] + r[2][1].y * vw));
+            const float tx = q0.y, ty = q1.y, tz = q2.y;
+            const float l2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+            const bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
+            const float rl = __builtin_amdgcn_rsqf(good ? l2 : 1.0f);
+            if (v < v_lim) {
+                st3<NTS>(op + (size_t)v * 3, q0.x, q1.x, q2.x);
+                st3<NTS>(on + (size_t)v * 3, good ? tx * rl : vx[k].y, good ? ty * rl : vy[k].y, good ? tz * rl : vz[k].y);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one vertex at a time: bounds the live palette rows (12 x float4)
+        }
+    }
+}
+#endif  // RZ_ALL_VARIANTS
+
+// zero-weight influence still gathers its bone's rows, so it stays the SAME bone: fma(0, row, m) keeps m's bits only while the
+// row is the one the full-palette form would have read), ranks them ascending, writes the list and the joints as slots of it.
+__global__ void __launch_bounds__(kBlock) rz_run_subsets_kernel(const uint32_t *j01, const uint32_t *j23, uint32_t v_lim, uint32_t per,
+                                                                uint32_t B, uint16_t *list, uint32_t *count, uint32_t *rj01, uint32_t *rj23)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t nw = (B + 31) / 32;
+    uint32_t *bits = reinterpret_cast<uint32_t *>(smem);            // [nw] bone bitmap
+    uint32_t *before = bits + nw;                                    // [nw + 1] listed bones in front of each word
+    uint16_t *slot = reinterpret_cast<uint16_t *>(before + nw + 1);  // [B]
+    const uint32_t tid = threadIdx.x, run = blockIdx.x;
+    const uint32_t v0 = run * per, v1 = min(v_lim, v0 + per), bmax = B - 1;
+    for (uint32_t i = tid; i < nw; i += kBlock) bits[i] = 0;
+    __syncthreads();
+    for (uint32_t v = v0 + tid; v < v1; v += kBlock) {
+        const uint32_t a = j01[v], b = j23[v];
+        const uint32_t j[4] = { min(a & 0xffffu, bmax), min(a >> 16, bmax), min(b & 0xffffu, bmax), min(b >> 16, bmax) };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicOr(&bits[j[k] >> 5], 1u << (j[k] & 31u));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < nw; ++i) { before[i] = acc; acc += __popc(bits[i]); }
+        before[nw] = acc;
+        count[run] = acc;
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < B; b += kBlock) {
+        const uint32_t w = bits[b >> 5], m = 1u << (b & 31u);
+        if (w & m) {
+            const uint32_t sl = before[b >> 5] + __popc(w & (m - 1u));
+            slot[b] = (uint16_t)sl;
+            list[(size_t)run * B + sl] = (uint16_t)b;
+        }
+    }
+    __syncthreads();
+    for (uint32_t v = v0 + tid; v < v1; v += kBlock) {
+        const uint32_t a = j01[v], b = j23[v];
+        rj01[v] = (uint32_t)slot[min(a & 0xffffu, bmax)] | ((uint32_t)slot[min(a >> 16, bmax)] << 16);
+        rj23[v] = (uint32_t)slot[min(b & 0xffffu, bmax)] | ((uint32_t)slot[min(b >> 16, bmax)] << 16);
+    }
+}
+
+}  // namespace
+
+size_t rz_skin_instances_lds_bytes(int G, uint32_t bones, bool dma, bool subsets)
+{
+    // finished palettes are 48 B per (pose, bone). One-launch frame: the whole-palette form stages the world matrices in
+    // the palette region's place (64-byte slots, re-packed in place); the subset form stages them behind it (48 + 64).
+    const size_t per = dma ? 48 : (subsets ? 112 : 64);
+    return (size_t)G * bones * per;
+}
+
+template <int BLOCK>
+static hipError_t launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
+                                        bool nts, size_t lds, hipStream_t st)
+{
+    const bool sub = p.sub_list != nullptr;
+    auto k = sub ? (nts ? rz_skin_instances_kernel<BLOCK, true, true> : rz_skin_instances_kernel<BLOCK, false, true>)
+                 : (nts ? rz_skin_instances_kernel<BLOCK, true, false> : rz_skin_instances_kernel<BLOCK, false, false>);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid(grid_x, (n_inst + G - 1) / G);
+    if (grid.x > 0xffffu || grid.y > 0xffffu || p.B > 0xffff || (sub && p.sub_stride != p.B)) return hipErrorInvalidValue;      // (k_grid packs both; the lists' stride is the bone count)
+    // leading arguments = what the front of a workgroup needs, preloaded into SGPRs (see the kernel)
+    const float4 *k_src = p.dma ? p.palette : reinterpret_cast<const float4 *>(p.world);
+    const uint32_t k_grid = grid.x | (grid.y << 16), k_bf = (uint32_t)p.B | (p.inst_order ? 1u << 16 : 0u) | (p.dma ? 1u << 17 : 0u);
+    hipLaunchKernelGGL(k, grid, dim3(BLOCK), lds, st, p.sub_count, p.sub_list, k_src, p.inv_bind, G, n_inst, verts_per_wg, k_grid, k_bf, p.Vp, p);
+    return hipGetLastError();
+}
+
+hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
+                                    int block, bool nts, size_t lds_bytes, hipStream_t st)
+{
+    if (block == 1024) return launch_skin_instances<1024>(p, G, n_inst, verts_per_wg, grid_x, nts, lds_bytes, st);
+    if (block == 512) return launch_skin_instances<512>(p, G, n_inst, verts_per_wg, grid_x, nts, lds_bytes, st);
+    return launch_skin_instances<256>(p, G, n_inst, verts_per_wg, grid_x, nts, lds_bytes, st);
+}
+
+hipError_t rz_launch_run_subsets(const uint32_t *j01, const uint32_t *j23, uint32_t v_lim, uint32_t per, uint32_t runs, uint32_t B,
+                                 uint16_t *list, uint32_t *count, uint32_t *rj01, uint32_t *rj23, hipStream_t st)
+{
+    if (runs == 0) return hipSuccess;
+    const uint32_t nw = (B + 31) / 32;
+    const size_t lds = (size_t)(2 * nw + 1) * 4 + (size_t)B * 2;
+    hipLaunchKernelGGL(rz_run_subsets_kernel, dim3(runs), dim3(kBlock), lds, st, j01, j23, v_lim, per, B, list, count, rj01, rj23);
+    return hipGetLastError();
+}
+
+hipError_t rz_launch_skin_instances_reg(const RzDeformParams &p, int n_inst, int poses_per_wg, uint32_t grid_x, bool nts,
+                                        hipStream_t st)
+{
+#ifdef RZ_ALL_VARIANTS
+    constexpr int KV = 8;
+    const size_t lds = (size_t)2 * p.B * 48;
+    auto k = nts ? rz_skin_instances_reg_kernel<KV, true> : rz_skin_instances_reg_kernel<KV, false>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid(grid_x, (n_inst + poses_per_wg - 1) / poses_per_wg);
+    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p, n_inst, poses_per_wg);
+    return hipGetLastError();
+#else
+    (void)p; (void)n_inst; (void)poses_per_wg; (void)grid_x; (void)nts; (void)st;
+    return hipErrorInvalidValue;       // the register-resident crowd kernel (measured slower, inst_loop = 9) is a tools-only variant
+#endif
+}
