@@ -544,13 +544,19 @@ class DeformContext:
         if g("effective_poses_per_wg") > 0:
             return "rz_skin_instances_reg_kernel<8, %s>" % tf("effective_nt_store")
         if g("effective_inst_group") > 0:
+            try:
+                fused = g("effective_closure_bones") > 0        # the hierarchy solved in the crowd kernel's front (ABI 5)
+            except RzError:
+                fused = False
+            if fused:
+                return "rz_skin_instances_fk_kernel<%d, %s>" % (g("effective_inst_block"), tf("effective_nt_store"))
             return "rz_skin_instances_kernel<%d, %s, %s>" % (g("effective_inst_block"), tf("effective_nt_store"), tf("effective_subsets"))
         mode = g("morph_mode")
-        s_, u = g("effective_split"), (g("effective_unroll") if mode == 1 else 1)
-        if mode != 1:
-            s_ = 4 if s_ >= 4 else 1
-        return "rz_deform_kernel<%d, %d, %d, %s, %s, %s, %s>" % (s_, 8 if (mode == 1 and u >= 8) else (4 if mode == 1 else 1), mode,
-                                                                 tf("effective_nt"), tf("effective_nt_store"), tf("effective_geo"), tf("effective_fast"))
+        s_ = g("effective_split")
+        if mode == 1:
+            return "rz_deform_dense_kernel<%d, %d, %s, %s, %s, %s>" % (s_, 8 if g("effective_unroll") >= 8 else 4, tf("effective_nt"), tf("effective_nt_store"),
+                                                                       tf("effective_geo"), tf("effective_fast"))
+        return "rz_deform_small_kernel<%d, %d, %s, %s, %s>" % (4 if s_ >= 4 else 1, mode, tf("effective_nt_store"), tf("effective_geo"), tf("effective_fast"))
 
     def time_frames(self, frames):
         t = RzTiming()

@@ -163,7 +163,8 @@ int ensure_pose_buffers(rz_ctx *c)
 void free_animation(rz_ctx *c)
 {
     drop_graph(c);
-    dfree(c->an_bone_range); dfree(c->an_feed_range); dfree(c->an_feed_off);
+    dfree(c->an_feed_range); dfree(c->an_feed_off);
+    c->an_host_range.clear(); c->an_host_mrec.clear();
     dfree(c->an_key_frame); dfree(c->an_key_pos); dfree(c->an_mkey_frame); dfree(c->an_mkey_weight); dfree(c->an_feed_ratio);
     dfree(c->an_key_rot); dfree(c->an_key_interp);
     c->has_animation = false;
@@ -265,8 +266,8 @@ int rz_destroy(rz_ctx *c)
     if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
     if (c->lender) {                      // a fork frees nothing it borrowed
         c->geom = nullptr; c->j01 = c->j23 = c->wq = nullptr; c->inv_bind = nullptr;
-        c->fk_rec = nullptr;
-        c->an_bone_range = c->an_feed_range = nullptr; c->an_feed_off = nullptr;
+        c->fk_rec = nullptr; c->fk_anc_more = nullptr;
+        c->an_feed_range = nullptr; c->an_feed_off = nullptr;
         c->an_key_frame = c->an_key_pos = c->an_mkey_frame = c->an_mkey_weight = c->an_feed_ratio = nullptr; c->an_key_rot = nullptr; c->an_key_interp = nullptr;
         c->bm_off = c->bm_morph = nullptr; c->bm_rot = c->bm_tr = nullptr;
         c->dense = nullptr; c->sp_ptr = nullptr; c->sp_entries = nullptr; c->edge = nullptr;
@@ -279,7 +280,8 @@ int rz_destroy(rz_ctx *c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     dfree(c->geom); dfree(c->j01); dfree(c->j23); dfree(c->wq); dfree(c->inv_bind);
     dfree(c->rj01); dfree(c->rj23); dfree(c->sub_list); dfree(c->sub_count); dfree(c->zc_tag);
-    dfree(c->fk_rec);
+    dfree(c->subfk_rec); dfree(c->subfk_count);
+    dfree(c->fk_rec); dfree(c->fk_anc_more);
     free_animation(c); dfree(c->an_frames);
     dfree(c->pose_blk[0]); dfree(c->pose_blk[1]);
     dfree(c->ovr_off); dfree(c->ovr_bone); dfree(c->ovr_world);
@@ -331,8 +333,8 @@ int rz_fork(rz_ctx *parent, rz_ctx **out)
     if (int r = rz_create(parent->device, &c)) return r;
     c->V = parent->V; c->Vp = parent->Vp; c->geom = parent->geom; c->j01 = parent->j01; c->j23 = parent->j23; c->wq = parent->wq;
     c->B = parent->B; c->inv_bind = parent->inv_bind;
-    c->has_topology = parent->has_topology; c->fk_rec = parent->fk_rec; c->fk_levels = parent->fk_levels;
-    c->has_animation = parent->has_animation; c->an_bone_range = parent->an_bone_range; c->an_feed_range = parent->an_feed_range;
+    c->has_topology = parent->has_topology; c->fk_rec = parent->fk_rec; c->fk_anc_more = parent->fk_anc_more; c->fk_rounds = parent->fk_rounds;
+    c->has_animation = parent->has_animation; c->an_feed_range = parent->an_feed_range;
     c->an_feed_off = parent->an_feed_off; c->an_key_frame = parent->an_key_frame; c->an_key_pos = parent->an_key_pos;
     c->an_mkey_frame = parent->an_mkey_frame; c->an_mkey_weight = parent->an_mkey_weight; c->an_feed_ratio = parent->an_feed_ratio;
     c->an_key_rot = parent->an_key_rot; c->an_key_interp = parent->an_key_interp; c->an_M = parent->an_M;

@@ -19,6 +19,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -101,11 +102,17 @@ struct rz_ctx {
     float *inv_bind = nullptr;          // B x 16
     // optional topology for on-device FK
     bool has_topology = false;
-    uint4 *fk_rec = nullptr;            // [B][2] one 32-byte record per bone (deform_kernels.h: RzFkParams::bone_rec)
+    // the hierarchy's static block (kernels/fk.hip.h): [B][4] bone records (topology | bind | the motion's track | ancestors of the first
+    // two doubling rounds) + [an_M][2] vertex-morph records; rebuilt by rebuild_fk_static when the topology or the motion changes
+    uint4 *fk_rec = nullptr;
+    uint2 *fk_anc_more = nullptr;       // [fk_rounds - 2][B] ancestor tables of the doubling rounds beyond the second (depth > 16)
+    int fk_rounds = 0;                  // radix-4 doubling rounds = ceil(log4(depth))
+    std::vector<uint4> fk_host;         // host copy of the bone records (w2 is filled in from an_host_range)
+    std::vector<uint4> an_host_range, an_host_mrec;     // the motion's per-bone track records / per-morph records (host copies)
     bool pose_local_t = false;
     // device-side motion sampling (rz_upload_animation / rz_set_pose_sampled)
     bool has_animation = false, pose_sampled = false;
-    uint4 *an_bone_range = nullptr, *an_feed_range = nullptr;     // (first key, end, first frame, last frame) per bone / per morph feed
+    uint4 *an_feed_range = nullptr;     // (first key, end, first frame, last frame) per morph feed
     uint32_t *an_feed_off = nullptr;
     float *an_key_frame = nullptr, *an_key_pos = nullptr, *an_mkey_frame = nullptr, *an_mkey_weight = nullptr, *an_feed_ratio = nullptr;
     float4 *an_key_rot = nullptr;
@@ -115,7 +122,6 @@ struct rz_ctx {
     bool frames_inline = false;         // one character: the frame rides in the kernel arguments (frame0), nothing is uploaded
     float frame0 = 0.0f;
     size_t an_frames_alloc = 0;          // the current local pose carries translations (behind the rotations in its slot)
-    int fk_levels = 0;                  // depth of the hierarchy
     float4 *local_q = nullptr;          // I x B   (current pose slot)
 
     bool pose_local = false;            // the current pose came from rz_set_pose_local
@@ -242,6 +248,17 @@ struct rz_ctx {
     bool sub_valid = false;
     int t_subsets = -1;                 // "inst_subsets": -1 / 1 = stage only the bones a vertex run names when that is a gain, 0 = always the whole palette
     bool palette_stale = false;         // the last crowd frame formed its palettes in LDS only (subset form): rz_read_palette forms them on demand
+    // Crowd frames of device-animated poses with the hierarchy solved in the skin kernel's front (kernels/crowd.hip:
+    // rz_skin_instances_fk_kernel): per vertex run the closure of its named bones under "parent of", one 80-byte record per closure
+    // slot — derived from the run lists and the hierarchy's static data, rebuilt when either changes (plan.cpp: ensure_subfk)
+    uint4 *subfk_rec = nullptr;
+    uint32_t *subfk_count = nullptr;
+    size_t subfk_rec_alloc = 0, subfk_count_alloc = 0;
+    uint32_t subfk_stride = 0, subfk_rounds = 0;
+    bool subfk_valid = false;
+    uint64_t subfk_sub_gen = 0, subfk_fk_gen = 0;   // what it was built against
+    uint64_t sub_gen = 0, fk_gen = 0;               // bumped when the run lists / the hierarchy's static block are rebuilt
+    bool fk_stale = false;              // the last crowd frame solved its hierarchy in LDS only: rz_read_world / rz_read_palette run rz_fk_kernel on demand
     int t_graph = 0;                    // "graph" tuning key: rz_deform_n replays captured hipGraphs of kGraphFrames frames
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_sig = 0;             // signature of everything the captured launches depend on
@@ -293,6 +310,7 @@ void set_ring(rz_ctx *c, int slot);
 void point_pose_slot(rz_ctx *c, int k);
 int ensure_pose_buffers(rz_ctx *c);
 void free_animation(rz_ctx *c);
+int rebuild_fk_static(rz_ctx *c);      // upload.cpp: the device block behind fk_rec from the host copies
 void free_bone_morphs(rz_ctx *c);
 void forget_search(rz_ctx *c);
 void free_morphs(rz_ctx *c);
@@ -305,13 +323,15 @@ template <typename T> int to_device(T **dst, const void *src, size_t count)
 }
 
 // ---- plan.cpp ----
-struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; int inst_block; bool fuse_fk; bool subsets; uint32_t sub_bones; uint64_t inst_lds; bool pf; uint32_t sp_cap; };
+struct Plan { RzVariant v; uint32_t grid_x, n_quads, quads_per_wave; bool prep, dma; int inst_group; uint32_t verts_per_wg; int poses_per_wg; uint32_t out_cap; int inst_block; bool fuse_fk; bool subsets; uint32_t sub_bones; uint64_t inst_lds; bool pf; uint32_t sp_cap; bool subfk; };
 // Launch shape of an instanced, morph-free crowd frame (rz_skin_instances_kernel): G poses per workgroup share one decode of each
 // vertex; the grid is (vertex runs, pose groups), `total` workgroups in all.
 struct InstShape { int G, blk, blk_full; bool want_in_kernel; uint32_t per, runs; };
 bool inst_shape(const rz_ctx *c, InstShape *s);
 Plan make_plan(const rz_ctx *c);
 int ensure_run_subsets(rz_ctx *c);
+int ensure_subfk(rz_ctx *c);
+RzSubFk subfk_params(const rz_ctx *c);
 int frame_plan(rz_ctx *c, Plan *pl);
 RzDeformParams deform_params(const rz_ctx *c, const Plan &pl);
 RzPrepParams prep_params(const rz_ctx *c);

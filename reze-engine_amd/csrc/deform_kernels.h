@@ -24,9 +24,7 @@ struct RzPrepParams {
 // counterpart — its loader drops positions and interpolation bytes, engine/src/vmd-loader.ts:129-140).
 struct RzSampleParams {
     const float *frames;          // [I] fractional frame (30 fps) each instance is posed at; nullptr = no sampling
-    const uint4 *bone_range;      // [B] (first key, one past the last key, bits(frame of the first key), bits(frame of the last key)) of
-                                  //     the track that drives the bone; first == end = the motion does not key it (identity / zero).
-                                  //     One load gives the sampler everything it needs to guess the key span.
+                                  // (the track record of every bone is word 2 of its bone record: RzFkParams::bone_rec)
     const float *key_frame;       // [K] ascending inside a track
     const float4 *key_rot;        // [K]
     const float *key_pos;         // [K][3]
@@ -46,16 +44,20 @@ struct RzSampleParams {
 struct RzFkParams {
     const float4 *local_q;      // [I][B] local rotations (x,y,z,w)
     const float *local_t;       // [I][B][3] local translations (SkeletonRuntime.localTranslations) or nullptr = all zero
-    // static topology, one 32-byte record per bone (two 16-byte loads):
-    //   word 0: parent (-1 = root) | append parent (-1 = no append rotation) | bits(append ratio) | flags (bit 0: append-move —
-    //           the append parent's local translation * ratio is appended too, model.ts:388-393)
-    //   word 1: bits of the parent-relative bind translation x y z | 0
-    const uint4 *bone_rec;      // [B][2]
+    // static data of the solve, ONE block per skeleton (kernels/fk.hip.h): 64-byte bone records
+    //   w0: parent (-1 = root) | append parent (-1 = no append rotation) | bits(append ratio) | flags (bit 0: append-move —
+    //       the append parent's local translation * ratio is appended too, model.ts:388-393)
+    //   w1: bits of the parent-relative bind translation x y z | 0
+    //   w2: the motion's track of the bone (first key, end, bits(first frame), bits(last frame)); zeros without a motion
+    //   w3: ancestors for the radix-4 doubling rounds 0 and 1 (a1 | a2 << 16, a3, a4 | a8 << 16, a12; 0xffff = above the root)
+    // followed by [sample.M] 32-byte vertex-morph records (first feed's key range | first feed, end of feeds, bits(ratio), 0)
+    const uint4 *bone_rec;      // [B][4] (+ [M][2])
+    const uint2 *anc_more;      // [n_rounds - 2][B] (a1 | a2 << 16, a3) for the doubling rounds beyond the second (hierarchies deeper than 16), or null
     const float *inv_bind;      // [B][16]
     float *world;               // [I][B][16] out
     float4 *palette;            // [I][B][3] out
     int B;
-    int n_levels;               // depth of the hierarchy (1 = roots only): the solve runs ceil(log2(n_levels)) doubling rounds
+    int n_rounds;               // radix-4 doubling rounds = ceil(log4(depth of the hierarchy)); 0 = roots only
     // physics hand-off (engine.ts:2379-2381, physics.ts:715-751): world matrices that replace the solved ones AFTER the
     // hierarchy solve — children keep the matrices solved from the un-overridden parent, exactly like the reference's
     // in-place boneWorldMatrices.set(). Entries sorted by instance; ovr_off[i]..ovr_off[i+1] are instance i's.
@@ -180,8 +182,8 @@ struct RzVariant {
 };
 
 // LDS the hierarchy solve needs behind the palette rows: per bone 48 B (local rotation | record | bind translation, then the
-// second matrix buffer of the doubling rounds) + 8 B (two ancestor indices) + 12 B (local translation), 16-byte rounded
-__host__ __device__ inline size_t rz_fk_scratch_bytes(int B) { return ((size_t)B * 68 + 15) & ~(size_t)15; }
+// second matrix buffer of the doubling rounds) + 12 B (local translation), 16-byte rounded
+__host__ __device__ inline size_t rz_fk_scratch_bytes(int B) { return ((size_t)B * 60 + 15) & ~(size_t)15; }
 
 hipError_t rz_launch_prep(const RzPrepParams &p, uint32_t instances, hipStream_t st);
 hipError_t rz_launch_fk(const RzFkParams &p, uint32_t instances, hipStream_t st);
@@ -198,6 +200,17 @@ hipError_t rz_launch_skin_instances_reg(const RzDeformParams &p, int n_inst, int
                                         hipStream_t st);
 hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
                                     int block, bool nts, size_t lds_bytes, hipStream_t st);
+// Crowd frame with the hierarchy solved in the skin kernel's front (kernels/crowd.hip: rz_skin_instances_fk_kernel): per vertex run the
+// closure of its named bones under "parent of", one 80-byte record per closure slot (plan.cpp: ensure_subfk)
+struct RzSubFk {
+    const uint32_t *count;      // [runs] closure slots of each run
+    const uint4 *rec;           // [runs][stride][5]
+    uint32_t stride;            // closure slots of the largest run
+    uint32_t rounds;            // radix-4 doubling rounds the deepest closure needs (<= 3)
+};
+hipError_t rz_launch_skin_instances_fk(const RzDeformParams &p, const RzSubFk &f, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
+                                       int block, bool nts, size_t lds_bytes, hipStream_t st);
+size_t rz_skin_instances_fk_lds_bytes(int G, uint32_t closure, uint32_t named);
 // LDS bytes of the instanced skin kernel: G poses of `bones` staged bones (the whole skeleton, or the largest run subset)
 size_t rz_skin_instances_lds_bytes(int G, uint32_t bones, bool dma, bool subsets);
 // per vertex run of `per` vertices: the ascending list of bones its vertices name + the joints rewritten as slots of it

@@ -20,7 +20,7 @@ int launch_fk(rz_ctx *c, hipStream_t st)
     if (lds > 160 * 1024)
         return fail(RZ_ERR_UNSUPPORTED, "skeleton too large for the hierarchy solve on the device: %u bones need %zu B of LDS (116 B per bone + the pose's morph weights; the limit is 160 KB)", c->B, lds);
     HIP_TRY(rz_launch_fk(fp, c->I, st));
-    c->palette_stale = false;
+    c->palette_stale = false; c->fk_stale = false;
     return RZ_OK;
 }
 
@@ -35,7 +35,7 @@ int launch_prep(rz_ctx *c, hipStream_t st)
 // kernel. The FK kernel already writes the palette, so prep is only still needed for its morph compaction.
 int launch_front(rz_ctx *c, const Plan &pl, hipStream_t st)
 {
-    if (pl.fuse_fk) return RZ_OK;       // the deform kernel solves the hierarchy itself
+    if (pl.fuse_fk || pl.subfk) return RZ_OK;       // the deform / crowd kernel solves the hierarchy itself
     if (c->pose_local) {
         if (int r = launch_fk(c, st)) return r;
         if (pl.prep && c->morph_mode == 1)
@@ -51,6 +51,11 @@ int launch_deform(rz_ctx *c, const Plan &pl)
     RzDeformParams p = deform_params(c, pl);
     if (pl.poses_per_wg > 0) {
         HIP_TRY(rz_launch_skin_instances_reg(p, (int)c->I, pl.poses_per_wg, pl.grid_x, pl.v.nts, c->stream));
+        return RZ_OK;
+    }
+    if (pl.inst_group > 0 && pl.subfk) {
+        HIP_TRY(rz_launch_skin_instances_fk(p, subfk_params(c), pl.inst_group, (int)c->I, pl.verts_per_wg, pl.grid_x, pl.inst_block, pl.v.nts, (size_t)pl.inst_lds, c->stream));
+        c->fk_stale = true;                 // neither world matrices nor palettes of this pose are in memory: formed on demand (rz_read_world / rz_read_palette)
         return RZ_OK;
     }
     if (pl.inst_group > 0) {
@@ -76,7 +81,7 @@ bool want_overlap(const rz_ctx *c, const Plan &pl)
 {
     // OPT-IN (overlap = 1): measured on MI355X / ROCm 7.2 the two cross-stream hand-offs per frame cost more than the front
     // kernels they hide — C4 39.0 -> 44.8 us with rz_prep_kernel in front, 43.4 -> 62.1 us with rz_fk_kernel
-    return c->t_overlap == 1 && c->I > 1 && c->morph_mode != 2 && !c->t_graph && (pl.prep || c->pose_local);
+    return c->t_overlap == 1 && c->I > 1 && c->morph_mode != 2 && !c->t_graph && (pl.prep || c->pose_local) && !pl.subfk;
 }
 
 // Switching protocols is rare (instance count, tuning keys): drain both streams so that nothing enqueued under the old
@@ -155,6 +160,8 @@ static uint64_t frame_signature(rz_ctx *c, const Plan &pl)
     h = fnv(h, &pp, sizeof pp);
     const RzFkParams fp = fk_params(c);
     h = fnv(h, &fp, sizeof fp);
+    const RzSubFk sf = subfk_params(c);
+    h = fnv(h, &sf, sizeof sf);
     const uint64_t misc[6] = { c->I, c->pose_local, c->pose_local_t, c->pose_sampled, (uint64_t)c->morph_mode, (uint64_t)c->aabb_on };
     return fnv(h, misc, sizeof misc);
 }
@@ -242,6 +249,11 @@ int rz_read_palette(rz_ctx *c, uint32_t instance, float *rows3x4)
 {
     if (int r = use(c)) return r;
     if (instance >= c->I || !rows3x4 || !c->palette) return fail(RZ_ERR_INVALID, "bad palette read");
+    if (c->fk_stale) {
+        // the last frame was a crowd frame that solved its hierarchy in the skin kernel's front: run the solve as a kernel of its own
+        // now — the same functions on the same pose, the same bits (kernels/fk.hip.h)
+        if (int r = launch_fk(c, c->stream)) return r;
+    }
     if (c->palette_stale) {
         // the last frame was a bone-subset crowd frame: its workgroups formed the rows of their own bones in LDS and nobody
         // wrote the skinMatrixBuffer. Form it now from the resident world matrices — rz_prep_kernel's chain is the skin
@@ -313,7 +325,7 @@ int rz_time_frames(rz_ctx *c, uint32_t frames, rz_timing *out)
     out->deform_kernel_ms = ms / frames;
     // the front kernels alone (only part of the frame when the plan is not the one-launch FAST form); everything has
     // drained at this point, so they may run on the context's stream whatever the protocol
-    if ((pl.prep || c->pose_local) && !pl.fuse_fk) {
+    if ((pl.prep || c->pose_local) && !pl.fuse_fk && !pl.subfk) {
         HIP_TRY(hipStreamSynchronize(c->up_stream));
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
         for (uint32_t f = 0; f < frames; ++f)

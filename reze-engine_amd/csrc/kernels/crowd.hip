@@ -1,5 +1,5 @@
 // kernels/crowd.hip — instanced skin (BASELINE config C4: many poses of one static mesh) and its plan-time bone-subset pass.
-#include "common.hip.h"
+#include "fk.hip.h"
 
 namespace {
 
@@ -209,99 +209,154 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const uint32_t
         }
     }
     RZ_STAMP(2);                 // palettes formed and published: the front is over
-    for (uint32_t vb = v_begin; vb < v_end; vb += BLOCK) {   // workgroup-uniform trip count (the ballots below need whole waves)
-        if (vb == v_begin + BLOCK) RZ_STAMP(3);      // first vertex step done (8 poses written)
-        const uint32_t vn = vert_of(vb + BLOCK);
-        float xn = 0, yn = 0, zn = 0, nxn = 0, nyn = 0, nzn = 0;
-        uint32_t j01n = 0, j23n = 0, wqn = 0;
-        if (vn < v_end) {
-            xn = p.geom[0 * Vp + vn]; yn = p.geom[1 * Vp + vn]; zn = p.geom[2 * Vp + vn];
-            nxn = p.geom[3 * Vp + vn]; nyn = p.geom[4 * Vp + vn]; nzn = p.geom[5 * Vp + vn];
-            j01n = jp01[vn]; j23n = jp23[vn]; wqn = p.weights[vn];
-        }
-        const bool live = v < v_end;
-        // decode once per vertex (engine.ts:255-258)
-        const uint32_t b0 = wq & 255u, b1 = (wq >> 8) & 255u, b2 = (wq >> 16) & 255u, b3 = wq >> 24;
-        const uint32_t isum = b0 + b1 + b2 + b3;
-        const bool ok = isum != 0u;
-        const float inv = __builtin_amdgcn_rcpf((float)(ok ? isum : 1u));
-        const float w0 = ok ? (float)b0 * inv : 1.0f, w1 = (float)b1 * inv, w2 = (float)b2 * inv, w3 = (float)b3 * inv;
-        const uint32_t jmax = SUB ? 0xffffu : bmax;     // SUB: slots are in range by construction
-        const uint32_t o0 = min(j01 & 0xffffu, jmax) * rstride, o1 = min(j01 >> 16, jmax) * rstride,
-                       o2 = min(j23 & 0xffffu, jmax) * rstride, o3 = min(j23 >> 16, jmax) * rstride;
-        float *dp = p.out_pos + ((size_t)inst0 * Vp + v) * 3;
-        float *dn = p.out_nrm + ((size_t)inst0 * Vp + v) * 3;
-        // Packed-math form (v_pk_fma_f32 = two f32 FMAs per lane per instruction): palette rows are blended as
-        // (xy),(zw) register pairs straight out of ds_read_b128, and position + normal are transformed together
-        // as the pairs (x,nx),(y,ny),(z,nz), so one FMA chain yields (p_r, n_r) for row r. Every chain is spelled out
-        // with explicit FMAs in the order of skin_vertex() above — bones ascending from w0 * row, then
-        // fma(m.z, z, fma(m.y, y, fma(m.x, x, m.w))) — so a pose of a crowd has the SAME BITS as that pose run alone
-        // through rz_deform_kernel (tests/test_gpu_round2.py checks it at full C4 size).
-        const f2 vx = {x, nx}, vy = {y, ny}, vz = {z, nz};
-        const f2 W0 = {w0, w0}, W1 = {w1, w1}, W2 = {w2, w2}, W3 = {w3, w3};
-#ifdef RZ_ABLATE
-        if (p.dbg == 2 || p.dbg == 7) {          // dbg 2 / 7: ablation — the output stream without gathers / math
-            if (live)
-                for (int g = 0; g < ng; ++g) {
-                    st3<NTS>(dp, x, y, z); st3<NTS>(dn, nx, ny, nz);
-                    dp += Vp * 3; dn += Vp * 3;
-                }
-            x = xn; y = yn; z = zn; nx = nxn; ny = nyn; nz = nzn; j01 = j01n; j23 = j23n; wq = wqn;
-            v = vn;
-            continue;
-        }
-#endif
-        auto pose_loop = [&](auto nb_tag) {
-            constexpr int NB = decltype(nb_tag)::value;
-            const float4 *pg = pal;
-#pragma unroll 2
-            for (int g = 0; g < ng; ++g) {
-                f2 r[3][2];
+#include "crowd_pose_loop.inc.h"
+    RZ_STAMP(5);                 // last vertex step issued
+    RZ_TL_FLUSH(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (BLOCK / 64) + wave);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Crowd frame of DEVICE-ANIMATED poses in ONE launch (round 5): the front of every workgroup solves the part of the hierarchy its
+// vertex run needs, straight into its LDS palettes — no rz_fk_kernel in front (6.4-6.6 us of a 38 us frame), no world matrices or
+// palettes through memory. A run names ns bones (the subset lists); the plan (plan.cpp: ensure_subfk) has closed that list under
+// "parent of" — the CLOSURE, nc bones: on the synthetic C4 mesh 36 named, ~75 with their ancestors, of 200 — and written one 80-byte
+// record per closure slot: (bone | palette slot << 16, append parent, bits(append ratio), flags) (bind x y z) (ancestor SLOTS of the
+// radix-4 doubling rounds 0, 1) (round 2) (the motion's track of the bone). Work item (pose g of the group, closure slot c), at most two
+// per thread: record -> the pose's rotation / translation of that bone (or the keys of its track's guessed span) + inverse bind matrix
+// -> local matrix into LDS -> doubling rounds over the closure (kernels/fk.hip.h: fk_round; a bone's world matrix depends on its own
+// chain only, so it has the bits rz_fk_kernel gives it) -> palette rows of the named bones. Then the pose loop of rz_skin_instances_kernel.
+// Leading (preloaded) arguments: k_cnt = closure slots per run, k_rec = the records, k_src = the poses' local rotations [I][B] (sampled
+// poses: the per-instance frame numbers), k_inv_bind; k_g = poses per workgroup | sampled << 16 | has translations << 17;
+// k_bf = bone count | inst_order << 16 | doubling rounds << 18 | record stride (closure slots) << 20.
+// LDS: two matrix buffers of G x nc x 48 B, then the palettes G x ns x 48 B.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSubFkWords = 5;          // uint4 per closure record
+
+template <int BLOCK, bool NTS>
+__global__ void __launch_bounds__(BLOCK) rz_skin_instances_fk_kernel(const uint32_t *k_cnt, const uint4 *k_rec, const float4 *k_src, const float *k_inv_bind,
+                                                                     const uint32_t k_g, const int n_inst, const uint32_t verts_per_wg, const uint32_t k_grid,
+                                                                     const uint32_t k_bf, const uint32_t k_Vp, const RzDeformParams p)
+{
+    constexpr bool SUB = true;
+    constexpr int rstride = 3;
+    const int kB = (int)(k_bf & 0xffffu), G = (int)(k_g & 0xffffu);
+    const bool k_order = (k_bf >> 16) & 1u, sampled = (k_g >> 16) & 1u, has_lt = (k_g >> 17) & 1u;
+    const int n_rounds = (int)((k_bf >> 18) & 3u), rec_stride = (int)(k_bf >> 20);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    (void)lane; (void)wave;
+    RZ_TL_DECL;
+    RZ_STAMP(0);                 // entry
+    const uint32_t n_groups = k_grid >> 16, lin = blockIdx.x + (k_grid & 0xffffu) * blockIdx.y;
+    const uint32_t wg_group = k_order ? lin % n_groups : blockIdx.y, wg_run = k_order ? lin / n_groups : blockIdx.x;
+    const int inst0 = (int)wg_group * G;
+    const int ng = min(G, n_inst - inst0);
+    const int nc = (int)k_cnt[wg_run];
+    const uint4 *recs = k_rec + (size_t)wg_run * rec_stride * kSubFkWords;
+    float4 *mA = reinterpret_cast<float4 *>(smem), *mB = mA + (size_t)G * nc * 3, *pal = mB + (size_t)G * nc * 3;
+    // this thread's work items e = tid, tid + BLOCK: (pose g, closure slot c); past the end the LAST item is re-read (unpredicated loads)
+    constexpr int NIT = 2;
+    const int n_items = ng * nc;
+    int ig[NIT], ic[NIT];
+    bool on[NIT];
+    uint4 w0[NIT], w1[NIT], w2[NIT], w3[NIT], w4[NIT];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float4 a = pg[o0 + k];
-                    r[k][0] = W0 * f2{a.x, a.y};
-                    r[k][1] = W0 * f2{a.z, a.w};
-                    if (NB >= 2) {
-                        const float4 c = pg[o1 + k];
-                        r[k][0] = pk_fma(W1, f2{c.x, c.y}, r[k][0]);
-                        r[k][1] = pk_fma(W1, f2{c.z, c.w}, r[k][1]);
-                    }
-                    if (NB >= 4) {
-                        const float4 d = pg[o2 + k], e = pg[o3 + k];
-                        r[k][0] = pk_fma(W3, f2{e.x, e.y}, pk_fma(W2, f2{d.x, d.y}, r[k][0]));
-                        r[k][1] = pk_fma(W3, f2{e.z, e.w}, pk_fma(W2, f2{d.z, d.w}, r[k][1]));
-                    }
-                }
-                // (p_r, t_r) = fma(m_r.z, (z,nz), fma(m_r.y, (y,ny), fma(m_r.x, (x,nx), (m_r.w, 0))))
-                f2 q[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const f2 m_xy = r[k][0], m_zw = r[k][1];
-                    q[k] = pk_fma(f2{m_zw.x, m_zw.x}, vz, pk_fma(f2{m_xy.y, m_xy.y}, vy, pk_fma(f2{m_xy.x, m_xy.x}, vx, f2{m_zw.y, 0.0f})));
-                }
-                const float tx = q[0].y, ty = q[1].y, tz = q[2].y;
-                const float l2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
-                const bool good = (l2 > 0.0f) && (l2 < __builtin_inff());
-                const float rl = __builtin_amdgcn_rsqf(good ? l2 : 1.0f);
-                if (live && (RZ_DBG(p) != 1 || l2 == 1234.5f)) {   // dbg 1 (tools-only build): compute without the output stream
-                    st3<NTS>(dp, q[0].x, q[1].x, q[2].x);
-                    st3<NTS>(dn, good ? tx * rl : nx, good ? ty * rl : ny, good ? tz * rl : nz);
-                }
-                pg += lrows;
-                dp += Vp * 3;
-                dn += Vp * 3;
-            }
-        };
-        const bool any34 = __ballot((wq >> 16) != 0u) != 0ull;
-        const bool any2 = __ballot(((wq >> 8) & 255u) != 0u) != 0ull;
-        if (__ballot(live) == 0ull) {}                     // a wave past the end of the run (last step only)
-        else if (any34) pose_loop(std::integral_constant<int, 4>{});
-        else if (any2) pose_loop(std::integral_constant<int, 2>{});
-        else pose_loop(std::integral_constant<int, 1>{});
-        x = xn; y = yn; z = zn; nx = nxn; ny = nyn; nz = nzn; j01 = j01n; j23 = j23n; wq = wqn;
-        v = vn;
+    for (int k = 0; k < NIT; ++k) {
+        const int e = tid + k * BLOCK;
+        on[k] = e < n_items;
+        const int ec = min(e, max(n_items - 1, 0));
+        ig[k] = ec / max(nc, 1); ic[k] = ec - ig[k] * nc;
+        const uint4 *r = recs + (size_t)ic[k] * kSubFkWords;
+        w0[k] = r[0]; w1[k] = r[1]; w2[k] = r[2]; w3[k] = r[3];
+        w4[k] = sampled ? r[4] : make_uint4(0, 0, 0, 0);
     }
+    // the run's first vertex (its loads land under the solve)
+    const size_t Vp = k_Vp;
+    const uint32_t v_begin = wg_run * verts_per_wg;
+    const uint32_t v_end = min(p.n_quads * 4u, v_begin + verts_per_wg);
+    const uint32_t bmax = (uint32_t)(p.B - 1);
+    auto vert_of = [&](const uint32_t vb) { return vb + (uint32_t)tid; };
+    uint32_t v = vert_of(v_begin);
+    float x = 0, y = 0, z = 0, nx = 0, ny = 0, nz = 0;
+    uint32_t j01 = 0, j23 = 0, wq = 0;
+    const uint32_t *jp01 = p.rj01, *jp23 = p.rj23;
+    if (v < v_end) {
+        x = p.geom[0 * Vp + v]; y = p.geom[1 * Vp + v]; z = p.geom[2 * Vp + v];
+        nx = p.geom[3 * Vp + v]; ny = p.geom[4 * Vp + v]; nz = p.geom[5 * Vp + v];
+        j01 = jp01[v]; j23 = jp23[v]; wq = p.weights[v];
+    }
+    const int ns = (int)p.sub_count[wg_run];          // named bones = palette slots of this run
+    const int lrows = ns * 3;
+    // ---- the pose of every item: uploaded rotations (+ translations), or the motion sampled at the instance's frame ----
+    float4 q[NIT], apq[NIT], ib0[NIT], ib1[NIT], ib2[NIT], ib3[NIT];
+    float ltx[NIT], lty[NIT], ltz[NIT], apx[NIT], apy[NIT], apz[NIT];
+    const float *glt = p.fk.local_t;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const uint32_t bone = w0[k].x & 0xffffu, pslot = w0[k].x >> 16;
+        const int ap = (int)w0[k].y;
+        const size_t ib_row = (size_t)(inst0 + ig[k]) * kB;
+        ltx[k] = lty[k] = ltz[k] = apx[k] = apy[k] = apz[k] = 0.0f;
+        apq[k] = make_float4(0.f, 0.f, 0.f, 1.f);
+        if (sampled) {
+            const float frame = reinterpret_cast<const float *>(k_src)[inst0 + ig[k]];
+            BoneKeys bk = bone_issue(p.fk.sample, frame, w4[k]);
+            BoneKeys ak;
+            uint4 apr = make_uint4(0, 0, 0, 0);
+            if (ap >= 0) apr = p.fk.bone_rec[4 * (size_t)ap + 2];                 // the append parent's track: its LOCAL pose is all that is needed
+            ak = bone_issue(p.fk.sample, frame, apr);
+            bone_finish(p.fk.sample, frame, bk, q[k], ltx[k], lty[k], ltz[k]);
+            if (ap >= 0) bone_finish(p.fk.sample, frame, ak, apq[k], apx[k], apy[k], apz[k]);
+        } else {
+            q[k] = k_src[ib_row + bone];
+            if (has_lt) { const float *t = glt + (ib_row + bone) * 3; ltx[k] = t[0]; lty[k] = t[1]; ltz[k] = t[2]; }
+            if (ap >= 0) {
+                apq[k] = k_src[ib_row + (size_t)ap];
+                if (has_lt) { const float *t = glt + (ib_row + (size_t)ap) * 3; apx[k] = t[0]; apy[k] = t[1]; apz[k] = t[2]; }
+            }
+        }
+        ib0[k] = ib1[k] = ib2[k] = ib3[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pslot != kNoAnc) {
+            const float4 *gi = reinterpret_cast<const float4 *>(k_inv_bind) + (size_t)bone * 4;
+            ib0[k] = gi[0]; ib1[k] = gi[1]; ib2[k] = gi[2]; ib3[k] = gi[3];
+        }
+    }
+    // ---- local matrices into buffer A ----
+    float4 rm[NIT][3];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        fk_local_matrix(q[k], w0[k], __uint_as_float(w1[k].x), __uint_as_float(w1[k].y), __uint_as_float(w1[k].z), sampled || has_lt, ltx[k], lty[k], ltz[k],
+                        apq[k], apx[k], apy[k], apz[k], rm[k][0], rm[k][1], rm[k][2]);
+        if (on[k]) { float4 *d = mA + ((size_t)ig[k] * nc + ic[k]) * 3; d[0] = rm[k][0]; d[1] = rm[k][1]; d[2] = rm[k][2]; }
+    }
+    RZ_STAMP(1);                 // local matrices formed
+    __syncthreads();
+    // ---- doubling rounds over the closure (ancestor SLOTS; a pose's matrices sit nc x 3 float4 apart) ----
+    float4 *src = mA, *dst = mB;
+    for (int r = 0; r < n_rounds; ++r) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const uint32_t lo = r == 0 ? w2[k].x : r == 1 ? w2[k].z : w3[k].x, hi = r == 0 ? w2[k].y : r == 1 ? w2[k].w : w3[k].y;
+            fk_round(src + (size_t)ig[k] * nc * 3, lo & 0xffffu, lo >> 16, hi & 0xffffu, rm[k][0], rm[k][1], rm[k][2]);
+            if (on[k]) { float4 *d = dst + ((size_t)ig[k] * nc + ic[k]) * 3; d[0] = rm[k][0]; d[1] = rm[k][1]; d[2] = rm[k][2]; }
+        }
+        __syncthreads();
+        float4 *t4 = src; src = dst; dst = t4;
+    }
+    // ---- palette rows of the named bones ----
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const uint32_t pslot = w0[k].x >> 16;
+        if (on[k] && pslot != kNoAnc) {
+            float4 q0, q1, q2;
+            fk_palette_rows(rm[k][0], rm[k][1], rm[k][2], ib0[k], ib1[k], ib2[k], ib3[k], q0, q1, q2);
+            float4 *d = pal + ((size_t)ig[k] * ns + pslot) * 3;
+            d[0] = q0; d[1] = q1; d[2] = q2;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the first vertex has landed)
+    __syncthreads();
+    RZ_STAMP(2);                 // palettes formed and published: the front is over
+#include "crowd_pose_loop.inc.h"
     RZ_STAMP(5);                 // last vertex step issued
     RZ_TL_FLUSH(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (BLOCK / 64) + wave);
 }
@@ -486,6 +541,37 @@ static hipError_t launch_skin_instances(const RzDeformParams &p, int G, int n_in
     const uint32_t k_grid = grid.x | (grid.y << 16), k_bf = (uint32_t)p.B | (p.inst_order ? 1u << 16 : 0u) | (p.dma ? 1u << 17 : 0u);
     hipLaunchKernelGGL(k, grid, dim3(BLOCK), lds, st, p.sub_count, p.sub_list, k_src, p.inv_bind, G, n_inst, verts_per_wg, k_grid, k_bf, p.Vp, p);
     return hipGetLastError();
+}
+
+size_t rz_skin_instances_fk_lds_bytes(int G, uint32_t closure, uint32_t named) { return (size_t)G * (2 * (size_t)closure + named) * 48; }
+
+template <int BLOCK>
+static hipError_t launch_skin_instances_fk(const RzDeformParams &p, const RzSubFk &f, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x, bool nts,
+                                           size_t lds, hipStream_t st)
+{
+    auto k = nts ? rz_skin_instances_fk_kernel<BLOCK, true> : rz_skin_instances_fk_kernel<BLOCK, false>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid(grid_x, (n_inst + G - 1) / G);
+    const bool sampled = p.fk.sample.frames != nullptr;
+    // what the kernel can take: two 16-bit grid fields, 16 bits of bone count, 12 bits of record stride, 2 bits of rounds, two work items per thread
+    if (grid.x > 0xffffu || grid.y > 0xffffu || p.B > 0xffff || f.stride > 0xfffu || f.rounds > 3 || (size_t)G * f.stride > 2 * (size_t)BLOCK || !p.sub_count || !p.rj01)
+        return hipErrorInvalidValue;
+    const float4 *k_src = sampled ? reinterpret_cast<const float4 *>(p.fk.sample.frames) : p.fk.local_q;
+    const uint32_t k_g = (uint32_t)G | (sampled ? 1u << 16 : 0u) | (p.fk.local_t ? 1u << 17 : 0u);
+    const uint32_t k_grid = grid.x | (grid.y << 16), k_bf = (uint32_t)p.B | (p.inst_order ? 1u << 16 : 0u) | (f.rounds << 18) | (f.stride << 20);
+    hipLaunchKernelGGL(k, grid, dim3(BLOCK), lds, st, f.count, f.rec, k_src, p.inv_bind, k_g, n_inst, verts_per_wg, k_grid, k_bf, p.Vp, p);
+    return hipGetLastError();
+}
+
+hipError_t rz_launch_skin_instances_fk(const RzDeformParams &p, const RzSubFk &f, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,
+                                       int block, bool nts, size_t lds_bytes, hipStream_t st)
+{
+    if (block == 1024) return launch_skin_instances_fk<1024>(p, f, G, n_inst, verts_per_wg, grid_x, nts, lds_bytes, st);
+    if (block == 512) return launch_skin_instances_fk<512>(p, f, G, n_inst, verts_per_wg, grid_x, nts, lds_bytes, st);
+    return launch_skin_instances_fk<256>(p, f, G, n_inst, verts_per_wg, grid_x, nts, lds_bytes, st);
 }
 
 hipError_t rz_launch_skin_instances(const RzDeformParams &p, int G, int n_inst, uint32_t verts_per_wg, uint32_t grid_x,

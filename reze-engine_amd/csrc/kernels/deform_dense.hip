@@ -35,6 +35,21 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
                                                                     const uint32_t k_Vp, const uint32_t k_nq, const uint32_t k_qpw, const uint32_t *k_j01,
                                                                     const uint32_t *k_j23, const uint32_t *k_wq, const RzDeformParams p, const RzMorphList ml)
 {
+    // Where the wave's first loads take their addresses from. The small-frame kernel reads the PRELOADED leading arguments (SGPRs at
+    // wave start: deform_parts.hip.h). For a frame that is one long stream that only pays at S = 8 (C3: 30 k vertices, 7.3 vs 7.6 us);
+    // with fewer, longer-lived waves the kernel is FASTER reading everything out of `p` as in round 3 — measured in one process,
+    // alternating builds (profiles/r5_ab_dense_entry.txt): 1/8 shard of C5 (S = 4) 17.52 -> 16.63 us, C5 (S = 2) 127.2 -> 126.0 us.
+    // (-DRZ_DENSE_LEAD_MASK=<bits by log2 S> overrides the choice for A/B builds.)
+#ifndef RZ_DENSE_LEAD_MASK
+#define RZ_DENSE_LEAD_MASK 8
+#endif
+    constexpr bool LEAD = (RZ_DENSE_LEAD_MASK >> (S == 1 ? 0 : S == 2 ? 1 : S == 4 ? 2 : 3)) & 1;
+    const float *a_geom = LEAD ? k_geom : p.geom;
+    const float *a_world = LEAD ? k_world : (FAST ? (p.st_tag ? p.st_world : p.world) : (p.fk_on ? reinterpret_cast<const float *>(p.fk.bone_rec) : nullptr));
+    const float *a_inv_bind = LEAD ? k_inv_bind : (FAST ? p.inv_bind : reinterpret_cast<const float *>((uintptr_t)(p.fk_on ? p.fk.sample.M : 0)));
+    const uint32_t a_Vp = LEAD ? k_Vp : p.Vp, a_nq = LEAD ? k_nq : p.n_quads, a_qpw = LEAD ? k_qpw : p.quads_per_wave;
+    const uint32_t *a_j01 = LEAD ? k_j01 : p.joints01, *a_j23 = LEAD ? k_j23 : p.joints23, *a_wq = LEAD ? k_wq : p.weights;
+    const uint32_t a_bf = LEAD ? k_bf : ((uint32_t)p.B | (p.pf_src ? 1u << 16 : 0u) | (p.st_tag ? 1u << 17 : 0u) | (p.world_copy ? 1u << 18 : 0u));
     constexpr int QPW = 64 / S;              // quads per wave
     constexpr int VW = 4 * QPW;              // vertices per wave per tile
     constexpr int NPL = GEO ? 9 : 3;         // scratch planes per wave
@@ -44,27 +59,30 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
     const int tid = threadIdx.x;
     const int inst = blockIdx.y;
     const int lane = tid & 63, wave = tid >> 6;
-    const int kB = (int)(k_bf & 0xffffu);            // == p.B
+    const int kB = (int)(a_bf & 0xffffu);            // == p.B
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *pal = reinterpret_cast<float4 *>(smem);                       // B*3 float4
     RZ_TL_DECL;
     RZ_STAMP(0);                 // entry
 
     // Zero-copy pose prefetch (see RzDeformParams): workgroup 0 of such a launch is the helper, the workers shift by one.
-    const bool pf_on = (k_bf >> 16) & 1u;            // == p.pf_src != nullptr (only one-launch and fused-hierarchy frames ever carry one)
+    const bool pf_on = (a_bf >> 16) & 1u;            // == p.pf_src != nullptr (only one-launch and fused-hierarchy frames ever carry one)
     if (pf_on && blockIdx.x == 0) {
         pose_prefetch_helper(p, tid);
         return;
     }
     const uint32_t wid = blockIdx.x - (pf_on ? 1u : 0u);                 // worker index of this workgroup
+    // fused-hierarchy frame (!FAST, fk_on): the static records of this thread's bones and morph are asked for before anything else
+    FkEarly fke;
+    if (!FAST && a_world) fke = fk_issue_static(reinterpret_cast<const uint4 *>(a_world), kB, (int)(uintptr_t)a_inv_bind, tid);
     // THIS frame's pose: staged in device memory by the previous frame's helper, or still in its pinned slot. The answer is one
     // tag away, and waiting for it before asking for the matrices would put two memory latencies in a row in front of the
     // palette. So a frame that MAY find its pose staged (spec) asks for the tag and, at once, for the matrices of the staged
     // copy (the device pose block: valid memory whatever it holds); the tag is looked at when the palette is formed, and
     // only a miss then fetches the matrices from the pinned slot.
-    const bool spec = FAST && ((k_bf >> 17) & 1u);                       // == p.st_tag != nullptr
-    const float *world_in = k_world;                                     // == spec ? p.st_world : p.world (re-pointed at the pinned slot on a miss)
-    const bool from_host = ((k_bf >> 18) & 1u) && !spec;                 // (p.world_copy != nullptr) the matrices are asked for over the host link up front
+    const bool spec = FAST && ((a_bf >> 17) & 1u);                       // == p.st_tag != nullptr
+    const float *world_in = a_world;                                     // == spec ? p.st_world : p.world (re-pointed at the pinned slot on a miss)
+    const bool from_host = ((a_bf >> 18) & 1u) && !spec;                 // (p.world_copy != nullptr) the matrices are asked for over the host link up front
 
     // FAST: this thread's bone (tid < B covers the first 256 bones) — its world and inverse-bind matrices are
     // requested FIRST, as plain loads into registers, so they are the oldest entries of the vmcnt queue: the palette
@@ -85,19 +103,19 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
         world_pending = false;
     };
     if (FAST && early) {
-        const float4 *gi = reinterpret_cast<const float4 *>(k_inv_bind) + eb * 4;
+        const float4 *gi = reinterpret_cast<const float4 *>(a_inv_bind) + eb * 4;
         if (!late_world) load_world();
         ei0 = gi[0]; ei1 = gi[1]; ei2 = gi[2]; ei3 = gi[3];
     }
     const int s = lane / QPW;                // morph slice of this lane
     const int qi = lane % QPW;
-    const size_t Vp = k_Vp;
+    const size_t Vp = a_Vp;
     const size_t plane4 = Vp / 4;            // float4 per plane
     // persistent, evenly balanced partition: every wave of the grid owns one contiguous run of quads
     // (a multiple of 8 quads = 128 B per plane) and walks it QPW quads at a time; the last step is masked.
     const uint32_t wave_global = wid * (kBlock / 64) + wave;
-    const size_t q_begin = (size_t)wave_global * k_qpw;
-    const size_t q_end = min((size_t)k_nq, q_begin + k_qpw);
+    const size_t q_begin = (size_t)wave_global * a_qpw;
+    const size_t q_end = min((size_t)a_nq, q_begin + a_qpw);
 
     // rest geometry of the quad (slice 0 only), issued at the top of a step so it overlaps the morph stream. The skin phase's
     // attribute loads stay behind the morph phase: the kernel lives at 245 VGPRs.
@@ -106,13 +124,13 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
     auto issue = [&](const size_t qw) {
         const size_t q = qw + qi;
         if (s == 0 && q < q_end) {
-            const float4 *G = reinterpret_cast<const float4 *>(k_geom) + q;
+            const float4 *G = reinterpret_cast<const float4 *>(a_geom) + q;
             gx = G[0]; gy = G[plane4]; gz = G[2 * plane4];
             if (GEO) {
                 gnx = G[3 * plane4]; gny = G[4 * plane4]; gnz = G[5 * plane4];
-                gj01 = reinterpret_cast<const uint4 *>(k_j01)[q];
-                gj23 = reinterpret_cast<const uint4 *>(k_j23)[q];
-                gw = reinterpret_cast<const uint4 *>(k_wq)[q];
+                gj01 = reinterpret_cast<const uint4 *>(a_j01)[q];
+                gj23 = reinterpret_cast<const uint4 *>(a_j23)[q];
+                gw = reinterpret_cast<const uint4 *>(a_wq)[q];
             }
         }
     };
@@ -127,7 +145,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
         // FUSED single-character frame: hierarchy solve (and motion sampling) as this workgroup's prologue, then the ordered
         // compaction of the pose's morph weights into the LDS list
         __shared__ int fz_cnt[kBlock / 64];
-        float *lds_mw = fused_hierarchy_prologue<true>(p.fk, p.st_tag, p.st_expect, p.st_morph_w, p.morph_w, p.morph_w_copy, p.M, pal, scratch_all, wid, RZ_TL_FK);
+        float *lds_mw = fused_hierarchy_prologue<true>(p.fk, fke, p.st_tag, p.st_expect, p.st_morph_w, p.morph_w, p.morph_w_copy, p.M, pal, scratch_all, wid, RZ_TL_FK);
         fused_count = compact_active(lds_mw, p.M, p.Mpad, s_idx, s_w, fz_cnt);
         __syncthreads();
     } else if (!FAST) {
@@ -379,8 +397,10 @@ static hipError_t launch_one(const RzDeformParams &p, const RzMorphList &ml, dim
     }
     // the leading arguments (kernel-argument preload: deform_parts.hip.h) repeat fields of `p`; k_world is the pose the kernel asks for
     // FIRST — the copy a helper may have staged when the frame looks for one, else p.world
-    const float *k_world = (FAST && p.st_tag) ? p.st_world : p.world;
-    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p.geom, k_world, p.inv_bind, rz_deform_k_bf(p, grid.x), p.Vp, p.n_quads, p.quads_per_wave, p.joints01, p.joints23, p.weights, p, ml);
+    // (!FAST: the hierarchy's static block and the motion's morph count ride in the two matrix slots, deform_parts.hip.h)
+    const float *k_world = FAST ? (p.st_tag ? p.st_world : p.world) : (p.fk_on ? reinterpret_cast<const float *>(p.fk.bone_rec) : nullptr);
+    const float *k_inv_bind = FAST ? p.inv_bind : reinterpret_cast<const float *>((uintptr_t)(p.fk_on ? p.fk.sample.M : 0));
+    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p.geom, k_world, k_inv_bind, rz_deform_k_bf(p, grid.x), p.Vp, p.n_quads, p.quads_per_wave, p.joints01, p.joints23, p.weights, p, ml);
     return hipGetLastError();
 }
 

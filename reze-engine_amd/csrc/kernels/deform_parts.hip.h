@@ -8,6 +8,10 @@
 // to k_j23; k_wq follows by scalar load like `p`). The leading arguments therefore repeat what the FIRST loads of a wave need — the
 // matrices, the partition, the mesh planes — and
 //   k_bf = bone count | helper-workgroup flag << 16 | may-be-staged flag << 17 | pose-in-pinned-memory flag << 18 | worker workgroups << 19.
+// Launches that are NOT the one-launch form (!FAST) do not read the matrices themselves, so their k_world / k_inv_bind slots carry what
+// a fused-hierarchy frame (fk_on) needs first instead: k_world = the hierarchy's static block (RzFkParams::bone_rec; null = no fused
+// solve), k_inv_bind = the number of vertex morphs the motion samples, as an integer — the records of the thread's bones and morph are
+// then on their way before `p` has arrived (kernels/fk.hip.h: fk_issue_static).
 // Everything else comes out of `p` by scalar loads, which take ~0.9 us to arrive (profiles/r4_timeline_c2.txt: "entry -> prologue
 // done"): a 3-17 us frame no longer waits for them before asking for its matrices and its mesh.
 #pragma once
@@ -148,7 +152,7 @@ __device__ __forceinline__ void aabb_commit(const RzDeformParams &p, const int i
 // leaves the pose in the device block for the frames that replay it. `stage_weights`: the uploaded (not sampled) morph weights are
 // parked in LDS first — the morph modes and bone morphs need them. Returns where the pose's morph weights sit in LDS. Ends with a barrier.
 template <bool STAGE_WEIGHTS_ALWAYS>
-__device__ __forceinline__ float *fused_hierarchy_prologue(const RzFkParams &fk, const uint64_t *st_tag, const uint64_t st_expect, const float *st_morph_w,
+__device__ __forceinline__ float *fused_hierarchy_prologue(const RzFkParams &fk, const FkEarly &early, const uint64_t *st_tag, const uint64_t st_expect, const float *st_morph_w,
                                                            const float *morph_w, float *morph_w_copy, const int M, float4 *pal, float *work, const uint32_t wid,
                                                            unsigned long long *tl_f)
 {
@@ -168,7 +172,7 @@ __device__ __forceinline__ float *fused_hierarchy_prologue(const RzFkParams &fk,
             if (wid == 0 && morph_w_copy && (!fspec || miss)) morph_w_copy[i] = w;
         }
     }
-    fk_solve<true>(fk, 0, pal, fscr, lds_mw, wid == 0, ftag, tl_f);       // ends with a barrier: pal and lds_mw are complete
+    fk_solve<true>(fk, early, 0, pal, fscr, lds_mw, wid == 0, ftag, tl_f);       // ends with a barrier: pal and lds_mw are complete
     return lds_mw;
 }
 

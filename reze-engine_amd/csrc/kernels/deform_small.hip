@@ -61,6 +61,9 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_small_kernel(const float 
         return;
     }
     const uint32_t wid = blockIdx.x - (pf_on ? 1u : 0u);                 // worker index of this workgroup
+    // fused-hierarchy frame (!FAST, fk_on): the static records of this thread's bones and morph are asked for before anything else
+    FkEarly fke;
+    if (!FAST && k_world) fke = fk_issue_static(reinterpret_cast<const uint4 *>(k_world), kB, (int)(uintptr_t)k_inv_bind, tid);
     // THIS frame's pose: staged in device memory by the previous frame's helper, or still in its pinned slot (see deform_dense.hip).
     // Sparse weights are needed at once: that mode waits for the tag.
     const bool spec = FAST && ((k_bf >> 17) & 1u);                       // == p.st_tag != nullptr
@@ -165,7 +168,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_small_kernel(const float 
     const float *morph_w_in = (staged_now && p.st_morph_w) ? p.st_morph_w : p.morph_w;
     if (!FAST && p.fk_on) {
         // FUSED single-character frame: hierarchy solve (and motion sampling) as this workgroup's prologue
-        float *lds_mw = fused_hierarchy_prologue<MODE != 0>(p.fk, p.st_tag, p.st_expect, p.st_morph_w, p.morph_w, p.morph_w_copy, p.M, pal, scratch_all, wid, RZ_TL_FK);
+        float *lds_mw = fused_hierarchy_prologue<MODE != 0>(p.fk, fke, p.st_tag, p.st_expect, p.st_morph_w, p.morph_w, p.morph_w_copy, p.M, pal, scratch_all, wid, RZ_TL_FK);
         if (MODE == 2)
             for (int i = tid; i < p.M; i += kBlock) s_w[i] = lds_mw[i];
         __syncthreads();
@@ -426,8 +429,10 @@ static hipError_t launch_one(const RzDeformParams &p, dim3 grid, size_t lds, hip
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const float *k_world = (FAST && p.st_tag) ? p.st_world : p.world;      // the pose the kernel asks for FIRST (deform_dense.hip: launch_one)
-    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p.geom, k_world, p.inv_bind, rz_deform_k_bf(p, grid.x), p.Vp, p.n_quads, p.quads_per_wave, p.joints01, p.joints23, p.weights, p);
+    // (!FAST: the hierarchy's static block and the motion's morph count ride in the two matrix slots, deform_parts.hip.h)
+    const float *k_world = FAST ? (p.st_tag ? p.st_world : p.world) : (p.fk_on ? reinterpret_cast<const float *>(p.fk.bone_rec) : nullptr);
+    const float *k_inv_bind = FAST ? p.inv_bind : reinterpret_cast<const float *>((uintptr_t)(p.fk_on ? p.fk.sample.M : 0));
+    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, p.geom, k_world, k_inv_bind, rz_deform_k_bf(p, grid.x), p.Vp, p.n_quads, p.quads_per_wave, p.joints01, p.joints23, p.weights, p);
     return hipGetLastError();
 }
 

@@ -6,6 +6,12 @@
 
 namespace {
 
+// Every function of this header is inlined into several kernels (rz_fk_kernel, the deform kernels' fused prologue, the crowd kernel's
+// front), and frames that differ only in WHICH kernel solved the hierarchy are held to the same bits (tests/test_gpu_round5.py). The
+// compiler's choice of which multiply to fuse into which add depends on the code around it, so contraction is switched off here and
+// every FMA is spelled out (hipcc's default, -ffp-contract=fast-honor-pragmas, restored at the end of the file).
+#pragma clang fp contract(off)
+
 // ------------------------------------------------------------------------------------------------
 // forward kinematics on the device: the reference's Model.computeWorldMatrices
 // (engine/src/model.ts:330-420) for I poses at once, fused with the palette product (engine.ts:926-928).
@@ -30,7 +36,7 @@ __device__ __forceinline__ void quat_to_rows(float x, float y, float z, float w,
 }
 
 // ------------------------------------------------------------------------------------------------
-// sample_bone / sample_morph — MMD motion sampling, run by rz_fk_kernel's staging pass for every (instance, bone) and
+// bone_issue / bone_finish / sample_morph — MMD motion sampling, run by the hierarchy solve's staging pass for every (instance, bone) and
 // (instance, vertex morph) when the pose comes from rz_set_pose_sampled:
 //   rotation  slerp between the surrounding keys, parameter warped by the later key's R Bezier curve
 //   position  per-axis lerp, each axis warped by its own X / Y / Z curve
@@ -166,12 +172,6 @@ __device__ __forceinline__ void bone_finish(const RzSampleParams &p, float frame
     tx = pa0 + (pb0 - pa0) * cx; ty = pa1 + (pb1 - pa1) * cy; tz = pa2 + (pb2 - pa2) * cz;
 }
 
-__device__ __forceinline__ void sample_bone(const RzSampleParams &p, float frame, int bone, float4 &q, float &tx, float &ty, float &tz)
-{
-    BoneKeys k = bone_issue(p, frame, p.bone_range[bone]);
-    bone_finish(p, frame, k, q, tx, ty, tz);
-}
-
 struct MorphKeys { int mode; uint32_t i0; KeyRange kr; float f_a, f_b, w_a, w_b; };     // mode as in BoneKeys
 
 __device__ __forceinline__ MorphKeys morph_issue(const RzSampleParams &p, float frame, const uint4 rec)
@@ -243,29 +243,142 @@ __device__ __forceinline__ void affine_mul(const float4 p0, const float4 p1, con
     float W[12];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        W[i * 4 + 0] = P[i * 4] * l0.x + P[i * 4 + 1] * l1.x + P[i * 4 + 2] * l2.x;
-        W[i * 4 + 1] = P[i * 4] * l0.y + P[i * 4 + 1] * l1.y + P[i * 4 + 2] * l2.y;
-        W[i * 4 + 2] = P[i * 4] * l0.z + P[i * 4 + 1] * l1.z + P[i * 4 + 2] * l2.z;
-        W[i * 4 + 3] = P[i * 4] * l0.w + P[i * 4 + 1] * l1.w + P[i * 4 + 2] * l2.w + P[i * 4 + 3];
+        W[i * 4 + 0] = fmaf(P[i * 4 + 2], l2.x, fmaf(P[i * 4 + 1], l1.x, P[i * 4] * l0.x));
+        W[i * 4 + 1] = fmaf(P[i * 4 + 2], l2.y, fmaf(P[i * 4 + 1], l1.y, P[i * 4] * l0.y));
+        W[i * 4 + 2] = fmaf(P[i * 4 + 2], l2.z, fmaf(P[i * 4 + 1], l1.z, P[i * 4] * l0.z));
+        W[i * 4 + 3] = fmaf(P[i * 4 + 2], l2.w, fmaf(P[i * 4 + 1], l1.w, fmaf(P[i * 4], l0.w, P[i * 4 + 3])));
     }
     w0 = make_float4(W[0], W[1], W[2], W[3]); w1 = make_float4(W[4], W[5], W[6], W[7]); w2 = make_float4(W[8], W[9], W[10], W[11]);
 }
 
+// ---- static data of the solve -------------------------------------------------------------------------------------------------
+// ONE block of device memory per skeleton (rebuilt when the topology or the motion changes: upload.cpp rebuild_fk_static):
+//   [B] bone records of 64 bytes, four uint4:
+//       w0  parent (-1 = root) | append parent (-1 = none) | bits(append ratio) | flags (bit 0: append-move, model.ts:388-393)
+//       w1  bits of the parent-relative bind translation x y z | 0
+//       w2  the motion's track of this bone: (first key, one past the last key, bits(first key's frame), bits(last key's frame));
+//           first == end = the motion does not key it. One load gives the sampler everything it needs to guess the key span.
+//       w3  ancestors for the first two radix-4 doubling rounds: round 0 (a1 | a2 << 16, a3), round 1 (a4 | a8 << 16, a12),
+//           a_k = the bone k levels up, 0xffff = above the root
+//   [M] vertex-morph records of 32 bytes behind them (with a motion): the key range of the morph's FIRST feed, then
+//       (first feed, one past the last feed, bits(ratio of the first feed), 0) — one round trip to the keys instead of
+//       offsets -> feed record -> keys.
+// The leading kernel arguments carry its address (and FkAux) so that a wave asks for its records before it reads anything else.
+struct FkEarly {           // the records of this thread's two bones (tid, tid + 256) and of its vertex morph
+    uint4 a0, a1, a2, a3, b0, b1, b2, b3, m0, m1;
+};
+constexpr uint32_t kNoAnc = 0xffffu;
+
+// FkAux, one preloaded 64-bit kernel argument: bits(frame of a single sampled character) | vertex morphs of the motion << 32 | doubling rounds << 48
+__device__ __forceinline__ FkEarly fk_issue_static(const uint4 *rec, const int B, const int M, const int tid)
+{
+    // (unpredicated: threads past the last bone / morph re-read the last record — a dead load is cheaper than the wait the compiler
+    // puts behind a divergent block of loads, NOTEBOOK.md R4.9)
+    FkEarly e;
+    const uint4 *ra = rec + (size_t)min(tid, B - 1) * 4, *rb = rec + (size_t)min(tid + kBlock, B - 1) * 4;
+    e.a0 = ra[0]; e.a1 = ra[1]; e.a2 = ra[2]; e.a3 = ra[3];
+    e.b0 = rb[0]; e.b1 = rb[1]; e.b2 = rb[2]; e.b3 = rb[3];
+    e.m0 = make_uint4(0, 0, 0, 0); e.m1 = e.m0;
+    if (M > 0) {
+        const uint4 *rm = rec + (size_t)B * 4 + (size_t)min(tid, M - 1) * 2;
+        e.m0 = rm[0]; e.m1 = rm[1];
+    }
+    return e;
+}
+
+// L = T(bind + t) * R(q) * T(add) of one bone, rows 0..2 (model.ts:355-414): `apq` = its append parent's LOCAL rotation (used when
+// the record names one), `apt` = that parent's local translation (append-move)
+__device__ __forceinline__ void fk_local_matrix(const float4 q, const uint4 rec, const float bx, const float by, const float bz, const bool has_t,
+                                                const float ltx, const float lty, const float ltz, float4 a, const float apx, const float apy,
+                                                const float apz, float4 &l0, float4 &l1, float4 &l2)
+{
+    float R[9];
+    quat_to_rows(q.x, q.y, q.z, q.w, R);
+    const int ap = (int)rec.y;
+    const float ratio_raw = __uint_as_float(rec.z);
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;       // append-move: T(add) of L = T(bind) * R * T(add)
+    if (ap >= 0) {
+        const float ratio = fminf(1.0f, fmaxf(-1.0f, ratio_raw));
+        if (fabsf(ratio) > 1e-6f) {
+            if (has_t && (rec.w & 1u)) {             // model.ts:388-393 uses the UNclamped ratio here
+                ax = apx * ratio_raw; ay = apy * ratio_raw; az = apz * ratio_raw;
+            }
+            const float t = fabsf(ratio);
+            if (ratio < 0.0f) { a.x = -a.x; a.y = -a.y; a.z = -a.z; }
+            const float4 sl = slerp_from_identity(a, t);
+            float A[9], X[9];
+            quat_to_rows(sl.x, sl.y, sl.z, sl.w, A);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) X[i * 3 + j] = fmaf(A[i * 3 + 2], R[6 + j], fmaf(A[i * 3 + 1], R[3 + j], A[i * 3] * R[j]));
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = X[i];
+        }
+    }
+    // translation column of L = T(bind + local) * R * T(add)  =  bind + local + R * add
+    float tx = bx, ty = by, tz = bz;
+    if (has_t) {
+        tx += ltx; ty += lty; tz += ltz;
+        tx += fmaf(R[2], az, fmaf(R[1], ay, R[0] * ax));
+        ty += fmaf(R[5], az, fmaf(R[4], ay, R[3] * ax));
+        tz += fmaf(R[8], az, fmaf(R[7], ay, R[6] * ax));
+    }
+    l0 = make_float4(R[0], R[1], R[2], tx);
+    l1 = make_float4(R[3], R[4], R[5], ty);
+    l2 = make_float4(R[6], R[7], R[8], tz);
+}
+
+// One radix-4 doubling round for one bone held in registers: M <- M[a3] * (M[a2] * (M[a1] * M)), a_k = the bone k * 4^round levels
+// up (kNoAnc = above the root: the run has reached it). `src` holds every bone's product after the previous round, 3 float4 per bone.
+__device__ __forceinline__ void fk_round(const float4 *src, const uint32_t a1, const uint32_t a2, const uint32_t a3, float4 &m0, float4 &m1, float4 &m2)
+{
+    if (a1 == kNoAnc) return;
+    // all three ancestors' rows are asked for at once (the addresses are known from the start): one LDS latency per round
+    const uint32_t c2 = a2 == kNoAnc ? a1 : a2, c3 = a3 == kNoAnc ? a1 : a3;
+    const float4 p0 = src[a1 * 3], p1 = src[a1 * 3 + 1], p2 = src[a1 * 3 + 2];
+    const float4 q0 = src[c2 * 3], q1 = src[c2 * 3 + 1], q2 = src[c2 * 3 + 2];
+    const float4 r0 = src[c3 * 3], r1 = src[c3 * 3 + 1], r2 = src[c3 * 3 + 2];
+    affine_mul(p0, p1, p2, m0, m1, m2, m0, m1, m2);
+    if (a2 != kNoAnc) affine_mul(q0, q1, q2, m0, m1, m2, m0, m1, m2);
+    if (a3 != kNoAnc) affine_mul(r0, r1, r2, m0, m1, m2, m0, m1, m2);
+}
+
+// palette rows 0..2 of W * IB for one bone (IB general 4x4, column-major; engine.ts:926-928): ((w0*b0 + w1*b1) + w2*b2) + w3*b3
+__device__ __forceinline__ void fk_palette_rows(const float4 w0, const float4 w1, const float4 w2, const float4 i0, const float4 i1, const float4 i2,
+                                                const float4 i3, float4 &q0, float4 &q1, float4 &q2)
+{
+    const float W[12] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w };
+    const float4 ibm[4] = { i0, i1, i2, i3 };
+    float r[3][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 bc = ibm[c];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            r[i][c] = fmaf(W[i * 4 + 3], bc.w, fmaf(W[i * 4 + 2], bc.z, fmaf(W[i * 4 + 1], bc.y, W[i * 4] * bc.x)));
+    }
+    q0 = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]); q1 = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]);
+    q2 = make_float4(r[2][0], r[2][1], r[2][2], r[2][3]);
+}
+
 // The body of the hierarchy solve, shared by rz_fk_kernel (one workgroup per pose, results to global memory) and by the
-// FUSED single-character frame, where every workgroup of rz_deform_kernel runs it as its prologue: `wl` is then the deform
+// FUSED single-character frame, where every workgroup of the deform kernels runs it as its prologue: `wl` is then the deform
 // kernel's LDS palette (it ends up holding rows 0..2 of W * inverseBind), `scr` aliases its wave scratch, the sampled morph
 // weights go to `lds_mw`, and only workgroup 0 (`to_global`) also leaves world matrices / palette / weights in memory.
 //
-// Shape of the solve (round 4): the topology comes as ONE 32-byte record per bone (two 16-byte loads instead of seven scalar
-// arrays), and the parent chain is resolved by POINTER DOUBLING instead of level by level: every bone holds the product M of
-// the local matrices of a run of its ancestors ending at itself and the index A of the bone above that run; a round does
-// M[b] = M[A[b]] * M[b], A[b] = A[A[b]] for all bones at once (ping-pong buffers, one barrier), so ceil(log2(depth)) rounds
-// — 4 for a 12-level tree — replace depth - 1 barrier-separated levels. The products are associated differently from the
-// reference's parent-first recursion ((L0 L1)(L2 L3) instead of ((L0 L1) L2) L3): same f32 error class, ~1e-7 per product.
-// LDS behind `scr`: rz_fk_scratch_bytes(B) = B x (48 + 8 + 12) bytes. Ends with a barrier.
+// Shape of the solve: the static data of a thread's bones and morph arrive as FkEarly — requested by the caller before it reads its
+// kernel arguments (round 5; rounds 1-4 asked for them 0.9 us later, behind the scalar loads of `p`) — then the pose (sampled: the
+// keys of the guessed spans; uploaded: rotations / translations), then the parent chains are resolved by RADIX-4 POINTER DOUBLING
+// over ancestor tables computed at upload time: every bone holds the product M of the local matrices of a run of its ancestors
+// ending at itself; round r multiplies in the runs ending 4^r, 2 * 4^r and 3 * 4^r levels up, so ceil(log4(depth)) rounds — 2 for
+// a 12-level tree (4 radix-2 rounds of ~0.38 us each in round 4, six barrier-separated levels before that) — each ONE LDS latency,
+// three products and a barrier. The products are associated differently from the reference's parent-first recursion: same f32
+// error class, ~1e-7 per product (tests/test_gpu_round4.py: test_pointer_doubling_hierarchy_solve, against float64).
+// LDS behind `scr`: rz_fk_scratch_bytes(B) = B x (48 + 12) bytes. Ends with a barrier.
 template <bool FUSED>
-__device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, float4 *wl, unsigned char *scr, float *lds_mw, const bool to_global,
-                                         const uint64_t st_tagv = 0ull, unsigned long long *fs = nullptr)
+__device__ __forceinline__ void fk_solve(const RzFkParams &p, const FkEarly &early, const int inst, float4 *wl, unsigned char *scr, float *lds_mw,
+                                         const bool to_global, const uint64_t st_tagv = 0ull, unsigned long long *fs = nullptr)
 {
 #ifdef RZ_ABLATE
 #define RZ_FSTAMP(k) do { if (fs) fs[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -278,15 +391,13 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
     uint4 *s_rec = reinterpret_cast<uint4 *>(sq + p.B);              // [B] (parent, append parent, bits(append ratio), flags)
     float4 *s_bind = reinterpret_cast<float4 *>(s_rec + p.B);        // [B] parent-relative bind translation
     float4 *m2 = reinterpret_cast<float4 *>(scr);                    // [B][3] aliases the three arrays above
-    int *s_anc = reinterpret_cast<int *>(scr + (size_t)p.B * 48);    // [2][B] ping-pong ancestor indices
-    float *s_lt = reinterpret_cast<float *>(s_anc + 2 * (size_t)p.B);   // [B][3] local translations of this pose
+    float *s_lt = reinterpret_cast<float *>(scr + (size_t)p.B * 48);    // [B][3] local translations of this pose
     const int tid = threadIdx.x;
     const float4 *lq = p.local_q + (size_t)inst * p.B;
     const float *glt = p.local_t ? p.local_t + (size_t)inst * p.B * 3 : nullptr;
     const bool sampled = p.sample.frames != nullptr || p.sample.frames_inline;      // rz_set_pose_sampled: the pose is evaluated right here
     const bool bone_morphs = p.bm_off != nullptr;
     const bool has_t = sampled || glt != nullptr || bone_morphs;
-    const float *lt = has_t ? s_lt : nullptr;
     const float frame = sampled ? (p.sample.frames_inline ? p.sample.frame0 : p.sample.frames[inst]) : 0.0f;
     float *world = p.world + (size_t)inst * p.B * 16;
     float4 *pal = p.palette + (size_t)inst * p.B * 3;
@@ -297,58 +408,19 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         const float4 *Im = reinterpret_cast<const float4 *>(p.inv_bind + (size_t)tid * 16);
         pib0 = Im[0]; pib1 = Im[1]; pib2 = Im[2]; pib3 = Im[3];
     }
-    // Sampled pose, the common sizes (<= 512 bones: two per thread; <= 256 vertex morphs: one per thread): the track records of
-    // the thread's bones AND the feed list of its morph are requested together, then all their keys, then the morph's keys —
-    // three dependent round trips for the whole pose. Bone loop followed by morph loop (rounds 2-3) was five: records -> keys,
-    // then feed offsets -> feed record -> keys ("pose staged" 4.2 / 6.3 us median / max after a wave's entry then, 4.2 / 5.7 now: NOTEBOOK.md R4.2, profiles/r4_timeline_sampled-demo.txt).
-    const bool inter = sampled;
-    int m_done = 0;                       // vertex morphs [0, m_done) have been sampled by the interleaved pass
-    if (inter) {
-        const int b0 = tid, b1 = tid + kBlock;
-        const bool hb0 = b0 < p.B, hb1 = b1 < p.B, hm = tid < p.sample.M;
-        uint4 ra0, ra1, rb0, rb1;
-        uint4 tr0 = make_uint4(0, 0, 0, 0), tr1 = tr0;
-        if (hb0) { ra0 = p.bone_rec[2 * b0]; ra1 = p.bone_rec[2 * b0 + 1]; tr0 = p.sample.bone_range[b0]; }
-        if (hb1) { rb0 = p.bone_rec[2 * b1]; rb1 = p.bone_rec[2 * b1 + 1]; tr1 = p.sample.bone_range[b1]; }
-        uint32_t f0 = 0u, f1 = 0u;
-        if (hm) { f0 = p.sample.feed_off[tid]; f1 = p.sample.feed_off[tid + 1]; }
-        BoneKeys k0 = bone_issue(p.sample, frame, tr0), k1 = bone_issue(p.sample, frame, tr1);
-        uint4 fr = make_uint4(0, 0, 0, 0);
-        float ratio0 = 0.0f;
-        if (f1 > f0) { fr = p.sample.feed_range[f0]; ratio0 = p.sample.feed_ratio[f0]; }
-        const MorphKeys mk = morph_issue(p.sample, frame, fr);
-        auto park = [&](const int b, BoneKeys &k, const uint4 r0, const uint4 r1) {
-            float4 q;
-            float tx, ty, tz;
-            bone_finish(p.sample, frame, k, q, tx, ty, tz);
-            sq[b] = q; s_rec[b] = r0;
-            s_bind[b] = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), 0.0f);
-            s_lt[b * 3] = tx; s_lt[b * 3 + 1] = ty; s_lt[b * 3 + 2] = tz;
-        };
-        if (hb0) park(b0, k0, ra0, ra1);
-        if (hb1) park(b1, k1, rb0, rb1);
-        if (hm) {
-            bool keyed;
-            const float wk = morph_finish(p.sample, frame, mk, keyed);
-            float w = 0.0f;
-            if (keyed) w += wk * ratio0;
-            if (f1 > f0 + 1u) w = sample_feeds(p.sample, frame, f0 + 1u, f1, w);      // group-morph tracks that feed it too
-            if (FUSED || bone_morphs) lds_mw[tid] = w;
-            if (to_global) p.sample.morph_w[(size_t)inst * p.sample.M + tid] = w;
-        }
-        m_done = min(p.sample.M, kBlock);
-    }
-    // one cooperative pass stages everything the later passes touch: the record loads are issued in front of the pose
-    // (sampled: the track record, then its keys), so the static topology rides under the pose's own latency
-    for (int i = inter ? tid + 2 * kBlock : tid; i < p.B; i += kBlock) {
-        const uint4 r0 = p.bone_rec[2 * i], r1 = p.bone_rec[2 * i + 1];
-        float4 q;
-        float tx = 0.0f, ty = 0.0f, tz = 0.0f;
-        if (sampled) {
-            sample_bone(p.sample, frame, i, q, tx, ty, tz);
-        } else if (FUSED && p.st_local_q) {
-            // zero-copy pose that the previous frame's helper may have staged: the staged copy is asked for at once, the tag
-            // (requested by the caller) decides afterwards; a miss re-reads the pinned slot and workgroup 0 keeps the pose
+    const int b0 = tid, b1 = tid + kBlock;
+    const bool hb0 = b0 < p.B, hb1 = b1 < p.B;
+    auto park = [&](const int b, const float4 q, const float tx, const float ty, const float tz, const uint4 r0, const uint4 r1) {
+        sq[b] = q; s_rec[b] = r0;
+        s_bind[b] = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), 0.0f);
+        if (has_t) { s_lt[b * 3] = tx; s_lt[b * 3 + 1] = ty; s_lt[b * 3 + 2] = tz; }
+    };
+    // an uploaded pose's bone: from the copy the previous frame's helper may have staged (FUSED zero-copy frame: the staged copy is
+    // asked for at once, the tag — requested by the caller — decides afterwards; a miss re-reads the pinned slot and workgroup 0 keeps
+    // the pose for the replays), else from where the pose lies
+    auto uploaded = [&](const int i, float4 &q, float &tx, float &ty, float &tz) {
+        tx = ty = tz = 0.0f;
+        if (FUSED && p.st_local_q) {
             q = p.st_local_q[i];
             if (glt) { tx = p.st_local_t[i * 3]; ty = p.st_local_t[i * 3 + 1]; tz = p.st_local_t[i * 3 + 2]; }
             if (st_tagv != p.st_expect) {
@@ -367,9 +439,46 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
                 if (glt) { p.copy_t[i * 3] = tx; p.copy_t[i * 3 + 1] = ty; p.copy_t[i * 3 + 2] = tz; }
             }
         }
-        sq[i] = q; s_rec[i] = r0;
-        s_bind[i] = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), 0.0f);
-        if (has_t) { s_lt[i * 3] = tx; s_lt[i * 3 + 1] = ty; s_lt[i * 3 + 2] = tz; }
+    };
+    // Staging pass. Sampled pose, the common sizes (<= 512 bones: two per thread; <= 256 vertex morphs: one per thread): the keys of
+    // the thread's two bones AND of its morph's first feed are requested together — with the records already here, ONE more round
+    // trip for the whole pose (rounds 2-3: five, round 4: three).
+    int m_done = 0;                       // vertex morphs [0, m_done) have been sampled by the interleaved pass
+    if (sampled) {
+        const bool hm = tid < p.sample.M;
+        BoneKeys k0 = bone_issue(p.sample, frame, hb0 ? early.a2 : make_uint4(0, 0, 0, 0)), k1 = bone_issue(p.sample, frame, hb1 ? early.b2 : make_uint4(0, 0, 0, 0));
+        const uint32_t f0 = hm ? early.m1.x : 0u, f1 = hm ? early.m1.y : 0u;
+        const float ratio0 = __uint_as_float(early.m1.z);
+        const MorphKeys mk = morph_issue(p.sample, frame, f1 > f0 ? early.m0 : make_uint4(0, 0, 0, 0));
+        float4 q;
+        float tx, ty, tz;
+        if (hb0) { bone_finish(p.sample, frame, k0, q, tx, ty, tz); park(b0, q, tx, ty, tz, early.a0, early.a1); }
+        if (hb1) { bone_finish(p.sample, frame, k1, q, tx, ty, tz); park(b1, q, tx, ty, tz, early.b0, early.b1); }
+        if (hm) {
+            bool keyed;
+            const float wk = morph_finish(p.sample, frame, mk, keyed);
+            float w = 0.0f;
+            if (keyed) w += wk * ratio0;
+            if (f1 > f0 + 1u) w = sample_feeds(p.sample, frame, f0 + 1u, f1, w);      // group-morph tracks that feed it too
+            if (FUSED || bone_morphs) lds_mw[tid] = w;
+            if (to_global) p.sample.morph_w[(size_t)inst * p.sample.M + tid] = w;
+        }
+        m_done = min(p.sample.M, kBlock);
+    } else {
+        float4 q;
+        float tx, ty, tz;
+        if (hb0) { uploaded(b0, q, tx, ty, tz); park(b0, q, tx, ty, tz, early.a0, early.a1); }
+        if (hb1) { uploaded(b1, q, tx, ty, tz); park(b1, q, tx, ty, tz, early.b0, early.b1); }
+    }
+    for (int i = tid + 2 * kBlock; i < p.B; i += kBlock) {      // skeletons beyond 512 bones: the rest, record by record
+        const uint4 r0 = p.bone_rec[4 * i], r1 = p.bone_rec[4 * i + 1];
+        float4 q;
+        float tx, ty, tz;
+        if (sampled) {
+            BoneKeys k = bone_issue(p.sample, frame, p.bone_rec[4 * i + 2]);
+            bone_finish(p.sample, frame, k, q, tx, ty, tz);
+        } else uploaded(i, q, tx, ty, tz);
+        park(i, q, tx, ty, tz, r0, r1);
     }
     if (sampled)        // vertex-morph weights of this pose: consumed by the prep / deform kernels that follow (FUSED: by this very workgroup)
         for (int m = m_done + tid; m < p.sample.M; m += kBlock) {      // (morphs beyond the interleaved pass)
@@ -379,7 +488,7 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         }
     else if (bone_morphs && !FUSED)         // (FUSED: the caller has staged the uploaded weights already)
         for (int m = tid; m < p.bm_M; m += kBlock) lds_mw[m] = p.bm_w[(size_t)inst * p.bm_M + m];
-    RZ_FSTAMP(0);             // pose staged (sampled), before the barrier
+    RZ_FSTAMP(0);             // pose staged, before the barrier
     __syncthreads();
     RZ_FSTAMP(1);
     if (bone_morphs) {
@@ -404,98 +513,64 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         }
         __syncthreads();
     }
-    // Pass A, every bone in parallel: its LOCAL matrix L = T(bind + t) * R * T(add) (rows 0..2) into `wl`, its parent into
-    // the first ancestor buffer. The quaternion / append / slerp math is off the rounds' critical path.
-    for (int b = tid; b < p.B; b += kBlock) {
-        const float4 q = sq[b];
-        const uint4 rec = s_rec[b];
-        const float4 bind = s_bind[b];
-        float R[9];
-        quat_to_rows(q.x, q.y, q.z, q.w, R);
-        const int ap = (int)rec.y;
-        const float ratio_raw = __uint_as_float(rec.z);
-        float ax = 0.0f, ay = 0.0f, az = 0.0f;       // append-move: T(add) of L = T(bind) * R * T(add)
-        if (ap >= 0) {
-            const float ratio = fminf(1.0f, fmaxf(-1.0f, ratio_raw));
-            if (fabsf(ratio) > 1e-6f) {
-                if (lt && (rec.w & 1u)) {                // model.ts:388-393 uses the UNclamped ratio here
-                    ax = lt[ap * 3] * ratio_raw; ay = lt[ap * 3 + 1] * ratio_raw; az = lt[ap * 3 + 2] * ratio_raw;
-                }
-                float4 a = sq[ap];
-                const float t = fabsf(ratio);
-                if (ratio < 0.0f) { a.x = -a.x; a.y = -a.y; a.z = -a.z; }
-                const float4 sl = slerp_from_identity(a, t);
-                float A[9], X[9];
-                quat_to_rows(sl.x, sl.y, sl.z, sl.w, A);
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) X[i * 3 + j] = A[i * 3] * R[j] + A[i * 3 + 1] * R[3 + j] + A[i * 3 + 2] * R[6 + j];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) R[i] = X[i];
-            }
-        }
-        // translation column of L = T(bind + local) * R * T(add)  =  bind + local + R * add
-        float tx = bind.x, ty = bind.y, tz = bind.z;
-        if (lt) {
-            tx += lt[b * 3]; ty += lt[b * 3 + 1]; tz += lt[b * 3 + 2];
-            tx += R[0] * ax + R[1] * ay + R[2] * az;
-            ty += R[3] * ax + R[4] * ay + R[5] * az;
-            tz += R[6] * ax + R[7] * ay + R[8] * az;
-        }
-        wl[b * 3] = make_float4(R[0], R[1], R[2], tx);
-        wl[b * 3 + 1] = make_float4(R[3], R[4], R[5], ty);
-        wl[b * 3 + 2] = make_float4(R[6], R[7], R[8], tz);
-        s_anc[b] = (int)rec.x;
-    }
-    RZ_FSTAMP(2);             // local matrices formed
-    __syncthreads();          // (also: every read of region X is done, the rounds may write it)
-    // Doubling rounds. Round k reads (M, A) from one buffer pair and writes the other: M'[b] = M[A[b]] * M[b], A'[b] = A[A[b]];
-    // a bone whose run has reached its root (A < 0) is carried over unchanged. After ceil(log2(levels)) rounds every A is -1
-    // and M is the world matrix (roots: W = L from the start).
-    // A thread's first two bones (skeletons up to 512 bones: all of them) keep their matrix and their ancestor index in REGISTERS
-    // across the rounds: a round then reads only the ancestor's matrix and the ancestor's ancestor — both addressed by a value the
-    // thread already holds, so one LDS latency per round instead of two dependent ones — and writes its own for the others.
-    float4 *src = wl, *dst = m2;
-    int *asrc = s_anc, *adst = s_anc + p.B;
+    // Pass A, every bone in parallel: its LOCAL matrix L = T(bind + t) * R * T(add) (rows 0..2). The quaternion / append / slerp math
+    // is off the rounds' critical path. A thread's first two bones (skeletons up to 512 bones: all of them) keep their matrix in
+    // REGISTERS from here to the palette: a round reads only its ancestors' rows and writes its own for the others.
     constexpr int NBR = 2;
     float4 rm[NBR][3];
-    int ra[NBR];
+    auto local_of = [&](const int b, float4 &l0, float4 &l1, float4 &l2) {
+        const uint4 rec = s_rec[b];
+        const float4 bind = s_bind[b];
+        const int ap = (int)rec.y;
+        const float4 a = ap >= 0 ? sq[ap] : make_float4(0.f, 0.f, 0.f, 1.f);
+        float apx = 0.0f, apy = 0.0f, apz = 0.0f, ltx = 0.0f, lty = 0.0f, ltz = 0.0f;
+        if (has_t) {
+            ltx = s_lt[b * 3]; lty = s_lt[b * 3 + 1]; ltz = s_lt[b * 3 + 2];
+            if (ap >= 0 && (rec.w & 1u)) { apx = s_lt[ap * 3]; apy = s_lt[ap * 3 + 1]; apz = s_lt[ap * 3 + 2]; }
+        }
+        fk_local_matrix(sq[b], rec, bind.x, bind.y, bind.z, has_t, ltx, lty, ltz, a, apx, apy, apz, l0, l1, l2);
+    };
 #pragma unroll
     for (int k = 0; k < NBR; ++k) {
         const int b = tid + k * kBlock;
-        ra[k] = -1;
         rm[k][0] = rm[k][1] = rm[k][2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (b < p.B) { ra[k] = asrc[b]; rm[k][0] = src[b * 3]; rm[k][1] = src[b * 3 + 1]; rm[k][2] = src[b * 3 + 2]; }
+        if (b < p.B) {
+            local_of(b, rm[k][0], rm[k][1], rm[k][2]);
+            wl[b * 3] = rm[k][0]; wl[b * 3 + 1] = rm[k][1]; wl[b * 3 + 2] = rm[k][2];
+        }
     }
-    for (int span = 1; span < p.n_levels; span <<= 1) {
+    for (int b = tid + NBR * kBlock; b < p.B; b += kBlock) {
+        float4 l0, l1, l2;
+        local_of(b, l0, l1, l2);
+        wl[b * 3] = l0; wl[b * 3 + 1] = l1; wl[b * 3 + 2] = l2;
+    }
+    RZ_FSTAMP(2);             // local matrices formed
+    __syncthreads();          // (also: every read of region X is done, the rounds may write it)
+    // Doubling rounds (ping-pong between `wl` and region X). Rounds 0 and 1 take their ancestors from the bone record's w3; deeper
+    // hierarchies (> 16 levels) read the further rounds' tables from memory (p.anc_more: [rounds - 2][B] x (a1 | a2 << 16, a3)).
+    float4 *src = wl, *dst = m2;
+    for (int r = 0; r < p.n_rounds; ++r) {
 #pragma unroll
         for (int k = 0; k < NBR; ++k) {
             const int b = tid + k * kBlock;
             if (b < p.B) {
-                const int a = ra[k];
-                if (a >= 0) {
-                    ra[k] = asrc[a];
-                    affine_mul(src[a * 3], src[a * 3 + 1], src[a * 3 + 2], rm[k][0], rm[k][1], rm[k][2], rm[k][0], rm[k][1], rm[k][2]);
-                }
+                const uint4 w3 = k == 0 ? early.a3 : early.b3;
+                uint32_t lo = r == 0 ? w3.x : w3.z, hi = r == 0 ? w3.y : w3.w;
+                if (r >= 2) { const uint2 am = p.anc_more[(size_t)(r - 2) * p.B + b]; lo = am.x; hi = am.y; }
+                fk_round(src, lo & 0xffffu, lo >> 16, hi & 0xffffu, rm[k][0], rm[k][1], rm[k][2]);
                 dst[b * 3] = rm[k][0]; dst[b * 3 + 1] = rm[k][1]; dst[b * 3 + 2] = rm[k][2];
-                adst[b] = ra[k];
             }
         }
-        for (int b = tid + NBR * kBlock; b < p.B; b += kBlock) {       // bones beyond the register slots: through LDS, as before
-            const int a = asrc[b];
+        for (int b = tid + NBR * kBlock; b < p.B; b += kBlock) {       // bones beyond the register slots: through LDS
+            uint32_t lo, hi;
+            if (r < 2) { const uint4 w3 = p.bone_rec[4 * b + 3]; lo = r == 0 ? w3.x : w3.z; hi = r == 0 ? w3.y : w3.w; }
+            else { const uint2 am = p.anc_more[(size_t)(r - 2) * p.B + b]; lo = am.x; hi = am.y; }
             float4 w0 = src[b * 3], w1 = src[b * 3 + 1], w2 = src[b * 3 + 2];
-            int an = -1;
-            if (a >= 0) {
-                an = asrc[a];
-                affine_mul(src[a * 3], src[a * 3 + 1], src[a * 3 + 2], w0, w1, w2, w0, w1, w2);
-            }
+            fk_round(src, lo & 0xffffu, lo >> 16, hi & 0xffffu, w0, w1, w2);
             dst[b * 3] = w0; dst[b * 3 + 1] = w1; dst[b * 3 + 2] = w2;
-            adst[b] = an;
         }
         __syncthreads();
         float4 *t4 = src; src = dst; dst = t4;
-        int *ti = asrc; asrc = adst; adst = ti;
     }
     RZ_FSTAMP(3);             // doubling rounds done
     if (p.ovr_off) {
@@ -511,37 +586,34 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const int inst, fl
         __syncthreads();
     }
     // all rounds done: one parallel pass writes the world matrices and the palette
-    for (int b = tid; b < p.B; b += kBlock) {
-        const float4 w0 = src[b * 3], w1 = src[b * 3 + 1], w2 = src[b * 3 + 2];
-        const float W[12] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w };
+    auto emit = [&](const int b, const float4 w0, const float4 w1, const float4 w2, const bool mine) {
         // world, column-major 4x4 (what queue.writeBuffer(worldMatrixBuffer) would have carried)
         if (to_global) {
             float4 *wo = reinterpret_cast<float4 *>(world + (size_t)b * 16);
-            wo[0] = make_float4(W[0], W[4], W[8], 0.0f);
-            wo[1] = make_float4(W[1], W[5], W[9], 0.0f);
-            wo[2] = make_float4(W[2], W[6], W[10], 0.0f);
-            wo[3] = make_float4(W[3], W[7], W[11], 1.0f);
+            wo[0] = make_float4(w0.x, w1.x, w2.x, 0.0f);
+            wo[1] = make_float4(w0.y, w1.y, w2.y, 0.0f);
+            wo[2] = make_float4(w0.z, w1.z, w2.z, 0.0f);
+            wo[3] = make_float4(w0.w, w1.w, w2.w, 1.0f);
         }
-        // palette rows 0..2 of W * IB (IB general 4x4, column-major)
         const float4 *Im = reinterpret_cast<const float4 *>(p.inv_bind + (size_t)b * 16);
-        const bool mine = b == tid;
-        const float4 ibm[4] = { mine ? pib0 : Im[0], mine ? pib1 : Im[1], mine ? pib2 : Im[2], mine ? pib3 : Im[3] };
-        float r[3][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 bc = ibm[c];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                r[i][c] = fmaf(W[i * 4 + 3], bc.w, fmaf(W[i * 4 + 2], bc.z, fmaf(W[i * 4 + 1], bc.y, W[i * 4] * bc.x)));
-        }
-        const float4 q0 = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]), q1 = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]),
-                     q2 = make_float4(r[2][0], r[2][1], r[2][2], r[2][3]);
+        float4 q0, q1, q2;
+        fk_palette_rows(w0, w1, w2, mine ? pib0 : Im[0], mine ? pib1 : Im[1], mine ? pib2 : Im[2], mine ? pib3 : Im[3], q0, q1, q2);
         if (to_global) { pal[b * 3] = q0; pal[b * 3 + 1] = q1; pal[b * 3 + 2] = q2; }
         if (FUSED) { wl[b * 3] = q0; wl[b * 3 + 1] = q1; wl[b * 3 + 2] = q2; }     // bone b's rows (in wl or in the other buffer) are only ever read by this thread in this pass
+    };
+    if (!p.ovr_off) {                   // (overrides land in LDS: the registers are only good without them; workgroup-uniform)
+#pragma unroll
+        for (int k = 0; k < NBR; ++k)
+            if (tid + k * kBlock < p.B) emit(tid + k * kBlock, rm[k][0], rm[k][1], rm[k][2], k == 0);
+        for (int b = tid + NBR * kBlock; b < p.B; b += kBlock) emit(b, src[b * 3], src[b * 3 + 1], src[b * 3 + 2], false);
+    } else {
+        for (int b = tid; b < p.B; b += kBlock) emit(b, src[b * 3], src[b * 3 + 1], src[b * 3 + 2], b == tid);
     }
     RZ_FSTAMP(4);             // palette rows written
     if (FUSED) __syncthreads();
 #undef RZ_FSTAMP
 }
+
+#pragma clang fp contract(fast)
 
 }  // namespace

@@ -40,13 +40,15 @@ __global__ void __launch_bounds__(kBlock) rz_prep_kernel(RzPrepParams p)
     }
 }
 
-__global__ void __launch_bounds__(kBlock) rz_fk_kernel(RzFkParams p)
+// One workgroup per pose. The leading arguments are preloaded into SGPRs (kernels/deform_parts.hip.h): the static block and the two
+// counts a thread needs to ask for its records before `p` has arrived.
+__global__ void __launch_bounds__(kBlock) rz_fk_kernel(const uint4 *k_rec, const uint32_t k_B, const uint32_t k_M, const RzFkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FkEarly early = fk_issue_static(k_rec, (int)k_B, (int)k_M, (int)threadIdx.x);
     unsigned char *scr = smem + (size_t)p.B * 48;
-    fk_solve<false>(p, (int)blockIdx.x, reinterpret_cast<float4 *>(smem), scr, reinterpret_cast<float *>(scr + rz_fk_scratch_bytes(p.B)), true);
+    fk_solve<false>(p, early, (int)blockIdx.x, reinterpret_cast<float4 *>(smem), scr, reinterpret_cast<float *>(scr + rz_fk_scratch_bytes(p.B)), true);
 }
-
 
 #ifdef RZ_ALL_VARIANTS
 
@@ -111,12 +113,12 @@ size_t rz_fk_lds_bytes(const RzFkParams &p)
 hipError_t rz_launch_fk(const RzFkParams &p, uint32_t instances, hipStream_t st)
 {
     const size_t lds = rz_fk_lds_bytes(p);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;      // (the host checks first and says why: launch_fk in reze_deform.cpp)
+    if (lds > 160 * 1024) return hipErrorInvalidValue;      // (the host checks first and says why: launch_fk in frame.cpp)
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rz_fk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(rz_fk_kernel, dim3(instances), dim3(kBlock), lds, st, p);
+    hipLaunchKernelGGL(rz_fk_kernel, dim3(instances), dim3(kBlock), lds, st, p.bone_rec, (uint32_t)p.B, (uint32_t)p.sample.M, p);
     return hipGetLastError();
 }
 

@@ -84,6 +84,7 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     p.out_cap = pl.out_cap;
     p.sp_cap = pl.sp_cap;
     if (pl.subsets) { p.rj01 = c->rj01; p.rj23 = c->rj23; p.sub_list = c->sub_list; p.sub_count = c->sub_count; p.sub_stride = (int)c->sub_B; }
+    if (pl.subfk) p.fk = fk_params(c);          // (the crowd kernel's front reads the pose, the motion and the bone records through it)
     if (pl.fuse_fk) {
         p.fk = fk_params(c); p.fk_on = 1;
         if (c->zc_cur >= 0 && c->zc_local && !c->pose_sampled && (!c->local_resident || !c->mw_resident)) {
@@ -128,6 +129,8 @@ bool inst_shape(const rz_ctx *c, InstShape *s)
     inst_runs(c, s->G, s->blk, c->t_subsets != 0, &s->per, &s->runs);
     return true;
 }
+
+bool subfk_wanted(const rz_ctx *c);
 
 Plan make_plan(const rz_ctx *c)
 {
@@ -250,6 +253,14 @@ Plan make_plan(const rz_ctx *c)
                 pl.subsets = true; pl.sub_bones = c->sub_max; pl.inst_lds = lds;
                 pl.inst_group = is.G; pl.inst_block = blk; pl.verts_per_wg = is.per; pl.grid_x = is.runs;
                 pl.prep = !is.want_in_kernel; pl.dma = !is.want_in_kernel;
+                // device-animated poses: the hierarchy solved in the front of the skin kernel — one launch per frame — when the closure
+                // records of these very lists are there, a workgroup's (pose, closure bone) items fit two per thread, and the two matrix
+                // buffers + the palettes fit the LDS budget; else rz_fk_kernel in front, as before
+                if (subfk_wanted(c) && c->subfk_valid && c->subfk_sub_gen == c->sub_gen && c->subfk_fk_gen == c->fk_gen &&
+                    (size_t)is.G * c->subfk_stride <= 2 * (size_t)blk) {
+                    const size_t lf = rz_skin_instances_fk_lds_bytes(is.G, c->subfk_stride, c->sub_max);
+                    if (lf <= lds_budget) { pl.subfk = true; pl.prep = false; pl.dma = false; pl.inst_lds = lf; }
+                }
             }
         }
         if (!sub) {
@@ -316,13 +327,116 @@ int ensure_run_subsets(rz_ctx *c)
     for (uint32_t n : counts) mx = std::max(mx, n);
     c->sub_per = is.per; c->sub_runs = is.runs; c->sub_B = c->B; c->sub_max = mx;
     c->sub_valid = true;
+    c->sub_gen++;
     return RZ_OK;
 }
 
 // Plan of the next frame: the run lists first (the plan only takes the subset form when they match its shape).
+// Can the next crowd frame solve its hierarchy in the skin kernel's front? A device-animated crowd in the bone-subset form, nothing
+// acting on the solved pose between the solve and the palette (bone morphs fold weights in, physics overrides replace world matrices:
+// both stay with rz_fk_kernel), "fuse_fk" not switched off.
+bool subfk_wanted(const rz_ctx *c)
+{
+    return c->I > 1 && c->pose_local && c->has_topology && c->t_fusefk != 0 && c->t_subsets != 0 && c->sub_valid && c->sub_max < c->B &&
+           !(c->bm_count && c->M) && c->ovr_count == 0 && c->fk_host.size() == (size_t)c->B * 4;
+}
+
+// The closure records of the current run lists (see ctx.h). Host work + one readback of the lists, only when the lists or the
+// hierarchy's static data changed — never per frame.
+int ensure_subfk(rz_ctx *c)
+{
+    if (!subfk_wanted(c)) return RZ_OK;
+    if (c->subfk_sub_gen == c->sub_gen && c->subfk_fk_gen == c->fk_gen) return RZ_OK;      // built, or found unfit, for exactly these lists and this hierarchy
+    c->subfk_valid = false;
+    c->subfk_sub_gen = c->sub_gen; c->subfk_fk_gen = c->fk_gen;         // (also remembers a refusal: no retry per frame)
+    const uint32_t runs = c->sub_runs, B = c->B;
+    std::vector<uint16_t> lists((size_t)runs * B);
+    std::vector<uint32_t> counts(runs);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    HIP_TRY(hipMemcpy(lists.data(), c->sub_list, lists.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(counts.data(), c->sub_count, (size_t)runs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const bool motion = c->has_animation && c->an_host_range.size() == B;
+    auto parent = [&](uint32_t b) { return (int32_t)c->fk_host[4 * (size_t)b].x; };
+    std::vector<std::vector<uint32_t>> closures(runs);
+    std::vector<uint32_t> depth(B, 0);
+    uint32_t stride = 0, max_depth = 0;
+    std::vector<uint8_t> in(B);
+    for (uint32_t r = 0; r < runs; ++r) {
+        std::fill(in.begin(), in.end(), 0);
+        for (uint32_t k = 0; k < counts[r]; ++k)
+            for (int32_t b = lists[(size_t)r * B + k]; b >= 0 && !in[b]; b = parent((uint32_t)b)) in[b] = 1;
+        for (uint32_t b = 0; b < B; ++b)
+            if (in[b]) closures[r].push_back(b);
+        stride = std::max<uint32_t>(stride, (uint32_t)closures[r].size());
+        for (uint32_t b : closures[r]) {
+            uint32_t d = 0;
+            for (int32_t a = parent(b); a >= 0; a = parent((uint32_t)a)) ++d;
+            depth[b] = d; max_depth = std::max(max_depth, d);
+        }
+    }
+    uint32_t rounds = 0;
+    for (uint32_t span = 1; span < max_depth + 1; span *= 4) ++rounds;
+    if (rounds > 3 || stride > 0xfffu || stride == 0) return RZ_OK;      // deeper than 64 levels / wider than the record stride field: rz_fk_kernel keeps these
+    std::vector<uint4> rec((size_t)runs * stride * 5, make_uint4(0u, 0u, 0u, 0u));
+    std::vector<uint32_t> ccount(runs);
+    std::vector<uint32_t> slot(B), pslot(B);
+    for (uint32_t r = 0; r < runs; ++r) {
+        const std::vector<uint32_t> &cl = closures[r];
+        ccount[r] = (uint32_t)cl.size();
+        std::fill(pslot.begin(), pslot.end(), 0xffffu);
+        for (uint32_t k = 0; k < counts[r]; ++k) pslot[lists[(size_t)r * B + k]] = k;       // the run lists are ascending: k is the slot the joints were rewritten to
+        for (uint32_t k = 0; k < cl.size(); ++k) slot[cl[k]] = k;
+        auto anc_slot = [&](uint32_t b, uint32_t d) -> uint32_t {
+            int32_t cur = (int32_t)b;
+            for (uint32_t k = 0; k < d && cur >= 0; ++k) cur = parent((uint32_t)cur);
+            return cur < 0 ? 0xffffu : slot[(uint32_t)cur];
+        };
+        for (uint32_t k = 0; k < cl.size(); ++k) {
+            const uint32_t b = cl[k];
+            uint4 *w = &rec[((size_t)r * stride + k) * 5];
+            const uint4 t = c->fk_host[4 * (size_t)b], bind = c->fk_host[4 * (size_t)b + 1];
+            w[0] = make_uint4(b | (pslot[b] << 16), t.y, t.z, t.w);
+            w[1] = bind;
+            uint32_t a[3][2] = { { 0xffffffffu, 0xffffu }, { 0xffffffffu, 0xffffu }, { 0xffffffffu, 0xffffu } };
+            uint32_t span = 1;
+            for (uint32_t q = 0; q < rounds; ++q, span *= 4) {
+                a[q][0] = anc_slot(b, span) | (anc_slot(b, 2 * span) << 16);
+                a[q][1] = anc_slot(b, 3 * span);
+            }
+            w[2] = make_uint4(a[0][0], a[0][1], a[1][0], a[1][1]);
+            w[3] = make_uint4(a[2][0], a[2][1], 0u, 0u);
+            w[4] = motion ? c->an_host_range[b] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    if (rec.size() > c->subfk_rec_alloc) {
+        dfree(c->subfk_rec);
+        HIP_TRY(hipMalloc(&c->subfk_rec, rec.size() * sizeof(uint4)));
+        c->subfk_rec_alloc = rec.size();
+    }
+    if (runs > c->subfk_count_alloc) {
+        dfree(c->subfk_count);
+        HIP_TRY(hipMalloc(&c->subfk_count, (size_t)runs * sizeof(uint32_t)));
+        c->subfk_count_alloc = runs;
+    }
+    HIP_TRY(hipMemcpy(c->subfk_rec, rec.data(), rec.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->subfk_count, ccount.data(), (size_t)runs * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->subfk_stride = stride; c->subfk_rounds = rounds;
+    c->subfk_valid = true;
+    return RZ_OK;
+}
+
+RzSubFk subfk_params(const rz_ctx *c)
+{
+    RzSubFk f;
+    f.count = c->subfk_count; f.rec = c->subfk_rec; f.stride = c->subfk_stride; f.rounds = c->subfk_rounds;
+    return f;
+}
+
 int frame_plan(rz_ctx *c, Plan *pl)
 {
     if (int r = ensure_run_subsets(c)) return r;
+    if (int r = ensure_subfk(c)) return r;
     *pl = make_plan(c);
     return RZ_OK;
 }
@@ -343,8 +457,8 @@ RzFkParams fk_params(const rz_ctx *c)
     memset(&p, 0, sizeof p);            // padding too: frame_signature() hashes the struct
     p.local_q = src_local_q(c);
     p.local_t = c->pose_local_t ? reinterpret_cast<const float *>(p.local_q + (size_t)c->I * c->B) : nullptr;
-    p.bone_rec = c->fk_rec; p.inv_bind = c->inv_bind;
-    p.world = c->world; p.palette = c->palette; p.B = (int)c->B; p.n_levels = c->fk_levels;
+    p.bone_rec = c->fk_rec; p.anc_more = c->fk_anc_more; p.inv_bind = c->inv_bind;
+    p.world = c->world; p.palette = c->palette; p.B = (int)c->B; p.n_rounds = c->fk_rounds;
     if (c->ovr_count) { p.ovr_off = c->ovr_off; p.ovr_bone = c->ovr_bone; p.ovr_world = c->ovr_world; }
     if (c->bm_count && c->M) {
         p.bm_off = c->bm_off; p.bm_morph = c->bm_morph; p.bm_rot = c->bm_rot; p.bm_tr = c->bm_tr;
@@ -353,7 +467,7 @@ RzFkParams fk_params(const rz_ctx *c)
     if (c->pose_sampled) {
         RzSampleParams &q = p.sample;
         q.frames = c->frames_inline ? nullptr : c->an_frames; q.frames_inline = c->frames_inline ? 1 : 0; q.frame0 = c->frame0;
-        q.bone_range = c->an_bone_range; q.key_frame = c->an_key_frame;
+        q.key_frame = c->an_key_frame;
         q.key_rot = c->an_key_rot; q.key_pos = c->an_key_pos; q.key_interp = c->an_key_interp;
         q.mkey_frame = c->an_mkey_frame; q.mkey_weight = c->an_mkey_weight;
         q.feed_off = c->an_feed_off; q.feed_range = c->an_feed_range; q.feed_ratio = c->an_feed_ratio;

@@ -395,6 +395,9 @@ int rz_read_world(rz_ctx *c, uint32_t instance, float *world16)
         memcpy(world16, c->zc_host[c->zc_cur], (size_t)c->B * 16 * sizeof(float));
         return RZ_OK;
     }
+    if (c->fk_stale) {                                  // a crowd frame that solved its hierarchy in LDS only: the solve as a kernel of its own, now
+        if (int r = launch_fk(c, c->stream)) return r;
+    }
     HIP_TRY(hipStreamSynchronize(c->up_stream));        // rz_fk_kernel may have written them on the front stream
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(world16, c->world + (size_t)instance * c->B * 16, (size_t)c->B * 16 * sizeof(float), hipMemcpyDeviceToHost));

@@ -229,7 +229,10 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
         // what the NEXT frame will launch: a crowd's plan depends on the run lists of its launch shape, so bring them up to
         // date first (as every entry point that launches frames does) instead of describing the whole-palette fallback
         if (int r = use(c)) return r;
-        if (c->V && c->B) if (int r = ensure_run_subsets(c)) return r;
+        if (c->V && c->B) {
+            if (int r = ensure_run_subsets(c)) return r;
+            if (int r = ensure_subfk(c)) return r;
+        }
     }
     if (!strcmp(key, "morph_split")) *value = c->t_split;
     else if (!strcmp(key, "unroll")) *value = c->t_unroll;
@@ -246,7 +249,7 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "effective_nt")) *value = make_plan(c).v.nt && c->morph_mode == 1 ? 1 : 0;
     else if (!strcmp(key, "effective_nt_store")) *value = make_plan(c).v.nts ? 1 : 0;
     else if (!strcmp(key, "effective_geo")) *value = make_plan(c).v.geo ? 1 : 0;
-    else if (!strcmp(key, "effective_prep")) { const Plan pl = make_plan(c); *value = ((pl.prep || c->pose_local) && !pl.fuse_fk) ? 1 : 0; }
+    else if (!strcmp(key, "effective_prep")) { const Plan pl = make_plan(c); *value = ((pl.prep || c->pose_local) && !pl.fuse_fk && !pl.subfk) ? 1 : 0; }
     else if (!strcmp(key, "effective_split")) *value = make_plan(c).v.S;
     else if (!strcmp(key, "effective_unroll")) *value = make_plan(c).v.U;
     else if (!strcmp(key, "effective_fast")) *value = make_plan(c).v.fast ? 1 : 0;
@@ -256,7 +259,8 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "overlap")) *value = c->t_overlap;
     else if (!strcmp(key, "zero_copy")) *value = c->t_zerocopy;
     else if (!strcmp(key, "fuse_fk")) *value = c->t_fusefk;
-    else if (!strcmp(key, "effective_fuse_fk")) *value = make_plan(c).fuse_fk ? 1 : 0;
+    else if (!strcmp(key, "effective_fuse_fk")) { const Plan pl = make_plan(c); *value = (pl.fuse_fk || pl.subfk) ? 1 : 0; }
+    else if (!strcmp(key, "effective_closure_bones")) *value = make_plan(c).subfk ? (int)c->subfk_stride : 0;
     else if (!strcmp(key, "pose_resident")) *value = (c->zc_cur < 0 || (c->world_resident && c->mw_resident && c->local_resident)) ? 1 : 0;
     else if (!strcmp(key, "effective_overlap")) *value = want_overlap(c, make_plan(c)) ? 1 : 0;
     else if (!strcmp(key, "effective_inst_block")) *value = make_plan(c).inst_block;
@@ -279,6 +283,14 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
             HIP_TRY(hipMemcpy(tags, c->zc_tag, sizeof tags, hipMemcpyDeviceToHost));
             *value = tags[c->pose_slot] == c->zc_seq_cur ? 1 : 0;
         }
+    }
+    else if (!strncmp(key, "addr_", 5)) {
+        // diagnostics (tools/placement.py): where the allocator put a buffer — bits [12, 43) of its device address, i.e. the address in
+        // 4 KB pages (where a buffer lands relative to the 2 MB large-page frame moves the C5 frame by 3 %: NOTEBOOK.md R5.3)
+        const void *ptr = !strcmp(key, "addr_dense") ? (const void *)c->dense : !strcmp(key, "addr_out") ? (const void *)c->out_pos :
+                          !strcmp(key, "addr_nrm") ? (const void *)c->out_nrm : !strcmp(key, "addr_geom") ? (const void *)c->geom : nullptr;
+        if (!ptr && strcmp(key, "addr_dense") && strcmp(key, "addr_out") && strcmp(key, "addr_nrm") && strcmp(key, "addr_geom")) return fail(RZ_ERR_INVALID, "unknown tuning key '%s'", key);
+        *value = (int)(((uintptr_t)ptr >> 12) & 0x7fffffffu);
     }
     else if (!strcmp(key, "effective_subsets")) *value = make_plan(c).subsets ? 1 : 0;
     else if (!strcmp(key, "effective_subset_bones")) *value = (int)make_plan(c).sub_bones;

@@ -3,6 +3,28 @@
 
 using namespace rzi;
 
+namespace rzi {
+
+// The device block behind fk_rec: the bone records with the CURRENT motion's tracks filled in, then the motion's vertex-morph records.
+// Called when either side changes (the caller has drained the stream); a context without a topology has no block.
+int rebuild_fk_static(rz_ctx *c)
+{
+    if (!c->has_topology || c->fk_host.size() != (size_t)c->B * 4) return RZ_OK;
+    const bool motion = c->has_animation && c->an_host_range.size() == c->B;
+    const size_t nm = motion ? c->an_host_mrec.size() / 2 : 0;
+    std::vector<uint4> blk(c->fk_host);
+    blk.resize((size_t)c->B * 4 + nm * 2);
+    for (uint32_t b = 0; b < c->B; ++b) blk[4 * (size_t)b + 2] = motion ? c->an_host_range[b] : make_uint4(0u, 0u, 0u, 0u);
+    for (size_t k = 0; k < nm * 2; ++k) blk[(size_t)c->B * 4 + k] = c->an_host_mrec[k];
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    dfree(c->fk_rec);
+    c->fk_gen++;                        // (the closure records of crowd frames carry copies of these: plan.cpp ensure_subfk)
+    return to_device(&c->fk_rec, blk.data(), blk.size());
+}
+
+}  // namespace rzi
+
 namespace {
 
 int upload_skinning(rz_ctx *c, uint32_t V, const uint16_t *joints4, const uint8_t *weights4)
@@ -140,7 +162,14 @@ int rz_upload_morphs_dense(rz_ctx *c, uint32_t M, const float *deltas)
     if (M == 0) return ensure_pose_buffers(c);
     if (!deltas) return fail(RZ_ERR_INVALID, "null morph deltas");
     const size_t Vp = c->Vp, V = c->V;
-    HIP_TRY(hipMalloc(&c->dense, (size_t)M * 3 * Vp * sizeof(float)));
+    size_t dense_off = 0;
+#ifdef RZ_ALL_VARIANTS
+    // tools-only build: place the morph planes `RZ_DENSE_OFFSET` bytes into a larger allocation (tools/placement.py: how much of the C5
+    // frame's box-to-box spread is WHERE the 768 MB land). The offset is lost on free: hipFree gets the shifted pointer — leak, tools only.
+    if (const char *e = getenv("RZ_DENSE_OFFSET")) dense_off = (size_t)strtoull(e, nullptr, 0) / 256 * 256;
+#endif
+    HIP_TRY(hipMalloc(&c->dense, (size_t)M * 3 * Vp * sizeof(float) + dense_off));
+    c->dense += dense_off / sizeof(float);
     if (Vp != V) HIP_TRY(hipMemsetAsync(c->dense, 0, (size_t)M * 3 * Vp * sizeof(float), c->stream));
     // stream the host array through a bounded device staging buffer, re-laying each morph into planes
     const uint32_t batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(M, (64u << 20) / (V * 12)));
@@ -251,25 +280,44 @@ int rz_upload_skeleton_topology(rz_ctx *c, uint32_t B, const int32_t *parents, c
     }
     int n_levels = 0;
     for (uint32_t b = 0; b < B; ++b) n_levels = std::max(n_levels, level[b] + 1);
-    // one 32-byte record per bone: (parent, append parent, bits(append ratio), flags) (bits(bind x y z), 0)
-    std::vector<uint4> rec((size_t)B * 2);
+    // ancestors by level: up[b][d] for d = 1, 2, ... (parents may come in any order)
+    auto ancestor = [&](uint32_t b, uint32_t d) -> uint32_t {
+        int32_t cur = (int32_t)b;
+        for (uint32_t k = 0; k < d && cur >= 0; ++k) cur = parents[cur];
+        return cur < 0 ? 0xffffu : (uint32_t)cur;
+    };
+    int n_rounds = 0;
+    for (int span = 1; span < n_levels; span *= 4) ++n_rounds;          // radix-4 pointer doubling: ceil(log4(depth)) rounds
+    // 64-byte bone records (kernels/fk.hip.h): topology | bind translation | the motion's track (rebuild_fk_static) | ancestors of rounds 0, 1
+    std::vector<uint4> rec((size_t)B * 4);
+    std::vector<uint2> more((size_t)std::max(0, n_rounds - 2) * B);
     for (uint32_t b = 0; b < B; ++b) {
         const int32_t ap = (append_parent && append_parent[b] >= 0 && append_parent[b] < (int32_t)B) ? append_parent[b] : -1;
         const float ratio = append_ratio ? append_ratio[b] : 1.0f;
         uint32_t rb, bx, by, bz;
         memcpy(&rb, &ratio, 4);
         memcpy(&bx, bind_translation3 + (size_t)b * 3, 4); memcpy(&by, bind_translation3 + (size_t)b * 3 + 1, 4); memcpy(&bz, bind_translation3 + (size_t)b * 3 + 2, 4);
-        rec[2 * b] = make_uint4((uint32_t)(parents[b] < 0 ? -1 : parents[b]), (uint32_t)ap, rb, (append_move && append_move[b]) ? 1u : 0u);
-        rec[2 * b + 1] = make_uint4(bx, by, bz, 0u);
+        rec[4 * b] = make_uint4((uint32_t)(parents[b] < 0 ? -1 : parents[b]), (uint32_t)ap, rb, (append_move && append_move[b]) ? 1u : 0u);
+        rec[4 * b + 1] = make_uint4(bx, by, bz, 0u);
+        rec[4 * b + 2] = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t span = 1, w[4] = { 0xffffffffu, 0xffffu, 0xffffffffu, 0xffffu };
+        for (int r = 0; r < n_rounds; ++r, span *= 4) {
+            const uint32_t a1 = ancestor(b, span), a2 = ancestor(b, 2 * span), a3 = ancestor(b, 3 * span);
+            if (r < 2) { w[2 * r] = a1 | (a2 << 16); w[2 * r + 1] = a3; }
+            else more[(size_t)(r - 2) * B + b] = make_uint2(a1 | (a2 << 16), a3);
+        }
+        rec[4 * b + 3] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     drop_graph(c);
     c->ovr_count = 0;
-    dfree(c->fk_rec);
-    if (int r = to_device(&c->fk_rec, rec.data(), rec.size())) return r;
-    c->fk_levels = n_levels;
+    dfree(c->fk_anc_more);
+    if (!more.empty())
+        if (int r = to_device(&c->fk_anc_more, more.data(), more.size())) return r;
+    c->fk_host = std::move(rec);
+    c->fk_rounds = n_rounds;
     c->has_topology = true;
-    return RZ_OK;
+    return rebuild_fk_static(c);
 }
 
 int rz_upload_bone_morphs(rz_ctx *c, uint32_t n, const uint32_t *morph, const uint32_t *bone, const float *translation3, const float *rotation4)
@@ -370,7 +418,6 @@ int rz_upload_animation(rz_ctx *c, const rz_animation *a)
     };
     for (uint32_t b = 0; b < c->B; ++b) bone_range[b] = record(a->key_off, a->key_frame, bone_track[b]);
     for (uint32_t f = 0; f < F; ++f) feed_range[f] = record(a->mkey_off, a->mkey_frame, a->feed_track[f]);
-    if (int r = to_device(&c->an_bone_range, bone_range.data(), c->B)) return r;
     if (int r = to_device(&c->an_key_frame, a->key_frame, K)) return r;
     if (int r = to_device(&c->an_key_rot, a->key_rot4, K)) return r;
     if (int r = to_device(&c->an_key_pos, a->key_pos3, (size_t)K * 3)) return r;
@@ -381,9 +428,22 @@ int rz_upload_animation(rz_ctx *c, const rz_animation *a)
     if (int r = to_device(&c->an_feed_off, feed_off.data(), (size_t)c->M + 1)) return r;
     if (int r = to_device(&c->an_feed_range, feed_range.data(), F)) return r;
     if (int r = to_device(&c->an_feed_ratio, a->feed_ratio, F)) return r;
+    // per vertex morph: the key range of its FIRST feed and (first feed, end of feeds, bits(its ratio)) — the sampler's one record per morph
+    std::vector<uint4> mrec((size_t)c->M * 2, make_uint4(0u, 0u, 0u, 0u));
+    for (uint32_t m = 0; m < c->M && F; ++m) {
+        const uint32_t f0 = feed_off[m], f1 = feed_off[m + 1];
+        if (f1 > f0) {
+            uint32_t rb;
+            memcpy(&rb, &a->feed_ratio[f0], 4);
+            mrec[2 * m] = feed_range[f0];
+            mrec[2 * m + 1] = make_uint4(f0, f1, rb, 0u);
+        }
+    }
+    c->an_host_range = std::move(bone_range);
+    c->an_host_mrec = std::move(mrec);
     c->an_M = c->M;
     c->has_animation = true;
-    return RZ_OK;
+    return rebuild_fk_static(c);
 }
 
 int rz_upload_edge_scale(rz_ctx *c, uint32_t V, const float *edge_size)

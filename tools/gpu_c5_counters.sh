@@ -17,7 +17,7 @@ for d in sorted(glob.glob('gpurun_out/c5cnt/*_g*/')):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(d + 'p_counter_collection.csv')):
         k = r['Kernel_Name']
-        if 'rz_deform_kernel' in k: agg[k.split('::')[-1].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
+        if 'rz_deform_' in k: agg[k.split('::')[-1].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in agg.items():
         print(os.path.basename(d.rstrip('/')), k, " ".join("%s=%.0f" % (c, sum(x) / len(x)) for c, x in sorted(v.items())), "n=%d" % len(next(iter(v.values()))))
 P

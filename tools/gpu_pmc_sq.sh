@@ -25,7 +25,7 @@ for d in sorted(glob.glob('gpurun_out/sq/*_g*/')):
     if not f: print(d, 'no csv'); continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        if 'rz_deform_kernel' in r['Kernel_Name']:
+        if 'rz_deform_' in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     print(os.path.basename(d.rstrip('/')), {k: round(sum(v) / len(v), 1) for k, v in agg.items()})
 P

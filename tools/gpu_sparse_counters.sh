@@ -25,7 +25,7 @@ for d in sorted(glob.glob('gpurun_out/spcnt/*_g*/')):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f[0])):
         k = r['Kernel_Name']
-        if 'rz_deform_kernel' not in k: continue
+        if 'rz_deform_' not in k: continue
         k = k.split('::')[-1].split('(')[0]
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in agg.items():

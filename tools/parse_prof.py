@@ -38,7 +38,7 @@ def counters(path):
 def dominant(agg, counter):
     best = None
     for k, d in agg.items():
-        if ("rz_deform_kernel" in k or "rz_skin_instances" in k) and counter in d:
+        if ("rz_deform_" in k or "rz_skin_instances" in k) and counter in d:
             if best is None or d[counter][1] > agg[best][counter][1]:
                 best = k
     return best
@@ -67,7 +67,7 @@ def stats_table(path, title, out, trace=None):
             shapes = collections.defaultdict(list)
             for r in csv.DictReader(open(trace)):
                 k = r["Kernel_Name"]
-                if "rz_deform_kernel" not in k and "rz_skin_instances" not in k:
+                if "rz_deform_" not in k and "rz_skin_instances" not in k:
                     continue
                 wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
                 grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(wg, 1)
@@ -105,13 +105,15 @@ for name, (title, V, B, M, I) in WORK.items():
     # (the launch-shape search tries several; bench.py looks up the one its plan ends up with, and only that one)
     shape = "V%d_B%d_M%d_I%d%s" % (V, B, M, I, "_demo" if name == "demo" else "")
     for kf in sorted(fe):
-        if not ("rz_deform_kernel" in kf or "rz_skin_instances" in kf) or "FETCH_SIZE" not in fe[kf] or kf not in wr or "WRITE_SIZE" not in wr[kf]:
+        if not ("rz_deform_" in kf or "rz_skin_instances" in kf) or "FETCH_SIZE" not in fe[kf] or kf not in wr or "WRITE_SIZE" not in wr[kf]:
             continue
         if fe[kf]["FETCH_SIZE"][1] < 30:
             continue
         fetch_kib, write_kib = fe[kf]["FETCH_SIZE"][0], wr[kf]["WRITE_SIZE"][0]
         kname = kf.replace("void (anonymous namespace)::", "").split("(")[0]
-        nts = "true" in kname.split("<")[1].split(",")[4] if "rz_deform_kernel" in kname else ("true" in kname.split("<")[1].split(",")[1])
+        targs = kname.split("<")[1].split(",")
+        # position of NTS (nontemporal output stores) in the template list: dense <S, U, NT, NTS, ...>, small <S, MODE, NTS, ...>, crowd <BLOCK, NTS, ...>
+        nts = "true" in targs[3 if "rz_deform_dense" in kname else (2 if "rz_deform_small" in kname else 1)]
         read_b = fetch_kib * 1024 * f_read
         write_b = write_kib * 1024 * (f_write3 if nts else f_write3_plain)
         if I > 1:

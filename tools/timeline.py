@@ -2,7 +2,7 @@
 Every wave stamps the chip-wide 100 MHz counter (10 ns steps) at: 0 entry, 1 prologue done, 2 first step's morph phase done,
 3 palette published, 4 first step's skin phase issued, 5 last step done, 6 all stores acknowledged (crowd kernel: 0 entry,
 1 staged matrices landed, 2 palettes published, 3 first vertex step done, 5 last step issued, 6 stores acknowledged).
-usage: python tools/timeline.py <config> [key=value ...]     config: c2 c3 demo sparse2 shard c5 c4 | sampled-c2 sampled-demo local-c2"""
+usage: python tools/timeline.py <config> [key=value ...]     config: c2 c3 demo sparse2 shard c5 c4 | sampled-c2 sampled-demo local-c2 local-c4 sampled-c4"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -49,10 +49,10 @@ if anim:
                          feed_off=np.arange(M + 1), feed_track=np.arange(M), feed_ratio=np.ones(M, np.float32))
         ctx.upload_animation(np.arange(B), np.arange(B + 1) * nk, np.tile(np.arange(nk) * 10.0, B), kq, (rng.random((B, nk, 3), dtype=np.float32) - 0.5) * 0.2,
                              np.tile(np.array([20] * 8 + [107] * 8, np.uint8), B * nk), **extra)
-        ctx.set_pose_sampled(np.array([13.5], np.float32))
+        ctx.set_pose_sampled((13.5 + 0.37 * np.arange(I)).astype(np.float32) % 70.0)
     else:
-        q = rng.normal(size=(B, 4)).astype(np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
-        ctx.set_pose_local(q, None, mw)
+        q = rng.normal(size=(I, B, 4)).astype(np.float32); q /= np.linalg.norm(q, axis=2, keepdims=True)
+        ctx.set_pose_local(q if I > 1 else q[0], None, mw)
 else:
     ctx.set_pose(world, mw)
 for _ in range(5):
