@@ -77,6 +77,7 @@ def parse_args():
                          "(small frames: shards at N >= 4, single characters); the C5 frame at N = 1 stays on one stream")
     ap.add_argument("--no-pair-loop", action="store_true", help="skip the secondary loop with two frames in flight")
     ap.add_argument("--no-sampled-loop", action="store_true", help="skip the secondary per-frame loop with the motion sampled on the GPU")
+    ap.add_argument("--no-numa-bind", action="store_true", help="leave the process where the launcher put it instead of binding it to the cores of its GPU's NUMA node")
     ap.add_argument("--no-autotune", action="store_true", help="skip rz_autotune (setup-time search over launch shapes) and use the built-in heuristics")
     return ap.parse_args()
 
@@ -194,6 +195,22 @@ def main():
             sys.stderr.write("[bench] --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a line for a run "
                              "that is not the one asked for\n" % (args.gpus, world_size))
         sys.exit(3)
+
+    # Every rank runs on the cores of ITS GPU's NUMA node (what numactl --cpunodebind does; rz_device_numa_node): per-frame inputs cross
+    # the host link, and a thread on the other socket pays for every HIP call and every pulled byte (profiles/r5_crowd_upload_numa.txt:
+    # a host-animated C4 frame 63 us from the GPU's node, 80-82 us from the other). Before torch / the HIP runtime start their threads.
+    full_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    numa = None
+    if not args.no_numa_bind:
+        try:
+            from reze_engine_amd import capi as _capi
+            n_dev = _capi.device_count()
+            one_each = world_size > 1 and n_dev == 1 and any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+            dev = 0 if (one_each or world_size == 1) else (local_rank % max(1, n_dev) if args.share_gpu else local_rank)
+            if dev < n_dev:
+                numa = _capi.bind_to_device_node(dev)
+        except Exception as e:          # noqa: BLE001
+            sys.stderr.write("[bench] rank %d: no NUMA binding (%r)\n" % (rank, e))
 
     import torch
     # a launcher may hand every rank ITS OWN GPU through *_VISIBLE_DEVICES (each rank then sees exactly one device, index 0)
@@ -671,6 +688,8 @@ def main():
     cpu = None
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
         try:
+            if full_affinity is not None:
+                os.sched_setaffinity(0, full_affinity)      # the CPU baseline runs on ALL the host's cores, not on one node's
             cpu = cpu_baseline(args, mesh, deltas, mw, sparse)
         except Exception as e:          # noqa: BLE001
             sys.stderr.write("[bench] cpu baseline failed: %r\n" % (e,))
@@ -708,6 +727,7 @@ def main():
                 "parallelism": "vertex-shard x%d" % world_size,
                 "launched_by": "self (python -m torch.distributed.run, re-executed by bench.py)" if os.environ.get("REZE_BENCH_SELF_LAUNCHED") == "1"
                                else ("external launcher (WORLD_SIZE in the environment)" if "WORLD_SIZE" in os.environ else "single process"),
+                "numa_binding": numa,       # rank 0's: {"gpu_node", "cpus"}, null = not bound (one node, unknown, or --no-numa-bind)
                 "bone_hierarchy_solve": ("device (motion sampling + hierarchy solve in rz_fk_kernel)" if args.device_sampling else "device (rz_fk_kernel)") if args.device_fk else "host",
                 "autotune": tuned is not None,
                 "autotune_rule": "heuristic plan (entry 0) unless a candidate's median-of-5-rounds time, MAX over ranks, is >= 2 % faster and its slowest round beats the heuristic's fastest; every rank adopts the same entry",

@@ -32,7 +32,7 @@ extern "C" {
 
 /* 5 (round 5): shards are cut at 256 vertices (4: 1 024 before round 4's change, which should have bumped this), so the chunk stride of the
  * gathered buffer changed; rz_gather_chunk exports it instead of making callers re-derive it. */
-#define RZ_ABI_VERSION 5
+#define RZ_ABI_VERSION 6
 
 typedef struct rz_ctx rz_ctx;
 
@@ -62,6 +62,13 @@ int rz_abi_version(void);
 
 /* Number of visible HIP devices. */
 int rz_device_count(int *count);
+/* The NUMA node of the host the device hangs off, from its PCI address (sysfs); *node = -1 when the system does not say (one socket,
+ * no sysfs). No reference counterpart (a browser tab has no say in where it runs). Per-frame inputs cross the host link: a thread
+ * that feeds a GPU from the OTHER socket pays for it twice — every doorbell / queue write / signal read of a HIP call crosses the
+ * socket link (+14 us of host time per rz_set_pose of a 256-character crowd on 2 x EPYC 9575F), and so does every byte the GPU pulls
+ * out of pinned memory that thread first touched (2.5 MB: 57 -> 77 us). The library never moves the caller's threads; bench.py binds
+ * each rank to its GPU's node with this (profiles/r5_crowd_upload_numa.txt), a Node host would be started under numactl. */
+int rz_device_numa_node(int device, int *node);
 
 /* Engine.init()  engine/src/engine.ts:157-185 (requestAdapter/requestDevice): bind to one GPU,
  * create the stream, events and staging memory. */
@@ -256,7 +263,12 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * for launch-bound replay of small frames), "zero_copy" (-1 auto = on, 0: every pose is copied to the device; one character's
  * per-frame inputs are otherwise read by the frame's kernels straight from a pinned, device-mapped slot), "fuse_fk" (-1 auto, 0, 1:
  * a device-animated single character solves its bone hierarchy inside the deform kernel — one launch per frame — instead of
- * rz_fk_kernel [+ rz_prep_kernel] in front), "overlap" (-1 / 0 off, 1: crowds run their front kernels on the upload stream under
+ * rz_fk_kernel [+ rz_prep_kernel] in front), "pose_pull" (-1 auto: the world matrices of a pose of more than 256 KB — a crowd's — are pulled out of their pinned ring slot by a
+ * kernel on the upload stream, as the upper three rows of every affine matrix [a pose with any other bottom row travels whole]; local
+ * rotations, a quarter of the bytes, stay with the copy engine, which does not disturb the frame they run under; 1: every such pose
+ * is pulled; 0: the runtime copies every pose as it was handed over; rz_get_tuning("pose_pulled") / ("pose_rows") tell what the
+ * last upload did),
+ * "overlap" (-1 / 0 off, 1: crowds run their front kernels on the upload stream under
  * the previous frame's skin kernel — measured slower on this runtime, kept for experiments). There is no key that makes a frame
  * emit anything but the deformed mesh: ablation switches exist only in a tools-only build and "dbg" is rejected here.
  * rz_get_tuning also answers "effective_split" / "effective_unroll" / "effective_grid" / "effective_fast" / "effective_out_cap" /

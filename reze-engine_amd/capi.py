@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libreze_deform.so")
 
 # every symbol include/reze_deform.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_destroy", "rz_shard_range", "rz_gather_chunk",
+    "rz_last_error", "rz_abi_version", "rz_device_count", "rz_device_numa_node", "rz_create", "rz_destroy", "rz_shard_range", "rz_gather_chunk",
     "rz_upload_mesh", "rz_upload_mesh_soa", "rz_upload_skeleton", "rz_upload_morphs_dense",
     "rz_upload_morphs_sparse", "rz_set_instances", "rz_set_pose", "rz_upload_skeleton_topology", "rz_set_pose_local", "rz_upload_bone_morphs", "rz_upload_animation", "rz_set_pose_sampled", "rz_override_world", "rz_read_world", "rz_deform", "rz_deform_n", "rz_fork", "rz_deform_pair", "rz_sync", "rz_read",
     "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_autotune", "rz_autotune_measure", "rz_autotune_pick",
@@ -82,6 +82,8 @@ def load(path=None):
     L.rz_last_error.argtypes = []
     L.rz_abi_version.argtypes = []
     L.rz_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
+    if hasattr(L, "rz_device_numa_node"):      # (absent from libraries older than ABI 6)
+        L.rz_device_numa_node.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.rz_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.rz_destroy.argtypes = [vp]
     L.rz_shard_range.argtypes = [u32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(u32), ctypes.POINTER(u32)]
@@ -194,6 +196,41 @@ def comm_init_all(contexts, v_total):
     _chk(load().rz_comm_init_all(arr, len(contexts), int(v_total)))
     for c in contexts:
         c.v_total = int(v_total)
+
+
+def device_numa_node(device=0, lib=None):
+    """NUMA node of the host the device hangs off (rz_device_numa_node), -1 when the system does not say."""
+    L = lib if lib is not None else load()
+    n = ctypes.c_int(-1)
+    _chk(L.rz_device_numa_node(int(device), ctypes.byref(n)), L)
+    return n.value
+
+
+def bind_to_device_node(device=0, lib=None):
+    """Restrict the calling process to the cores of the device's NUMA node (what numactl --cpunodebind does): per-frame inputs cross the
+    host link, and feeding a GPU from the other socket costs host time per HIP call and link bandwidth per pulled byte
+    (include/reze_deform.h: rz_device_numa_node). Call it before contexts are created — pinned rings are first touched by the thread that
+    creates them. Returns {"gpu_node": n, "cpus": "64-127,192-255"} or None when there is nothing to do (unknown node, one node,
+    the node's cores are outside the affinity mask the process was given)."""
+    node = device_numa_node(device, lib)
+    if node < 0 or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            text = f.read().strip()
+        if len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()]) < 2:
+            return None
+    except OSError:
+        return None
+    cpus = set()
+    for part in text.split(","):
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    cpus &= os.sched_getaffinity(0)
+    if not cpus:
+        return None
+    os.sched_setaffinity(0, cpus)
+    return {"gpu_node": node, "cpus": text}
 
 
 def allgather_all(contexts, with_normals=False):

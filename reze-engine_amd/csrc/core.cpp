@@ -6,6 +6,8 @@
 // There is NO CPU fallback: without a working HIP device every call fails.
 #include "ctx.h"
 
+#include <cctype>
+
 using namespace rzi;
 
 namespace rzi {
@@ -110,14 +112,28 @@ void set_ring(rz_ctx *c, int slot)
 }
 
 // Lay the CURRENT instance / bone / morph counts out over pose slot k and make it the current slot.
-void point_pose_slot(rz_ctx *c, int k)
+void point_pose_at(rz_ctx *c, float *block)
 {
     const size_t I = c->I, B = c->B, Mq = std::max<uint32_t>(c->M, 1);
     c->mw_pad = (I * Mq + 3) / 4 * 4;
+    c->world = block;
+    c->morph_w = block + I * B * 16;
+    c->local_q = reinterpret_cast<float4 *>(block + I * B * 16 + c->mw_pad);
+}
+
+void point_pose_slot(rz_ctx *c, int k)
+{
     c->pose_slot = k;
-    c->world = c->pose_blk[k];
-    c->morph_w = c->pose_blk[k] + I * B * 16;
-    c->local_q = reinterpret_cast<float4 *>(c->pose_blk[k] + I * B * 16 + c->mw_pad);
+    point_pose_at(c, c->pose_blk[k]);
+}
+
+// (callers have drained both streams)
+void free_big_ring(rz_ctx *c)
+{
+    for (int k = 0; k < rz_ctx::kBigBlocks; ++k) dfree(c->big_blk[k]);
+    c->big_floats = 0;
+    c->big_uploads = 0;
+    c->big_ev_seq[0] = c->big_ev_seq[1] = ~0ull;
 }
 
 int ensure_pose_buffers(rz_ctx *c)
@@ -127,7 +143,8 @@ int ensure_pose_buffers(rz_ctx *c)
     if (c->I <= c->pose_alloc_I && c->B <= c->pose_alloc_B && Mq <= c->pose_alloc_M && c->world) return RZ_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->up_stream));
-    for (int k = 0; k < 2; ++k) { dfree(c->pose_blk[k]); c->free_recorded[k] = false; }
+    for (int k = 0; k < 2; ++k) dfree(c->pose_blk[k]);
+    free_big_ring(c);
     c->world = nullptr; c->morph_w = nullptr; c->local_q = nullptr;
     for (int k = 0; k < 2; ++k) { dfree(c->palette_ring[k]); dfree(c->act_idx_ring[k]); dfree(c->act_w_ring[k]); dfree(c->act_count_ring[k]); c->skin_recorded[k] = false; }
     c->palette = nullptr; c->act_idx = nullptr; c->act_w = nullptr; c->act_count = nullptr;
@@ -215,6 +232,24 @@ int rz_device_count(int *count)
     return RZ_OK;
 }
 
+int rz_device_numa_node(int device, int *node)
+{
+    if (!node) return fail(RZ_ERR_INVALID, "null node");
+    *node = -1;
+    char bus[32] = {0};
+    hipError_t e = hipDeviceGetPCIBusId(bus, (int)sizeof bus, device);
+    if (e != hipSuccess) return fail(RZ_ERR_NO_DEVICE, "hipDeviceGetPCIBusId(%d): %s", device, hipGetErrorString(e));
+    for (char *p = bus; *p; ++p) *p = (char)tolower((unsigned char)*p);      // sysfs spells the address in lower case
+    char path[128];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    if (FILE *f = fopen(path, "r")) {
+        int n = -1;
+        if (fscanf(f, "%d", &n) == 1) *node = n;
+        fclose(f);
+    }
+    return RZ_OK;
+}
+
 int rz_create(int device, rz_ctx **out)
 {
     if (!out) return fail(RZ_ERR_INVALID, "null out");
@@ -237,8 +272,7 @@ int rz_create(int device, rz_ctx **out)
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking);
     for (int k = 0; k < 2 && se == hipSuccess; ++k) {
-        se = hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming);
-        if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_free[k], hipEventDisableTiming);
+        se = hipEventCreateWithFlags(&c->big_ev[k], hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_front[k], hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_skin[k], hipEventDisableTiming);
     }
@@ -284,12 +318,12 @@ int rz_destroy(rz_ctx *c)
     dfree(c->fk_rec); dfree(c->fk_anc_more);
     free_animation(c); dfree(c->an_frames);
     dfree(c->pose_blk[0]); dfree(c->pose_blk[1]);
+    free_big_ring(c);
     dfree(c->ovr_off); dfree(c->ovr_bone); dfree(c->ovr_world);
     free_bone_morphs(c);
     free_morphs(c);
     for (int k = 0; k < 2; ++k) {
-        if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]);
-        if (c->ev_free[k]) (void)hipEventDestroy(c->ev_free[k]);
+        if (c->big_ev[k]) (void)hipEventDestroy(c->big_ev[k]);
     }
     for (int k = 0; k < 2; ++k) {
         dfree(c->palette_ring[k]); dfree(c->act_idx_ring[k]); dfree(c->act_w_ring[k]); dfree(c->act_count_ring[k]);
@@ -345,7 +379,7 @@ int rz_fork(rz_ctx *parent, rz_ctx **out)
     c->I = parent->I;
     c->t_split = parent->t_split; c->t_unroll = parent->t_unroll; c->t_grid_cap = parent->t_grid_cap; c->t_nt = parent->t_nt; c->t_nts = parent->t_nts;
     c->t_geo = parent->t_geo; c->t_fast = parent->t_fast; c->t_instloop = parent->t_instloop; c->t_outcap = parent->t_outcap; c->t_instblock = parent->t_instblock;
-    c->t_instorder = parent->t_instorder; c->t_overlap = parent->t_overlap; c->t_zerocopy = parent->t_zerocopy; c->t_fusefk = parent->t_fusefk;
+    c->t_instorder = parent->t_instorder; c->t_overlap = parent->t_overlap; c->t_zerocopy = parent->t_zerocopy; c->t_pull = parent->t_pull; c->t_fusefk = parent->t_fusefk;
     c->t_graph = parent->t_graph; c->tuned_by_search = parent->tuned_by_search; c->t_subsets = parent->t_subsets; c->t_prefetch = parent->t_prefetch;
     c->lender = parent;
     parent->n_forks++;

@@ -147,7 +147,7 @@ struct rz_ctx {
     uint32_t I = 1;
     float *world = nullptr;             // I x B x 16   (current pose slot)
     // Per-frame INPUTS are double-buffered and uploaded on their own stream, so the upload of pose f+1 overlaps the
-    // kernels of pose f: ev_up[k] = slot k has landed (the compute stream waits for it), ev_free[k] = everything
+    // kernels of pose f: stage_ev[ring slot] = the pose has landed (the compute stream waits for it), ev_free[k] = everything
     // that reads slot k has been enqueued up to here (the upload stream waits for it before overwriting the slot).
     // One device block per pose slot: [world I*B*16 | morph weights pad4(I*max(M,1)) | local rotations I*B*4 | local
     // translations I*B*3] floats. A world-matrix pose fills [world | weights], a local pose [weights | rotations (|
@@ -159,8 +159,18 @@ struct rz_ctx {
     size_t mw_pad = 0;                              // floats reserved for the morph weights in the current layout (multiple of 4)
     int pose_slot = 0;
     hipStream_t up_stream = nullptr;
-    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
-    bool free_recorded[2] = {false, false};
+    // Poses of more than 256 KB (crowds) travel on the upload stream into a ring of kBigBlocks device blocks of their own (same
+    // layout as pose_blk), so the upload of pose f+1 runs under the frame of pose f. A block is overwritten kBigBlocks uploads after
+    // it was filled; that its readers are done is proven like a zero-copy slot's: ONE event per kBigBlocks / 2 uploads, recorded on
+    // the compute stream at upload time and polled by the host before the block's next tenant is enqueued — no per-frame "slot is
+    // free" hand-off between the streams (round 4 had one: a record on the compute stream + a wait on the upload stream per frame,
+    // measured at 5 - 8 us per frame: tools/overlapbench, profiles/r5_overlapbench.txt). 8 x 3.3 MB for C4.
+    static constexpr int kBigBlocks = 8;
+    float *big_blk[kBigBlocks] = {};
+    size_t big_floats = 0;
+    uint64_t big_uploads = 0;
+    hipEvent_t big_ev[2] = {nullptr, nullptr};
+    uint64_t big_ev_seq[2] = {~0ull, ~0ull};
     float4 *palette = nullptr;          // I x B x 3   (current ring slot)
     float *morph_w = nullptr;           // I x M   (current pose slot)
     uint32_t *act_idx = nullptr;        // I x Mpad    (current ring slot)
@@ -197,7 +207,12 @@ struct rz_ctx {
 
     // pinned staging ring for rz_set_pose
     void *stage[kStageSlots] = {};
+    void *stage_dev[kStageSlots] = {};  // the slots' device addresses (device-mapped ring), or null: this ring can only be copied from
     size_t stage_bytes = 0;
+    // Crowd poses (more than 256 KB) are PULLED out of the ring slot by rz_pull_pose_kernel on the upload stream instead of copied by
+    // hipMemcpyAsync, world matrices as their upper three rows (pose.cpp: upload_pose_copy)
+    int t_pull = -1;                    // "pose_pull": -1 = world-matrix poses, 1 = every pose of more than 256 KB, 0 = hipMemcpyAsync of the pose as the host handed it over
+    bool last_upload_pulled = false, last_upload_rows = false;      // what the most recent copy upload did (rz_get_tuning: pose_pulled / pose_rows)
     hipEvent_t stage_ev[kStageSlots] = {};
     bool stage_used[kStageSlots] = {};
     int stage_next = 0;
@@ -308,6 +323,8 @@ template <class T> struct Scratch {
 int ensure_outputs(rz_ctx *c);
 void set_ring(rz_ctx *c, int slot);
 void point_pose_slot(rz_ctx *c, int k);
+void point_pose_at(rz_ctx *c, float *block);     // the current pose lives in `block` (pose_blk[k] or a block of the big-pose ring)
+void free_big_ring(rz_ctx *c);
 int ensure_pose_buffers(rz_ctx *c);
 void free_animation(rz_ctx *c);
 int rebuild_fk_static(rz_ctx *c);      // upload.cpp: the device block behind fk_rec from the host copies

@@ -216,6 +216,8 @@ size_t rz_skin_instances_lds_bytes(int G, uint32_t bones, bool dma, bool subsets
 // per vertex run of `per` vertices: the ascending list of bones its vertices name + the joints rewritten as slots of it
 hipError_t rz_launch_run_subsets(const uint32_t *j01, const uint32_t *j23, uint32_t v_lim, uint32_t per, uint32_t runs, uint32_t B,
                                  uint16_t *list, uint32_t *count, uint32_t *rj01, uint32_t *rj23, hipStream_t st);
+// a crowd's per-frame pose pulled out of a pinned, device-mapped slot (kernels/front.hip: rz_pull_pose_kernel)
+hipError_t rz_launch_pull_pose(const void *src, void *dst, uint32_t bones, size_t raw_bytes, hipStream_t st);
 uint32_t rz_quads_per_tile(int S);
 bool rz_has_all_variants();      // false in the product: only the variants a plan can select by default are compiled in
 #ifdef RZ_ALL_VARIANTS

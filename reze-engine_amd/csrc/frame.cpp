@@ -93,7 +93,6 @@ int set_overlap(rz_ctx *c, bool on)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->overlap_on = on;
     c->skin_recorded[0] = c->skin_recorded[1] = false;
-    c->free_recorded[0] = c->free_recorded[1] = false;
     return RZ_OK;
 }
 

@@ -1,5 +1,5 @@
 // kernels/front.hip — what a frame may launch in FRONT of its deform / skin kernel (rz_prep_kernel: palette + active-morph list;
-// rz_fk_kernel: hierarchy solve + motion sampling), the one-off upload re-layout kernels, and the host-side launch dispatch.
+// rz_fk_kernel: hierarchy solve + motion sampling; rz_pull_pose_kernel: a crowd's pose over the host link), the one-off upload re-layout kernels, and the host-side launch dispatch.
 #include "fk.hip.h"
 
 namespace {
@@ -48,6 +48,63 @@ __global__ void __launch_bounds__(kBlock) rz_fk_kernel(const uint4 *k_rec, const
     const FkEarly early = fk_issue_static(k_rec, (int)k_B, (int)k_M, (int)threadIdx.x);
     unsigned char *scr = smem + (size_t)p.B * 48;
     fk_solve<false>(p, early, (int)blockIdx.x, reinterpret_cast<float4 *>(smem), scr, reinterpret_cast<float *>(scr + rz_fk_scratch_bytes(p.B)), true);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// rz_pull_pose_kernel: a crowd's per-frame pose (0.8 - 3.3 MB for 256 characters) comes down by a PULL. The host lays the pose out in
+// a pinned, device-mapped ring slot; 16 workgroups read it over the host link with 16-byte loads (1 KiB contiguous per wave
+// instruction, three in flight per lane) and store it into the device pose block. Measured against hipMemcpyAsync from the same
+// pinned memory, back to back on one stream (tools/pullbench, profiles/r5_pullbench.txt): 3.28 MB 84 -> 62 us, 0.82 MB 24 -> 18 us —
+// the copy engine path costs ~24 us per upload whatever the size; more workgroups or more loads in flight per lane pull SLOWER.
+// World matrices travel as their upper three rows (the bottom row of an affine matrix is 0 0 0 1; the host checks that while it
+// packs): 48 B per bone as the four columns' x y z, i.e. exactly three float4. A wave takes 64 bones per step — three coalesced
+// loads, an exchange through its own 3 KB of LDS, then every lane writes its bone's 4 x 4 matrix (engine.ts:2383-2389 uploads all
+// sixteen floats; every reader of the world matrices keeps the reference's layout).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPullBlock = 512, kPullGrid = 16;
+
+__global__ void __launch_bounds__(kPullBlock) rz_pull_pose_kernel(const float4 *src, float4 *dst, const uint32_t bones, const uint32_t raw4,
+                                                                  const uint32_t raw_words)
+{
+    __shared__ float4 sh[kPullBlock / 64][192];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (bones) {
+        const uint32_t gw = blockIdx.x * (kPullBlock / 64) + wave, nw = gridDim.x * (kPullBlock / 64), last = bones * 3u - 1u;
+        float4 *mine = sh[wave];
+        for (uint32_t b0 = gw * 64u; b0 < bones; b0 += nw * 64u) {
+            const uint32_t base = b0 * 3u + lane;
+            const float4 v0 = src[min(base, last)], v1 = src[min(base + 64u, last)], v2 = src[min(base + 128u, last)];
+            mine[lane] = v0; mine[64u + lane] = v1; mine[128u + lane] = v2;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float4 a = mine[3u * lane], b = mine[3u * lane + 1u], c = mine[3u * lane + 2u];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();            // every lane has read its bone before the next step's columns land
+            if (b0 + lane < bones) {
+                float4 *d = dst + (size_t)(b0 + lane) * 4;
+                d[0] = make_float4(a.x, a.y, a.z, 0.0f);
+                d[1] = make_float4(a.w, b.x, b.y, 0.0f);
+                d[2] = make_float4(b.z, b.w, c.x, 0.0f);
+                d[3] = make_float4(c.y, c.z, c.w, 1.0f);
+            }
+        }
+    }
+    // what travels as it is: morph weights behind the matrices; local rotations / translations
+    const float4 *rs = src + (size_t)bones * 3;
+    float4 *rd = dst + (size_t)bones * 4;
+    if (raw4) {
+        const uint32_t stride = gridDim.x * kPullBlock, last = raw4 - 1u;
+        for (uint32_t i = blockIdx.x * kPullBlock + threadIdx.x; i < raw4; i += stride * 4u) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = rs[min(i + u * stride, last)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rd[min(i + u * stride, last)] = v[u];      // (beyond the end: the last element again, the same value)
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < raw_words)
+        reinterpret_cast<float *>(rd + raw4)[threadIdx.x] = reinterpret_cast<const float *>(rs + raw4)[threadIdx.x];
 }
 
 #ifdef RZ_ALL_VARIANTS
@@ -119,6 +176,18 @@ hipError_t rz_launch_fk(const RzFkParams &p, uint32_t instances, hipStream_t st)
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(rz_fk_kernel, dim3(instances), dim3(kBlock), lds, st, p.bone_rec, (uint32_t)p.B, (uint32_t)p.sample.M, p);
+    return hipGetLastError();
+}
+
+
+// `src` = device address of the pinned slot: [bones x 48 B of packed matrix columns | raw_bytes carried as they are]; `dst` = the
+// device pose block, where the matrices arrive as 4 x 4 and the rest behind them. raw_bytes is a multiple of 4.
+hipError_t rz_launch_pull_pose(const void *src, void *dst, uint32_t bones, size_t raw_bytes, hipStream_t st)
+{
+    if ((raw_bytes & 3u) || raw_bytes / 16 > 0xffffffffull || (uint64_t)bones * 3u > 0xffffffffull) return hipErrorInvalidValue;
+    if (bones == 0 && raw_bytes == 0) return hipSuccess;
+    hipLaunchKernelGGL(rz_pull_pose_kernel, dim3(kPullGrid), dim3(kPullBlock), 0, st, static_cast<const float4 *>(src), static_cast<float4 *>(dst),
+                       bones, (uint32_t)(raw_bytes / 16), (uint32_t)((raw_bytes & 15u) / 4));
     return hipGetLastError();
 }
 

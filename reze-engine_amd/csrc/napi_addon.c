@@ -136,6 +136,21 @@ static napi_value fn_device_count(napi_env env, napi_callback_info info)
     return v;
 }
 
+/* deviceNumaNode(device) -> node, -1 = unknown (rz_device_numa_node: start the process on that node's cores, e.g. under numactl) */
+static napi_value fn_device_numa_node(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1], v;
+    int32_t device = 0;
+    int node = -1;
+    napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
+    if (argc >= 1) napi_get_value_int32(env, argv[0], &device);
+    const int rc = rz_device_numa_node(device, &node);
+    if (rc != RZ_OK) return throw_rz(env, rc);
+    napi_create_int32(env, node, &v);
+    return v;
+}
+
 static napi_value fn_create(napi_env env, napi_callback_info info)
 {
     ARGS(1);
@@ -870,7 +885,7 @@ static napi_value fn_read_gathered(napi_env env, napi_callback_info info)
 static napi_value init(napi_env env, napi_value exports)
 {
     static const struct { const char *name; napi_callback fn; } table[] = {
-        { "abiVersion", fn_abi_version }, { "deviceCount", fn_device_count }, { "create", fn_create },
+        { "abiVersion", fn_abi_version }, { "deviceCount", fn_device_count }, { "deviceNumaNode", fn_device_numa_node }, { "create", fn_create },
         { "destroy", fn_destroy }, { "shardRange", fn_shard_range }, { "gatherChunk", fn_gather_chunk }, { "uploadMesh", fn_upload_mesh },
         { "uploadMeshSoa", fn_upload_mesh_soa }, { "uploadSkeleton", fn_upload_skeleton },
         { "uploadMorphsDense", fn_upload_morphs_dense }, { "uploadMorphsSparse", fn_upload_morphs_sparse },

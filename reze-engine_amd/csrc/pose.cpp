@@ -1,6 +1,8 @@
 // pose.cpp — per-frame inputs: the pinned staging ring, zero-copy slots and their prefetch protocol, copies (ctx.h).
 #include "ctx.h"
 
+#include <immintrin.h>
+
 using namespace rzi;
 
 namespace rzi {
@@ -51,13 +53,25 @@ extern "C" {
 // Pinned staging ring for per-frame inputs: a slot is reused only after the copy that read it has completed.
 static int stage_acquire(rz_ctx *c, size_t need, int *slot_out)
 {
-    if (need > c->stage_bytes) {
+    if (need > c->stage_bytes || !c->stage[0]) {
         HIP_TRY(hipStreamSynchronize(c->up_stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        need = (need + 4095) / 4096 * 4096;
         for (int i = 0; i < kStageSlots; ++i) {
-            if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; }
-            HIP_TRY(hipHostMalloc(&c->stage[i], need, hipHostMallocDefault));
+            if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; c->stage_dev[i] = nullptr; }
             c->stage_used[i] = false;
+        }
+        c->stage_bytes = 0;
+        for (int i = 0; i < kStageSlots; ++i) {
+            // device-mapped, so that a crowd's pose can be pulled out of the slot by a kernel; a slot that cannot be mapped is still good for copies
+            if (hipHostMalloc(&c->stage[i], need, hipHostMallocMapped) != hipSuccess) {
+                (void)hipGetLastError();
+                c->stage[i] = nullptr;
+                HIP_TRY(hipHostMalloc(&c->stage[i], need, hipHostMallocDefault));
+            } else if (hipHostGetDevicePointer(&c->stage_dev[i], c->stage[i], 0) != hipSuccess) {
+                (void)hipGetLastError();
+                c->stage_dev[i] = nullptr;
+            }
         }
         c->stage_bytes = need;
     }
@@ -133,6 +147,55 @@ struct PoseParts {
     size_t mb, mwb, total;                    // weight bytes handed over / their padded place / bytes of the whole range
 };
 
+// World matrices of a crowd travel as their upper three rows: 48 B per bone — the four columns' x y z, in the reference's
+// column-major order (math.ts) — instead of 64. Only rows 0..2 of world * inverseBind ever reach a vertex (engine.ts:926-928 forms
+// the product, vs() :262-272 keeps xyz), and they depend on rows 0..2 of the world matrix alone; the bottom row of an affine matrix
+// is 0 0 0 1 and rz_pull_pose_kernel writes it back, so the device block holds what the host handed over — IF every bottom row is
+// exactly that (bit patterns: -0 is not 0), which the packing loop checks in passing (returns false: the caller sends the pose as it
+// is). Four bones per step: four 64-byte loads, three two-source permutes, three 64-byte NON-TEMPORAL stores — measured on the GPU
+// box's EPYC 9575F (tools/packbench, profiles/r5_packbench.txt) as fast as the memcpy it replaces while the ring is cache-resident
+// (43 us for C4's 51 200 bones), and unlike cached stores it stays there when two contexts' rings (2 x 8 x 2.5 MB) no longer fit a
+// CCD's L3: masked 48-byte stores then read every line for ownership first and the per-frame loop of a context and its fork went from
+// 63 to 127-180 us per frame. (Needs AVX-512; without it the pose is not packed.)
+__attribute__((target("avx512f"))) static bool pack_rows_avx512(const float *world, size_t bones, float *out)
+{
+    // out0 = m0[xyz of columns 0..3] m1[c0.xyz c1.x] | out1 = m1[c1.yz c2.xyz c3.xyz] m2[c0.xyz c1.xyz c2.xy] | out2 = m2[c2.z c3.xyz] m3[all twelve]
+    const __m512i i0 = _mm512_setr_epi32(0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14, 16 + 0, 16 + 1, 16 + 2, 16 + 4);
+    const __m512i i1 = _mm512_setr_epi32(5, 6, 8, 9, 10, 12, 13, 14, 16 + 0, 16 + 1, 16 + 2, 16 + 4, 16 + 5, 16 + 6, 16 + 8, 16 + 9);
+    const __m512i i2 = _mm512_setr_epi32(10, 12, 13, 14, 16 + 0, 16 + 1, 16 + 2, 16 + 4, 16 + 5, 16 + 6, 16 + 8, 16 + 9, 16 + 10, 16 + 12, 16 + 13, 16 + 14);
+    const __m512i bottom = _mm512_setr_epi32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x3f800000);
+    __m512i acc = _mm512_setzero_si512();
+    size_t b = 0;
+    if ((reinterpret_cast<uintptr_t>(out) & 63u) == 0) {
+        for (; b + 4 <= bones; b += 4) {
+            const float *w = world + b * 16;
+            const __m512 m0 = _mm512_loadu_ps(w), m1 = _mm512_loadu_ps(w + 16), m2 = _mm512_loadu_ps(w + 32), m3 = _mm512_loadu_ps(w + 48);
+            _mm512_stream_ps(out + b * 12, _mm512_permutex2var_ps(m0, i0, m1));
+            _mm512_stream_ps(out + b * 12 + 16, _mm512_permutex2var_ps(m1, i1, m2));
+            _mm512_stream_ps(out + b * 12 + 32, _mm512_permutex2var_ps(m2, i2, m3));
+            // lanes 3, 7, 11, 15 of every matrix against 0 0 0 1
+            const __m512i x01 = _mm512_or_si512(_mm512_xor_si512(_mm512_castps_si512(m0), bottom), _mm512_xor_si512(_mm512_castps_si512(m1), bottom));
+            const __m512i x23 = _mm512_or_si512(_mm512_xor_si512(_mm512_castps_si512(m2), bottom), _mm512_xor_si512(_mm512_castps_si512(m3), bottom));
+            acc = _mm512_or_si512(acc, _mm512_or_si512(x01, x23));
+        }
+    }
+    __mmask16 bad = _mm512_mask_test_epi32_mask((__mmask16)0x8888, acc, acc);
+    const __m512i pick = _mm512_setr_epi32(0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14, 3, 7, 11, 15);
+    for (; b < bones; ++b) {                    // the last one to three bones
+        const __m512 m = _mm512_loadu_ps(world + b * 16);
+        _mm512_mask_storeu_ps(out + b * 12, (__mmask16)0x0fff, _mm512_permutexvar_ps(pick, m));
+        bad |= _mm512_mask_cmpneq_epi32_mask((__mmask16)0x8888, _mm512_castps_si512(m), bottom);
+    }
+    _mm_sfence();                               // the streaming stores are visible before anything that follows (the pull's launch)
+    return bad == 0;
+}
+
+static bool can_pack_rows()
+{
+    static const bool ok = __builtin_cpu_supports("avx512f");
+    return ok;
+}
+
 static void lay_out_pose(const rz_ctx *c, const PoseParts &pp, char *st)
 {
     char *st_mw = pp.local ? st : st + pp.pbytes;
@@ -165,7 +228,6 @@ static int upload_pose_zero_copy(rz_ctx *c, const PoseParts &pp)
     *hdr = seq;
     c->zc_seq_cur = seq;
     point_pose_slot(c, c->pose_slot ^ 1);   // where the pose will live once something makes it resident
-    c->free_recorded[c->pose_slot] = false;
     c->zc_cur = zs; c->zc_local = pp.local; c->zc_kind = kind; c->zc_total = pp.total;
     c->zc_mw_off = pp.local ? 0 : pp.pbytes; c->zc_lq_off = pp.mwb;
     c->world_resident = pp.local;           // a local pose has no world matrices to bring over: rz_fk_kernel writes them
@@ -174,8 +236,47 @@ static int upload_pose_zero_copy(rz_ctx *c, const PoseParts &pp)
     return RZ_OK;
 }
 
-// The pose goes through a pinned ring slot into the OTHER device slot as ONE copy — on the upload stream for big poses, so
-// the upload overlaps whatever the compute stream is still running on the current slot; the compute stream then waits for it.
+// A block of the big-pose ring for the next upload of more than 256 KB (ctx.h): (re)allocate the ring when the layout grew, record
+// the one-in-four event, make sure the readers of the block's previous tenant (kBigBlocks uploads ago) are done.
+static int big_acquire(rz_ctx *c, float **block)
+{
+    constexpr uint64_t N = rz_ctx::kBigBlocks, P = N / 2;
+    const size_t Mq = std::max<uint32_t>(c->M, 1);
+    const size_t need = (size_t)c->pose_alloc_I * c->pose_alloc_B * 16 + (((size_t)c->pose_alloc_I * std::max<size_t>(c->pose_alloc_M, Mq) + 3) / 4 * 4) +
+                        (size_t)c->pose_alloc_I * c->pose_alloc_B * 7 + 4;
+    if (!c->big_blk[0] || c->big_floats < need) {
+        HIP_TRY(hipStreamSynchronize(c->up_stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        drop_graph(c);
+        free_big_ring(c);
+        for (uint64_t k = 0; k < N; ++k) {
+            HIP_TRY(hipMalloc(&c->big_blk[k], need * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(c->big_blk[k], 0, need * sizeof(float), c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->big_floats = need;
+    }
+    const uint64_t u = c->big_uploads;
+    if (u % P == 0) {
+        const int e = (int)((u / P) & 1);
+        HIP_TRY(hipEventRecord(c->big_ev[e], c->stream));     // everything launched before upload u, i.e. every reader of uploads < u
+        c->big_ev_seq[e] = u;
+    }
+    if (u >= N) {
+        // previous tenant = upload u - N, read by frames launched before upload u - N + 1: covered by the event of the first multiple
+        // of P that is >= u - N + 1 — it is <= u - P, the older of the two events kept (the arithmetic of zc_acquire)
+        const uint64_t cand = (u - (N - 1) + (P - 1)) / P * P;
+        const int e = (int)((cand / P) & 1);
+        if (c->big_ev_seq[e] != cand) return fail(RZ_ERR_HIP, "big-pose ring bookkeeping is inconsistent (upload %llu)", (unsigned long long)u);
+        if (int r = poll_event(c->big_ev[e], "big-pose ring")) return r;
+    }
+    *block = c->big_blk[u % N];
+    c->big_uploads = u + 1;
+    return RZ_OK;
+}
+
+// The pose goes through a pinned ring slot into a device block the running frames do not read — on the upload stream for big poses,
+// so the upload overlaps whatever the compute stream is still running; the compute stream then waits for it.
 static int upload_pose_copy(rz_ctx *c, const PoseParts &pp)
 {
     c->zc_cur = -1;
@@ -184,41 +285,49 @@ static int upload_pose_copy(rz_ctx *c, const PoseParts &pp)
     c->world_resident = c->mw_resident = c->local_resident = true;
     int slot = 0;
     if (int r = stage_acquire(c, std::max<size_t>((size_t)c->I * c->B * 64 + pp.mwb, pp.mwb + (size_t)c->I * c->B * 28), &slot)) return r;
-    // Large poses (instanced crowds: MBs) take the upload stream: everything enqueued so far reads the current device
-    // slot, so mark it, fill the other slot once ITS last readers are done, and make the compute stream wait for it.
-    // Small ones that are copied at all (zero_copy = 0, small crowds) go down the compute stream itself — measured on C5,
-    // the two extra packets of the cross-stream hand-off (marker + barrier) cost 3 us more per frame than the copy they hide.
-    const int cur = c->pose_slot, k = cur ^ 1;
+    // Large poses (instanced crowds: MBs) take the upload stream and a block of the big-pose ring (ctx.h): nothing enqueued so far
+    // reads that block. Small ones that are copied at all (zero_copy = 0, small crowds) go down the compute stream itself, into the
+    // other of the two pose blocks — measured on C5, the two extra packets of a cross-stream hand-off (marker + barrier) cost 3 us
+    // more per frame than the copy they hide.
     // Overlapped-front protocol (crowds, opt-in): EVERY per-frame input travels on the upload stream and is consumed there,
     // by the front kernels — stream order is the only ordering needed, no event at all.
     const bool piped = !c->overlap_on && pp.total > (256u << 10);
     hipStream_t us = (piped || c->overlap_on) ? c->up_stream : c->stream;
-    if (c->overlap_on) {
-        c->free_recorded[0] = c->free_recorded[1] = false;
-    } else if (piped) {
-        HIP_TRY(hipEventRecord(c->ev_free[cur], c->stream));
-        c->free_recorded[cur] = true;
-        // Slot k was last current two uploads ago; its readers (and the FK kernel that WRITES its world matrices) were
-        // all enqueued before the upload after it. If that upload was a piped one it left ev_free[k] behind them; if it
-        // was a small in-stream one it recorded nothing, so fall back to "everything enqueued so far" (no overlap for
-        // this one frame, but never a torn or clobbered pose).
-        if (!c->free_recorded[k]) HIP_TRY(hipEventRecord(c->ev_free[k], c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->up_stream, c->ev_free[k], 0));
-    } else {
-        c->free_recorded[cur] = false;      // the slot's readers are about to be enqueued and nothing will mark their end
+    float *block = nullptr;
+    if (piped) {
+        if (int r = big_acquire(c, &block)) return r;
     }
     char *st = static_cast<char *>(c->stage[slot]);
-    lay_out_pose(c, pp, st);
-    point_pose_slot(c, k);                  // c->world / c->morph_w / c->local_q now name slot k under the current counts
+    // How it crosses the host link (tools/overlapbench, tools/pullbench: profiles/r5_overlapbench.txt, r5_pullbench.txt):
+    //  * world matrices of a crowd are PULLED out of the slot by rz_pull_pose_kernel (kernels/front.hip), three rows per bone: the
+    //    upload is what such a frame is bound by (3.28 MB: 84 us per hipMemcpyAsync back to back, 62 us pulled, 47 us pulled as rows),
+    //    and that the pull's 16 workgroups slow a concurrent skin kernel down (27 -> 35 us) hides under it;
+    //  * local rotations (a quarter of the bytes) are shorter than the frame they run under: the copy engine leaves that frame alone
+    //    (27.7 us per frame with the copy running, 35.5 us with the pull), so they stay with hipMemcpyAsync ("pose_pull" = 1 pulls them too).
+    const bool pull = (piped || c->overlap_on) && c->stage_dev[slot] && (pp.total & 3u) == 0 && (c->t_pull == 1 || (c->t_pull < 0 && !pp.local));
+    const size_t bones = (size_t)c->I * c->B;
+    bool rows = false;
+    if (pull && !pp.local && can_pack_rows()) {
+        rows = pack_rows_avx512(static_cast<const float *>(pp.primary), bones, reinterpret_cast<float *>(st));
+        if (rows && c->M > 0) {
+            char *st_mw = st + bones * 48;
+            if (pp.morph_weights && pp.mb) memcpy(st_mw, pp.morph_weights, pp.mb); else memset(st_mw, 0, pp.mb);
+            if (pp.mwb > pp.mb) memset(st_mw + pp.mb, 0, pp.mwb - pp.mb);
+        }
+    }
+    if (!rows) lay_out_pose(c, pp, st);     // (a matrix that is not affine: the whole pose as it was handed over)
+    // c->world / c->morph_w / c->local_q now name the pose's block under the current counts
+    if (piped) point_pose_at(c, block);
+    else point_pose_slot(c, (c->pose_slot & 1) ^ 1);
     void *dst = pp.local ? static_cast<void *>(c->morph_w) : static_cast<void *>(c->world);
-    HIP_TRY(hipMemcpyAsync(dst, st, pp.total, hipMemcpyHostToDevice, us));
+    if (pull) HIP_TRY(rz_launch_pull_pose(c->stage_dev[slot], dst, rows ? (uint32_t)bones : 0u, rows ? pp.total - pp.pbytes : pp.total, us));
+    else HIP_TRY(hipMemcpyAsync(dst, st, pp.total, hipMemcpyHostToDevice, us));
+    c->last_upload_pulled = pull; c->last_upload_rows = rows;
+    // one event says both "the ring slot may be written again" (the host polls it eight uploads later) and "the pose has landed" (the
+    // compute stream waits for it): a record is ~1.4 us of stream time, and the upload stream is what a host-animated crowd is bound by
     HIP_TRY(hipEventRecord(c->stage_ev[slot], us));
     c->stage_used[slot] = true;
-    if (piped) {
-        HIP_TRY(hipEventRecord(c->ev_up[k], c->up_stream));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_up[k], 0));
-    }
-    c->free_recorded[k] = false;            // slot k gets new readers from here on: its old end-of-readers mark is void
+    if (piped) HIP_TRY(hipStreamWaitEvent(c->stream, c->stage_ev[slot], 0));
     return RZ_OK;
 }
 

@@ -204,6 +204,9 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
     } else if (!strcmp(key, "zero_copy")) {
         if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "zero_copy must be -1 (auto = on for one character), 0 (every pose is copied to the device) or 1");
         c->t_zerocopy = value;
+    } else if (!strcmp(key, "pose_pull")) {
+        if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "pose_pull must be -1 (auto: a crowd's world matrices are pulled, local rotations copied), 0 (every pose is copied by hipMemcpyAsync as it was handed over) or 1 (every pose of more than 256 KB is pulled)");
+        c->t_pull = value;
     } else if (!strcmp(key, "overlap")) {
         if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "overlap must be -1 (auto = off), 0 (off) or 1 (crowds: front kernels on the upload stream)");
         c->t_overlap = value;
@@ -258,6 +261,9 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "inst_order")) *value = c->t_instorder;
     else if (!strcmp(key, "overlap")) *value = c->t_overlap;
     else if (!strcmp(key, "zero_copy")) *value = c->t_zerocopy;
+    else if (!strcmp(key, "pose_pull")) *value = c->t_pull;
+    else if (!strcmp(key, "pose_pulled")) *value = c->last_upload_pulled ? 1 : 0;      // the most recent copied pose came down by rz_pull_pose_kernel ...
+    else if (!strcmp(key, "pose_rows")) *value = c->last_upload_rows ? 1 : 0;          // ... its world matrices as three rows per bone
     else if (!strcmp(key, "fuse_fk")) *value = c->t_fusefk;
     else if (!strcmp(key, "effective_fuse_fk")) { const Plan pl = make_plan(c); *value = (pl.fuse_fk || pl.subfk) ? 1 : 0; }
     else if (!strcmp(key, "effective_closure_bones")) *value = make_plan(c).subfk ? (int)c->subfk_stride : 0;

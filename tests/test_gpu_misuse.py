@@ -27,7 +27,7 @@ def expect_fail(name, rc):
 fp = ctypes.POINTER(ctypes.c_float)
 # null context everywhere
 for name in rz.capi.SYMBOLS:
-    if name in ("rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_shard_range", "rz_gather_chunk", "rz_comm_unique_id",
+    if name in ("rz_last_error", "rz_abi_version", "rz_device_count", "rz_device_numa_node", "rz_create", "rz_shard_range", "rz_gather_chunk", "rz_comm_unique_id",
                 "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_destroy", "rz_rccl_info", "rz_autotune_pick"):      # rz_destroy(NULL) is a no-op, like free; rz_autotune_pick takes a table and returns an index
         continue
     f = getattr(L, name)

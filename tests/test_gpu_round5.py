@@ -138,3 +138,132 @@ def test_crowd_falls_back_to_the_fk_kernel_when_something_acts_on_the_solved_pos
     c.deform()
     assert np.isfinite(c.read(5)[0]).all()
     c.close()
+
+
+def _world_crowd(rz, V, B, I, seed, M=0):
+    mesh = synth.make_mesh(V, B, seed=seed)
+    worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=seed * 1000 + i) for i in range(I)]).astype(np.float32)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"])
+    c.upload_skeleton(mesh["inv_bind"])
+    mws = None
+    if M:
+        deltas, _ = synth.make_morphs_dense(V, M, seed=seed + 9)
+        c.upload_morphs_dense(deltas)
+        mws = np.random.default_rng(seed).random((I, M), dtype=np.float32)
+        mws[:, ::3] = 0.0
+    c.set_instances(I)
+    return c, mesh, worlds, mws
+
+
+@pytest.mark.parametrize("V,B,I,M,tune", [(6000, 201, 23, 0, {}), (30000, 200, 64, 0, {}), (5000, 201, 23, 5, {}), (6000, 201, 23, 0, dict(fast=0, overlap=1)),
+                                          (6000, 130, 33, 0, dict(inst_subsets=0))])
+def test_crowd_pose_pulled_as_three_rows_equals_the_copied_pose(rz, V, B, I, M, tune):
+    """A crowd's world matrices (more than 256 KB) come down by rz_pull_pose_kernel on the upload stream, as the upper three rows of every
+    matrix (pose.cpp: pack_rows_avx512; the reference uploads all sixteen floats, engine.ts:2383-2389). The device pose block must hold
+    exactly what rz_set_pose was handed — read back through rz_read_world — and the frame must equal the frame of the same pose copied by
+    hipMemcpyAsync ("pose_pull" = 0) BIT FOR BIT on every instance; bone counts that are no multiple of a wave's 64-bone step, morph
+    weights behind the matrices, the overlapped-front protocol and the whole-palette crowd form included. A pose with a matrix that is
+    not affine travels as it is (still pulled)."""
+    c, mesh, worlds, mws = _world_crowd(rz, V, B, I, seed=B + I + M, M=M)
+    c.set_tuning(**tune)
+    assert c.get_tuning("pose_pull") == -1
+    outs = {}
+    for pull in (-1, 0):
+        c.set_tuning(pose_pull=pull)
+        c.set_pose(worlds, mws)
+        assert c.get_tuning("pose_pulled") == (1 if pull else 0) and c.get_tuning("pose_rows") == (1 if pull else 0)
+        c.deform()
+        outs[pull] = _all_instances(c, I)
+        for i in (0, I // 2, I - 1):
+            assert np.array_equal(c.read_world(i).reshape(B, 16), worlds[i].reshape(B, 16)), "world matrices of instance %d (pose_pull = %d)" % (i, pull)
+    for i in range(I):
+        assert np.array_equal(outs[-1][i][0], outs[0][i][0]) and np.array_equal(outs[-1][i][1], outs[0][i][1]), "instance %d: pulled vs copied" % i
+    assert np.isfinite(outs[-1][I - 1][0]).all() and np.abs(outs[-1][I - 1][0]).max() > 0
+    # one projective bottom row somewhere: the pose is not packed, the frame does not change (rows 0..2 are all a vertex sees)
+    odd = worlds.copy().reshape(I, B, 16)
+    odd[I - 1, B - 1, 15] = 2.0
+    odd[0, 0, 3] = 0.25
+    c.set_tuning(pose_pull=-1)
+    c.set_pose(odd, mws)
+    assert c.get_tuning("pose_pulled") == 1 and c.get_tuning("pose_rows") == 0
+    c.deform()
+    for i in (0, I - 1):
+        assert np.array_equal(c.read_world(i).reshape(B, 16), odd[i])
+        got = c.read(i)
+        assert np.array_equal(got[0], outs[0][i][0]) and np.array_equal(got[1], outs[0][i][1])
+    c.close()
+
+
+@pytest.mark.parametrize("with_t", [True, False])
+def test_crowd_local_pose_pulled_equals_the_copied_pose(rz, with_t):
+    """Local rotations (+ translations, whose byte count is no multiple of 16 here) of a big crowd can take the same pull, as they are ("pose_pull" = 1)."""
+    V, B, I = 3000, 67, 271                      # 18 157 bones: 290 KB of rotations, 218 KB of translations
+    c, mesh, s = _crowd(rz, V, B, I, seed=12, depth_chain=9)
+    lt = s["lt"] if with_t else None
+    outs = {}
+    for pull in (1, 0, -1):                      # automatic mode leaves local poses with the copy engine (they are shorter than their frame)
+        c.set_tuning(pose_pull=pull)
+        c.set_pose_local(s["q"], None, lt)
+        assert c.get_tuning("pose_pulled") == (1 if pull == 1 else 0) and c.get_tuning("pose_rows") == 0
+        c.deform()
+        outs[pull] = _all_instances(c, I)
+    for i in range(I):
+        for other in (0, -1):
+            assert np.array_equal(outs[1][i][0], outs[other][i][0]) and np.array_equal(outs[1][i][1], outs[other][i][1]), "instance %d: pulled vs copied" % i
+    assert np.isfinite(outs[1][I - 1][0]).all()
+    c.close()
+
+
+def test_crowd_pose_ring_never_serves_a_stale_or_torn_pose(rz):
+    """Per-frame loop of a host-animated crowd with nothing waiting in between: every frame's upload goes through the pinned ring and the
+    pull (or copy) on the upload stream while earlier frames are still running (eight ring slots, eight device pose blocks whose reuse
+    one event per four uploads guards). Three different poses
+    cycled for 60 frames; after every frame the outputs of three instances are read back and must be the bits of that pose's frame run
+    alone — a pull that started too early (torn), a frame that started before its pull ended, or a ring slot overwritten under a pull
+    would show. World matrices and local rotations, on a context and its fork alternating (two frames in flight)."""
+    V, B, I = 8000, 200, 40
+    c, mesh, worlds, _ = _world_crowd(rz, V, B, I, seed=5)
+    poses = [worlds, worlds[::-1].copy(), np.roll(worlds, 7, axis=0).copy()]
+    picks = (0, 17, I - 1)
+    iso = []
+    for p in poses:
+        c.set_pose(p)
+        c.deform()
+        c.sync()
+        iso.append([c.read(i) for i in picks])
+    assert not np.array_equal(iso[0][0][0], iso[1][0][0])
+    f = c.fork()
+    ctxs = (c, f)
+    last = {}
+    for k in range(60):
+        x = ctxs[k & 1]
+        x.set_pose(poses[k % 3])
+        x.deform()
+        last[k & 1] = k % 3
+        if k % 7 == 6 or k >= 56:
+            for y in (0, 1):
+                for n, i in enumerate(picks):
+                    got = ctxs[y].read(i)
+                    assert np.array_equal(got[0], iso[last[y]][n][0]) and np.array_equal(got[1], iso[last[y]][n][1]), "frame %d context %d instance %d" % (k, y, i)
+    f.close()
+    # the same context now animated by local rotations through the same ring
+    c.close()
+    c, mesh, s = _crowd(rz, 6000, 120, 160, seed=8, depth_chain=10)
+    qs = [s["q"], s["q"][::-1].copy(), np.roll(s["q"], 5, axis=0).copy()]
+    iso = []
+    for q in qs:
+        c.set_pose_local(q)
+        c.deform()
+        iso.append([c.read(i) for i in picks])
+    for k in range(90):
+        if k == 45:
+            c.set_tuning(pose_pull=1)           # the second half pulled instead of copied
+        c.set_pose_local(qs[k % 3])
+        assert c.get_tuning("pose_pulled") == (1 if k >= 45 else 0)
+        c.deform()
+        if k % 5 == 4:
+            for n, i in enumerate(picks):
+                got = c.read(i)
+                assert np.array_equal(got[0], iso[k % 3][n][0]) and np.array_equal(got[1], iso[k % 3][n][1]), "local frame %d instance %d" % (k, i)
+    c.close()

@@ -43,7 +43,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "cpu"
 if mode == "cpu":
     n = 0
     for name in rz.capi.SYMBOLS:
-        if name in ("rz_last_error", "rz_abi_version", "rz_device_count", "rz_create", "rz_shard_range", "rz_gather_chunk", "rz_comm_unique_id", "rz_comm_init_all",
+        if name in ("rz_last_error", "rz_abi_version", "rz_device_count", "rz_device_numa_node", "rz_create", "rz_shard_range", "rz_gather_chunk", "rz_comm_unique_id", "rz_comm_init_all",
                     "rz_allgather_all", "rz_gather_direct", "rz_destroy", "rz_rccl_info", "rz_autotune_pick"):
             continue
         f = getattr(L, name)

@@ -93,6 +93,10 @@ for k in (1, 2, 3, 4, 5, 6):
 print("  segments, median / max over waves (us): " + " | ".join(seg))
 xcc = (t[:, 7] & 0xff).astype(int)
 print("  per XCD: " + " | ".join("x%d n=%d in %.2f..%.2f out ..%.2f" % (x, (xcc == x).sum(), us(t[xcc == x, 0]).min(), us(t[xcc == x, 0]).max(), us(t[xcc == x, 6]).max()) for x in sorted(set(xcc))))
+# where an XCD's lag comes from: median of every stamp per XCD, and the median wave's time between the first step and the last
+for k in (1, 2, 3, 5):
+    if (t[:, k] != 0).all():
+        print("  per XCD, median of stamp %d (%s): " % (k, names[k]) + " ".join("x%d %.2f" % (x, np.median(us(t[xcc == x, k]))) for x in sorted(set(xcc))))
 if (t[:, 8] != 0).any():
     f = t[t[:, 8] != 0]
     fn = ["pose staged", "barrier passed", "local matrices formed", "doubling rounds done", "palette rows written"]
