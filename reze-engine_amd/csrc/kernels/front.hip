@@ -96,11 +96,9 @@ __global__ void __launch_bounds__(kPullBlock) rz_pull_pose_kernel(const float4 *
     if (raw4) {
         const uint32_t stride = gridDim.x * kPullBlock, last = raw4 - 1u;
         for (uint32_t i = blockIdx.x * kPullBlock + threadIdx.x; i < raw4; i += stride * 4u) {
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = rs[min(i + u * stride, last)];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rd[min(i + u * stride, last)] = v[u];      // (beyond the end: the last element again, the same value)
+            const uint32_t i1 = min(i + stride, last), i2 = min(i + 2u * stride, last), i3 = min(i + 3u * stride, last);
+            const float4 v0 = rs[i], v1 = rs[i1], v2 = rs[i2], v3 = rs[i3];
+            rd[i] = v0; rd[i1] = v1; rd[i2] = v2; rd[i3] = v3;        // (beyond the end: the last element again, the same value)
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < raw_words)

@@ -20,6 +20,9 @@ libs = [(n, rz.capi.load(p)) for n, p in builds]
 SHAPES = {"c5": (1000000, 256, 64, 1), "shard": (125184, 256, 64, 1), "c3": (30000, 200, 64, 1), "c2": (30000, 200, 0, 1), "c4": (30000, 200, 0, 256)}
 for wl in workloads:
     ctxs = []
+    anim = None
+    if "-" in wl:                       # sampled-c2, sampled-demo, local-c2 ...: the pose comes from the device-side sampler / a local pose
+        anim, wl = wl.split("-")
     if wl in ("demo", "sparse2"):
         V, B, M, I = 28842, 349, 60, 1
         mesh = synth.make_mesh(V, B)
@@ -39,7 +42,24 @@ for wl in workloads:
             c.upload_morphs_dense(d)
         if I > 1:
             c.set_instances(I)
-        c.set_pose(worlds, mw)
+        if anim:
+            c.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+            rng = np.random.default_rng(1)
+            if anim == "sampled":
+                nk = 8
+                kq = rng.normal(size=(B, nk, 4)).astype(np.float32); kq /= np.linalg.norm(kq, axis=2, keepdims=True)
+                extra = {}
+                if M:
+                    extra = dict(mkey_off=np.arange(M + 1) * 2, mkey_frame=np.tile(np.array([0.0, 70.0], np.float32), M), mkey_weight=np.repeat(mw, 2),
+                                 feed_off=np.arange(M + 1), feed_track=np.arange(M), feed_ratio=np.ones(M, np.float32))
+                c.upload_animation(np.arange(B), np.arange(B + 1) * nk, np.tile(np.arange(nk) * 10.0, B), kq, (rng.random((B, nk, 3), dtype=np.float32) - 0.5) * 0.2,
+                                   np.tile(np.array([20] * 8 + [107] * 8, np.uint8), B * nk), **extra)
+                c.set_pose_sampled((13.5 + 0.37 * np.arange(I)).astype(np.float32) % 70.0)
+            else:
+                q = rng.normal(size=(I, B, 4)).astype(np.float32); q /= np.linalg.norm(q, axis=2, keepdims=True)
+                c.set_pose_local(q if I > 1 else q[0], mw)
+        else:
+            c.set_pose(worlds, mw)
         return c
     n = 200 if V >= 500000 else (500 if I > 1 else 1000)
     res = {name: [] for name, _ in libs}
@@ -69,12 +89,12 @@ for wl in workloads:
     base = np.median([k for k, _ in res[ctxs[0][0]]])
     for name, _ in ctxs:
         ks = [k for k, _ in res[name]]; fs = [f for _, f in res[name]]
-        print("%-8s %-10s kernel median %.3f us (%+.2f %% vs %s) frame median %.3f | kernel rounds: %s" % (
-            wl, name, np.median(ks), (np.median(ks) / base - 1) * 100, ctxs[0][0], np.median(fs), " ".join("%.2f" % k for k in ks)), flush=True)
+        print("%-12s %-10s kernel median %.3f us (%+.2f %% vs %s) frame median %.3f | kernel rounds: %s" % (
+            ((anim + "-") if anim else "") + wl, name, np.median(ks), (np.median(ks) / base - 1) * 100, ctxs[0][0], np.median(fs), " ".join("%.2f" % k for k in ks)), flush=True)
     # paired: in how many rounds was build k faster than the first build?
     for name, _ in ctxs[1:]:
         wins = sum(1 for a, b in zip(res[name], res[ctxs[0][0]]) if a[0] < b[0])
-        print("%-8s %-10s faster than %s in %d of %d rounds" % (wl, name, ctxs[0][0], wins, rounds), flush=True)
+        print("%-12s %-10s faster than %s in %d of %d rounds" % (((anim + "-") if anim else "") + wl, name, ctxs[0][0], wins, rounds), flush=True)
     for _, c in ctxs:
         if c is not None:
             c.close()
