@@ -153,6 +153,7 @@ struct RzDeformParams {
     const uint16_t *sub_list;   // [runs][sub_stride] ascending bone indices of each run's subset
     const uint32_t *sub_count;  // [runs]
     int sub_stride;
+    int sub_max;                // longest list of the launch shape: every list is padded to it with bone 0
     int dma;                    // FAST: stage raw matrices by LDS-DMA (else plain loads after the first morph phase)
     int B;
     int M;

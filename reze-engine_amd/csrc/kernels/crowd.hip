@@ -1,6 +1,10 @@
 // kernels/crowd.hip — instanced skin (BASELINE config C4: many poses of one static mesh) and its plan-time bone-subset pass.
 #include "fk.hip.h"
 
+#ifndef RZ_CROWD_PADDED
+#define RZ_CROWD_PADDED 1
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -36,7 +40,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const uint32_t
     // The leading arguments are preloaded into SGPRs at wave start (14 dwords; see rz_deform_kernel): what the FRONT of a workgroup
     // needs — the run's bone list, the matrices it stages (k_src = the poses' world matrices, or their finished palettes behind
     // rz_prep_kernel / rz_fk_kernel), the inverse bind matrices, the launch shape (k_grid = gridDim.x | gridDim.y << 16: the hidden
-    // arguments would be one more scalar load) and k_bf = bone count | inst_order << 16 | dma << 17.
+    // arguments would be one more scalar load) and k_bf = bone count | inst_order << 16 | dma << 17 | padded length of the run lists << 18.
     const int kB = (int)(k_bf & 0xffffu);
     const bool k_order = (k_bf >> 16) & 1u, k_dma = (k_bf >> 17) & 1u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -53,8 +57,14 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const uint32_t
     const int ng = min(G, n_inst - inst0);
     const int rows = kB * 3;                       // float4 per palette, in global memory and (finished) in LDS
     constexpr int rstride = 3;                      // float4 per bone of a finished palette
-    // SUB: this run's bone list (workgroup-uniform: scalar loads)
+    // SUB: this run's bone list. Its LENGTH is not read: every list is padded with bone 0 up to the plan's longest (k_bf >> 18), and a
+    // workgroup stages and converts that many slots — a few matrices nobody gathers, in exchange for one dependent scalar load less at
+    // the head of the front (count -> list -> matrices was three round trips in front of the first store; RZ_CROWD_PADDED = 0: round 3's form)
+#if RZ_CROWD_PADDED
+    const int ns = SUB ? (int)(k_bf >> 18) : 0;
+#else
     const int ns = SUB ? (int)k_sub_count[wg_run] : 0;
+#endif
     const uint16_t *sub = SUB ? k_sub_list + (size_t)wg_run * kB : nullptr;      // (the lists' stride is the bone count)
     const int lrows = SUB ? ns * 3 : rows;          // float4 per pose of the finished LDS palettes
     float4 *stage = pal + (size_t)G * ns * 3;       // SUB, one-launch frame: staged world matrices sit behind the palette region
@@ -505,6 +515,7 @@ __global__ void __launch_bounds__(kBlock) rz_run_subsets_kernel(const uint32_t *
             list[(size_t)run * B + sl] = (uint16_t)b;
         }
     }
+    for (uint32_t sl = before[nw] + tid; sl < B; sl += kBlock) list[(size_t)run * B + sl] = 0;      // padding: a valid bone (see the crowd kernel)
     __syncthreads();
     for (uint32_t v = v0 + tid; v < v1; v += kBlock) {
         const uint32_t a = j01[v], b = j23[v];
@@ -535,10 +546,10 @@ static hipError_t launch_skin_instances(const RzDeformParams &p, int G, int n_in
         if (e != hipSuccess) return e;
     }
     dim3 grid(grid_x, (n_inst + G - 1) / G);
-    if (grid.x > 0xffffu || grid.y > 0xffffu || p.B > 0xffff || (sub && p.sub_stride != p.B)) return hipErrorInvalidValue;      // (k_grid packs both; the lists' stride is the bone count)
+    if (grid.x > 0xffffu || grid.y > 0xffffu || p.B > 0xffff || (sub && (p.sub_stride != p.B || p.sub_max <= 0 || p.sub_max > 0x3fff))) return hipErrorInvalidValue;      // (k_grid packs both; the lists' stride is the bone count; k_bf carries their padded length in 14 bits)
     // leading arguments = what the front of a workgroup needs, preloaded into SGPRs (see the kernel)
     const float4 *k_src = p.dma ? p.palette : reinterpret_cast<const float4 *>(p.world);
-    const uint32_t k_grid = grid.x | (grid.y << 16), k_bf = (uint32_t)p.B | (p.inst_order ? 1u << 16 : 0u) | (p.dma ? 1u << 17 : 0u);
+    const uint32_t k_grid = grid.x | (grid.y << 16), k_bf = (uint32_t)p.B | (p.inst_order ? 1u << 16 : 0u) | (p.dma ? 1u << 17 : 0u) | (sub ? (uint32_t)p.sub_max << 18 : 0u);
     hipLaunchKernelGGL(k, grid, dim3(BLOCK), lds, st, p.sub_count, p.sub_list, k_src, p.inv_bind, G, n_inst, verts_per_wg, k_grid, k_bf, p.Vp, p);
     return hipGetLastError();
 }

@@ -83,7 +83,7 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
 #endif
     p.out_cap = pl.out_cap;
     p.sp_cap = pl.sp_cap;
-    if (pl.subsets) { p.rj01 = c->rj01; p.rj23 = c->rj23; p.sub_list = c->sub_list; p.sub_count = c->sub_count; p.sub_stride = (int)c->sub_B; }
+    if (pl.subsets) { p.rj01 = c->rj01; p.rj23 = c->rj23; p.sub_list = c->sub_list; p.sub_count = c->sub_count; p.sub_stride = (int)c->sub_B; p.sub_max = (int)c->sub_max; }
     if (pl.subfk) p.fk = fk_params(c);          // (the crowd kernel's front reads the pose, the motion and the bone records through it)
     if (pl.fuse_fk) {
         p.fk = fk_params(c); p.fk_on = 1;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Copies what tools/gpu_full.sh left under gpurun_out/full/ (scratch) into profiles/ (tracked) under the round's names, builds
-profiles/r4_autotune_stability.json from the consecutive runs, and regenerates DESIGN.md's tables (tools/design_tables.py)."""
+profiles/<tag>_autotune_stability.json from the consecutive runs (usage: collect_profiles.py [tag], default r5), and regenerates DESIGN.md's tables (tools/design_tables.py)."""
 import glob
 import json
 import os
@@ -9,7 +9,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC, DST, TAG = os.path.join(ROOT, "gpurun_out", "full"), os.path.join(ROOT, "profiles"), "r4"
+SRC, DST = os.path.join(ROOT, "gpurun_out", "full"), os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r5"
 n = 0
 for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))):
     try:

@@ -5,10 +5,10 @@
     python tools/design_tables.py --check    exit 1 when DESIGN.md's block differs from what profiles/ says (tests/test_docs.py)
 
 Sources (all written on the GPU box by tools/gpu_full.sh / tools/gpu_profile.sh -> tools/parse_prof.py, then copied to profiles/):
-    profiles/r4_bench_*.json          bench.py lines (the driver contract), one per workload
-    profiles/r4_kernel_stats_*.txt    rocprofv3 --kernel-trace --stats of the same bench commands
+    profiles/r5_bench_*.json          bench.py lines (the driver contract), one per workload
+    profiles/r5_kernel_stats_*.txt    rocprofv3 --kernel-trace --stats of the same bench commands
     profiles/pmc_traffic.json         HBM bytes per launch from the PMC passes, keyed "<shape>|<kernel>"
-    profiles/r4_autotune_stability.json   what the launch-shape search picked in consecutive runs
+    profiles/r5_autotune_stability.json   what the launch-shape search picked in consecutive runs
 """
 import glob
 import json
@@ -18,8 +18,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
-TAG = "r4"
-PREV = "r3"
+TAG = "r5"
+PREV = "r4"
 BEGIN = "<!-- BEGIN GENERATED (tools/design_tables.py — do not edit by hand) -->"
 END = "<!-- END GENERATED -->"
 
@@ -52,7 +52,7 @@ def load(suffix, tag=None):
 
 
 def rocprof_row(stats_name, kernel):
-    """(calls, avg_us, min_us, max_us[, workgroups]) of `kernel` in profiles/r4_kernel_stats_<name>.txt: its most-launched launch
+    """(calls, avg_us, min_us, max_us[, workgroups]) of `kernel` in profiles/r5_kernel_stats_<name>.txt: its most-launched launch
     shape when the file has the per-shape section (the plan the bench loops ran), else the all-shapes row of the stats"""
     p = os.path.join(PROF, "%s_kernel_stats_%s.txt" % (TAG, stats_name))
     if not os.path.exists(p):
@@ -111,9 +111,8 @@ def build():
         rows.append("| %s | %s | %s | %s | %s |" % (suffix, pair(ca.get("ms_per_step_one_stream"), cb.get("ms_per_step_one_stream")), pair(a["roofline"]["kernel_ms"], b["roofline"]["kernel_ms"]),
                                                  pair(ca.get("frame_ms_with_pose_upload"), cb.get("frame_ms_with_pose_upload")), pair(ca.get("frame_ms_device_sampled_pose"), cb.get("frame_ms_device_sampled_pose"))))
     if rows:
-        out.append("**Round %s → round %s, line by line** (`profiles/%s_bench_*.json` against `profiles/%s_bench_*.json`, µs; different boxes: differences under ≈ 3 %% are box noise — "
-                   "the C5 and C4 kernels are the round-3 kernels, so their rows ARE box noise (`profiles/%s_box_variance.txt`); the same-session A/B runs are in `profiles/%s_ab_*.txt`; "
-                   "the 1/8 shard is 125 952 vertices in round 3 and 125 184 in round 4):" % (PREV[1:], TAG[1:], PREV, TAG, TAG, TAG))
+        out.append("**Round %s → round %s, line by line** (`profiles/%s_bench_*.json` against `profiles/%s_bench_*.json`, µs; different boxes: differences under ≈ 3 %% are box noise "
+                   "(`profiles/r4_box_variance.txt`); the same-session A/B runs are in `profiles/%s_ab_*.txt`; round 5's lines run on the cores of the GPU's NUMA node (`config.numa_binding`)):" % (PREV[1:], TAG[1:], PREV, TAG, TAG))
         out.append("")
         out.append("| line | frame, one stream | kernel (events) | frame + pose upload | frame, pose sampled on the GPU |")
         out.append("|---|---|---|---|---|")
