@@ -196,22 +196,6 @@ def main():
                              "that is not the one asked for\n" % (args.gpus, world_size))
         sys.exit(3)
 
-    # Every rank runs on the cores of ITS GPU's NUMA node (what numactl --cpunodebind does; rz_device_numa_node): per-frame inputs cross
-    # the host link, and a thread on the other socket pays for every HIP call and every pulled byte (profiles/r5_crowd_upload_numa.txt:
-    # a host-animated C4 frame 63 us from the GPU's node, 80-82 us from the other). Before torch / the HIP runtime start their threads.
-    full_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
-    numa = None
-    if not args.no_numa_bind:
-        try:
-            from reze_engine_amd import capi as _capi
-            n_dev = _capi.device_count()
-            one_each = world_size > 1 and n_dev == 1 and any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
-            dev = 0 if (one_each or world_size == 1) else (local_rank % max(1, n_dev) if args.share_gpu else local_rank)
-            if dev < n_dev:
-                numa = _capi.bind_to_device_node(dev)
-        except Exception as e:          # noqa: BLE001
-            sys.stderr.write("[bench] rank %d: no NUMA binding (%r)\n" % (rank, e))
-
     import torch
     # a launcher may hand every rank ITS OWN GPU through *_VISIBLE_DEVICES (each rank then sees exactly one device, index 0)
     isolated = (world_size > 1 and torch.cuda.device_count() == 1 and
@@ -254,6 +238,21 @@ def main():
                 sys.stderr.write("[bench] %d ranks but they resolve to %d distinct GPU(s): one process per GPU (--share-gpu rehearses N > 1 on fewer GPUs)\n"
                                  % (world_size, len(set(ids))))
             sys.exit(4)
+
+    # Every rank runs on the cores of ITS GPU's NUMA node (what numactl --cpunodebind does; rz_device_numa_node): per-frame inputs cross
+    # the host link, and a thread on the other socket pays for every HIP call and every pulled byte (profiles/r5_crowd_upload_numa.txt:
+    # a host-animated C4 frame 63 us from the GPU's node, 80-82 us from the other). AFTER torch has brought its HIP runtime up (the
+    # library must bind to the copy the process already carries — loading it first put a second runtime under torch's RCCL and
+    # ncclCommInitRank failed); sched_setaffinity moves the calling thread, which makes every HIP call from here on and first-touches
+    # the pinned rings, and the threads it starts.
+    full_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    numa = None
+    if not args.no_numa_bind and torch.cuda.is_available():
+        try:
+            from reze_engine_amd import capi as _capi
+            numa = _capi.bind_to_device_node(local_rank)
+        except Exception as e:          # noqa: BLE001
+            sys.stderr.write("[bench] rank %d: no NUMA binding (%r)\n" % (rank, e))
 
     import reze_engine_amd as rz
     from reze_engine_amd import synth

@@ -237,8 +237,13 @@ int rz_device_numa_node(int device, int *node)
     if (!node) return fail(RZ_ERR_INVALID, "null node");
     *node = -1;
     char bus[32] = {0};
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) {
+        (void)hipGetLastError();        // (the runtime keeps a failed call's error for the next hipGetLastError(): a launch check would report it)
+        return fail(RZ_ERR_NO_DEVICE, "no device %d (%d visible)", device, n_dev);
+    }
     hipError_t e = hipDeviceGetPCIBusId(bus, (int)sizeof bus, device);
-    if (e != hipSuccess) return fail(RZ_ERR_NO_DEVICE, "hipDeviceGetPCIBusId(%d): %s", device, hipGetErrorString(e));
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(RZ_ERR_NO_DEVICE, "hipDeviceGetPCIBusId(%d): %s", device, hipGetErrorString(e)); }
     for (char *p = bus; *p; ++p) *p = (char)tolower((unsigned char)*p);      // sysfs spells the address in lower case
     char path[128];
     snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);

@@ -35,9 +35,11 @@ const char *last_error();
 #define HIP_TRY(expr)                                                                               \
     do {                                                                                            \
         hipError_t e_ = (expr);                                                                     \
-        if (e_ != hipSuccess)                                                                       \
+        if (e_ != hipSuccess) {                                                                     \
+            (void)hipGetLastError();    /* reported here: a later launch's hipGetLastError() must not see it again */ \
             return fail(e_ == hipErrorOutOfMemory ? RZ_ERR_OOM : RZ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
                         hipGetErrorString(e_), __FILE__, __LINE__);                                 \
+        }                                                                                           \
     } while (0)
 
 

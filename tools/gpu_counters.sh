@@ -3,9 +3,9 @@
 # gpu_c5_counters.sh, gpu_pmc_sq.sh, gpu_sparse_counters.sh). One PMC group per rocprofv3 run (kernel-trace only, as gpurun demands);
 # FETCH_SIZE / WRITE_SIZE traffic comes from gpu_profile.sh. The write-path groups are also collected for tools/storebench — the same
 # 184 MB written with no loads and no math — so the C4 kernel's store stalls can be read against the fill's own.
-#   usage: tools/gpu_counters.sh [workload ...]      default: c5 shard c4 c4fk demo store      -> gpurun_out/counters/summary_<workload>.txt
+#   usage: [PMC_GROUPS="1 2 3"] tools/gpu_counters.sh [workload ...]      default: c5 shard c4 c4fk demo store, all five groups      -> gpurun_out/counters/summary_<workload>.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/counters; rm -rf $O; mkdir -p $O
+O=$R/gpurun_out/counters; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 COMMON="--no-cpu-baseline --no-autotune --no-sampled-loop --frames-in-flight 1 --no-pair-loop --clock-warm-seconds 0.3"
 declare -A CMD
@@ -27,7 +27,7 @@ G4="SQ_INST_CYCLES_VMEM_WR SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_AC
 G5="TCP_TCC_WRITE_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_UTCL1_REQUEST_sum"
 WL=${@:-c5 shard c4 c4fk demo store}
 for c in $WL; do
-  groups="1 2 3 4 5"; [ $c = store ] && groups="1 4 5"
+  groups=${PMC_GROUPS:-"1 2 3 4 5"}; [ $c = store ] && groups="1 4 5"
   for g in $groups; do
     eval "PM=\$G$g"
     timeout 150 rocprofv3 --kernel-trace --pmc $PM --output-format csv -d $O/${c}_g$g -o p -- ${CMD[$c]} > $O/${c}_g$g.log 2>&1 || echo "FAILED $c g$g: $(tail -1 $O/${c}_g$g.log)"

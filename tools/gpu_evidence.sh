@@ -20,7 +20,9 @@ timelines)
     timeout 200 python tools/timeline.py $c 2>&1 | grep -v "amdgpu.ids" > $O/timeline_$c.txt; head -1 $O/timeline_$c.txt | cut -c1-200
   done ;;
 counters)
-  bash tools/gpu_counters.sh c5 shard c4 c4fk demo 2>&1 | grep -v "^$" | tail -40
+  rm -rf gpurun_out/counters
+  PMC_GROUPS="1 2 3" bash tools/gpu_counters.sh c5 shard demo 2>&1 | grep -v "^$" | tail -20      # (the write-path groups matter for the store-bound crowd kernels)
+  bash tools/gpu_counters.sh c4 c4fk 2>&1 | grep -v "^$" | tail -20
   cd $R; mkdir -p $O/counters; cp gpurun_out/counters/summary_*.txt $O/counters/ 2>/dev/null ;;
 micro)
   timeout 120 tools/overlapbench 2>&1 | tee $O/overlapbench.txt | tail -4

@@ -16,13 +16,13 @@ CFG[demo]="--config demo --steps 300 --warmup 20"
 for c in c5 shard c4 c3 demo; do
   B="python $R/bench.py ${CFG[$c]} --no-cpu-baseline --no-sampled-loop --frames-in-flight 1 --no-pair-loop"
   echo "== $c: kernel trace + stats"
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$c -o bench -- $B > $O/trace_$c.log 2>&1 || echo "FAILED trace $c"
+  timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$c -o bench -- $B > $O/trace_$c.log 2>&1 || echo "FAILED trace $c"
   grep '^{' $O/trace_$c.log | tail -1 > $O/line_$c.json
   echo "== $c: pmc FETCH_SIZE / WRITE_SIZE"
-  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$c -o bench -- $B > $O/fetch_$c.log 2>&1 || echo "FAILED fetch $c"
-  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_$c -o bench -- $B > $O/write_$c.log 2>&1 || echo "FAILED write $c"
+  timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$c -o bench -- $B > $O/fetch_$c.log 2>&1 || echo "FAILED fetch $c"
+  timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_$c -o bench -- $B > $O/write_$c.log 2>&1 || echo "FAILED write $c"
 done
 echo "== calibration (membench quick) FETCH_SIZE / WRITE_SIZE"
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch -o mb -- $R/tools/membench quick > $O/cal_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/cal_write -o mb -- $R/tools/membench quick > $O/cal_write.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch -o mb -- $R/tools/membench quick > $O/cal_fetch.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/cal_write -o mb -- $R/tools/membench quick > $O/cal_write.log 2>&1
 cd $R; find gpurun_out/prof -name "*.csv" | wc -l; du -sh gpurun_out/prof
