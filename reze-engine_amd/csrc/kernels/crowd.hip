@@ -14,7 +14,7 @@ namespace {
 // the four joints as palette row offsets, the four weights as floats — and then loops over the G poses:
 // 12 ds_read_b128 + blend + transform + 24 B store per pose. The static mesh is read I/G times instead
 // of I times, and the per-pose body has no global load in front of it (the generic kernel was latency-
-// bound here: 43 % of wave time in s_waitcnt, VALU 30 %, LDS 31 % — profiles/r1_sq_counters.txt).
+// bound here: 43 % of wave time in s_waitcnt, VALU 30 %, LDS 31 % — profiles/archive/r1_sq_counters.txt).
 // grid = (vertex runs, instance groups); block = 256; dynamic LDS = G * B * 48 bytes.
 // ------------------------------------------------------------------------------------------------
 
@@ -27,7 +27,7 @@ namespace {
 // SUB = bone-subset form. A vertex run names only a few of the skeleton's bones (PMX meshes are bone-local: the synthetic C4
 // mesh's 3 750-vertex runs touch ~34 of 200), and rz_run_subsets_kernel has listed them per run and rewritten the joints as
 // slots of that list. The workgroup stages ONLY those bones of its G poses: 8 x 34 matrices instead of 8 x 200 — the front of
-// every workgroup (LDS-DMA + palette product, during which the CU stores nothing) shrinks from 2.9 us to 1.3 us (profiles/r3_c4_front.txt), and the
+// every workgroup (LDS-DMA + palette product, during which the CU stores nothing) shrinks from 2.9 us to 1.3 us (profiles/archive/r3_c4_front.txt), and the
 // group's LDS footprint from 102 KB to 30 KB. World matrices are staged behind the palette region, so the product needs no
 // in-place rounds. The palette rows a vertex gathers hold the same bits wherever they sit in LDS: outputs do not change.
 // (Tried and measured slower or without effect, then removed again — NOTEBOOK.md R3.1 / R3.4 / R3.9: forcing three workgroups per CU
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const uint32_t
         // one-launch frame (!dma): the group's WORLD matrices are staged instead, whole (64-byte slots, the same linear
         // 16-byte LDS-DMA); the conversion pass below multiplies by the inverse bind matrix and re-packs the rows to the
         // same 48-byte stride. (Leaving them in the 64-byte slots made every fourth bone share its LDS banks: 52 % of the
-        // skin loop's LDS cycles were bank conflicts, against 11 % at 48 bytes — profiles/r2_sq_counters_c4.txt.)
+        // skin loop's LDS cycles were bank conflicts, against 11 % at 48 bytes — profiles/archive/r2_sq_counters_c4.txt.)
         const float4 *src = k_src + (size_t)inst0 * kB * (k_dma ? 3 : 4);
         const int n = (RZ_DBG(p) == 6 || RZ_DBG(p) == 7 || RZ_DBG(p) == 8) ? 0 : (k_dma ? ng * rows : ng * kB * 4);   // dbg 6 / 7 (tools-only build): no palette staging
         for (int c = wave * 64; c < n; c += BLOCK) {

@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
 // ---- launch: which instantiations the library carries ----
 // The PRODUCT instantiates what a plan can select by default or through rz_autotune: rest geometry by 4-byte loads (GEO = false),
 // nontemporal morph loads (NT = true), 8 morphs in flight (U = 8) — 16 kernels. The variants measured slower everywhere (GEO = true,
-// NT = false, U = 4: profiles/r1_*sweep*) live in the tools-only build (-DRZ_ALL_VARIANTS, `make variants`), where the parity tests
+// NT = false, U = 4: profiles/archive/r1_*sweep*) live in the tools-only build (-DRZ_ALL_VARIANTS, `make variants`), where the parity tests
 // still cover every one of them; in the product rz_set_tuning refuses the keys that would select them.
 #ifdef RZ_ALL_VARIANTS
 constexpr bool kAllVariants = true;

@@ -10,8 +10,8 @@ namespace {
 int auto_split(const rz_ctx *c)
 {
     if (c->morph_mode != 1) return 1;
-    // S lanes share a quad, so waves = quads * S / 64. Measured on MI355X (profiles/r1_a_sweep*, and the search tables of
-    // profiles/r3_bench_*.json): 126 k verts -> S = 4, 30 k -> S = 8, i.e. aim for ~1500 waves, never beyond 8; and even
+    // S lanes share a quad, so waves = quads * S / 64. Measured on MI355X (profiles/archive/r1_a_sweep*, and the search tables of
+    // profiles/archive/r3_bench_*.json): 126 k verts -> S = 4, 30 k -> S = 8, i.e. aim for ~1500 waves, never beyond 8; and even
     // the 1 M-vertex mesh (3 906 waves at S = 1) streams 3 % faster with two lanes per quad (122.8 vs 127.0 us; S = 4 is
     // within 0.4 % of S = 2), so a dense frame never runs below S = 2 — which also keeps rz_autotune's pick on the
     // heuristic plan instead of flipping between two near-equal candidates from run to run.
@@ -29,7 +29,7 @@ void inst_runs(const rz_ctx *c, int G, int blk, bool for_subsets, uint32_t *per,
     // workgroups. With bone subsets (15-30 KB of LDS) two 512-thread workgroups fit a CU and more, shorter runs name fewer
     // bones (36 -> 17 per run at 1024 workgroups), but whether that pays depends on the box: tools/c4_subsets.py measured
     // 256 / 512 / 768 / 1024 workgroups at 33.4 / 34.3 / 32.9 / 32.6 us on one MI355X and 33.1-33.4 / 42 / 42 / 42 us on two
-    // others (profiles/r3_c4_subsets.txt). One workgroup per CU is the shape that is good everywhere, so it is the default;
+    // others (profiles/archive/r3_c4_subsets.txt). One workgroup per CU is the shape that is good everywhere, so it is the default;
     // rz_autotune tries the others on the box it runs on.
     (void)for_subsets;
     const uint32_t wg_per_cu = blk == 256 ? 2u : 1u;
@@ -120,7 +120,7 @@ bool inst_shape(const rz_ctx *c, InstShape *s)
     // workgroup size. Whole palettes: 512 threads for the one-launch frame (one workgroup of 8 waves per CU shares the 102 KB
     // group), 256 behind rz_prep_kernel / rz_fk_kernel (two workgroups of 80 KB each: measured best in round 2). Bone subsets
     // (30 KB): 512 threads in both forms — with finished rows staged the 512-thread kernel runs C4 in 32.1 us against 34.5 us
-    // for 256 threads (tools/c4_subsets.py, fast = 0 rows of profiles/r3_c4_subsets.txt).
+    // for 256 threads (tools/c4_subsets.py, fast = 0 rows of profiles/archive/r3_c4_subsets.txt).
     const bool forced = c->t_instblock == 256 || c->t_instblock == 512 || c->t_instblock == 1024;
     s->blk_full = forced ? c->t_instblock : (s->want_in_kernel ? 512 : 256);
     s->blk = forced ? c->t_instblock : (c->t_subsets != 0 ? 512 : s->blk_full);
@@ -173,7 +173,7 @@ Plan make_plan(const rz_ctx *c)
     pl.prep = !v.fast && !pl.fuse_fk;
     // persistent, balanced grid: `cap` workgroups in total, every wave owns an equal contiguous run of quads
     const uint32_t waves_per_wg = 4, qpw_step = 64 / (uint32_t)v.S;
-    // measured (profiles/r1_*sweep*): 2 workgroups per CU for one big mesh, 8 per instance when instanced
+    // measured (profiles/archive/r1_*sweep*): 2 workgroups per CU for one big mesh, 8 per instance when instanced
     uint32_t cap = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : std::max(2u * (uint32_t)c->n_cu, 8u * c->I);
     // Pose prefetch: the first frame of a zero-copy world pose carries one helper workgroup that stages the NEXT pose (if the
     // host has written it already) — it takes one of the grid's slots, the workers share the mesh among cap - 1.

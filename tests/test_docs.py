@@ -23,10 +23,42 @@ def test_design_prose_quotes_no_tracked_line_numbers():
     a, b = text.index(dt.BEGIN), text.index(dt.END)
     prose = text[:a] + text[b:]
     assert not re.search(r"tracked (bench )?line[^\n]{0,40}\d", prose), "a tracked-line number is quoted outside the generated block"
-    # every profiles/ file the document names exists
-    for name in set(re.findall(r"profiles/([A-Za-z0-9_.*-]+)", text)):
+    # every profiles/ file the document names exists (files of rounds 1-3 live under profiles/archive/)
+    for name in set(re.findall(r"profiles/([A-Za-z0-9_.*/-]+)", text)):
         if "*" in name:
             import glob
             assert glob.glob(os.path.join(ROOT, "profiles", name)), "DESIGN.md names profiles/%s, which matches nothing" % name
         else:
             assert os.path.exists(os.path.join(ROOT, "profiles", name.rstrip(".,;:)"))), "DESIGN.md names profiles/%s, which does not exist" % name
+
+
+def test_design_prose_fracs_are_the_tracked_lines():
+    """Round-4 review: DESIGN.md's prose said "0.720 / 0.718" while the tracked C4 line said 0.698 / 0.706. Every roofline fraction the
+    prose QUOTES (a number next to the word frac / fraction / roofline, outside the generated block) must be one the tracked lines of the
+    current round carry — `roofline.frac` or `roofline.frame_frac` of some profiles/<tag>_bench_*.json, or of a stability run, to the
+    printed precision — unless it is a stated TARGET (>=, <=, "target") or the sentence cites an experiment's own profiles/ file."""
+    import glob
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import design_tables as dt
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    a, b = text.index(dt.BEGIN), text.index(dt.END)
+    prose = text[:a] + text[b + len(dt.END):]
+    tracked = set()
+    for f in glob.glob(os.path.join(ROOT, "profiles", "%s_bench_*.json" % dt.TAG)):
+        d = json.load(open(f))
+        for k in ("frac", "frame_frac"):
+            v = d.get("roofline", {}).get(k)
+            if v is not None:
+                tracked.update({"%.2f" % v, "%.3f" % v})
+    sj = os.path.join(ROOT, "profiles", "%s_autotune_stability.json" % dt.TAG)
+    assert tracked, "no tracked bench lines of round %s under profiles/" % dt.TAG
+    bad = []
+    for line in prose.splitlines():
+        for m in re.finditer(r"(frac(?:tion)?|roofline)[^0-9\n]{0,24}(0\.\d{2,3})\b", line):
+            lead = line[max(0, m.start(2) - 12):m.start(2)]
+            if re.search(r"(≥|≤|>=|<=|target)", lead) or "profiles/" in line:
+                continue
+            if m.group(2) not in tracked:
+                bad.append((m.group(2), line.strip()[:140]))
+    assert not bad, "fractions quoted in DESIGN.md's prose that no tracked line of round %s carries: %r" % (dt.TAG, bad)
