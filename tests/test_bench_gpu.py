@@ -45,6 +45,8 @@ def _check(d, n_gpus, steps, verts):
     assert sum(x["verts"] for x in ranks) == verts and all(x["kernel_ms"] > 0 and x["kernel"].startswith("rz_") for x in ranks)
     assert d["config"]["kernel_ms_max_over_ranks"] >= d["config"]["kernel_ms_min_over_ranks"] > 0
     assert d["config"]["frame_ms_with_pose_upload"] > 0 and d["config"]["frame_ms_device_sampled_pose"] > 0
+    nb = d["config"]["numa_binding"]                # rank 0 ran on its GPU's node, or says that there was nothing to bind to
+    assert nb is None or (nb["gpu_node"] >= 0 and nb["cpus"])
 
 
 @pytest.mark.gpu

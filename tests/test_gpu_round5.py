@@ -267,3 +267,39 @@ def test_crowd_pose_ring_never_serves_a_stale_or_torn_pose(rz):
                 got = c.read(i)
                 assert np.array_equal(got[0], iso[k % 3][n][0]) and np.array_equal(got[1], iso[k % 3][n][1]), "local frame %d instance %d" % (k, i)
     c.close()
+
+
+def test_numa_node_query_and_binding(rz):
+    """rz_device_numa_node reads the NUMA node of the device's PCI function out of sysfs (-1 when the system does not say); binding to it
+    (capi.bind_to_device_node: what bench.py does for every rank) must leave the process on cores of exactly that node — checked in a
+    child process, so this one keeps its affinity. A device that does not exist is refused, and the refusal leaves no stale HIP error
+    behind for the next launch check (the N-API misuse script found that one)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    node = rz.capi.device_numa_node(0)
+    assert isinstance(node, int) and node >= -1
+    with pytest.raises(rz.capi.RzError):
+        rz.capi.device_numa_node(99)
+    c = rz.DeformContext(0)                                     # a launch right after the refused query: no stale error may surface
+    mesh = synth.make_mesh(2000, 8)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); c.upload_skeleton(mesh["inv_bind"])
+    c.set_pose(mesh["world"]); c.deform()
+    assert np.isfinite(c.read()[0]).all()
+    c.close()
+    code = ("import json, os, sys; sys.path.insert(0, %r); import reze_engine_amd as rz; "
+            "b = rz.capi.bind_to_device_node(0); print(json.dumps({'b': b, 'cpus': sorted(os.sched_getaffinity(0))}))" % root)
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-800:]
+    r = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    if node < 0 or r["b"] is None:
+        assert r["b"] is None                                   # one node / unknown: nothing bound
+        return
+    assert r["b"]["gpu_node"] == node
+    want = set()
+    for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+        lo, _, hi = part.partition("-")
+        want.update(range(int(lo), int(hi or lo) + 1))
+    assert set(r["cpus"]) and set(r["cpus"]) <= want
