@@ -384,7 +384,7 @@ int rz_fork(rz_ctx *parent, rz_ctx **out)
     c->I = parent->I;
     c->t_split = parent->t_split; c->t_unroll = parent->t_unroll; c->t_grid_cap = parent->t_grid_cap; c->t_nt = parent->t_nt; c->t_nts = parent->t_nts;
     c->t_geo = parent->t_geo; c->t_fast = parent->t_fast; c->t_instloop = parent->t_instloop; c->t_outcap = parent->t_outcap; c->t_instblock = parent->t_instblock;
-    c->t_instorder = parent->t_instorder; c->t_overlap = parent->t_overlap; c->t_zerocopy = parent->t_zerocopy; c->t_pull = parent->t_pull; c->t_fusefk = parent->t_fusefk;
+    c->t_instorder = parent->t_instorder; c->t_overlap = parent->t_overlap; c->t_zerocopy = parent->t_zerocopy; c->t_pull = parent->t_pull; c->t_fkplain = parent->t_fkplain; c->t_fusefk = parent->t_fusefk;
     c->t_graph = parent->t_graph; c->tuned_by_search = parent->tuned_by_search; c->t_subsets = parent->t_subsets; c->t_prefetch = parent->t_prefetch;
     c->lender = parent;
     parent->n_forks++;

@@ -213,6 +213,7 @@ struct rz_ctx {
     size_t stage_bytes = 0;
     // Crowd poses (more than 256 KB) are PULLED out of the ring slot by rz_pull_pose_kernel on the upload stream instead of copied by
     // hipMemcpyAsync, world matrices as their upper three rows (pose.cpp: upload_pose_copy)
+    int t_fkplain = -1;                 // "fuse_fk_plain": -1 / 1 = the fused frame of a plain pose runs the specialised kernel variant, 0 = always the generic one
     int t_pull = -1;                    // "pose_pull": -1 = world-matrix poses, 1 = every pose of more than 256 KB, 0 = hipMemcpyAsync of the pose as the host handed it over
     bool last_upload_pulled = false, last_upload_rows = false;      // what the most recent copy upload did (rz_get_tuning: pose_pulled / pose_rows)
     hipEvent_t stage_ev[kStageSlots] = {};

@@ -126,6 +126,7 @@ struct RzDeformParams {
     // leaves world matrices, palette and sampled weights in memory (rz_read_world / rz_read_palette).
     RzFkParams fk;
     int fk_on;
+    int fk_kind;                // 0: the generic solve; 1 / 2: the kernel variant specialised for a PLAIN uploaded / sampled pose (kernels/fk.hip.h: fk_solve<FUSED, KIND>)
     const uint32_t *sp_ptr;     // [Vp+1]   (MODE 2) per-vertex CSR row pointers
     const float4 *sp_entries;   // [E]      (dx,dy,dz,bits(morph))
     float *out_pos;             // [I][Vp][3]

@@ -151,7 +151,7 @@ __device__ __forceinline__ void aabb_commit(const RzDeformParams &p, const int i
 // compared after the speculative loads of the staged copy have been issued), else still in its pinned slot; on a miss workgroup 0
 // leaves the pose in the device block for the frames that replay it. `stage_weights`: the uploaded (not sampled) morph weights are
 // parked in LDS first — the morph modes and bone morphs need them. Returns where the pose's morph weights sit in LDS. Ends with a barrier.
-template <bool STAGE_WEIGHTS_ALWAYS>
+template <bool STAGE_WEIGHTS_ALWAYS, int KIND = 0>
 __device__ __forceinline__ float *fused_hierarchy_prologue(const RzFkParams &fk, const FkEarly &early, const uint64_t *st_tag, const uint64_t st_expect, const float *st_morph_w,
                                                            const float *morph_w, float *morph_w_copy, const int M, float4 *pal, float *work, const uint32_t wid,
                                                            unsigned long long *tl_f)
@@ -159,10 +159,10 @@ __device__ __forceinline__ float *fused_hierarchy_prologue(const RzFkParams &fk,
     const int tid = threadIdx.x;
     unsigned char *fscr = reinterpret_cast<unsigned char *>(work);
     float *lds_mw = reinterpret_cast<float *>(fscr + rz_fk_scratch_bytes(fk.B));
-    const bool sampled = fk.sample.frames != nullptr || fk.sample.frames_inline;
-    const bool fspec = st_tag != nullptr;
+    const bool sampled = KIND == 2 || (KIND == 0 && (fk.sample.frames != nullptr || fk.sample.frames_inline));
+    const bool fspec = KIND != 2 && st_tag != nullptr;
     const uint64_t ftag = fspec ? *st_tag : 0ull;
-    if ((STAGE_WEIGHTS_ALWAYS || fk.bm_off) && !sampled) {
+    if ((STAGE_WEIGHTS_ALWAYS || (KIND == 0 && fk.bm_off)) && !sampled) {
         const float *mw0 = fspec ? st_morph_w : morph_w;               // uploaded weights (staged copy, pinned slot or device block)
         for (int i = tid; i < M; i += kBlock) {
             float w = mw0[i];
@@ -172,7 +172,7 @@ __device__ __forceinline__ float *fused_hierarchy_prologue(const RzFkParams &fk,
             if (wid == 0 && morph_w_copy && (!fspec || miss)) morph_w_copy[i] = w;
         }
     }
-    fk_solve<true>(fk, early, 0, pal, fscr, lds_mw, wid == 0, ftag, tl_f);       // ends with a barrier: pal and lds_mw are complete
+    fk_solve<true, KIND>(fk, early, 0, pal, fscr, lds_mw, wid == 0, ftag, tl_f);       // ends with a barrier: pal and lds_mw are complete
     return lds_mw;
 }
 

@@ -33,7 +33,7 @@
 
 namespace {
 
-template <int S, int MODE, bool NTS, bool GEO, bool FAST>
+template <int S, int MODE, bool NTS, bool GEO, bool FAST, int FKV = 0>
 __global__ void __launch_bounds__(kBlock, 2) rz_deform_small_kernel(const float *k_geom, const float *k_world, const float *k_inv_bind, const uint32_t k_bf,
                                                                     const uint32_t k_Vp, const uint32_t k_nq, const uint32_t k_qpw, const uint32_t *k_j01,
                                                                     const uint32_t *k_j23, const uint32_t *k_wq, const RzDeformParams p)
@@ -166,13 +166,14 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_small_kernel(const float 
     const uint64_t st_tagv = spec ? *p.st_tag : 0ull;                   // requested here, compared later (workgroup-uniform)
     const bool staged_now = MODE == 2 && spec && st_tagv == p.st_expect;
     const float *morph_w_in = (staged_now && p.st_morph_w) ? p.st_morph_w : p.morph_w;
-    if (!FAST && p.fk_on) {
-        // FUSED single-character frame: hierarchy solve (and motion sampling) as this workgroup's prologue
-        float *lds_mw = fused_hierarchy_prologue<MODE != 0>(p.fk, fke, p.st_tag, p.st_expect, p.st_morph_w, p.morph_w, p.morph_w_copy, p.M, pal, scratch_all, wid, RZ_TL_FK);
+    if (!FAST && (FKV != 0 || p.fk_on)) {
+        // FUSED single-character frame: hierarchy solve (and motion sampling) as this workgroup's prologue (FKV 1 / 2: the variant
+        // specialised for a plain uploaded / sampled pose — the launcher only picks it for fused frames)
+        float *lds_mw = fused_hierarchy_prologue<MODE != 0, FKV>(p.fk, fke, p.st_tag, p.st_expect, p.st_morph_w, p.morph_w, p.morph_w_copy, p.M, pal, scratch_all, wid, RZ_TL_FK);
         if (MODE == 2)
             for (int i = tid; i < p.M; i += kBlock) s_w[i] = lds_mw[i];
         __syncthreads();
-    } else if (!FAST) {
+    } else if (!FAST && FKV == 0) {
         const float4 *gpal = p.palette + (size_t)inst * p.B * 3;
         for (int i = tid; i < p.B * 3; i += kBlock) pal[i] = gpal[i];
         if (MODE == 2) {
@@ -420,10 +421,14 @@ constexpr bool kAllVariants = true;
 constexpr bool kAllVariants = false;
 #endif
 
-template <int S, int MODE, bool NTS, bool GEO, bool FAST>
+template <int S, int MODE, bool NTS, bool GEO, bool FAST, int FKV = 0>
 static hipError_t launch_one(const RzDeformParams &p, dim3 grid, size_t lds, hipStream_t st)
 {
-    auto k = rz_deform_small_kernel<S, MODE, NTS, GEO, FAST>;
+    if constexpr (!FAST && !GEO && FKV == 0) {          // the fused frame of a plain pose: the specialised variants (fk_solve<true, KIND>)
+        if (p.fk_on && p.fk_kind == 1) return launch_one<S, MODE, NTS, GEO, FAST, 1>(p, grid, lds, st);
+        if (p.fk_on && p.fk_kind == 2) return launch_one<S, MODE, NTS, GEO, FAST, 2>(p, grid, lds, st);
+    }
+    auto k = rz_deform_small_kernel<S, MODE, NTS, GEO, FAST, FKV>;
     if (p.B > 0xffff) return hipErrorInvalidValue;      // k_bf carries the bone count in 16 bits
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

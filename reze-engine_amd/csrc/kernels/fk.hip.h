@@ -376,10 +376,16 @@ __device__ __forceinline__ void fk_palette_rows(const float4 w0, const float4 w1
 // three products and a barrier. The products are associated differently from the reference's parent-first recursion: same f32
 // error class, ~1e-7 per product (tests/test_gpu_round4.py: test_pointer_doubling_hierarchy_solve, against float64).
 // LDS behind `scr`: rz_fk_scratch_bytes(B) = B x (48 + 12) bytes. Ends with a barrier.
-template <bool FUSED>
+// KIND specialises the body at compile time for the two common single-character poses (the deform kernels' fused frame, round 5): the
+// generic form carries every feature behind workgroup-uniform branches — 47 KB of code in front of a 10 KB deform kernel, of which a frame
+// executes every instruction once. KIND 1 = an uploaded pose, KIND 2 = a sampled pose, both PLAIN: no bone morphs, no physics overrides,
+// at most 512 bones (two per thread), at most two doubling rounds (<= 16 levels) — the host picks the variant when all of that holds
+// (RzDeformParams::fk_kind) and the generic form (KIND 0) otherwise. Same device functions, same bits.
+template <bool FUSED, int KIND = 0>
 __device__ __forceinline__ void fk_solve(const RzFkParams &p, const FkEarly &early, const int inst, float4 *wl, unsigned char *scr, float *lds_mw,
                                          const bool to_global, const uint64_t st_tagv = 0ull, unsigned long long *fs = nullptr)
 {
+    constexpr bool PLAIN = KIND != 0;
 #ifdef RZ_ABLATE
 #define RZ_FSTAMP(k) do { if (fs) fs[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -395,8 +401,8 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const FkEarly &ear
     const int tid = threadIdx.x;
     const float4 *lq = p.local_q + (size_t)inst * p.B;
     const float *glt = p.local_t ? p.local_t + (size_t)inst * p.B * 3 : nullptr;
-    const bool sampled = p.sample.frames != nullptr || p.sample.frames_inline;      // rz_set_pose_sampled: the pose is evaluated right here
-    const bool bone_morphs = p.bm_off != nullptr;
+    const bool sampled = KIND == 2 || (KIND == 0 && (p.sample.frames != nullptr || p.sample.frames_inline));      // rz_set_pose_sampled: the pose is evaluated right here
+    const bool bone_morphs = !PLAIN && p.bm_off != nullptr;
     const bool has_t = sampled || glt != nullptr || bone_morphs;
     const float frame = sampled ? (p.sample.frames_inline ? p.sample.frame0 : p.sample.frames[inst]) : 0.0f;
     float *world = p.world + (size_t)inst * p.B * 16;
@@ -470,6 +476,7 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const FkEarly &ear
         if (hb0) { uploaded(b0, q, tx, ty, tz); park(b0, q, tx, ty, tz, early.a0, early.a1); }
         if (hb1) { uploaded(b1, q, tx, ty, tz); park(b1, q, tx, ty, tz, early.b0, early.b1); }
     }
+    if constexpr (!PLAIN)
     for (int i = tid + 2 * kBlock; i < p.B; i += kBlock) {      // skeletons beyond 512 bones: the rest, record by record
         const uint4 r0 = p.bone_rec[4 * i], r1 = p.bone_rec[4 * i + 1];
         float4 q;
@@ -539,6 +546,7 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const FkEarly &ear
             wl[b * 3] = rm[k][0]; wl[b * 3 + 1] = rm[k][1]; wl[b * 3 + 2] = rm[k][2];
         }
     }
+    if constexpr (!PLAIN)
     for (int b = tid + NBR * kBlock; b < p.B; b += kBlock) {
         float4 l0, l1, l2;
         local_of(b, l0, l1, l2);
@@ -556,11 +564,12 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const FkEarly &ear
             if (b < p.B) {
                 const uint4 w3 = k == 0 ? early.a3 : early.b3;
                 uint32_t lo = r == 0 ? w3.x : w3.z, hi = r == 0 ? w3.y : w3.w;
-                if (r >= 2) { const uint2 am = p.anc_more[(size_t)(r - 2) * p.B + b]; lo = am.x; hi = am.y; }
+                if (!PLAIN && r >= 2) { const uint2 am = p.anc_more[(size_t)(r - 2) * p.B + b]; lo = am.x; hi = am.y; }
                 fk_round(src, lo & 0xffffu, lo >> 16, hi & 0xffffu, rm[k][0], rm[k][1], rm[k][2]);
                 dst[b * 3] = rm[k][0]; dst[b * 3 + 1] = rm[k][1]; dst[b * 3 + 2] = rm[k][2];
             }
         }
+        if constexpr (!PLAIN)
         for (int b = tid + NBR * kBlock; b < p.B; b += kBlock) {       // bones beyond the register slots: through LDS
             uint32_t lo, hi;
             if (r < 2) { const uint4 w3 = p.bone_rec[4 * b + 3]; lo = r == 0 ? w3.x : w3.z; hi = r == 0 ? w3.y : w3.w; }
@@ -573,7 +582,8 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const FkEarly &ear
         float4 *t4 = src; src = dst; dst = t4;
     }
     RZ_FSTAMP(3);             // doubling rounds done
-    if (p.ovr_off) {
+    const bool overrides = !PLAIN && p.ovr_off != nullptr;
+    if (overrides) {
         // physics-driven bones: the supplied world matrix replaces the solved one (rows 0..2 of the column-major 4x4)
         for (int k = p.ovr_off[inst] + tid; k < p.ovr_off[inst + 1]; k += kBlock) {
             const int b = p.ovr_bone[k];
@@ -601,11 +611,12 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const FkEarly &ear
         if (to_global) { pal[b * 3] = q0; pal[b * 3 + 1] = q1; pal[b * 3 + 2] = q2; }
         if (FUSED) { wl[b * 3] = q0; wl[b * 3 + 1] = q1; wl[b * 3 + 2] = q2; }     // bone b's rows (in wl or in the other buffer) are only ever read by this thread in this pass
     };
-    if (!p.ovr_off) {                   // (overrides land in LDS: the registers are only good without them; workgroup-uniform)
+    if (!overrides) {                   // (overrides land in LDS: the registers are only good without them; workgroup-uniform)
 #pragma unroll
         for (int k = 0; k < NBR; ++k)
             if (tid + k * kBlock < p.B) emit(tid + k * kBlock, rm[k][0], rm[k][1], rm[k][2], k == 0);
-        for (int b = tid + NBR * kBlock; b < p.B; b += kBlock) emit(b, src[b * 3], src[b * 3 + 1], src[b * 3 + 2], false);
+        if constexpr (!PLAIN)
+            for (int b = tid + NBR * kBlock; b < p.B; b += kBlock) emit(b, src[b * 3], src[b * 3 + 1], src[b * 3 + 2], false);
     } else {
         for (int b = tid; b < p.B; b += kBlock) emit(b, src[b * 3], src[b * 3 + 1], src[b * 3 + 2], b == tid);
     }

@@ -204,6 +204,9 @@ int rz_set_tuning(rz_ctx *c, const char *key, int value)
     } else if (!strcmp(key, "zero_copy")) {
         if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "zero_copy must be -1 (auto = on for one character), 0 (every pose is copied to the device) or 1");
         c->t_zerocopy = value;
+    } else if (!strcmp(key, "fuse_fk_plain")) {
+        if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "fuse_fk_plain must be -1 (auto = on), 0 (the fused frame always runs the generic hierarchy solve) or 1");
+        c->t_fkplain = value;
     } else if (!strcmp(key, "pose_pull")) {
         if (value < -1 || value > 1) return fail(RZ_ERR_INVALID, "pose_pull must be -1 (auto: a crowd's world matrices are pulled, local rotations copied), 0 (every pose is copied by hipMemcpyAsync as it was handed over) or 1 (every pose of more than 256 KB is pulled)");
         c->t_pull = value;
@@ -262,6 +265,8 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "overlap")) *value = c->t_overlap;
     else if (!strcmp(key, "zero_copy")) *value = c->t_zerocopy;
     else if (!strcmp(key, "pose_pull")) *value = c->t_pull;
+    else if (!strcmp(key, "fuse_fk_plain")) *value = c->t_fkplain;
+    else if (!strcmp(key, "effective_fk_kind")) { Plan pl; if (int r = frame_plan(c, &pl)) return r; *value = deform_params(c, pl).fk_kind; }
     else if (!strcmp(key, "pose_pulled")) *value = c->last_upload_pulled ? 1 : 0;      // the most recent copied pose came down by rz_pull_pose_kernel ...
     else if (!strcmp(key, "pose_rows")) *value = c->last_upload_rows ? 1 : 0;          // ... its world matrices as three rows per bone
     else if (!strcmp(key, "fuse_fk")) *value = c->t_fusefk;

@@ -88,10 +88,10 @@ class Walk:
 
     def new_tuning(self):
         key = self.rng.choice(["morph_split", "unroll", "grid_cap", "geo_lds", "nontemporal", "nt_store", "fast", "out_cap", "inst_loop", "graph",
-                               "inst_block", "overlap", "zero_copy", "fuse_fk", "inst_order", "inst_subsets", "pose_prefetch", "pose_pull"])
+                               "inst_block", "overlap", "zero_copy", "fuse_fk", "inst_order", "inst_subsets", "pose_prefetch", "pose_pull", "fuse_fk_plain"])
         val = {"morph_split": [0, 1, 2, 4, 8], "unroll": [0, 4, 8], "grid_cap": [0, 1, 7, 64, 2048], "geo_lds": [0, 1], "nontemporal": [0, 1],
                "nt_store": [-1, 0, 1], "fast": [-1, 0, 1], "out_cap": [-1, 0, 64, 640], "inst_loop": [-1, 0, 2, 5, 8, 9, 12, 16, 33], "graph": [0, 1],
-               "inst_block": [0, 256, 512, 1024], "overlap": [-1, 0, 1], "zero_copy": [-1, 0, 1], "fuse_fk": [-1, 0, 1], "inst_order": [0, 1], "inst_subsets": [-1, 0, 1], "pose_prefetch": [-1, 0, 1], "pose_pull": [-1, 0, 1]}[key]
+               "inst_block": [0, 256, 512, 1024], "overlap": [-1, 0, 1], "zero_copy": [-1, 0, 1], "fuse_fk": [-1, 0, 1], "inst_order": [0, 1], "inst_subsets": [-1, 0, 1], "pose_prefetch": [-1, 0, 1], "pose_pull": [-1, 0, 1], "fuse_fk_plain": [-1, 0, 1]}[key]
         v = int(self.rng.choice(val))
         if not self.all_variants and ((key == "unroll" and v == 4) or (key == "geo_lds" and v == 1) or (key == "nontemporal" and v == 0) or (key == "inst_loop" and v == 9)):
             with pytest.raises(self.rz.capi.RzError):       # the product refuses the keys of variants it does not carry ...

@@ -303,3 +303,52 @@ def test_numa_node_query_and_binding(rz):
         lo, _, hi = part.partition("-")
         want.update(range(int(lo), int(hi or lo) + 1))
     assert set(r["cpus"]) and set(r["cpus"]) <= want
+
+
+@pytest.mark.parametrize("morphs", ["none", "sparse"])
+def test_fused_frame_of_a_plain_pose_runs_the_specialised_solve_with_the_same_bits(rz, morphs):
+    """The fused single-character frame of a PLAIN pose (no bone morphs, no overrides, <= 512 bones, <= 16 levels) runs a kernel variant
+    whose hierarchy solve is specialised at compile time for an uploaded / a sampled pose (fk_solve<true, KIND>: a third / two thirds of
+    the generic kernel's code, no scalar spills). Same device functions: the frame must equal the generic kernel's ("fuse_fk_plain" = 0)
+    bit for bit, for local rotations, rotations + translations and a sampled motion; a pose the variants do not cover (a bone morph
+    uploaded, an override set) goes back to the generic kernel by itself."""
+    V, B = 20000, 300
+    mesh = synth.make_mesh(V, B, seed=31)
+    rng = np.random.default_rng(9)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); c.upload_skeleton(mesh["inv_bind"])
+    mw = None
+    if morphs == "sparse":
+        off, vi, d3, mw = synth.make_morphs_sparse(V, 24, density=0.03)
+        c.upload_morphs_sparse(off, vi, d3)
+    c.upload_skeleton_topology(mesh["parents"], mesh["bind"])
+    q = rng.normal(size=(B, 4)).astype(np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    lt = ((rng.random((B, 3), dtype=np.float32) - 0.5) * 0.2).astype(np.float32)
+    nk = 7
+    kq = rng.normal(size=(B, nk, 4)).astype(np.float32); kq /= np.linalg.norm(kq, axis=2, keepdims=True)
+    c.upload_animation(np.arange(B), np.arange(B + 1) * nk, np.tile(np.cumsum(rng.integers(1, 9, size=nk)).astype(np.float32), B), kq.reshape(-1, 4),
+                       ((rng.random((B * nk, 3), dtype=np.float32) - 0.5) * 0.2).astype(np.float32), rng.integers(1, 127, size=(B * nk, 16)).astype(np.uint8))
+    poses = {"local": lambda: c.set_pose_local(q, mw), "local+t": lambda: c.set_pose_local(q, mw, lt), "sampled": lambda: c.set_pose_sampled(np.array([11.3], np.float32))}
+    for name, put in poses.items():
+        outs = {}
+        for plain in (-1, 0):
+            c.set_tuning(fuse_fk_plain=plain, fuse_fk=1)
+            put()
+            assert c.get_tuning("effective_fuse_fk") == 1
+            assert c.get_tuning("effective_fk_kind") == ((2 if name == "sampled" else 1) if plain else 0), name
+            c.deform()
+            outs[plain] = (c.read(), c.read_world(0), c.read_palette(0))
+            c.deform_n(3)
+            assert np.array_equal(c.read()[0], outs[plain][0][0])
+        assert np.array_equal(outs[-1][0][0], outs[0][0][0]) and np.array_equal(outs[-1][0][1], outs[0][0][1]), name
+        assert np.array_equal(outs[-1][1], outs[0][1]) and np.array_equal(outs[-1][2], outs[0][2]), name
+        assert np.isfinite(outs[-1][0][0]).all()
+    # something the variants do not cover
+    c.set_tuning(fuse_fk_plain=-1)
+    c.set_pose_local(q, mw)
+    w = c.read_world(0)
+    c.override_world(np.array([3], np.uint32), w[3:4].copy())
+    assert c.get_tuning("effective_fk_kind") == 0
+    c.override_world(np.zeros(0, np.uint32), np.zeros((0, 16), np.float32))
+    assert c.get_tuning("effective_fk_kind") == 1
+    c.close()
