@@ -263,7 +263,7 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * for launch-bound replay of small frames), "zero_copy" (-1 auto = on, 0: every pose is copied to the device; one character's
  * per-frame inputs are otherwise read by the frame's kernels straight from a pinned, device-mapped slot), "fuse_fk" (-1 auto, 0, 1:
  * a device-animated single character solves its bone hierarchy inside the deform kernel — one launch per frame — instead of
- * rz_fk_kernel [+ rz_prep_kernel] in front), "fuse_fk_plain" (-1 auto / 1: the fused frame of a PLAIN pose — no bone morphs, no overrides, <= 512 bones, <= 16 levels, <= 256 morphs —
+ * rz_fk_kernel [+ rz_prep_kernel] in front), "fuse_fk_plain" (-1 auto / 1: the fused frame of a PLAIN pose — no physics overrides, <= 512 bones, <= 256 morphs —
  * runs a kernel variant whose hierarchy solve is specialised for an uploaded / a sampled pose; 0: always the generic solve; same bits;
  * rz_get_tuning("effective_fk_kind") says which: 0 generic, 1 uploaded, 2 sampled),
  * "pose_pull" (-1 auto: the world matrices of a pose of more than 256 KB — a crowd's — are pulled out of their pinned ring slot by a

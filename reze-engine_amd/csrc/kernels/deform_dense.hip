@@ -30,7 +30,7 @@ namespace {
 
 // __launch_bounds__(256, 2): the persistent grid is two workgroups per CU (2 waves per SIMD), so the register allocator may use up
 // to 256 VGPRs but not one more (a 257th would halve residency).
-template <int S, int U, bool NT, bool NTS, bool GEO, bool FAST>
+template <int S, int U, bool NT, bool NTS, bool GEO, bool FAST, int FKV = 0>
 __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float *k_geom, const float *k_world, const float *k_inv_bind, const uint32_t k_bf,
                                                                     const uint32_t k_Vp, const uint32_t k_nq, const uint32_t k_qpw, const uint32_t *k_j01,
                                                                     const uint32_t *k_j23, const uint32_t *k_wq, const RzDeformParams p, const RzMorphList ml)
@@ -141,14 +141,14 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
     float *scratch_all = s_w + (LDS_LIST ? p.Mpad : 0);                   // 16-B aligned: Mpad % 4 == 0
     const uint64_t st_tagv = spec ? *p.st_tag : 0ull;                   // requested here, compared later (workgroup-uniform)
     int fused_count = 0;
-    if (!FAST && p.fk_on) {
-        // FUSED single-character frame: hierarchy solve (and motion sampling) as this workgroup's prologue, then the ordered
-        // compaction of the pose's morph weights into the LDS list
+    if (!FAST && (FKV != 0 || p.fk_on)) {
+        // FUSED single-character frame: hierarchy solve (and motion sampling) as this workgroup's prologue (FKV 1 / 2: specialised for a
+        // plain uploaded / sampled pose, kernels/fk.hip.h), then the ordered compaction of the pose's morph weights into the LDS list
         __shared__ int fz_cnt[kBlock / 64];
-        float *lds_mw = fused_hierarchy_prologue<true>(p.fk, fke, p.st_tag, p.st_expect, p.st_morph_w, p.morph_w, p.morph_w_copy, p.M, pal, scratch_all, wid, RZ_TL_FK);
+        float *lds_mw = fused_hierarchy_prologue<true, FKV>(p.fk, fke, p.st_tag, p.st_expect, p.st_morph_w, p.morph_w, p.morph_w_copy, p.M, pal, scratch_all, wid, RZ_TL_FK);
         fused_count = compact_active(lds_mw, p.M, p.Mpad, s_idx, s_w, fz_cnt);
         __syncthreads();
-    } else if (!FAST) {
+    } else if (!FAST && FKV == 0) {
         const float4 *gpal = p.palette + (size_t)inst * p.B * 3;
         for (int i = tid; i < p.B * 3; i += kBlock) pal[i] = gpal[i];
         const uint32_t *gi = p.act_idx + (size_t)inst * p.Mpad;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
     }
 
     RZ_STAMP(1);                 // prologue done (hierarchy solve / staged palette + morph list)
-    const int count = FAST ? ml.count : (p.fk_on ? fused_count : p.act_count[inst]);
+    const int count = FAST ? ml.count : ((FKV != 0 || p.fk_on) ? fused_count : p.act_count[inst]);
     float *scr = scratch_all + (size_t)wave * NPL * VW;
     const uint32_t bmax = (uint32_t)(p.B - 1);
     float *opos = p.out_pos + (size_t)inst * Vp * 3;
@@ -386,10 +386,14 @@ constexpr bool kAllVariants = true;
 constexpr bool kAllVariants = false;
 #endif
 
-template <int S, int U, bool NT, bool NTS, bool GEO, bool FAST>
+template <int S, int U, bool NT, bool NTS, bool GEO, bool FAST, int FKV = 0>
 static hipError_t launch_one(const RzDeformParams &p, const RzMorphList &ml, dim3 grid, size_t lds, hipStream_t st)
 {
-    auto k = rz_deform_dense_kernel<S, U, NT, NTS, GEO, FAST>;
+    if constexpr (!FAST && !GEO && NT && U == 8 && FKV == 0) {      // the fused frame of a plain pose: the specialised variants (the shapes a plan selects)
+        if (p.fk_on && p.fk_kind == 1) return launch_one<S, U, NT, NTS, GEO, FAST, 1>(p, ml, grid, lds, st);
+        if (p.fk_on && p.fk_kind == 2) return launch_one<S, U, NT, NTS, GEO, FAST, 2>(p, ml, grid, lds, st);
+    }
+    auto k = rz_deform_dense_kernel<S, U, NT, NTS, GEO, FAST, FKV>;
     if (p.B > 0xffff) return hipErrorInvalidValue;      // k_bf carries the bone count in 16 bits (the 48 B per bone LDS palette keeps it far below today)
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -162,7 +162,7 @@ __device__ __forceinline__ float *fused_hierarchy_prologue(const RzFkParams &fk,
     const bool sampled = KIND == 2 || (KIND == 0 && (fk.sample.frames != nullptr || fk.sample.frames_inline));
     const bool fspec = KIND != 2 && st_tag != nullptr;
     const uint64_t ftag = fspec ? *st_tag : 0ull;
-    if ((STAGE_WEIGHTS_ALWAYS || (KIND == 0 && fk.bm_off)) && !sampled) {
+    if ((STAGE_WEIGHTS_ALWAYS || fk.bm_off) && !sampled) {
         const float *mw0 = fspec ? st_morph_w : morph_w;               // uploaded weights (staged copy, pinned slot or device block)
         for (int i = tid; i < M; i += kBlock) {
             float w = mw0[i];

@@ -378,8 +378,8 @@ __device__ __forceinline__ void fk_palette_rows(const float4 w0, const float4 w1
 // LDS behind `scr`: rz_fk_scratch_bytes(B) = B x (48 + 12) bytes. Ends with a barrier.
 // KIND specialises the body at compile time for the two common single-character poses (the deform kernels' fused frame, round 5): the
 // generic form carries every feature behind workgroup-uniform branches — 47 KB of code in front of a 10 KB deform kernel, of which a frame
-// executes every instruction once. KIND 1 = an uploaded pose, KIND 2 = a sampled pose, both PLAIN: no bone morphs, no physics overrides,
-// at most 512 bones (two per thread), at most two doubling rounds (<= 16 levels) — the host picks the variant when all of that holds
+// executes every instruction once. KIND 1 = an uploaded pose, KIND 2 = a sampled pose, both PLAIN: no physics overrides,
+// at most 512 bones (two per thread), at most 256 vertex morphs (one per thread) — the host picks the variant when all of that holds
 // (RzDeformParams::fk_kind) and the generic form (KIND 0) otherwise. Same device functions, same bits.
 template <bool FUSED, int KIND = 0>
 __device__ __forceinline__ void fk_solve(const RzFkParams &p, const FkEarly &early, const int inst, float4 *wl, unsigned char *scr, float *lds_mw,
@@ -402,7 +402,7 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const FkEarly &ear
     const float4 *lq = p.local_q + (size_t)inst * p.B;
     const float *glt = p.local_t ? p.local_t + (size_t)inst * p.B * 3 : nullptr;
     const bool sampled = KIND == 2 || (KIND == 0 && (p.sample.frames != nullptr || p.sample.frames_inline));      // rz_set_pose_sampled: the pose is evaluated right here
-    const bool bone_morphs = !PLAIN && p.bm_off != nullptr;
+    const bool bone_morphs = p.bm_off != nullptr;
     const bool has_t = sampled || glt != nullptr || bone_morphs;
     const float frame = sampled ? (p.sample.frames_inline ? p.sample.frame0 : p.sample.frames[inst]) : 0.0f;
     float *world = p.world + (size_t)inst * p.B * 16;
@@ -487,7 +487,7 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const FkEarly &ear
         } else uploaded(i, q, tx, ty, tz);
         park(i, q, tx, ty, tz, r0, r1);
     }
-    if (sampled)        // vertex-morph weights of this pose: consumed by the prep / deform kernels that follow (FUSED: by this very workgroup)
+    if (sampled && !PLAIN)        // vertex-morph weights of this pose: consumed by the prep / deform kernels that follow (FUSED: by this very workgroup)
         for (int m = m_done + tid; m < p.sample.M; m += kBlock) {      // (morphs beyond the interleaved pass)
             const float w = sample_morph(p.sample, frame, m);
             if (FUSED || bone_morphs) lds_mw[m] = w;
@@ -564,7 +564,7 @@ __device__ __forceinline__ void fk_solve(const RzFkParams &p, const FkEarly &ear
             if (b < p.B) {
                 const uint4 w3 = k == 0 ? early.a3 : early.b3;
                 uint32_t lo = r == 0 ? w3.x : w3.z, hi = r == 0 ? w3.y : w3.w;
-                if (!PLAIN && r >= 2) { const uint2 am = p.anc_more[(size_t)(r - 2) * p.B + b]; lo = am.x; hi = am.y; }
+                if (r >= 2) { const uint2 am = p.anc_more[(size_t)(r - 2) * p.B + b]; lo = am.x; hi = am.y; }
                 fk_round(src, lo & 0xffffu, lo >> 16, hi & 0xffffu, rm[k][0], rm[k][1], rm[k][2]);
                 dst[b * 3] = rm[k][0]; dst[b * 3 + 1] = rm[k][1]; dst[b * 3 + 2] = rm[k][2];
             }

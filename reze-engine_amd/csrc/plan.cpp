@@ -87,9 +87,9 @@ RzDeformParams deform_params(const rz_ctx *c, const Plan &pl)
     if (pl.subfk) p.fk = fk_params(c);          // (the crowd kernel's front reads the pose, the motion and the bone records through it)
     if (pl.fuse_fk) {
         p.fk = fk_params(c); p.fk_on = 1;
-        // the specialised variants (fk_solve<true, KIND>): no bone morphs, no physics overrides, two bones per thread, two doubling rounds,
-        // one morph per thread; "fuse_fk_plain" = 0 keeps the generic kernel (A/B, tests)
-        const bool plain = c->t_fkplain != 0 && !p.fk.bm_off && !p.fk.ovr_off && c->B <= 512 && p.fk.n_rounds <= 2 && c->M <= 256 && (!c->pose_sampled || c->an_M <= 256);
+        // the specialised variants (fk_solve<true, KIND>): no physics overrides, two bones per thread, one morph per thread;
+        // "fuse_fk_plain" = 0 keeps the generic kernel (A/B, tests)
+        const bool plain = c->t_fkplain != 0 && !p.fk.ovr_off && c->B <= 512 && c->M <= 256 && (!c->pose_sampled || c->an_M <= 256);
         p.fk_kind = plain ? (c->pose_sampled ? 2 : 1) : 0;
         if (c->zc_cur >= 0 && c->zc_local && !c->pose_sampled && (!c->local_resident || !c->mw_resident)) {
             // zero-copy local pose, first frame: workgroup 0 makes it resident (every later frame of this pose reads the device

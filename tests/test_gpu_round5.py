@@ -307,11 +307,11 @@ def test_numa_node_query_and_binding(rz):
 
 @pytest.mark.parametrize("morphs", ["none", "sparse"])
 def test_fused_frame_of_a_plain_pose_runs_the_specialised_solve_with_the_same_bits(rz, morphs):
-    """The fused single-character frame of a PLAIN pose (no bone morphs, no overrides, <= 512 bones, <= 16 levels) runs a kernel variant
+    """The fused single-character frame of a PLAIN pose (no physics overrides, <= 512 bones, <= 256 morphs) runs a kernel variant
     whose hierarchy solve is specialised at compile time for an uploaded / a sampled pose (fk_solve<true, KIND>: a third / two thirds of
     the generic kernel's code, no scalar spills). Same device functions: the frame must equal the generic kernel's ("fuse_fk_plain" = 0)
-    bit for bit, for local rotations, rotations + translations and a sampled motion; a pose the variants do not cover (a bone morph
-    uploaded, an override set) goes back to the generic kernel by itself."""
+    bit for bit, for local rotations, rotations + translations and a sampled motion; a pose the variants do not cover (an override set) goes back to
+    the generic kernel by itself."""
     V, B = 20000, 300
     mesh = synth.make_mesh(V, B, seed=31)
     rng = np.random.default_rng(9)
