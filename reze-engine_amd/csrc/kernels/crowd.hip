@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const uint32_t
 // -> local matrix into LDS -> doubling rounds over the closure (kernels/fk.hip.h: fk_round; a bone's world matrix depends on its own
 // chain only, so it has the bits rz_fk_kernel gives it) -> palette rows of the named bones. Then the pose loop of rz_skin_instances_kernel.
 // Leading (preloaded) arguments: k_cnt = closure slots per run, k_rec = the records, k_src = the poses' local rotations [I][B] (sampled
-// poses: the per-instance frame numbers), k_inv_bind; k_g = poses per workgroup | sampled << 16 | has translations << 17;
+// poses: the per-instance frame numbers), k_inv_bind; k_g = poses per workgroup | sampled << 16 | has translations << 17 | padded length of the run lists << 18;
 // k_bf = bone count | inst_order << 16 | doubling rounds << 18 | record stride (closure slots) << 20.
 // LDS: two matrix buffers of G x nc x 48 B, then the palettes G x ns x 48 B.
 // ------------------------------------------------------------------------------------------------
@@ -260,7 +260,13 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_fk_kernel(const uint3
     const uint32_t wg_group = k_order ? lin % n_groups : blockIdx.y, wg_run = k_order ? lin / n_groups : blockIdx.x;
     const int inst0 = (int)wg_group * G;
     const int ng = min(G, n_inst - inst0);
+    // (neither the run's closure length nor its list length is read: records and lists are padded to the plan's longest — RZ_CROWD_PADDED,
+    // as in rz_skin_instances_kernel — which takes two dependent scalar loads out of the front)
+#if RZ_CROWD_PADDED
+    const int nc = rec_stride;
+#else
     const int nc = (int)k_cnt[wg_run];
+#endif
     const uint4 *recs = k_rec + (size_t)wg_run * rec_stride * kSubFkWords;
     float4 *mA = reinterpret_cast<float4 *>(smem), *mB = mA + (size_t)G * nc * 3, *pal = mB + (size_t)G * nc * 3;
     // this thread's work items e = tid, tid + BLOCK: (pose g, closure slot c); past the end the LAST item is re-read (unpredicated loads)
@@ -294,7 +300,11 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_fk_kernel(const uint3
         nx = p.geom[3 * Vp + v]; ny = p.geom[4 * Vp + v]; nz = p.geom[5 * Vp + v];
         j01 = jp01[v]; j23 = jp23[v]; wq = p.weights[v];
     }
+#if RZ_CROWD_PADDED
+    const int ns = (int)(k_g >> 18);                   // named bones = palette slots of a run (the longest list's)
+#else
     const int ns = (int)p.sub_count[wg_run];          // named bones = palette slots of this run
+#endif
     const int lrows = ns * 3;
     // ---- the pose of every item: uploaded rotations (+ translations), or the motion sampled at the instance's frame ----
     float4 q[NIT], apq[NIT], ib0[NIT], ib1[NIT], ib2[NIT], ib3[NIT];
@@ -571,7 +581,8 @@ static hipError_t launch_skin_instances_fk(const RzDeformParams &p, const RzSubF
     if (grid.x > 0xffffu || grid.y > 0xffffu || p.B > 0xffff || f.stride > 0xfffu || f.rounds > 3 || (size_t)G * f.stride > 2 * (size_t)BLOCK || !p.sub_count || !p.rj01)
         return hipErrorInvalidValue;
     const float4 *k_src = sampled ? reinterpret_cast<const float4 *>(p.fk.sample.frames) : p.fk.local_q;
-    const uint32_t k_g = (uint32_t)G | (sampled ? 1u << 16 : 0u) | (p.fk.local_t ? 1u << 17 : 0u);
+    if (p.sub_max <= 0 || p.sub_max > 0x3fff) return hipErrorInvalidValue;
+    const uint32_t k_g = (uint32_t)G | (sampled ? 1u << 16 : 0u) | (p.fk.local_t ? 1u << 17 : 0u) | ((uint32_t)p.sub_max << 18);
     const uint32_t k_grid = grid.x | (grid.y << 16), k_bf = (uint32_t)p.B | (p.inst_order ? 1u << 16 : 0u) | (f.rounds << 18) | (f.stride << 20);
     hipLaunchKernelGGL(k, grid, dim3(BLOCK), lds, st, f.count, f.rec, k_src, p.inv_bind, k_g, n_inst, verts_per_wg, k_grid, k_bf, p.Vp, p);
     return hipGetLastError();

@@ -412,6 +412,17 @@ int ensure_subfk(rz_ctx *c)
             w[3] = make_uint4(a[2][0], a[2][1], 0u, 0u);
             w[4] = motion ? c->an_host_range[b] : make_uint4(0u, 0u, 0u, 0u);
         }
+        // Padding up to the longest closure: the kernel does not read a run's closure length (one dependent load less in its front), it
+        // works through `stride` records per pose. A padding record poses bone 0 as a root with no palette slot, no append parent, no
+        // ancestors and no track: its matrix lands in its own LDS slot and nobody reads it.
+        for (uint32_t k = (uint32_t)cl.size(); k < stride; ++k) {
+            uint4 *w = &rec[((size_t)r * stride + k) * 5];
+            w[0] = make_uint4(0u | (0xffffu << 16), 0xffffffffu, 0u, 0u);
+            w[1] = make_uint4(0u, 0u, 0u, 0u);
+            w[2] = make_uint4(0xffffffffu, 0xffffu, 0xffffffffu, 0xffffu);
+            w[3] = make_uint4(0xffffffffu, 0xffffu, 0u, 0u);
+            w[4] = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
     if (rec.size() > c->subfk_rec_alloc) {
         dfree(c->subfk_rec);
