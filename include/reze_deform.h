@@ -276,7 +276,9 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * emit anything but the deformed mesh: ablation switches exist only in a tools-only build and "dbg" is rejected here.
  * rz_get_tuning also answers "effective_split" / "effective_unroll" / "effective_grid" / "effective_fast" / "effective_out_cap" /
  * "effective_inst_group" / "effective_inst_block" / "effective_fuse_fk" / "effective_overlap" / "pose_resident" /
- * "effective_subsets" / "effective_subset_bones" / "effective_inst_lds" and the counts
+ * "effective_subsets" / "effective_subset_bones" / "effective_inst_lds" / "effective_fk_kind" / "effective_variant" (the last template
+ * argument of the single-mesh frame kernel: 0 everything compiled in, 3 without the fused consumers, 1 / 2 also with the specialised
+ * hierarchy solve) and the counts
  * "verts" / "bones" / "morphs" / "instances". Unknown keys return RZ_ERR_INVALID.
  * NOT a pure getter for crowds: an "effective_*" key describes the frame the NEXT rz_deform will launch, and a crowd's plan depends on
  * the per-run bone lists of its launch shape — when the shape, the mesh or the skeleton changed since the last frame the call brings

@@ -590,10 +590,14 @@ class DeformContext:
             return "rz_skin_instances_kernel<%d, %s, %s>" % (g("effective_inst_block"), tf("effective_nt_store"), tf("effective_subsets"))
         mode = g("morph_mode")
         s_ = g("effective_split")
+        try:
+            var = ", %d" % g("effective_variant")       # (ABI 6: the kernel variant without the fused consumers / with the specialised solve)
+        except RzError:
+            var = ""
         if mode == 1:
-            return "rz_deform_dense_kernel<%d, %d, %s, %s, %s, %s>" % (s_, 8 if g("effective_unroll") >= 8 else 4, tf("effective_nt"), tf("effective_nt_store"),
-                                                                       tf("effective_geo"), tf("effective_fast"))
-        return "rz_deform_small_kernel<%d, %d, %s, %s, %s>" % (4 if s_ >= 4 else 1, mode, tf("effective_nt_store"), tf("effective_geo"), tf("effective_fast"))
+            return "rz_deform_dense_kernel<%d, %d, %s, %s, %s, %s%s>" % (s_, 8 if g("effective_unroll") >= 8 else 4, tf("effective_nt"), tf("effective_nt_store"),
+                                                                         tf("effective_geo"), tf("effective_fast"), var)
+        return "rz_deform_small_kernel<%d, %d, %s, %s, %s%s>" % (4 if s_ >= 4 else 1, mode, tf("effective_nt_store"), tf("effective_geo"), tf("effective_fast"), var)
 
     def time_frames(self, frames):
         t = RzTiming()

@@ -141,14 +141,14 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
     float *scratch_all = s_w + (LDS_LIST ? p.Mpad : 0);                   // 16-B aligned: Mpad % 4 == 0
     const uint64_t st_tagv = spec ? *p.st_tag : 0ull;                   // requested here, compared later (workgroup-uniform)
     int fused_count = 0;
-    if (!FAST && (FKV != 0 || p.fk_on)) {
+    if (!FAST && (FKV == 1 || FKV == 2 || p.fk_on)) {
         // FUSED single-character frame: hierarchy solve (and motion sampling) as this workgroup's prologue (FKV 1 / 2: specialised for a
         // plain uploaded / sampled pose, kernels/fk.hip.h), then the ordered compaction of the pose's morph weights into the LDS list
         __shared__ int fz_cnt[kBlock / 64];
-        float *lds_mw = fused_hierarchy_prologue<true, FKV>(p.fk, fke, p.st_tag, p.st_expect, p.st_morph_w, p.morph_w, p.morph_w_copy, p.M, pal, scratch_all, wid, RZ_TL_FK);
+        float *lds_mw = fused_hierarchy_prologue<true, (FKV == 1 || FKV == 2) ? FKV : 0>(p.fk, fke, p.st_tag, p.st_expect, p.st_morph_w, p.morph_w, p.morph_w_copy, p.M, pal, scratch_all, wid, RZ_TL_FK);
         fused_count = compact_active(lds_mw, p.M, p.Mpad, s_idx, s_w, fz_cnt);
         __syncthreads();
-    } else if (!FAST && FKV == 0) {
+    } else if (!FAST && FKV != 1 && FKV != 2) {
         const float4 *gpal = p.palette + (size_t)inst * p.B * 3;
         for (int i = tid; i < p.B * 3; i += kBlock) pal[i] = gpal[i];
         const uint32_t *gi = p.act_idx + (size_t)inst * p.Mpad;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
     }
 
     RZ_STAMP(1);                 // prologue done (hierarchy solve / staged palette + morph list)
-    const int count = FAST ? ml.count : ((FKV != 0 || p.fk_on) ? fused_count : p.act_count[inst]);
+    const int count = FAST ? ml.count : ((FKV == 1 || FKV == 2 || p.fk_on) ? fused_count : p.act_count[inst]);
     float *scr = scratch_all + (size_t)wave * NPL * VW;
     const uint32_t bmax = (uint32_t)(p.B - 1);
     float *opos = p.out_pos + (size_t)inst * Vp * 3;
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
                     j01 = p.joints01[v]; j23 = p.joints23[v]; wq = p.weights[v];
                 }
                 const Skinned o = skin_vertex(pal, x, y, z, nx, ny, nz, j01, j23, wq, bmax);
-                emit_vertex<NTS>(p, o, v, inst, Vp, cap, ob_pos, ob_nrm, (ob_fill + vl) * 3, opos, onrm, bb);
+                emit_vertex<NTS, FKV == 0>(p, o, v, inst, Vp, cap, ob_pos, ob_nrm, (ob_fill + vl) * 3, opos, onrm, bb);
             }
         };
 #pragma unroll 1
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
     if (cap && ob_fill) flush_out();
     if (FAST && need_palette) form_palette();    // a wave with an empty run still owes the workgroup its bones ...
     if (FAST && need_sync) __syncthreads();      // ... and its barrier
-    if (p.aabb) aabb_commit(p, inst, bb, lane, tid, wid, q_begin < q_end);
+    if (FKV == 0 && p.aabb) aabb_commit(p, inst, bb, lane, tid, wid, q_begin < q_end);
     RZ_TL_FLUSH(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + wave);
 }
 
@@ -389,9 +389,16 @@ constexpr bool kAllVariants = false;
 template <int S, int U, bool NT, bool NTS, bool GEO, bool FAST, int FKV = 0>
 static hipError_t launch_one(const RzDeformParams &p, const RzMorphList &ml, dim3 grid, size_t lds, hipStream_t st)
 {
-    if constexpr (!FAST && !GEO && NT && U == 8 && FKV == 0) {      // the fused frame of a plain pose: the specialised variants (the shapes a plan selects)
-        if (p.fk_on && p.fk_kind == 1) return launch_one<S, U, NT, NTS, GEO, FAST, 1>(p, ml, grid, lds, st);
-        if (p.fk_on && p.fk_kind == 2) return launch_one<S, U, NT, NTS, GEO, FAST, 2>(p, ml, grid, lds, st);
+    // FKV — which variant of the kernel (the shapes a plan selects only): 0 = everything compiled in (the fused consumers: outline hull,
+    // bounding box); 3 = without them; 1 / 2 = without them AND the hierarchy solve specialised for a plain uploaded / sampled pose
+    if constexpr (!GEO && NT && U == 8 && FKV == 0) {
+        if (!p.edge && !p.aabb) {
+            if constexpr (!FAST) {
+                if (p.fk_on && p.fk_kind == 1) return launch_one<S, U, NT, NTS, GEO, FAST, 1>(p, ml, grid, lds, st);
+                if (p.fk_on && p.fk_kind == 2) return launch_one<S, U, NT, NTS, GEO, FAST, 2>(p, ml, grid, lds, st);
+            }
+            return launch_one<S, U, NT, NTS, GEO, FAST, 3>(p, ml, grid, lds, st);
+        }
     }
     auto k = rz_deform_dense_kernel<S, U, NT, NTS, GEO, FAST, FKV>;
     if (p.B > 0xffff) return hipErrorInvalidValue;      // k_bf carries the bone count in 16 bits (the 48 B per bone LDS palette keeps it far below today)

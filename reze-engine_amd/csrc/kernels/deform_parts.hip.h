@@ -98,7 +98,10 @@ __device__ __forceinline__ void flush_parked(float *opos, float *onrm, const flo
 // One deformed vertex leaves the skin phase: parked (write batching) or stored, plus the fused consumers — the outline pass's
 // inverted hull (engine.ts:458-461: expandedPos = worldPos + worldNormal * edgeSize * 0.01) and the running
 // bounding box (padding vertices of the last quad stay out of it).
-template <bool NTS>
+// EPI = false: a kernel variant without the fused consumers (frames of a context that has neither an edge scale nor the bounding box
+// switched on — nearly all of them): the two uniform branches and the pointers behind them cost the latency-bound frames 2-3 %
+// (profiles/r5_ab_epi.txt).
+template <bool NTS, bool EPI = true>
 __device__ __forceinline__ void emit_vertex(const RzDeformParams &p, const Skinned &o, const size_t v, const int inst, const size_t Vp, const uint32_t cap,
                                             float *ob_pos, float *ob_nrm, const uint32_t li, float *opos, float *onrm, float (&bb)[6])
 {
@@ -109,12 +112,12 @@ __device__ __forceinline__ void emit_vertex(const RzDeformParams &p, const Skinn
         st3<NTS>(opos + v * 3, o.px, o.py, o.pz);
         st3<NTS>(onrm + v * 3, o.nx, o.ny, o.nz);
     }
-    if (p.edge) {
+    if (EPI && p.edge) {
         const float e = p.edge[v];
         st3<NTS>(p.out_hull + ((size_t)inst * Vp + v) * 3, o.px + (o.nx * e) * 0.01f, o.py + (o.ny * e) * 0.01f,
                  o.pz + (o.nz * e) * 0.01f);
     }
-    if (p.aabb && v < p.n_verts) {
+    if (EPI && p.aabb && v < p.n_verts) {
         bb[0] = fminf(bb[0], o.px); bb[1] = fminf(bb[1], o.py); bb[2] = fminf(bb[2], o.pz);
         bb[3] = fmaxf(bb[3], o.px); bb[4] = fmaxf(bb[4], o.py); bb[5] = fmaxf(bb[5], o.pz);
     }

@@ -166,14 +166,14 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_small_kernel(const float 
     const uint64_t st_tagv = spec ? *p.st_tag : 0ull;                   // requested here, compared later (workgroup-uniform)
     const bool staged_now = MODE == 2 && spec && st_tagv == p.st_expect;
     const float *morph_w_in = (staged_now && p.st_morph_w) ? p.st_morph_w : p.morph_w;
-    if (!FAST && (FKV != 0 || p.fk_on)) {
+    if (!FAST && (FKV == 1 || FKV == 2 || p.fk_on)) {
         // FUSED single-character frame: hierarchy solve (and motion sampling) as this workgroup's prologue (FKV 1 / 2: the variant
         // specialised for a plain uploaded / sampled pose — the launcher only picks it for fused frames)
-        float *lds_mw = fused_hierarchy_prologue<MODE != 0, FKV>(p.fk, fke, p.st_tag, p.st_expect, p.st_morph_w, p.morph_w, p.morph_w_copy, p.M, pal, scratch_all, wid, RZ_TL_FK);
+        float *lds_mw = fused_hierarchy_prologue<MODE != 0, (FKV == 1 || FKV == 2) ? FKV : 0>(p.fk, fke, p.st_tag, p.st_expect, p.st_morph_w, p.morph_w, p.morph_w_copy, p.M, pal, scratch_all, wid, RZ_TL_FK);
         if (MODE == 2)
             for (int i = tid; i < p.M; i += kBlock) s_w[i] = lds_mw[i];
         __syncthreads();
-    } else if (!FAST && FKV == 0) {
+    } else if (!FAST && FKV != 1 && FKV != 2) {
         const float4 *gpal = p.palette + (size_t)inst * p.B * 3;
         for (int i = tid; i < p.B * 3; i += kBlock) pal[i] = gpal[i];
         if (MODE == 2) {
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_small_kernel(const float 
                     j01 = su[6 * VW + vl]; j23 = su[7 * VW + vl]; wq = su[8 * VW + vl];
                 }
                 const Skinned o = skin_vertex(pal, x, y, z, nx, ny, nz, j01, j23, wq, bmax);
-                emit_vertex<NTS>(p, o, v, inst, Vp, cap, ob_pos, ob_nrm, (ob_fill + vl) * 3, opos, onrm, bb);
+                emit_vertex<NTS, FKV == 0>(p, o, v, inst, Vp, cap, ob_pos, ob_nrm, (ob_fill + vl) * 3, opos, onrm, bb);
             }
         };
         if constexpr (PRE) {
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_small_kernel(const float 
     if (FAST && need_palette) form_palette();    // a wave with an empty run still owes the workgroup its bones ...
     if (FAST && MODE == 2) publish_weights();    // ... its morph weights ...
     if (FAST && need_sync) __syncthreads();      // ... and its barrier
-    if (p.aabb) aabb_commit(p, inst, bb, lane, tid, wid, q_begin < q_end);
+    if (FKV == 0 && p.aabb) aabb_commit(p, inst, bb, lane, tid, wid, q_begin < q_end);
     RZ_TL_FLUSH(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + wave);
 }
 
@@ -424,9 +424,16 @@ constexpr bool kAllVariants = false;
 template <int S, int MODE, bool NTS, bool GEO, bool FAST, int FKV = 0>
 static hipError_t launch_one(const RzDeformParams &p, dim3 grid, size_t lds, hipStream_t st)
 {
-    if constexpr (!FAST && !GEO && FKV == 0) {          // the fused frame of a plain pose: the specialised variants (fk_solve<true, KIND>)
-        if (p.fk_on && p.fk_kind == 1) return launch_one<S, MODE, NTS, GEO, FAST, 1>(p, grid, lds, st);
-        if (p.fk_on && p.fk_kind == 2) return launch_one<S, MODE, NTS, GEO, FAST, 2>(p, grid, lds, st);
+    // FKV — which variant of the kernel: 0 = everything compiled in (the fused consumers: outline hull, bounding box); 3 = without them;
+    // 1 / 2 = without them AND the hierarchy solve specialised for a plain uploaded / sampled pose (fk_solve<true, KIND>)
+    if constexpr (!GEO && FKV == 0) {
+        if (!p.edge && !p.aabb) {
+            if constexpr (!FAST) {
+                if (p.fk_on && p.fk_kind == 1) return launch_one<S, MODE, NTS, GEO, FAST, 1>(p, grid, lds, st);
+                if (p.fk_on && p.fk_kind == 2) return launch_one<S, MODE, NTS, GEO, FAST, 2>(p, grid, lds, st);
+            }
+            return launch_one<S, MODE, NTS, GEO, FAST, 3>(p, grid, lds, st);
+        }
     }
     auto k = rz_deform_small_kernel<S, MODE, NTS, GEO, FAST, FKV>;
     if (p.B > 0xffff) return hipErrorInvalidValue;      // k_bf carries the bone count in 16 bits

@@ -266,6 +266,15 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
     else if (!strcmp(key, "zero_copy")) *value = c->t_zerocopy;
     else if (!strcmp(key, "pose_pull")) *value = c->t_pull;
     else if (!strcmp(key, "fuse_fk_plain")) *value = c->t_fkplain;
+    else if (!strcmp(key, "effective_variant")) {
+        // the last template argument of the single-mesh frame kernel the next frame launches (kernels/deform_small.hip / deform_dense.hip:
+        // launch_one): 0 everything compiled in, 3 without the fused consumers, 1 / 2 without them and with the specialised solve
+        Plan pl;
+        if (int r = frame_plan(c, &pl)) return r;
+        const RzDeformParams dp = deform_params(c, pl);
+        const bool shapes = !pl.v.geo && (pl.v.mode != 1 || (pl.v.nt && pl.v.U == 8));
+        *value = (!shapes || dp.edge || dp.aabb) ? 0 : ((!pl.v.fast && dp.fk_on && (dp.fk_kind == 1 || dp.fk_kind == 2)) ? dp.fk_kind : 3);
+    }
     else if (!strcmp(key, "effective_fk_kind")) { Plan pl; if (int r = frame_plan(c, &pl)) return r; *value = deform_params(c, pl).fk_kind; }
     else if (!strcmp(key, "pose_pulled")) *value = c->last_upload_pulled ? 1 : 0;      // the most recent copied pose came down by rz_pull_pose_kernel ...
     else if (!strcmp(key, "pose_rows")) *value = c->last_upload_rows ? 1 : 0;          // ... its world matrices as three rows per bone
