@@ -18,8 +18,27 @@ for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))):
     except Exception:       # noqa: BLE001
         print("skipping unreadable", f)
         continue
-    shutil.copy(f, os.path.join(DST, "%s_%s" % (TAG, os.path.basename(f))))
+    dst = os.path.join(DST, "%s_%s" % (TAG, os.path.basename(f)))
+    shutil.copy(f, dst)
     n += 1
+    # `roofline.traffic` is a LOOKUP in profiles/pmc_traffic.json by (workload shape, kernel) — a stored record, not something the line
+    # measures. A line printed before the round's PMC passes had run (the passes rename nothing, but a new kernel variant has no record
+    # until they have) carries null: look it up now, in the records of the same session, and say so.
+    try:
+        d = json.load(open(dst))
+        rf, c = d["roofline"], d["config"]
+        tj = os.path.join(DST, "pmc_traffic.json")
+        if rf.get("traffic") is None and os.path.exists(tj):
+            sparse = {"demo": "_demo", "sparse2": "_sparse2"}.get(os.path.basename(f)[len("bench_"):-len(".json")], "")
+            key = "V%d_B%d_M%d_I%d%s|%s" % (c["verts_per_gpu"], c["bones"], c["morphs"], c["instances"], sparse, rf["kernel"])
+            rec = json.load(open(tj))
+            if key in rec:
+                rf["traffic"] = rec[key]["hbm_bytes_per_launch"]
+                rf["traffic_source"] = "stored: profiles/pmc_traffic.json[%s] (%s) — looked up by tools/collect_profiles.py: the PMC passes ran after this line, in the same session" % (
+                    key, rec[key].get("command", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"))
+                json.dump(d, open(dst, "w"))
+    except Exception as e:      # noqa: BLE001
+        print("traffic lookup skipped for", f, e)
 stab = {}
 for name in ("c5", "c4"):
     runs = []
