@@ -337,7 +337,7 @@ void free_morphs(rz_ctx *c);
 template <typename T> int to_device(T **dst, const void *src, size_t count)
 {
     *dst = nullptr;
-    HIP_TRY(hipMalloc(dst, std::max<size_t>(count, 1) * sizeof(T)));
+    HIP_TRY(hipMalloc(dst, std::max<size_t>(count, 4) * sizeof(T)));      // (never fewer than four elements: the specialised sampler asks for key 0 unpredicated — three floats of a position)
     if (count) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
     return RZ_OK;
 }
