@@ -371,6 +371,17 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
     return RZ_OK;
 }
 
+#ifdef RZ_ALL_VARIANTS
+// tools-only build (make variants), test hook — not part of the C ABI: the host-side packing loop of a crowd's world matrices on its own
+// (no GPU involved), so that the CPU suite can hold it to its contract. Returns 1 = packed, 0 = some bottom row is not 0 0 0 1 (the pose
+// would travel whole), -1 = this host cannot pack (no AVX-512).
+__attribute__((visibility("default"))) int rz_debug_pack_rows(const float *world16, uint32_t bones, float *rows12)
+{
+    if (!can_pack_rows()) return -1;
+    return pack_rows_avx512(world16, bones, rows12) ? 1 : 0;
+}
+#endif
+
 int rz_set_pose(rz_ctx *c, const float *world, const float *morph_weights)
 {
     if (int r = use(c)) return r;
