@@ -168,11 +168,12 @@ def test_crowd_pose_pulled_as_three_rows_equals_the_copied_pose(rz, V, B, I, M, 
     c, mesh, worlds, mws = _world_crowd(rz, V, B, I, seed=B + I + M, M=M)
     c.set_tuning(**tune)
     assert c.get_tuning("pose_pull") == -1
+    packs = "avx512f" in open("/proc/cpuinfo").read()          # (a host without AVX-512 pulls the pose as it is: pose.cpp can_pack_rows)
     outs = {}
     for pull in (-1, 0):
         c.set_tuning(pose_pull=pull)
         c.set_pose(worlds, mws)
-        assert c.get_tuning("pose_pulled") == (1 if pull else 0) and c.get_tuning("pose_rows") == (1 if pull else 0)
+        assert c.get_tuning("pose_pulled") == (1 if pull else 0) and c.get_tuning("pose_rows") == (1 if pull and packs else 0)
         c.deform()
         outs[pull] = _all_instances(c, I)
         for i in (0, I // 2, I - 1):
