@@ -44,7 +44,8 @@ def parse_args():
     ap.add_argument("--verts", type=int, default=1000000)
     ap.add_argument("--bones", type=int, default=256)
     ap.add_argument("--morphs", type=int, default=64)
-    ap.add_argument("--instances", type=int, default=1, help="C4-style instancing (single GPU only)")
+    ap.add_argument("--instances", type=int, default=1, help="C4-style instancing; with --gpus N the crowd is sharded along the INSTANCE axis: every rank "
+                                                              "holds the whole mesh and poses ceil(I / N) of the instances, no collective, no communicator (SURVEY 8e)")
     ap.add_argument("--config", choices=["c5", "c4", "c3", "c2", "demo", "sparse2"], default=None,
                     help="BASELINE.json shortcut: c5 = 1M/256/64 (default), c4 = 256 x 30k/200/0, c3 = 30k/200/64, c2 = 30k/200/0; "
                          "demo = the demo model's shape: 28 842 verts / 349 bones / 60 SPARSE vertex morphs with its statistics (36 397 offsets, "
@@ -257,9 +258,23 @@ def main():
     import reze_engine_amd as rz
     from reze_engine_amd import synth
 
-    V_total = args.verts * (world_size if args.scaling == "weak" else 1)
-    B, M, I = args.bones, args.morphs, args.instances
-    b, n, _chunk = rz.shard.shard_of(V_total, world_size, rank)
+    B, M = args.bones, args.morphs
+    crowd = args.instances > 1
+    if crowd:
+        # BASELINE config 4 across GPUs: the crowd is cut along the INSTANCE axis (last sentence) — every rank holds the whole
+        # static mesh and poses its own contiguous range of instances; nothing is exchanged, no communicator is made
+        V_total = args.verts
+        I_total = args.instances * (world_size if args.scaling == "weak" else 1)
+        inst_begin, I = rz.shard.instances_of(I_total, world_size, rank)
+        if I == 0:
+            if rank == 0:
+                sys.stderr.write("[bench] %d instances over %d ranks leaves ranks without work\n" % (I_total, world_size))
+            sys.exit(5)
+        b, n = 0, V_total
+    else:
+        V_total = args.verts * (world_size if args.scaling == "weak" else 1)
+        I_total, inst_begin, I = 1, 0, 1
+        b, n, _chunk = rz.shard.shard_of(V_total, world_size, rank)
 
     # every rank generates ITS OWN shard of the same block-seeded mesh (synth.make_mesh_range): an 8-rank node never
     # builds eight copies of the 1 M-vertex mesh + 768 MB of morph targets on the host, and N = 1 ... 8 deform the same mesh
@@ -289,9 +304,9 @@ def main():
         ctx.upload_morphs_sparse(*sparse)
     worlds = mesh["world"]
     mws = mw
-    if I > 1:
+    if crowd:
         ctx.set_instances(I)
-        worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=1000 + i) for i in range(I)])
+        worlds = np.stack([synth.make_pose(mesh["parents"], mesh["bind"], B, seed=1000 + inst_begin + i) for i in range(I)])   # instance k has the same pose at every N
         if mw is not None:
             mws = np.tile(mw, (I, 1))
     for kv in filter(None, args.tune.split(",")):
@@ -300,7 +315,7 @@ def main():
     quats = None
     if args.device_fk:
         rng = np.random.default_rng(4242)
-        quats = rng.normal(size=(I, B, 4)).astype(np.float32)
+        quats = rng.normal(size=(I_total, B, 4)).astype(np.float32)[inst_begin:inst_begin + I]
         quats /= np.linalg.norm(quats, axis=2, keepdims=True)
         ctx.upload_skeleton_topology(mesh["parents"], mesh["bind"])
 
@@ -316,7 +331,7 @@ def main():
                          feed_off=np.arange(M + 1), feed_track=np.arange(M), feed_ratio=np.ones(M, np.float32))
         ctx.upload_animation(np.arange(B), np.arange(B + 1) * nk, np.tile(np.arange(nk) * 10.0, B), kq,
                              (rng.random((B, nk, 3), dtype=np.float32) - 0.5) * 0.2, np.tile(np.array([20] * 8 + [107] * 8, np.uint8), B * nk), **extra)
-        return rng.random(I).astype(np.float32) * 70.0
+        return (rng.random(I_total).astype(np.float32) * 70.0)[inst_begin:inst_begin + I]
 
     frames = None
     tick = [0]
@@ -428,20 +443,28 @@ def main():
                 fork.close()
             fork = None
 
-    def timed(run, sync_all):
+    # What is timed, and by which clock (round 6). The K steps sit between barrier + synchronize on both sides, as the contract says. Inside
+    # that bracket they are timed TWICE: by a hipEvent pair on the stream the frames run on (rz_time_span; SURVEY 8d prescribes event pairs
+    # around the back-to-back frames) and by the host's clock around the same call + synchronize. The host clock carries a fixed cost per
+    # timed region — the first launch, the wake-up from the final wait: ~20 us (profiles/r6_bench_shard8_steps20.json) — which is nothing
+    # in 500 steps of C5 and 6 % of the driver's 20 steps of a 16.6 us shard frame. `ms_per_step` / `value` are the event span; the host
+    # wall of the same K steps is reported beside it (config.ms_per_step_host_wall, config.host_fixed_cost_us_per_timed_region). Both are
+    # MAX over ranks.
+    def timed(span_call, sync_all):
         barrier()
         t0 = time.perf_counter()
-        run()
+        span_ms = span_call()           # enqueues exactly the K steps between two events and blocks until the closing event
         sync_all()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        wall = time.perf_counter() - t0
+        span = span_ms * 1e-3
         if dist is not None:
             dist.barrier()
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            t = torch.tensor([span, wall], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+            span, wall = float(t[0].item()), float(t[1].item())
+        return span, wall
 
     def sync_pair():
         ctx.sync()
@@ -455,31 +478,31 @@ def main():
         if args.frames_in_flight == "2":
             in_flight = 2
         elif args.frames_in_flight == "auto":
-            nc = max(20, min(args.steps, 200))
-            t1 = min(timed(lambda: ctx.deform_n(nc), ctx.sync) for _ in range(3)) / nc * 1e3
-            t2 = min(timed(lambda: ctx.deform_pair(fork, nc), sync_pair) for _ in range(3)) / nc * 1e3
+            nc = 200                    # (not a function of --steps: the driver's 20 steps must not decide the mode from 20 frames)
+            t1 = min(timed(lambda: ctx.time_span(nc), ctx.sync)[0] for _ in range(3)) / nc * 1e3
+            t2 = min(timed(lambda: ctx.time_span(nc, fork), sync_pair)[0] for _ in range(3)) / nc * 1e3
             in_flight = 2 if t2 < 0.97 * t1 else 1
             calib = {"frames": nc, "one_stream_ms": t1, "two_in_flight_ms": t2, "rule": "two in flight when >= 3 % faster (max over ranks, best of 3)"}
 
     def one_stream():
         ctx.deform_n(args.warmup)
-        return timed(lambda: ctx.deform_n(args.steps), ctx.sync)
+        return timed(lambda: ctx.time_span(args.steps), ctx.sync)
 
     def paired():
         ctx.deform_pair(fork, args.warmup)
         sync_pair()
-        return timed(lambda: ctx.deform_pair(fork, args.steps), sync_pair)
+        return timed(lambda: ctx.time_span(args.steps, fork), sync_pair)
 
     def kernel_timing():
-        """roofline of the dominant kernel: HIP events on the context's own stream, one kernel at a time"""
-        return ctx.time_frames(max(20, min(args.steps, 200)))
+        """roofline of the dominant kernel: HIP events on the context's own stream, one kernel at a time (200 frames whatever --steps is)"""
+        return ctx.time_frames(200)
 
     # Order: the K steps on ONE stream (the timed steps themselves, or — when two frames in flight were chosen — the
     # secondary number), then the kernel's own timing straight after them, in the same state of the GPU, then anything that
     # runs two kernels at once. A kernel cannot take longer than the step that contains it: if the event timing disagrees
     # with the one-stream step by more than 3 % it is measured again, once, and the line says so.
-    one_ms, pair_ms = None, None
-    one_el = one_stream()               # always: it is the headline whenever the overlapped step would be shorter than its own kernel
+    one_ms, pair_ms, pair_wall = None, None, None
+    one_el, one_wall = one_stream()     # always: it is the headline whenever the overlapped step would be shorter than its own kernel
     one_ms = one_el / args.steps * 1e3
     timing = kernel_timing()
     kcheck = {"rule": "kernel_ms <= 1.03 x ms_per_step_one_stream", "remeasured": False}
@@ -488,7 +511,7 @@ def main():
         kcheck["remeasured"] = True
     kcheck["ok"] = one_ms is None or timing["deform_kernel_ms"] <= 1.03 * one_ms
     if fork is not None and (in_flight == 2 or not args.no_pair_loop):
-        pair_el = paired()
+        pair_el, pair_wall = paired()
         pair_ms = pair_el / args.steps * 1e3
     # Headline rule (round 5): a step cannot be shorter than the kernel it contains. When two frames in flight bring the step UNDER the
     # event-timed kernel (small frames: C3 4.4 us per step against a 6.4 us kernel) that number is throughput of two overlapped frames,
@@ -501,6 +524,7 @@ def main():
     if in_flight == 2 and pair_ms is not None and (pair_ms < timing["deform_kernel_ms"] or pair_ms >= one_ms):
         headline_in_flight = 1
     elapsed = pair_el if headline_in_flight == 2 else one_el
+    elapsed_wall = pair_wall if headline_in_flight == 2 else one_wall
     if fork is not None:
         fork.close()
         fork = None
@@ -608,6 +632,41 @@ def main():
             with_upload_pair_ms = per_frame_loop(both, check_both, sync_both)
         if fk2 is not None:
             fk2.close()
+    # Caller-written poses (rz_map_pose / rz_commit_pose, ABI 7), crowds only: the per-frame loop of a host that writes its world matrices
+    # straight into the pinned ring slot the pull kernel reads — 48 B per bone, no pack, no copy in the library. `fill` stands in for the
+    # caller's pose solve: one memmove of the pre-packed rows into the slot (a solve writes them there in the first place);
+    # _protocol_only writes nothing and is what the library itself costs per frame.
+    mapped_ms, mapped_bare_ms, mapped_pair_ms = None, None, None
+    if crowd and quats is None and frames is None and hasattr(ctx, "mapped_frame_call"):
+        import ctypes
+        rows = np.ascontiguousarray(worlds.reshape(I, B, 4, 4)[:, :, :, :3], dtype=np.float32)
+        src = rows.ctypes.data
+
+        def fill(dst, nbytes):
+            ctypes.memmove(dst, src, nbytes)
+        try:
+            ROWS = rz.capi.POSE_ROWS12
+            mapped_ms = per_frame_loop(*ctx.mapped_frame_call(ROWS, fill))
+            mapped_bare_ms = per_frame_loop(*ctx.mapped_frame_call(ROWS, None))
+            put_pose()                  # (the bare loop left whatever the ring slots held as the resident pose)
+            if not args.no_pair_loop:
+                fk3 = ctx.fork()
+                ca, cb, flip3 = ctx.mapped_frame_call(ROWS, fill), fk3.mapped_frame_call(ROWS, fill), [0]
+
+                def both3():
+                    flip3[0] ^= 1
+                    (cb if flip3[0] else ca)[0]()
+
+                def check3():
+                    ca[1]()
+                    cb[1]()
+                mapped_pair_ms = per_frame_loop(both3, check3, lambda: (ctx.sync(), fk3.sync()))
+                fk3.close()
+        except Exception as e:          # noqa: BLE001  (secondary numbers never take the line down)
+            sys.stderr.write("[bench] mapped-pose loop failed on rank %d: %r\n" % (rank, e))
+        # every rank ran the same collectives inside per_frame_loop or raised before the first: a rank that failed reports None
+        if not all(gather(mapped_ms is not None)):
+            mapped_ms = mapped_bare_ms = mapped_pair_ms = None
     # ... and the same loop when the motion lives on the GPU (rz_set_pose_sampled: ONE float per instance per frame, bones
     # sampled + hierarchy solved by rz_fk_kernel): the per-frame loop that does not pay for the pose upload at any N
     sampled_ms = None
@@ -630,7 +689,7 @@ def main():
     # one record per rank, so a slow or oddly planned GPU is visible in the scaling file — gathered BEFORE the RCCL phase below,
     # so that the line has them whatever happens there
     eff = {k: ctx.get_tuning(k) for k in ("effective_split", "effective_grid", "effective_inst_group", "effective_subsets", "effective_subset_bones", "effective_inst_lds")}
-    mine = {"rank": rank, "device": local_rank, "verts": n, "kernel_ms": timing["deform_kernel_ms"], "frame_ms": timing["frame_ms"],
+    mine = {"rank": rank, "device": local_rank, "verts": n, "instances": I, "instance_begin": inst_begin, "kernel_ms": timing["deform_kernel_ms"], "frame_ms": timing["frame_ms"],
             "kernel": kernel_name, "grid": eff["effective_grid"], "morph_split": eff["effective_split"], "autotuned": tuned is not None, "rccl": None}
     per_rank = gather(mine)
 
@@ -639,7 +698,7 @@ def main():
     # It runs LAST and under a watchdog: a multi-GPU collective is the one thing a 1-GPU box cannot rehearse, and a hang in it
     # must cost the line its RCCL fields, not the line itself. ----
     ag_ms, hard_exit = None, False
-    want_comm = I == 1 and ((world_size > 1 and not args.no_allgather and (not args.share_gpu or args.rehearse_rccl)) or args.allgather)
+    want_comm = not crowd and ((world_size > 1 and not args.no_allgather and (not args.share_gpu or args.rehearse_rccl)) or args.allgather)
     if want_comm:
         import threading
         box = {"done": False, "ranks": None, "ag_ms": None}
@@ -683,7 +742,8 @@ def main():
                 r["rccl"] = {"error": "RCCL communicator / all-gather did not finish within %g s (watchdog)" % args.rccl_timeout}
             hard_exit = True            # a collective is stuck: no orderly shutdown is possible
     elif world_size > 1:
-        why = "--share-gpu: ranks share a GPU, RCCL needs one GPU per rank" if args.share_gpu else "--no-allgather"
+        why = ("a crowd is sharded along the instance axis: no exchange, no communicator (SURVEY 8e)" if crowd else
+               "--share-gpu: ranks share a GPU, RCCL needs one GPU per rank" if args.share_gpu else "--no-allgather")
         for r in per_rank:
             r["rccl"] = {"skipped": why}
 
@@ -697,9 +757,10 @@ def main():
             sys.stderr.write("[bench] cpu baseline failed: %r\n" % (e,))
 
     if rank == 0:
-        verts = V_total * I * args.steps
+        verts = V_total * I_total * args.steps
         kms = [r["kernel_ms"] for r in per_rank]
         names = {(1000000, 256, 64, 1): "C5", (30000, 200, 0, 256): "C4", (30000, 200, 64, 1): "C3", (30000, 200, 0, 1): "C2"}
+        shard_how = "instance-sharded" if crowd else "vertex-sharded"
         if sparse_kind == "demo":
             wl = ("demo-shaped: %d-vert / %d-bone / %d SPARSE vertex morphs with the demo model's statistics (%d offsets, largest %d, "
                   "all on one 1 800-vertex face region), vertex-sharded over %d GPU(s)" % (V_total, B, M, int(sparse[0][-1]) if world_size == 1 else -1,
@@ -707,8 +768,8 @@ def main():
         elif sparse_kind == "sparse2":
             wl = "sparse-2%%: %d-vert / %d-bone / %d SPARSE vertex morphs at 2 %% density spread over the mesh, vertex-sharded over %d GPU(s)" % (V_total, B, M, world_size)
         else:
-            wl = "%s: %d-vert / %d-bone / %d-dense-morph synthetic PMX%s, vertex-sharded over %d GPU(s)" % (
-                names.get((V_total, B, M, I), "custom"), V_total, B, M, (" x %d instances (per-instance palette in LDS)" % I) if I > 1 else "", world_size)
+            wl = "%s: %d-vert / %d-bone / %d-dense-morph synthetic PMX%s, %s over %d GPU(s)" % (
+                names.get((V_total, B, M, I_total), "custom"), V_total, B, M, (" x %d instances (per-instance palette in LDS)" % I_total) if crowd else "", shard_how, world_size)
         out = {
             "metric": "deformed verts/sec at 1/2/4/8 GPU; achieved HBM GB/s vs ~8 TB/s roofline",
             "value": verts / elapsed,
@@ -717,6 +778,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
+            "timed_by": "hipEvent pair on the frames' stream around exactly K steps (rz_time_span), inside barrier + synchronize on both sides, MAX over ranks; "
+                        "the host clock around the same K steps: config.ms_per_step_host_wall",
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -724,9 +787,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": wl,
-                "verts_total": V_total, "verts_per_gpu": n, "bones": B, "morphs": M, "instances": I,
+                "verts_total": V_total, "verts_per_gpu": n, "bones": B, "morphs": M, "instances": I_total, "instances_per_gpu": I,
                 "morph_layout": "sparse CSR" if sparse_kind else ("dense planes" if M else "none"),
-                "parallelism": "vertex-shard x%d" % world_size,
+                "parallelism": ("instance-shard x%d" if crowd else "vertex-shard x%d") % world_size,
                 "launched_by": "self (python -m torch.distributed.run, re-executed by bench.py)" if os.environ.get("REZE_BENCH_SELF_LAUNCHED") == "1"
                                else ("external launcher (WORLD_SIZE in the environment)" if "WORLD_SIZE" in os.environ else "single process"),
                 "numa_binding": numa,       # rank 0's: {"gpu_node", "cpus"}, null = not bound (one node, unknown, or --no-numa-bind)
@@ -751,6 +814,14 @@ def main():
                 "frames_in_flight_calibrated": in_flight,
                 "frames_in_flight_rule": "value / ms_per_step are the one-stream loop unless two frames in flight were calibrated faster (>= 3 %), their K timed steps were faster than the one-stream loop's too, AND their step is not shorter than the event-timed kernel (a step never undercuts its own kernel: such an overlap is reported in ms_per_step_two_frames_in_flight only)",
                 "frames_in_flight_choice": ("--frames-in-flight " + args.frames_in_flight) if calib is None else calib,
+                "ms_per_step_host_wall": elapsed_wall * 1e3 / args.steps,
+                "value_host_wall": verts / elapsed_wall,
+                "host_fixed_cost_us_per_timed_region": (elapsed_wall - elapsed) * 1e6,
+                "ms_per_step_one_stream_host_wall": one_wall * 1e3 / args.steps,
+                "frame_ms_with_pose_mapped": mapped_ms,
+                "frame_ms_with_pose_mapped_protocol_only": mapped_bare_ms,
+                "frame_ms_with_pose_mapped_two_in_flight": mapped_pair_ms,
+                "pose_mapped_note": "crowds: rz_map_pose(ROWS12) + the caller's write (one memmove of pre-packed 48 B rows into the pinned ring slot, standing in for a pose solve that writes there) + rz_commit_pose + rz_deform per frame; _protocol_only = without the write",
                 "ms_per_step_one_stream": one_ms,
                 "ms_per_step_two_frames_in_flight": pair_ms,
                 "speedup_basis": "compare N-GPU lines mode for mode: ms_per_step_one_stream(1) / ms_per_step_one_stream(N), or the _two_frames_in_flight pair; "

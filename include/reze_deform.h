@@ -31,8 +31,11 @@ extern "C" {
 #endif
 
 /* 5 (round 5): shards are cut at 256 vertices (4: 1 024 before round 4's change, which should have bumped this), so the chunk stride of the
- * gathered buffer changed; rz_gather_chunk exports it instead of making callers re-derive it. */
-#define RZ_ABI_VERSION 6
+ *    gathered buffer changed; rz_gather_chunk exports it instead of making callers re-derive it.
+ * 6 (round 5): + rz_device_numa_node.
+ * 7 (round 6): + rz_map_pose / rz_commit_pose (caller-written poses), rz_time_span (event-timed K-step span), rz_instance_range
+ *    (crowds sharded along the instance axis). Nothing removed or changed: a binding written against 5 or 6 keeps working. */
+#define RZ_ABI_VERSION 7
 
 typedef struct rz_ctx rz_ctx;
 
@@ -84,6 +87,12 @@ int rz_shard_range(uint32_t v_total, int nranks, int rank, uint32_t *begin, uint
  * grain — ask for it here rather than re-deriving the rule (the grain changed from 1 024 to 256 vertices with ABI 5). */
 int rz_gather_chunk(uint32_t v_total, int nranks, uint32_t *chunk);
 
+/* Crowds shard along the INSTANCE axis (last sentence): rank `rank` of `nranks` poses instances [begin, begin + count)
+ * of a crowd of `instances` characters — equal contiguous ranges of ceil(I / N), the last may be shorter, *count may be 0. Every rank
+ * holds the whole static mesh (rz_upload_mesh of all V vertices) and calls rz_set_instances(count); there is no collective at all,
+ * and no communicator (rz_comm_init refuses a crowd). The reference draws one model per engine (engine/src/engine.ts:1704-1721). */
+int rz_instance_range(uint32_t instances, int nranks, int rank, uint32_t *begin, uint32_t *count);
+
 /* setupModelBuffers()  engine/src/engine.ts:1734-1765: vertex buffer in the reference's
  * interleaved layout (8 floats/vertex: pos3 nrm3 uv2, engine.ts:340-347), joints Uint16x4
  * (:348-352), weights Unorm8x4 (:353-356). De-interleaved to planar SoA on upload.
@@ -114,6 +123,23 @@ int rz_set_instances(rz_ctx *ctx, uint32_t I);
  * world = I x B x 16 floats; morph_weights = I x M floats or NULL (all zero). Asynchronous H2D
  * through pinned staging; the data is consumed by the next rz_deform(). */
 int rz_set_pose(rz_ctx *ctx, const float *world, const float *morph_weights);
+
+/* Caller-written poses (ABI 7). updateModelPose()  engine/src/engine.ts:2383-2389 is ONE queue.writeBuffer of the matrices the pose
+ * solve left in Model's own Float32Array. rz_set_pose costs a crowd a copy on top of that: one host thread lays 3.3 MB out in the
+ * pinned ring (44 us for 256 x 200 bones) before the GPU can pull it. rz_map_pose hands the ring slot itself to the caller — *matrices
+ * points at room for I x B matrices in `layout`, *morph_weights (may be passed as NULL) at I x M floats, zero-filled — the caller (its
+ * pose solve, its worker threads) writes them in place, and rz_commit_pose does what is left of rz_set_pose: no pack, no copy.
+ *   RZ_POSE_WORLD16  64 B per bone: column-major float[16], math.ts's layout — what rz_set_pose takes
+ *   RZ_POSE_ROWS12   48 B per bone: the four columns' x y z (c0.xyz c1.xyz c2.xyz c3.xyz), i.e. the matrix without its bottom row, which
+ *                    for the affine matrices a pose solve produces is 0 0 0 1 and is written back as such on the device. Only for
+ *                    poses of more than 256 KB (a crowd's: rz_pull_pose_kernel expands them); a smaller pose is read in place by its
+ *                    frame and must be mapped as WORLD16 (RZ_ERR_UNSUPPORTED otherwise).
+ * The pointers are valid until rz_commit_pose or the next pose call on the context (rz_set_pose* cancels a mapping); the memory is
+ * pinned, cacheable host memory — plain stores. One mapping at a time per context (a fork has its own ring: two frames in flight map
+ * alternately). A slot comes back to the caller kStageSlots (8) / 32 commits later, after the GPU is done reading it (polled here). */
+enum { RZ_POSE_WORLD16 = 0, RZ_POSE_ROWS12 = 1 };
+int rz_map_pose(rz_ctx *ctx, int layout, float **matrices, float **morph_weights);
+int rz_commit_pose(rz_ctx *ctx);
 
 /* ---- forward kinematics on the device (optional) ----
  * rz_upload_skeleton_topology hands over what Model.computeWorldMatrices (engine/src/model.ts:330-420) reads from
@@ -243,6 +269,12 @@ int rz_read_aabb(rz_ctx *ctx, uint32_t instance, float min_max6[6]);
  * prep kernel alone the same way. Blocking. */
 int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
 
+/* Benchmark helper ("hipEvent pairs around the back-to-back frames"): `frames` frames of the resident pose exactly as
+ * rz_deform_n enqueues them — or, with a fork in `b`, as rz_deform_pair alternates them — between two events on the context's stream;
+ * blocks until they have drained and returns the span between the events in ms. The host's own clock around the same calls adds a
+ * fixed ~20 us per timed region (first launch + waking up from the wait), 6 % of 20 steps of a 16.6 us frame. b = NULL: one stream. */
+int rz_time_span(rz_ctx *a, rz_ctx *b, uint32_t frames, double *span_ms);
+
 /* Tuning knobs (bench sweeps / tests); 0 / -1 = automatic. Keys: "morph_split" (0,1,2,4,8 lanes
  * per vertex quad; without dense targets it only sets the wave step: 1 -> 256 vertices, >= 4 -> 64), "unroll" (0,4,8 morphs in flight per lane), "grid_cap" (total workgroups),
  * "geo_lds" (0/1: rest geometry transposed through LDS vs 4-byte loads), "nontemporal" (0/1,
@@ -283,7 +315,8 @@ int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
  * NOT a pure getter for crowds: an "effective_*" key describes the frame the NEXT rz_deform will launch, and a crowd's plan depends on
  * the per-run bone lists of its launch shape — when the shape, the mesh or the skeleton changed since the last frame the call brings
  * them up to date first, exactly as the next frame would (stream drained, one small kernel, one readback, a captured graph dropped).
- * Poll these keys at setup time or after a frame, not between a shape change and the frame in a latency-critical loop. */
+ * Poll these keys at setup time or after a frame, not between a shape change and the frame in a latency-critical loop. (An unknown
+ * "effective_*" key is refused before any of that work.) */
 int rz_set_tuning(rz_ctx *ctx, const char *key, int value);
 int rz_get_tuning(rz_ctx *ctx, const char *key, int *value);
 

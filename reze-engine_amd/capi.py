@@ -20,7 +20,11 @@ SYMBOLS = [
     "rz_read_palette", "rz_time_frames", "rz_set_tuning", "rz_get_tuning", "rz_autotune", "rz_autotune_measure", "rz_autotune_pick",
     "rz_autotune_apply", "rz_output_ptrs",
     "rz_comm_unique_id", "rz_rccl_info", "rz_comm_info", "rz_comm_init", "rz_allgather", "rz_read_gathered", "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_gather_fence", "rz_upload_edge_scale", "rz_read_hull", "rz_enable_aabb", "rz_read_aabb",
+    "rz_instance_range", "rz_map_pose", "rz_commit_pose", "rz_time_span",
 ]
+# symbols a library older than the current ABI lacks (ABI 5: rz_gather_chunk; 6: rz_device_numa_node; 7: the last four)
+OPTIONAL_SYMBOLS = {"rz_gather_chunk", "rz_device_numa_node", "rz_instance_range", "rz_map_pose", "rz_commit_pose", "rz_time_span"}
+POSE_WORLD16, POSE_ROWS12 = 0, 1
 
 
 class RzAnimation(ctypes.Structure):
@@ -133,8 +137,14 @@ def load(path=None):
     L.rz_allgather_all.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int]
     L.rz_gather_direct.argtypes = [ctypes.POINTER(vp), ctypes.c_int, u32, ctypes.c_int]
     L.rz_gather_fence.argtypes = [vp]
+    if hasattr(L, "rz_map_pose"):              # (ABI 7)
+        L.rz_instance_range.argtypes = [u32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+        L.rz_map_pose.argtypes = [vp, ctypes.c_int, ctypes.POINTER(fp), ctypes.POINTER(fp)]
+        L.rz_commit_pose.argtypes = [vp]
+        L.rz_time_span.argtypes = [vp, vp, u32, ctypes.POINTER(ctypes.c_double)]
     for name in SYMBOLS:
-        if name != "rz_last_error" and (name != "rz_gather_chunk" or hasattr(L, name)):
+        # (libraries older than the current ABI — tools/ab_inproc.py loads them side by side — lack the newer symbols: OPTIONAL_SYMBOLS)
+        if name != "rz_last_error" and (name not in OPTIONAL_SYMBOLS or hasattr(L, name)):
             getattr(L, name).restype = ctypes.c_int
     _libs[path] = L
     if path == os.path.abspath(LIB_PATH):
@@ -166,6 +176,14 @@ def shard_range(v_total, nranks, rank):
     b = ctypes.c_uint32(0)
     n = ctypes.c_uint32(0)
     _chk(load().rz_shard_range(int(v_total), int(nranks), int(rank), ctypes.byref(b), ctypes.byref(n)))
+    return b.value, n.value
+
+
+def instance_range(instances, nranks, rank):
+    """Pure host helper: (begin, count) of the instances `rank` poses when a crowd is sharded along the instance axis."""
+    b = ctypes.c_uint32(0)
+    n = ctypes.c_uint32(0)
+    _chk(load().rz_instance_range(int(instances), int(nranks), int(rank), ctypes.byref(b), ctypes.byref(n)))
     return b.value, n.value
 
 
@@ -518,6 +536,50 @@ class DeformContext:
                 raise RzError(-1, "a frame call failed: " + L.rz_last_error().decode("utf-8", "replace"))
         call.keep = keep
         return call, check
+
+    def map_pose(self, layout=POSE_WORLD16):
+        """rz_map_pose: (matrices, morph_weights) as numpy views OVER the pinned ring slot the next pose upload would have copied into —
+        [I, B, 16] or (POSE_ROWS12) [I, B, 12] floats, and [I, M] floats or None. Write them in place, then commit_pose(). The views
+        die with the commit (or the next pose call)."""
+        mp, wp = ctypes.POINTER(ctypes.c_float)(), ctypes.POINTER(ctypes.c_float)()
+        self._chk(self._L.rz_map_pose(self._h, int(layout), ctypes.byref(mp), ctypes.byref(wp)))
+        per = 12 if layout == POSE_ROWS12 else 16
+        mats = np.ctypeslib.as_array(mp, shape=(self.I, self.B, per))
+        mw = np.ctypeslib.as_array(wp, shape=(self.I, self.M)) if (self.M > 0 and wp) else None
+        return mats, mw
+
+    def commit_pose(self):
+        self._chk(self._L.rz_commit_pose(self._h))
+
+    def mapped_frame_call(self, layout, fill=None):
+        """Like frame_call, for caller-written poses: ONE rz_map_pose + fill(matrix pointer as int, bytes) + rz_commit_pose + rz_deform
+        through the raw C ABI. `fill` stands in for the caller's pose solve writing its matrices in place (None: nothing is written — the
+        protocol's own cost). Returns (call, check)."""
+        L, h = self._L, self._h
+        mp, wp = ctypes.POINTER(ctypes.c_float)(), ctypes.POINTER(ctypes.c_float)()
+        mref, wref = ctypes.byref(mp), ctypes.byref(wp)
+        nbytes = self.I * self.B * (48 if layout == POSE_ROWS12 else 64)
+        bad = []
+
+        def call():
+            if L.rz_map_pose(h, layout, mref, wref):
+                bad.append(1)
+                return
+            if fill is not None:
+                fill(ctypes.cast(mp, ctypes.c_void_p).value, nbytes)
+            if L.rz_commit_pose(h) or L.rz_deform(h):
+                bad.append(1)
+
+        def check():
+            if bad:
+                raise RzError(-1, "a mapped frame call failed: " + L.rz_last_error().decode("utf-8", "replace"))
+        return call, check
+
+    def time_span(self, frames, other=None):
+        """rz_time_span: ms between two events on the stream around `frames` back-to-back frames (with `other`, a fork: alternating)."""
+        ms = ctypes.c_double(0.0)
+        self._chk(self._L.rz_time_span(self._h, other._h if other is not None else None, int(frames), ctypes.byref(ms)))
+        return ms.value
 
     def deform(self):
         self._chk(self._L.rz_deform(self._h))

@@ -113,7 +113,7 @@ int rz_comm_init(rz_ctx *c, int nranks, int rank, const char id[128], uint32_t v
 {
     if (int r = use(c)) return r;
     if (nranks < 1 || rank < 0 || rank >= nranks || !id) return fail(RZ_ERR_INVALID, "bad communicator arguments");
-    if (c->I != 1) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive");
+    if (c->I != 1) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive: a crowd shards along the instance axis (rz_instance_range), with nothing to gather");
     if (c->V == 0) return fail(RZ_ERR_INVALID, "upload this rank's mesh shard before rz_comm_init");
     uint32_t b = 0, n = 0;
     if (int r = rz_shard_range(v_total, nranks, rank, &b, &n)) return r;
@@ -157,7 +157,7 @@ int rz_comm_init_all(rz_ctx **ctxs, int n, uint32_t v_total)
     for (int r = 0; r < n; ++r) {
         rz_ctx *c = ctxs[r];
         if (!c) return fail(RZ_ERR_INVALID, "null context in list");
-        if (c->I != 1) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive");
+        if (c->I != 1) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive: a crowd shards along the instance axis (rz_instance_range), with nothing to gather");
         uint32_t b = 0, cnt = 0;
         if (int e = rz_shard_range(v_total, n, r, &b, &cnt)) return e;
         if (cnt != c->V) return fail(RZ_ERR_INVALID, "context %d holds %u vertices but rz_shard_range assigns %u", r, c->V, cnt);
@@ -198,7 +198,7 @@ static int gather_direct_attach(rz_ctx **ctxs, int n, uint32_t v_total, int root
     for (int r = 0; r < n; ++r) {
         rz_ctx *c = ctxs[r];
         if (!c) return fail(RZ_ERR_INVALID, "null context in list");
-        if (c->I != 1) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive");
+        if (c->I != 1) return fail(RZ_ERR_UNSUPPORTED, "instancing and vertex sharding are exclusive: a crowd shards along the instance axis (rz_instance_range), with nothing to gather");
         uint32_t b = 0, cnt = 0;
         if (int e = rz_shard_range(v_total, n, r, &b, &cnt)) return e;
         if (cnt != c->V) return fail(RZ_ERR_INVALID, "context %d holds %u vertices but rz_shard_range assigns %u", r, c->V, cnt);

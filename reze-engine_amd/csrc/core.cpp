@@ -373,6 +373,9 @@ int rz_fork(rz_ctx *parent, rz_ctx **out)
     c->V = parent->V; c->Vp = parent->Vp; c->geom = parent->geom; c->j01 = parent->j01; c->j23 = parent->j23; c->wq = parent->wq;
     c->B = parent->B; c->inv_bind = parent->inv_bind;
     c->has_topology = parent->has_topology; c->fk_rec = parent->fk_rec; c->fk_anc_more = parent->fk_anc_more; c->fk_rounds = parent->fk_rounds;
+    // ... and the host-side mirrors the plan reads (plan.cpp: subfk_wanted / ensure_subfk build a crowd's closure records from them): without
+    // them a fork of a device-animated crowd never took the one-launch frame and a context and its fork alternated two frame shapes
+    c->fk_host = parent->fk_host; c->an_host_range = parent->an_host_range; c->an_host_mrec = parent->an_host_mrec; c->fk_gen = parent->fk_gen;
     c->has_animation = parent->has_animation; c->an_feed_range = parent->an_feed_range;
     c->an_feed_off = parent->an_feed_off; c->an_key_frame = parent->an_key_frame; c->an_key_pos = parent->an_key_pos;
     c->an_mkey_frame = parent->an_mkey_frame; c->an_mkey_weight = parent->an_mkey_weight; c->an_feed_ratio = parent->an_feed_ratio;

@@ -249,6 +249,14 @@ struct rz_ctx {
     size_t zc_total = 0, zc_mw_off = 0, zc_lq_off = 0;     // bytes in the slot, and where the weights / rotations sit in it
     bool world_resident = true, mw_resident = true, local_resident = true;   // which parts the device pose block holds
 
+    // rz_map_pose / rz_commit_pose: the slot handed out to the caller (map_layout < 0 = nothing mapped), and what it was sized for
+    int map_layout = -1;
+    bool map_zc = false;                // a slot of the zero-copy ring (one character) or of the staging ring (crowds)
+    int map_slot = 0;
+    uint64_t map_upload = 0;            // zero-copy: the upload index (1-based) zc_open gave the slot
+    uint32_t map_I = 0, map_B = 0, map_M = 0;
+    char *map_ptr = nullptr;
+
     // host-compacted active-morph list of the current pose (single-instance FAST path);
     // count < 0 means "more than kKargMorphs active: use the prep kernel"
     RzMorphList ml;
@@ -368,6 +376,7 @@ uint64_t zc_seq(const rz_ctx *c, uint64_t upload_index_1, int kind);
 // ---- frame.cpp ----
 int check_ready(rz_ctx *c);
 int launch_fk(rz_ctx *c, hipStream_t st);
+bool solve_on_demand(const rz_ctx *c);
 int launch_prep(rz_ctx *c, hipStream_t st);
 int launch_front(rz_ctx *c, const Plan &pl, hipStream_t st);
 int launch_deform(rz_ctx *c, const Plan &pl);

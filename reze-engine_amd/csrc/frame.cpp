@@ -31,6 +31,12 @@ int launch_prep(rz_ctx *c, hipStream_t st)
     return RZ_OK;
 }
 
+// rz_read_world / rz_read_palette after a crowd frame that solved its hierarchy in LDS only (fk_stale): the solve runs as a kernel of its
+// own — but only while the device-animated pose that frame deformed is still the current one. A new pose, skeleton or topology clears the
+// flag where it goes away (upload_pose, rz_set_pose_sampled, rz_upload_skeleton*); this is the second lock on the same door: rz_fk_kernel
+// on a pose block that holds world matrices, or on the records of a replaced skeleton, would overwrite the resident pose.
+bool solve_on_demand(const rz_ctx *c) { return c->fk_stale && c->pose_local && c->has_topology && c->pose_set && c->fk_rec; }
+
 // Everything a frame launches in front of the deform kernel: on-device FK (local-rotation poses) and/or the prep
 // kernel. The FK kernel already writes the palette, so prep is only still needed for its morph compaction.
 int launch_front(rz_ctx *c, const Plan &pl, hipStream_t st)
@@ -230,6 +236,35 @@ int rz_deform_pair(rz_ctx *a, rz_ctx *b, uint32_t frames)
     return RZ_OK;
 }
 
+// The K-step span of a benchmark's timed region, by a hipEvent pair ON the stream instead of the host's clock around
+// enqueue + synchronize: at 20 steps of a 16.6 us shard frame the host's fixed cost per timed region (first launch, wake-up from the
+// final wait: ~20 us, profiles/r6_bench_shard8_steps20.json) is 6 % of the region.
+int rz_time_span(rz_ctx *a, rz_ctx *b, uint32_t frames, double *span_ms)
+{
+    if (!span_ms || frames == 0) return fail(RZ_ERR_INVALID, "rz_time_span: bad arguments");
+    *span_ms = 0.0;
+    if (int r = use(a)) return r;
+    float ms = 0.f;
+    if (!b) {
+        HIP_TRY(hipEventRecord(a->ev0, a->stream));
+        if (int r = rz_deform_n(a, frames)) return r;
+        HIP_TRY(hipEventRecord(a->ev1, a->stream));
+    } else {
+        if (a == b || a->device != b->device) return fail(RZ_ERR_INVALID, "rz_time_span needs two different contexts on one device");
+        // the span opens on a's stream and b's first frame waits for it; it closes on a's stream behind b's last frame
+        HIP_TRY(hipEventRecord(a->ev0, a->stream));
+        HIP_TRY(hipStreamWaitEvent(b->stream, a->ev0, 0));
+        if (int r = rz_deform_pair(a, b, frames)) return r;
+        HIP_TRY(hipEventRecord(b->ev1, b->stream));
+        HIP_TRY(hipStreamWaitEvent(a->stream, b->ev1, 0));
+        HIP_TRY(hipEventRecord(a->ev1, a->stream));
+    }
+    HIP_TRY(hipEventSynchronize(a->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, a->ev0, a->ev1));
+    *span_ms = ms;
+    return RZ_OK;
+}
+
 int rz_read(rz_ctx *c, uint32_t instance, uint32_t v0, uint32_t n, float *pos3, float *nrm3)
 {
     if (int r = use(c)) return r;
@@ -248,7 +283,7 @@ int rz_read_palette(rz_ctx *c, uint32_t instance, float *rows3x4)
 {
     if (int r = use(c)) return r;
     if (instance >= c->I || !rows3x4 || !c->palette) return fail(RZ_ERR_INVALID, "bad palette read");
-    if (c->fk_stale) {
+    if (solve_on_demand(c)) {
         // the last frame was a crowd frame that solved its hierarchy in the skin kernel's front: run the solve as a kernel of its own
         // now — the same functions on the same pose, the same bits (kernels/fk.hip.h)
         if (int r = launch_fk(c, c->stream)) return r;

@@ -97,7 +97,21 @@ static napi_value undef(napi_env env)
 typedef struct ctx_slot {
     rz_ctx *ctx;
     napi_ref lender;        /* forks only */
+    napi_ref mapped[2];     /* the ArrayBuffers mapPose handed out over the pinned ring slot (matrices, morph weights): detached by commitPose */
 } ctx_slot;
+
+/* A view handed out by mapPose must not outlive the mapping: the slot goes back to the ring and the GPU reads it. Detaching the
+ * ArrayBuffers turns every later write through a stale Float32Array into a no-op on a zero-length buffer instead of a race. */
+static void detach_mapped(napi_env env, ctx_slot *slot)
+{
+    for (int k = 0; k < 2; ++k) {
+        if (!slot->mapped[k]) continue;
+        napi_value ab;
+        if (napi_get_reference_value(env, slot->mapped[k], &ab) == napi_ok && ab) napi_detach_arraybuffer(env, ab);
+        napi_delete_reference(env, slot->mapped[k]);
+        slot->mapped[k] = NULL;
+    }
+}
 
 static void release_lender(napi_env env, ctx_slot *slot)
 {
@@ -112,6 +126,7 @@ static void finalize_ctx(napi_env env, void *data, void *hint)
     (void)hint;
     ctx_slot *slot = (ctx_slot *)data;
     if (slot) {
+        detach_mapped(env, slot);
         if (slot->ctx) rz_destroy(slot->ctx);     /* a fork, or a lender whose forks are gone (they held it alive until now) */
         release_lender(env, slot);
         free(slot);
@@ -180,6 +195,7 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info)
     if (slot->ctx) {
         /* rz_destroy refuses a context whose forks are alive: the handle then STAYS valid (throwing away the pointer would
          * leak the mesh and morph targets for good) and the caller hears about it */
+        detach_mapped(env, slot);            /* the ring a mapped view points into goes with the context */
         int rc = rz_destroy(slot->ctx);
         if (rc) return throw_rz(env, rc);
         slot->ctx = NULL;
@@ -320,6 +336,93 @@ static napi_value fn_set_pose(napi_env env, napi_callback_info info)
     if (mw && nmw != (size_t)I * M) return throw_msg(env, "setPose: morphWeights must hold instances*morphs floats");
     int rc = rz_set_pose(ctx, (const float *)w, (const float *)mw);
     return rc ? throw_rz(env, rc) : undef(env);
+}
+
+static napi_value fn_instance_range(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    uint32_t it, b = 0, n = 0;
+    int32_t nr, r;
+    if (!get_u32(env, argv[0], &it) || !get_i32(env, argv[1], &nr) || !get_i32(env, argv[2], &r))
+        return throw_msg(env, "instanceRange(instances, nranks, rank)");
+    int rc = rz_instance_range(it, nr, r, &b, &n);
+    if (rc) return throw_rz(env, rc);
+    napi_value arr, vb, vn;
+    napi_create_array_with_length(env, 2, &arr);
+    napi_create_uint32(env, b, &vb);
+    napi_create_uint32(env, n, &vn);
+    napi_set_element(env, arr, 0, vb);
+    napi_set_element(env, arr, 1, vn);
+    return arr;
+}
+
+/* mapPose(ctx, layout) -> { matrices: Float32Array, morphWeights: Float32Array | null } — views OVER the pinned ring slot the next pose
+ * upload would have copied into (rz_map_pose): the pose solve writes its matrices in place (layout 0: 16 floats per bone, math.ts's
+ * layout; 1: 12 floats per bone, the four columns' x y z — crowds only), commitPose(ctx) hands them to the GPU without a copy and
+ * detaches the views. Replaces queue.writeBuffer(worldMatrixBuffer)  engine/src/engine.ts:2383-2389. */
+static napi_value fn_map_pose(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    void *p = NULL;
+    if (napi_get_value_external(env, argv[0], &p) != napi_ok || !p || !((ctx_slot *)p)->ctx) return throw_msg(env, "invalid or destroyed deform context");
+    ctx_slot *slot = (ctx_slot *)p;
+    int32_t layout = RZ_POSE_WORLD16;
+    if (argc > 1 && !get_i32(env, argv[1], &layout)) return throw_msg(env, "mapPose(ctx, layout = 0 | 1)");
+    detach_mapped(env, slot);            /* a mapping that was never committed */
+    float *mats = NULL, *mw = NULL;
+    int rc = rz_map_pose(slot->ctx, layout, &mats, &mw);
+    if (rc) return throw_rz(env, rc);
+    int B = 0, M = 0, I = 0;
+    if (rz_get_tuning(slot->ctx, "bones", &B) || rz_get_tuning(slot->ctx, "morphs", &M) || rz_get_tuning(slot->ctx, "instances", &I))
+        return throw_rz(env, RZ_ERR_INVALID);
+    const size_t nm = (size_t)I * B * (layout == RZ_POSE_ROWS12 ? 12 : 16), nw = (size_t)I * M;
+    napi_value out, ab, ta, nul;
+    napi_create_object(env, &out);
+    napi_get_null(env, &nul);
+    if (napi_create_external_arraybuffer(env, mats, nm * sizeof(float), NULL, NULL, &ab) != napi_ok ||
+        napi_create_typedarray(env, napi_float32_array, nm, ab, 0, &ta) != napi_ok)
+        return throw_msg(env, "mapPose: could not wrap the ring slot");
+    napi_create_reference(env, ab, 1, &slot->mapped[0]);
+    napi_set_named_property(env, out, "matrices", ta);
+    if (mw && nw) {
+        if (napi_create_external_arraybuffer(env, mw, nw * sizeof(float), NULL, NULL, &ab) != napi_ok ||
+            napi_create_typedarray(env, napi_float32_array, nw, ab, 0, &ta) != napi_ok)
+            return throw_msg(env, "mapPose: could not wrap the ring slot");
+        napi_create_reference(env, ab, 1, &slot->mapped[1]);
+        napi_set_named_property(env, out, "morphWeights", ta);
+    } else {
+        napi_set_named_property(env, out, "morphWeights", nul);
+    }
+    return out;
+}
+
+static napi_value fn_commit_pose(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    void *p = NULL;
+    if (napi_get_value_external(env, argv[0], &p) != napi_ok || !p || !((ctx_slot *)p)->ctx) return throw_msg(env, "invalid or destroyed deform context");
+    ctx_slot *slot = (ctx_slot *)p;
+    int rc = rz_commit_pose(slot->ctx);
+    detach_mapped(env, slot);
+    return rc ? throw_rz(env, rc) : undef(env);
+}
+
+/* timeSpan(ctx, forkCtx | null, frames) -> ms between two events on the stream around `frames` back-to-back frames (rz_time_span). */
+static napi_value fn_time_span(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    CTX(0);
+    rz_ctx *other = NULL;
+    napi_valuetype t;
+    uint32_t n;
+    if (napi_typeof(env, argv[1], &t) != napi_ok || !get_u32(env, argv[2], &n)) return throw_msg(env, "timeSpan(ctx, forkCtx | null, frames)");
+    if (t != napi_null && t != napi_undefined && !get_ctx(env, argv[1], &other)) return throw_msg(env, "timeSpan: the second argument is a fork or null");
+    double ms = 0.0;
+    int rc = rz_time_span(ctx, other, n, &ms);
+    if (rc) return throw_rz(env, rc);
+    napi_value v;
+    napi_create_double(env, ms, &v);
+    return v;
 }
 
 static napi_value fn_upload_topology(napi_env env, napi_callback_info info)
@@ -897,6 +1000,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "commUniqueId", fn_comm_unique_id }, { "rcclInfo", fn_rccl_info }, { "commInit", fn_comm_init }, { "allgather", fn_allgather },
         { "readGathered", fn_read_gathered }, { "commInitAll", fn_comm_init_all }, { "allgatherAll", fn_allgather_all },
         { "autotune", fn_autotune }, { "autotuneMeasure", fn_autotune_measure }, { "autotunePick", fn_autotune_pick }, { "autotuneApply", fn_autotune_apply }, { "commInfo", fn_comm_info }, { "uploadAnimation", fn_upload_animation }, { "setPoseSampled", fn_set_pose_sampled }, { "overrideWorld", fn_override_world }, { "uploadBoneMorphs", fn_upload_bone_morphs }, { "fork", fn_fork }, { "deformPair", fn_deform_pair }, { "gatherDirect", fn_gather_direct }, { "gatherFence", fn_gather_fence },
+        { "instanceRange", fn_instance_range }, { "mapPose", fn_map_pose }, { "commitPose", fn_commit_pose }, { "timeSpan", fn_time_span },
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value f;

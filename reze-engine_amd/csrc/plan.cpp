@@ -10,15 +10,17 @@ namespace {
 int auto_split(const rz_ctx *c)
 {
     if (c->morph_mode != 1) return 1;
-    // S lanes share a quad, so waves = quads * S / 64. Measured on MI355X (profiles/archive/r1_a_sweep*, and the search tables of
-    // profiles/archive/r3_bench_*.json): 126 k verts -> S = 4, 30 k -> S = 8, i.e. aim for ~1500 waves, never beyond 8; and even
-    // the 1 M-vertex mesh (3 906 waves at S = 1) streams 3 % faster with two lanes per quad (122.8 vs 127.0 us; S = 4 is
-    // within 0.4 % of S = 2), so a dense frame never runs below S = 2 — which also keeps rz_autotune's pick on the
-    // heuristic plan instead of flipping between two near-equal candidates from run to run.
+    // S lanes share a quad, so waves = quads * S / 64, and a wave step is 256 / S vertices whose skin phase (and output stores) follow
+    // its morph loads. Measured on MI355X, round 6 (tools/plan_sweep.py: 15 mesh sizes x {S} x {whole steps per wave}, round-robin
+    // medians, profiles/r6_plan_sweep.txt): the 1 M-vertex mesh streams 3 % faster with two lanes per quad than with one and S = 2 stays
+    // best down to ~300 k vertices; below that a wave at S = 2 is left with ONE long step — every wave loads first and skins last, nothing
+    // overlaps (250 k vertices: 37.4 us, against 34.7 us as two steps at S = 4) — so S = 4 down to ~95 k vertices, where the same
+    // happens to it, and S = 8 below (C3). A dense frame never runs at S = 1, which also keeps rz_autotune's pick on the heuristic plan
+    // instead of flipping between two near-equal candidates from run to run.
     const uint64_t quads = (uint64_t)c->Vp / 4 * c->I;
-    const uint64_t want = 1500;
     int S = 2;
-    while (S < 8 && quads * S / 64 < want) S <<= 1;
+    if (quads * 2 / 64 < 2400) S = 4;
+    if (quads * 4 / 64 < 1500) S = 8;
     while (S > 1 && (uint32_t)S > c->M) S >>= 1;
     return S;
 }
@@ -179,6 +181,9 @@ Plan make_plan(const rz_ctx *c)
     const uint32_t waves_per_wg = 4, qpw_step = 64 / (uint32_t)v.S;
     // measured (profiles/archive/r1_*sweep*): 2 workgroups per CU for one big mesh, 8 per instance when instanced
     uint32_t cap = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : std::max(2u * (uint32_t)c->n_cu, 8u * c->I);
+    // dense frames at S = 8 (under ~95 k vertices): ONE 32-vertex step per wave even where that takes a second round of workgroups —
+    // two steps per wave on half as many waves were 11-14 % slower at 63 k and 94 k vertices (profiles/r6_plan_sweep.txt)
+    if (v.mode == 1 && v.S == 8 && c->t_grid_cap <= 0 && c->I == 1) cap = std::max(cap, 4u * (uint32_t)c->n_cu);
     // Pose prefetch: the first frame of a zero-copy world pose carries one helper workgroup that stages the NEXT pose (if the
     // host has written it already) — it takes one of the grid's slots, the workers share the mesh among cap - 1.
     pl.pf = c->I == 1 && c->t_prefetch != 0 && c->zc_cur >= 0 && c->zc_seq_cur != 0 && c->zc_tag &&
@@ -190,6 +195,11 @@ Plan make_plan(const rz_ctx *c)
     gx = std::max<uint32_t>(1, std::min(gx, max_useful));
     uint32_t per_wave = (pl.n_quads + gx * waves_per_wg - 1) / (gx * waves_per_wg);
     per_wave = std::max<uint32_t>(8, round_up(per_wave, 8));
+    // dense frames: whole steps. A run of 2.5 or 3.5 steps ends every wave on a step with half its lanes idle — the stream runs at half
+    // rate for the last third of the frame; rounding the run up to whole steps (fewer workgroups) was 4.5 % faster at 875 k vertices and
+    // never slower where a run has at least two steps. Shorter runs keep the 8-quad grain: there, more workgroups beat whole steps
+    // (188 k vertices, S = 4: 1.5 steps on 489 workgroups 25.5 us, 2 steps on 367 27.8 us).
+    if (v.mode == 1 && c->t_grid_cap <= 0 && per_wave >= 2 * qpw_step) per_wave = round_up(per_wave, qpw_step);
     pl.quads_per_wave = per_wave;
     pl.grid_x = std::max<uint32_t>(1, (pl.n_quads + per_wave * waves_per_wg - 1) / (per_wave * waves_per_wg));
     // LDS write batching. Measured (tools/ablate_c5.py): parking a wave's WHOLE run and writing it once at the end

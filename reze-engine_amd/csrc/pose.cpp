@@ -209,22 +209,27 @@ static void lay_out_pose(const rz_ctx *c, const PoseParts &pp, char *st)
 }
 
 // One character: no copy at all. The pose is laid out in a pinned, device-mapped slot; the frame's own kernels read it.
-// Returns RZ_ERR_UNSUPPORTED when no such memory can be had (the caller copies instead).
-static int upload_pose_zero_copy(rz_ctx *c, const PoseParts &pp)
+// Header protocol of the pose prefetch: invalid while the pose is being written, its sequence number once it is complete (x86 stores
+// retire in program order; the fences keep the compiler from moving them). World-matrix poses are prefetched by the one-launch frame's
+// helper, local poses by the fused-hierarchy frame's (zc_seq: the kind is part of the number). zc_open takes the next slot and marks it
+// invalid (RZ_ERR_UNSUPPORTED when no such memory can be had: the caller copies instead); the pose is written (lay_out_pose, or the
+// caller of rz_map_pose); zc_publish writes the number and makes the slot the current pose.
+static int zc_open(rz_ctx *c, const PoseParts &pp, int *zs)
 {
-    int zs = 0;
-    if (int r = zc_acquire(c, std::max<size_t>(std::max<size_t>((size_t)c->B * 64 + pp.mwb, pp.mwb + (size_t)c->B * 28), 4096), &zs)) return r;
-    // header protocol of the pose prefetch: invalid while the pose is being written, its sequence number once it is complete
-    // (x86 stores retire in program order; the fences keep the compiler from moving them). World-matrix poses are prefetched
-    // by the one-launch frame's helper, local poses by the fused-hierarchy frame's (zc_seq: the kind is part of the number).
+    if (int r = zc_acquire(c, std::max<size_t>(std::max<size_t>((size_t)c->B * 64 + pp.mwb, pp.mwb + (size_t)c->B * 28), 4096), zs)) return r;
+    char *slot = static_cast<char *>(c->zc_host[*zs]);
+    *reinterpret_cast<volatile uint64_t *>(slot + c->zc_hdr_off) = 0;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    return RZ_OK;
+}
+
+static void zc_publish(rz_ctx *c, const PoseParts &pp, int zs, uint64_t upload_index_1)
+{
     char *slot = static_cast<char *>(c->zc_host[zs]);
     volatile uint64_t *hdr = reinterpret_cast<volatile uint64_t *>(slot + c->zc_hdr_off);
-    *hdr = 0;
-    std::atomic_thread_fence(std::memory_order_seq_cst);
-    lay_out_pose(c, pp, slot);
     std::atomic_thread_fence(std::memory_order_seq_cst);
     const int kind = pp.local ? (pp.sbytes ? 2 : 1) : 0;
-    const uint64_t seq = zc_seq(c, c->zc_uploads, kind);       // zc_uploads is already this upload's index + 1
+    const uint64_t seq = zc_seq(c, upload_index_1, kind);
     *hdr = seq;
     c->zc_seq_cur = seq;
     point_pose_slot(c, c->pose_slot ^ 1);   // where the pose will live once something makes it resident
@@ -233,6 +238,14 @@ static int upload_pose_zero_copy(rz_ctx *c, const PoseParts &pp)
     c->world_resident = pp.local;           // a local pose has no world matrices to bring over: rz_fk_kernel writes them
     c->mw_resident = false;
     c->local_resident = !pp.local;
+}
+
+static int upload_pose_zero_copy(rz_ctx *c, const PoseParts &pp)
+{
+    int zs = 0;
+    if (int r = zc_open(c, pp, &zs)) return r;
+    lay_out_pose(c, pp, static_cast<char *>(c->zc_host[zs]));
+    zc_publish(c, pp, zs, c->zc_uploads);       // zc_uploads is already this upload's index + 1
     return RZ_OK;
 }
 
@@ -275,36 +288,75 @@ static int big_acquire(rz_ctx *c, float **block)
     return RZ_OK;
 }
 
-// The pose goes through a pinned ring slot into a device block the running frames do not read — on the upload stream for big poses,
-// so the upload overlaps whatever the compute stream is still running; the compute stream then waits for it.
-static int upload_pose_copy(rz_ctx *c, const PoseParts &pp)
+// A pose that is copied (or pulled) to the device: it goes through a pinned ring slot into a device block the running frames do not read
+// — on the upload stream for big poses, so the upload overlaps whatever the compute stream is still running; the compute stream then
+// waits for it. Three steps, shared by rz_set_pose* (the library fills the slot: upload_pose_copy) and rz_map_pose / rz_commit_pose (the
+// caller does): copy_begin takes the slot, the slot is filled, copy_send enqueues everything.
+static size_t stage_need(const rz_ctx *c, const PoseParts &pp)
+{
+    return std::max<size_t>((size_t)c->I * c->B * 64 + pp.mwb, pp.mwb + (size_t)c->I * c->B * 28);
+}
+
+// Large poses (instanced crowds: MBs) take the upload stream and a block of the big-pose ring (ctx.h): nothing enqueued so far
+// reads that block. Small ones that are copied at all (zero_copy = 0, small crowds) go down the compute stream itself, into the
+// other of the two pose blocks — measured on C5, the two extra packets of a cross-stream hand-off (marker + barrier) cost 3 us
+// more per frame than the copy they hide.
+// Overlapped-front protocol (crowds, opt-in): EVERY per-frame input travels on the upload stream and is consumed there,
+// by the front kernels — stream order is the only ordering needed, no event at all.
+static bool pose_piped(const rz_ctx *c, const PoseParts &pp) { return !c->overlap_on && pp.total > (256u << 10); }
+
+// How it crosses the host link (tools/overlapbench, tools/pullbench: profiles/r5_overlapbench.txt, r5_pullbench.txt):
+//  * world matrices of a crowd are PULLED out of the slot by rz_pull_pose_kernel (kernels/front.hip), three rows per bone: the
+//    upload is what such a frame is bound by (3.28 MB: 84 us per hipMemcpyAsync back to back, 62 us pulled, 47 us pulled as rows),
+//    and that the pull's 16 workgroups slow a concurrent skin kernel down (27 -> 35 us) hides under it;
+//  * local rotations (a quarter of the bytes) are shorter than the frame they run under: the copy engine leaves that frame alone
+//    (27.7 us per frame with the copy running, 35.5 us with the pull), so they stay with hipMemcpyAsync ("pose_pull" = 1 pulls them too).
+static bool pose_pullable(const rz_ctx *c, const PoseParts &pp, int slot)
+{
+    return (pose_piped(c, pp) || c->overlap_on) && c->stage_dev[slot] && (pp.total & 3u) == 0;
+}
+
+static int copy_begin(rz_ctx *c, const PoseParts &pp, int *slot)
+{
+    return stage_acquire(c, stage_need(c, pp), slot);
+}
+
+// `rows`: the slot holds the world matrices as 48 B per bone (pack_rows_avx512's layout) followed by the weights; otherwise the pose in
+// lay_out_pose's layout. `pull`: rz_pull_pose_kernel instead of hipMemcpyAsync (always with `rows`).
+static int copy_send(rz_ctx *c, const PoseParts &pp, int slot, bool pull, bool rows)
 {
     c->zc_cur = -1;
     c->zc_seq_cur = 0;
     c->zc_epoch++;        // this copy overwrites a pose block a helper may have staged and tagged: no later zero-copy pose may match that tag
     c->world_resident = c->mw_resident = c->local_resident = true;
-    int slot = 0;
-    if (int r = stage_acquire(c, std::max<size_t>((size_t)c->I * c->B * 64 + pp.mwb, pp.mwb + (size_t)c->I * c->B * 28), &slot)) return r;
-    // Large poses (instanced crowds: MBs) take the upload stream and a block of the big-pose ring (ctx.h): nothing enqueued so far
-    // reads that block. Small ones that are copied at all (zero_copy = 0, small crowds) go down the compute stream itself, into the
-    // other of the two pose blocks — measured on C5, the two extra packets of a cross-stream hand-off (marker + barrier) cost 3 us
-    // more per frame than the copy they hide.
-    // Overlapped-front protocol (crowds, opt-in): EVERY per-frame input travels on the upload stream and is consumed there,
-    // by the front kernels — stream order is the only ordering needed, no event at all.
-    const bool piped = !c->overlap_on && pp.total > (256u << 10);
+    const bool piped = pose_piped(c, pp);
     hipStream_t us = (piped || c->overlap_on) ? c->up_stream : c->stream;
     float *block = nullptr;
     if (piped) {
         if (int r = big_acquire(c, &block)) return r;
     }
+    // c->world / c->morph_w / c->local_q now name the pose's block under the current counts
+    if (piped) point_pose_at(c, block);
+    else point_pose_slot(c, (c->pose_slot & 1) ^ 1);
+    void *dst = pp.local ? static_cast<void *>(c->morph_w) : static_cast<void *>(c->world);
+    const size_t bones = (size_t)c->I * c->B;
+    if (pull) HIP_TRY(rz_launch_pull_pose(c->stage_dev[slot], dst, rows ? (uint32_t)bones : 0u, rows ? pp.total - pp.pbytes : pp.total, us));
+    else HIP_TRY(hipMemcpyAsync(dst, c->stage[slot], pp.total, hipMemcpyHostToDevice, us));
+    c->last_upload_pulled = pull; c->last_upload_rows = rows;
+    // one event says both "the ring slot may be written again" (the host polls it eight uploads later) and "the pose has landed" (the
+    // compute stream waits for it): a record is ~1.4 us of stream time, and the upload stream is what a host-animated crowd is bound by
+    HIP_TRY(hipEventRecord(c->stage_ev[slot], us));
+    c->stage_used[slot] = true;
+    if (piped) HIP_TRY(hipStreamWaitEvent(c->stream, c->stage_ev[slot], 0));
+    return RZ_OK;
+}
+
+static int upload_pose_copy(rz_ctx *c, const PoseParts &pp)
+{
+    int slot = 0;
+    if (int r = copy_begin(c, pp, &slot)) return r;
     char *st = static_cast<char *>(c->stage[slot]);
-    // How it crosses the host link (tools/overlapbench, tools/pullbench: profiles/r5_overlapbench.txt, r5_pullbench.txt):
-    //  * world matrices of a crowd are PULLED out of the slot by rz_pull_pose_kernel (kernels/front.hip), three rows per bone: the
-    //    upload is what such a frame is bound by (3.28 MB: 84 us per hipMemcpyAsync back to back, 62 us pulled, 47 us pulled as rows),
-    //    and that the pull's 16 workgroups slow a concurrent skin kernel down (27 -> 35 us) hides under it;
-    //  * local rotations (a quarter of the bytes) are shorter than the frame they run under: the copy engine leaves that frame alone
-    //    (27.7 us per frame with the copy running, 35.5 us with the pull), so they stay with hipMemcpyAsync ("pose_pull" = 1 pulls them too).
-    const bool pull = (piped || c->overlap_on) && c->stage_dev[slot] && (pp.total & 3u) == 0 && (c->t_pull == 1 || (c->t_pull < 0 && !pp.local));
+    const bool pull = pose_pullable(c, pp, slot) && (c->t_pull == 1 || (c->t_pull < 0 && !pp.local));
     const size_t bones = (size_t)c->I * c->B;
     bool rows = false;
     if (pull && !pp.local && can_pack_rows()) {
@@ -316,46 +368,37 @@ static int upload_pose_copy(rz_ctx *c, const PoseParts &pp)
         }
     }
     if (!rows) lay_out_pose(c, pp, st);     // (a matrix that is not affine: the whole pose as it was handed over)
-    // c->world / c->morph_w / c->local_q now name the pose's block under the current counts
-    if (piped) point_pose_at(c, block);
-    else point_pose_slot(c, (c->pose_slot & 1) ^ 1);
-    void *dst = pp.local ? static_cast<void *>(c->morph_w) : static_cast<void *>(c->world);
-    if (pull) HIP_TRY(rz_launch_pull_pose(c->stage_dev[slot], dst, rows ? (uint32_t)bones : 0u, rows ? pp.total - pp.pbytes : pp.total, us));
-    else HIP_TRY(hipMemcpyAsync(dst, st, pp.total, hipMemcpyHostToDevice, us));
-    c->last_upload_pulled = pull; c->last_upload_rows = rows;
-    // one event says both "the ring slot may be written again" (the host polls it eight uploads later) and "the pose has landed" (the
-    // compute stream waits for it): a record is ~1.4 us of stream time, and the upload stream is what a host-animated crowd is bound by
-    HIP_TRY(hipEventRecord(c->stage_ev[slot], us));
-    c->stage_used[slot] = true;
-    if (piped) HIP_TRY(hipStreamWaitEvent(c->stream, c->stage_ev[slot], 0));
-    return RZ_OK;
+    return copy_send(c, pp, slot, pull, rows);
 }
 
-// Shared tail of rz_set_pose / rz_set_pose_local.
-static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void *secondary, size_t sbytes, bool local,
-                       const float *morph_weights)
+// What a new pose does to the context BEFORE its bytes move: the pose kind decides the plan, the plan decides which stream protocol the
+// frame (and therefore this upload) follows.
+static int pose_kind_changes(rz_ctx *c, bool local)
 {
-    // the pose kind decides the plan, the plan decides which stream protocol the frame (and therefore this upload) follows
     c->pose_set = false;
     c->pose_local = local;
     c->pose_sampled = false;
+    c->fk_stale = false;                // (it spoke of the pose this one replaces: rz_read_world / rz_read_palette must not solve THAT on demand any more)
     Plan upl;
     if (int r = frame_plan(c, &upl)) return r;          // the plan frames will use (run lists first), not the whole-palette fallback
-    if (int r = set_overlap(c, want_overlap(c, upl))) return r;
+    return set_overlap(c, want_overlap(c, upl));
+}
+
+static PoseParts pose_parts(const rz_ctx *c, const void *primary, size_t pbytes, const void *secondary, size_t sbytes, bool local, const float *morph_weights)
+{
     PoseParts pp;
     pp.primary = primary; pp.pbytes = pbytes; pp.secondary = secondary; pp.sbytes = sbytes; pp.morph_weights = morph_weights; pp.local = local;
     pp.mb = (size_t)c->I * c->M * sizeof(float);
     pp.mwb = ((size_t)c->I * std::max<uint32_t>(c->M, 1) + 3) / 4 * 4 * sizeof(float);
     pp.total = local ? pp.mwb + pbytes + sbytes : pbytes + (c->M > 0 ? pp.mwb : 0);
-    int rc = RZ_ERR_UNSUPPORTED;
-    if (!c->overlap_on && c->I == 1 && pp.total <= (256u << 10) && c->t_zerocopy != 0) {
-        rc = upload_pose_zero_copy(c, pp);
-        if (rc == RZ_ERR_UNSUPPORTED) c->t_zerocopy = 0;      // no pinned device-mapped memory: from now on every pose is copied
-    }
-    if (rc == RZ_ERR_UNSUPPORTED) rc = upload_pose_copy(c, pp);
-    if (rc) return rc;
-    c->pose_I = c->I;
-    // ordered compaction of the non-zero weights for the one-launch path (instance 0)
+    return pp;
+}
+
+static bool pose_zero_copy(const rz_ctx *c, const PoseParts &pp) { return !c->overlap_on && c->I == 1 && pp.total <= (256u << 10) && c->t_zerocopy != 0; }
+
+// ordered compaction of the non-zero weights for the one-launch path (instance 0)
+static void compact_morph_list(rz_ctx *c, const float *morph_weights)
+{
     memset(&c->ml, 0, sizeof c->ml);
     if (c->M > 0 && morph_weights && c->I == 1) {
         int n = 0;
@@ -367,6 +410,24 @@ static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void
         }
         c->ml.count = n <= kKargMorphs ? n : -1;
     }
+}
+
+// Shared tail of rz_set_pose / rz_set_pose_local.
+static int upload_pose(rz_ctx *c, const void *primary, size_t pbytes, const void *secondary, size_t sbytes, bool local,
+                       const float *morph_weights)
+{
+    c->map_layout = -1;                 // a pose handed over whole cancels a mapping that was never committed
+    if (int r = pose_kind_changes(c, local)) return r;
+    const PoseParts pp = pose_parts(c, primary, pbytes, secondary, sbytes, local, morph_weights);
+    int rc = RZ_ERR_UNSUPPORTED;
+    if (pose_zero_copy(c, pp)) {
+        rc = upload_pose_zero_copy(c, pp);
+        if (rc == RZ_ERR_UNSUPPORTED) c->t_zerocopy = 0;      // no pinned device-mapped memory: from now on every pose is copied
+    }
+    if (rc == RZ_ERR_UNSUPPORTED) rc = upload_pose_copy(c, pp);
+    if (rc) return rc;
+    c->pose_I = c->I;
+    compact_morph_list(c, morph_weights);
     c->pose_set = true;
     return RZ_OK;
 }
@@ -389,6 +450,93 @@ int rz_set_pose(rz_ctx *c, const float *world, const float *morph_weights)
     if (!world) return fail(RZ_ERR_INVALID, "null world matrices");
     if (int r = ensure_pose_buffers(c)) return r;
     return upload_pose(c, world, (size_t)c->I * c->B * 16 * sizeof(float), nullptr, 0, false, morph_weights);
+}
+
+// ---- caller-written poses (ABI 7) ----
+// rz_map_pose hands out the very memory the next pose upload would have copied the caller's matrices INTO — the next slot of the pinned
+// ring a crowd's pull kernel / the copy engine reads (poses of more than 256 KB), or of the zero-copy ring one character's frame reads
+// in place — and rz_commit_pose does what is left of rz_set_pose: nothing is packed, nothing is copied on the host. Which ring, and
+// whether the slot can hold the 48-byte rows form, is decided at map time from the state the context is in; if that state changed by
+// commit time (another instance count, tuning keys) the commit falls back to a plain rz_set_pose FROM the mapped memory (WORLD16) or
+// refuses (ROWS12: there is nothing on the host side that could expand the rows).
+int rz_map_pose(rz_ctx *c, int layout, float **matrices, float **morph_weights)
+{
+    if (int r = use(c)) return r;
+    if (matrices) *matrices = nullptr;
+    if (morph_weights) *morph_weights = nullptr;
+    if (!matrices) return fail(RZ_ERR_INVALID, "rz_map_pose: null out pointer");
+    if (layout != RZ_POSE_WORLD16 && layout != RZ_POSE_ROWS12) return fail(RZ_ERR_INVALID, "rz_map_pose: layout must be RZ_POSE_WORLD16 or RZ_POSE_ROWS12");
+    if (c->B == 0) return fail(RZ_ERR_INVALID, "no skeleton uploaded");
+    if (int r = ensure_pose_buffers(c)) return r;
+    c->map_layout = -1;
+    const size_t bones = (size_t)c->I * c->B;
+    // (the opt-in overlapped-front protocol moves every per-frame input onto the upload stream and decides that per pose KIND at upload
+    // time: such a context hands its poses over with rz_set_pose)
+    if (c->t_overlap == 1 || c->overlap_on) return fail(RZ_ERR_UNSUPPORTED, "rz_map_pose: not with the overlapped-front protocol (\"overlap\" = 1); hand the pose over with rz_set_pose");
+    const PoseParts pp = pose_parts(c, nullptr, bones * 64, nullptr, 0, false, nullptr);
+    char *st = nullptr;
+    if (pose_zero_copy(c, pp)) {
+        if (layout == RZ_POSE_ROWS12)
+            return fail(RZ_ERR_UNSUPPORTED, "rz_map_pose: a pose of %zu bytes is read in place by its frame, which wants whole 4 x 4 matrices: map it as RZ_POSE_WORLD16 (rows are for poses of more than 256 KB)", pp.total);
+        // Frames of the RESIDENT pose may be launched between this call and the commit. The ring's reuse proof (zc_acquire) counts every
+        // reader of an earlier upload as launched before this upload's slot was taken — so such a frame must not be the first one of a
+        // zero-copy pose, which reads its pinned slot: bring that pose into its device block now (one stream-ordered copy, rare).
+        if (c->pose_set)
+            if (int r = make_resident(c)) return r;
+        int zs = 0;
+        const int rc = zc_open(c, pp, &zs);
+        if (rc == RZ_OK) { c->map_zc = true; c->map_slot = zs; c->map_upload = c->zc_uploads; st = static_cast<char *>(c->zc_host[zs]); }
+        else if (rc == RZ_ERR_UNSUPPORTED) c->t_zerocopy = 0;       // no pinned device-mapped memory: from now on every pose is copied
+        else return rc;
+    }
+    if (!st) {
+        int slot = 0;
+        if (int r = copy_begin(c, pp, &slot)) return r;
+        if (layout == RZ_POSE_ROWS12 && !(pose_pullable(c, pp, slot) && c->t_pull != 0))
+            return fail(RZ_ERR_UNSUPPORTED, "rz_map_pose: rows need the pull kernel (a pose of more than 256 KB, a device-mapped ring, \"pose_pull\" != 0): map this pose as RZ_POSE_WORLD16");
+        c->map_zc = false; c->map_slot = slot;
+        st = static_cast<char *>(c->stage[slot]);
+    }
+    const size_t mat_bytes = bones * (layout == RZ_POSE_ROWS12 ? 48 : 64);
+    if (c->M > 0) {
+        memset(st + mat_bytes, 0, pp.mwb);          // weights the caller does not write are zero
+        if (morph_weights) *morph_weights = reinterpret_cast<float *>(st + mat_bytes);
+    }
+    *matrices = reinterpret_cast<float *>(st);
+    c->map_layout = layout; c->map_I = c->I; c->map_B = c->B; c->map_M = c->M; c->map_ptr = st;
+    return RZ_OK;
+}
+
+int rz_commit_pose(rz_ctx *c)
+{
+    if (int r = use(c)) return r;
+    if (c->map_layout < 0) return fail(RZ_ERR_INVALID, "rz_commit_pose without rz_map_pose (a pose call in between cancels a mapping)");
+    const int layout = c->map_layout;
+    const bool rows = layout == RZ_POSE_ROWS12;
+    c->map_layout = -1;
+    if (c->map_I != c->I || c->map_B != c->B || c->map_M != c->M) return fail(RZ_ERR_INVALID, "rz_commit_pose: the crowd, skeleton or morph set changed since rz_map_pose");
+    const size_t bones = (size_t)c->I * c->B;
+    char *st = c->map_ptr;
+    const float *mw = c->M > 0 ? reinterpret_cast<const float *>(st + bones * (rows ? 48 : 64)) : nullptr;
+    if (int r = pose_kind_changes(c, false)) return r;
+    const PoseParts pp = pose_parts(c, nullptr, bones * 64, nullptr, 0, false, nullptr);
+    // the same decisions as at map time, on the state as it is NOW
+    const bool zc_now = pose_zero_copy(c, pp);
+    bool same = c->map_zc ? (zc_now && c->zc_host[c->map_slot] == static_cast<void *>(st) && c->zc_uploads == c->map_upload)
+                          : (!zc_now && c->stage[c->map_slot] == static_cast<void *>(st));
+    const bool pull = !c->map_zc && same && pose_pullable(c, pp, c->map_slot) && (rows || c->t_pull == 1 || c->t_pull < 0);
+    if (rows && !pull) same = false;
+    if (!same) {
+        if (rows) return fail(RZ_ERR_UNSUPPORTED, "rz_commit_pose: the context changed since rz_map_pose and this pose can no longer be pulled as rows: map it again");
+        // a plain rz_set_pose out of the mapped memory (the slot it takes is the NEXT one of its ring, never the source)
+        return upload_pose(c, st, bones * 64, nullptr, 0, false, mw);
+    }
+    if (c->map_zc) zc_publish(c, pp, c->map_slot, c->map_upload);
+    else if (int r = copy_send(c, pp, c->map_slot, pull, rows)) return r;
+    c->pose_I = c->I;
+    compact_morph_list(c, mw);
+    c->pose_set = true;
+    return RZ_OK;
 }
 
 int rz_set_pose_local(rz_ctx *c, const float *local_rotations4, const float *local_translations3, const float *morph_weights)
@@ -418,6 +566,7 @@ int rz_set_pose_sampled(rz_ctx *c, const float *frames)
         c->an_frames_alloc = c->I;
     }
     c->pose_set = false;
+    c->fk_stale = false;
     c->pose_sampled = true;
     c->pose_local = true;
     c->pose_local_t = true;
@@ -515,7 +664,7 @@ int rz_read_world(rz_ctx *c, uint32_t instance, float *world16)
         memcpy(world16, c->zc_host[c->zc_cur], (size_t)c->B * 16 * sizeof(float));
         return RZ_OK;
     }
-    if (c->fk_stale) {                                  // a crowd frame that solved its hierarchy in LDS only: the solve as a kernel of its own, now
+    if (solve_on_demand(c)) {                           // a crowd frame that solved its hierarchy in LDS only: the solve as a kernel of its own, now
         if (int r = launch_fk(c, c->stream)) return r;
     }
     HIP_TRY(hipStreamSynchronize(c->up_stream));        // rz_fk_kernel may have written them on the front stream

@@ -232,6 +232,12 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
 {
     if (!c || !key || !value) return fail(RZ_ERR_INVALID, "null argument");
     if (!strncmp(key, "effective_", 10)) {
+        // (an unknown key is refused BEFORE the work below: it drains the stream and may rebuild the run lists)
+        static const char *const known[] = { "nt", "nt_store", "geo", "prep", "split", "unroll", "fast", "variant", "fk_kind", "fuse_fk", "closure_bones",
+                                             "overlap", "inst_block", "out_cap", "inst_group", "poses_per_wg", "grid", "subsets", "subset_bones", "inst_lds" };
+        bool ok = false;
+        for (const char *k : known) ok = ok || !strcmp(key + 10, k);
+        if (!ok) return fail(RZ_ERR_INVALID, "unknown tuning key '%s'", key);
         // what the NEXT frame will launch: a crowd's plan depends on the run lists of its launch shape, so bring them up to
         // date first (as every entry point that launches frames does) instead of describing the whole-palette fallback
         if (int r = use(c)) return r;

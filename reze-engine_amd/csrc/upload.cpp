@@ -90,6 +90,17 @@ int rz_gather_chunk(uint32_t v_total, int nranks, uint32_t *chunk)
     return RZ_OK;
 }
 
+int rz_instance_range(uint32_t instances, int nranks, int rank, uint32_t *begin, uint32_t *count)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks || !begin || !count)
+        return fail(RZ_ERR_INVALID, "bad instance-shard query (nranks=%d rank=%d)", nranks, rank);
+    const uint64_t per = ((uint64_t)instances + nranks - 1) / nranks;
+    const uint64_t b = std::min<uint64_t>(instances, per * (uint64_t)rank);
+    *begin = (uint32_t)b;
+    *count = (uint32_t)std::min<uint64_t>(per, instances - b);
+    return RZ_OK;
+}
+
 int rz_upload_mesh(rz_ctx *c, uint32_t V, const float *interleaved8, const uint16_t *joints4, const uint8_t *weights4)
 {
     if (int r = use(c)) return r;
@@ -146,7 +157,10 @@ int rz_upload_skeleton(rz_ctx *c, uint32_t B, const float *inverse_bind16)
     c->sub_valid = false;               // joints are clamped to the bone count when the run lists are built
     c->palette_stale = false;
     c->pose_set = false;
-    c->has_topology = false;            // belongs to the previous skeleton
+    c->has_topology = false;            // belongs to the previous skeleton ...
+    dfree(c->fk_rec); dfree(c->fk_anc_more);        // ... and so do its records (sized for the old bone count: nothing may read them for the new one)
+    c->fk_host.clear(); c->fk_rounds = 0; c->fk_gen++;
+    c->fk_stale = false; c->subfk_valid = false;
     free_bone_morphs(c);                // ... as do bone morphs (their entries name its bones)
     free_animation(c);                  // ... and so does an uploaded motion (its tracks name bones of that skeleton)
     return ensure_pose_buffers(c);
@@ -311,6 +325,7 @@ int rz_upload_skeleton_topology(rz_ctx *c, uint32_t B, const int32_t *parents, c
     HIP_TRY(hipStreamSynchronize(c->stream));
     drop_graph(c);
     c->ovr_count = 0;
+    c->fk_stale = false;                // (a crowd frame solved under the old topology: nothing of it can be formed on demand any more)
     dfree(c->fk_anc_more);
     if (!more.empty())
         if (int r = to_device(&c->fk_anc_more, more.data(), more.size())) return r;

@@ -13,6 +13,12 @@ def shard_of(v_total, world_size, rank):
     return begin, count, capi.gather_chunk(v_total, world_size)
 
 
+def instances_of(instances, world_size, rank):
+    """(begin, count): the instances this rank poses when a crowd (BASELINE config 4) is sharded along the instance axis — every rank
+    holds the whole static mesh, there is no collective and no communicator (last sentence)."""
+    return capi.instance_range(instances, world_size, rank)
+
+
 def cut_mesh(mesh, deltas, begin, count):
     """Slice the per-vertex arrays of a synth.make_mesh() dict (+ dense deltas [M,V,3]) to one shard."""
     part = {k: np.ascontiguousarray(mesh[k][begin:begin + count]) for k in ("pos", "nrm", "joints", "weights")}

@@ -83,6 +83,29 @@ if (process.argv[2] === '--live') { // on a GPU box: the same with a LIVE contex
   const pos = new Float32Array(V * 3), nrm = new Float32Array(V * 3)
   a.read(ctx, 0, 0, V, pos, nrm)
   if (!pos.every(Number.isFinite)) throw new Error('context damaged by the misuse')
+  // caller-written poses (ABI 7): mapPose hands out views over the pinned ring slot, commitPose detaches them; the frame is setPose's frame
+  const w2 = ib.map((x, i) => (i % 16 === 12 ? 0.25 * (1 + (i >> 4)) : x))      // translations along x
+  a.setPose(ctx, w2, null); a.deform(ctx)
+  const want = new Float32Array(V * 3)
+  a.read(ctx, 0, 0, V, want, null)
+  a.setPose(ctx, ib, null); a.deform(ctx)
+  const m = a.mapPose(ctx, 0)
+  if (!(m.matrices instanceof Float32Array) || m.matrices.length !== B * 16 || m.morphWeights !== null) throw new Error('mapPose: bad views')
+  m.matrices.set(w2)
+  a.commitPose(ctx); a.deform(ctx)
+  if (m.matrices.length !== 0) throw new Error('commitPose must detach the mapped views (length ' + m.matrices.length + ')')
+  const got = new Float32Array(V * 3)
+  a.read(ctx, 0, 0, V, got, null)
+  for (let i = 0; i < V * 3; i++) if (got[i] !== want[i]) throw new Error('mapped pose: vertex float ' + i + ' differs from setPose')
+  let mapBad = 0
+  try { a.commitPose(ctx) } catch (e) { mapBad += e instanceof Error ? 1 : 0 }           // nothing mapped
+  try { a.mapPose(ctx, 1) } catch (e) { mapBad += e instanceof Error ? 1 : 0 }           // rows are for poses of more than 256 KB
+  try { a.mapPose(ctx, 7) } catch (e) { mapBad += e instanceof Error ? 1 : 0 }
+  if (mapBad !== 3) throw new Error('commitPose without a mapping / rows for one character / an unknown layout must throw (' + mapBad + '/3)')
+  const stale = a.mapPose(ctx, 0)
   a.destroy(ctx)
+  if (stale.matrices.length !== 0) throw new Error('destroy must detach a mapped view')
+  const ir = a.instanceRange(100, 8, 7)
+  if (ir[0] !== 91 || ir[1] !== 9) throw new Error('instanceRange(100, 8, 7) = ' + ir)
 }
 console.log(JSON.stringify({ functions: Object.keys(a).length, thrown, returned, live, alive: true }))

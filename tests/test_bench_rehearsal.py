@@ -31,8 +31,8 @@ STUB = textwrap.dedent('''
 
     class DeformContext:
         def __init__(self, device=0, lib=None):
-            self.V = 0; self.busy_until = 0.0; self.tuning = {}
-        def _frame_s(self): return self.V / 1000.0 * US_PER_KVERT * 1e-6
+            self.V = 0; self.I = 1; self.busy_until = 0.0; self.tuning = {}
+        def _frame_s(self): return self.V * self.I / 1000.0 * US_PER_KVERT * 1e-6
         def _enqueue(self, frames):
             self.busy_until = max(self.busy_until, time.perf_counter()) + frames * self._frame_s()
         def upload_mesh(self, pos, nrm, j, w): self.V = len(pos)
@@ -41,7 +41,7 @@ STUB = textwrap.dedent('''
         def upload_morphs_sparse(self, *a): pass
         def upload_skeleton_topology(self, *a, **k): pass
         def upload_animation(self, *a, **k): pass
-        def set_instances(self, n): pass
+        def set_instances(self, n): self.I = n
         def set_pose(self, *a): pass
         def set_pose_local(self, *a, **k): pass
         def set_pose_sampled(self, *a): pass
@@ -65,8 +65,16 @@ STUB = textwrap.dedent('''
         def sync(self):
             d = self.busy_until - time.perf_counter()
             if d > 0: time.sleep(d)
+        def time_span(self, frames, other=None):
+            # the stand-in's "events": virtual GPU time from the first frame's start to the last frame's end
+            t0 = max(self.busy_until, time.perf_counter())
+            if other is None: self.deform_n(frames)
+            else: self.deform_pair(other, frames)
+            self.sync()
+            if other is not None: other.sync()
+            return (max(self.busy_until, other.busy_until if other is not None else 0.0) - t0) * 1e3
         def fork(self):
-            f = DeformContext(); f.V = self.V; return f
+            f = DeformContext(); f.V = self.V; f.I = self.I; return f
         def frame_call(self, kind, *a):
             return (lambda: self._enqueue(1)), (lambda: None)
         def time_frames(self, frames):
@@ -100,8 +108,12 @@ def _run(tmp_path, mode, extra=()):
         env["REZE_STUB_PAIR"] = "fades"
         extra.remove("--pair-fades")
 
-    cmd = [sys.executable, str(work / "bench.py"), "--gpus", "8", "--share-gpu", "--rehearse-rccl", "--dist-backend", "gloo", "--verts", "65536", "--bones", "16",
-           "--morphs", "2", "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-sampled-loop", "--clock-warm-seconds", "0", "--rccl-timeout", "6"] + list(extra)
+    shape = ["--verts", "65536", "--bones", "16", "--morphs", "2"]
+    if "--crowd" in extra:
+        extra.remove("--crowd")
+        shape = ["--verts", "1024", "--bones", "16", "--morphs", "0", "--instances", "100"]
+    cmd = [sys.executable, str(work / "bench.py"), "--gpus", "8", "--share-gpu", "--rehearse-rccl", "--dist-backend", "gloo"] + shape + [
+           "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-sampled-loop", "--clock-warm-seconds", "0", "--rccl-timeout", "6"] + list(extra)
     p = subprocess.run(cmd, cwd=str(work), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
     out = p.stdout.decode()
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
@@ -116,6 +128,12 @@ def _scaling_intact(d):
     assert 0.2 < d["ms_per_step"] < 0.8, d["ms_per_step"]
     assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert d["config"]["autotune_pick"] == 0 and d["config"]["ms_per_step_one_stream"] > 0
+    # round 6: the K steps are timed by events on the stream; the host's clock around the same steps is on the line beside them and can
+    # only be longer (it adds the fixed cost of a timed region)
+    c = d["config"]
+    assert "hipEvent" in d["timed_by"]
+    assert c["ms_per_step_host_wall"] >= d["ms_per_step"] > 0 and c["host_fixed_cost_us_per_timed_region"] >= 0
+    assert abs(c["value_host_wall"] - 65536 / (c["ms_per_step_host_wall"] * 1e-3)) <= 1e-6 * c["value_host_wall"]
 
 
 @pytest.mark.parametrize("mode", ["fail", "fail_allgather"])
@@ -152,3 +170,18 @@ def test_two_frames_in_flight_stay_the_headline_only_where_their_timed_steps_win
     assert c["frames_in_flight_calibrated"] == 2 and c["frames_in_flight"] == 1, (c["frames_in_flight_calibrated"], c["frames_in_flight"], c["frames_in_flight_choice"])
     assert c["ms_per_step_two_frames_in_flight"] > c["ms_per_step_one_stream"]
     assert abs(d["ms_per_step"] - c["ms_per_step_one_stream"]) < 1e-12
+
+
+def test_bench_c4_is_sharded_along_the_instance_axis(tmp_path):
+    """SURVEY 8e, last sentence: a crowd shards along the instance axis — every rank holds the whole mesh and poses ceil(I / N) of the
+    instances, nothing is exchanged and no communicator is made. 100 instances over 8 ranks: 13 x 7 + 9."""
+    d, p = _run(tmp_path, "fail", extra=["--crowd"])            # (a communicator that would fail is never asked for)
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["instances"] == 100 and c["parallelism"] == "instance-shard x8" and "instance-sharded" in c["workload"]
+    got = [(r["instance_begin"], r["instances"], r["verts"]) for r in c["ranks"]]
+    assert got == [(13 * k, 13 if k < 7 else 9, 1024) for k in range(8)], got
+    for r in c["ranks"]:
+        assert "skipped" in r["rccl"] and "instance axis" in r["rccl"]["skipped"], r
+    # the slowest rank poses 13 of the 100 characters: 13 x 1024 vertices x 40 us per 1000 = 0.53 ms per step
+    assert 0.4 < d["ms_per_step"] < 1.0 and abs(d["value"] - 1024 * 100 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert p.returncode == 0

@@ -359,6 +359,16 @@ def test_c5_full_size_parity_and_properties(ctx, oracle, rz):
     pg, ng = run_gpu(ctx, mesh, deltas=deltas, mw=mw, morph_split=1)
     ep, en = assert_parity(pg, ng, pr, nr, "C5 full")
     print("C5 full-size parity: max rel pos err %.3e, max nrm err %.3e" % (ep, en))
+    # (a') the DEFAULT plan — a fresh context nobody tuned: the very kernel the driver's bench line names — against the oracle too
+    d = rz.DeformContext(0)
+    d.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); d.upload_skeleton(mesh["inv_bind"]); d.upload_morphs_dense(deltas)
+    d.set_pose(mesh["world"], mw)
+    assert d.kernel_name() == "rz_deform_dense_kernel<2, 8, true, true, false, true, 3>", d.kernel_name()
+    d.deform()
+    pd, nd = d.read()
+    d.close()
+    epd, end = assert_parity(pd, nd, pr, nr, "C5 full, default plan")
+    print("C5 full-size parity, default plan: max rel pos err %.3e, max nrm err %.3e" % (epd, end))
     # (b) shard 3 of 8 with the same kernel variant
     b, n = rz.shard_range(V, 8, 3)
     shard = {k: mesh[k][b:b + n] for k in ("pos", "nrm", "joints", "weights")}

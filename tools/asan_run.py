@@ -43,7 +43,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "cpu"
 if mode == "cpu":
     n = 0
     for name in rz.capi.SYMBOLS:
-        if name in ("rz_last_error", "rz_abi_version", "rz_device_count", "rz_device_numa_node", "rz_create", "rz_shard_range", "rz_gather_chunk", "rz_comm_unique_id", "rz_comm_init_all",
+        if name in ("rz_last_error", "rz_abi_version", "rz_device_count", "rz_device_numa_node", "rz_create", "rz_shard_range", "rz_instance_range", "rz_gather_chunk", "rz_comm_unique_id", "rz_comm_init_all",
                     "rz_allgather_all", "rz_gather_direct", "rz_destroy", "rz_rccl_info", "rz_autotune_pick"):
             continue
         f = getattr(L, name)
@@ -61,7 +61,13 @@ if mode == "cpu":
                 continue
             ch = rz.capi.gather_chunk(v_total, nr)
             assert ch % 256 == 0 and ch >= spans[0][1] and all(b == min(v_total, r * ch) for r, (b, _) in enumerate(spans)), (v_total, nr, ch, spans)
+    for inst in (0, 1, 7, 8, 100, 256, 65535):       # crowds shard along the instance axis: contiguous, tiling, ceil(I / N) each
+        for nr in (1, 2, 3, 8, 64):
+            spans = [rz.capi.instance_range(inst, nr, r) for r in range(nr)]
+            per = -(-inst // nr)
+            assert sum(c for _, c in spans) == inst and all(b == min(inst, r * per) and c <= per for r, (b, c) in enumerate(spans)), (inst, nr, spans)
     b, c = ctypes.c_uint32(), ctypes.c_uint32()
+    assert L.rz_instance_range(10, 0, 0, ctypes.byref(b), ctypes.byref(c)) < 0 and L.rz_instance_range(10, 2, 2, ctypes.byref(b), ctypes.byref(c)) < 0 and L.rz_instance_range(10, 2, 0, None, None) < 0
     assert L.rz_shard_range(10, 0, 0, ctypes.byref(b), ctypes.byref(c)) < 0 and L.rz_shard_range(10, 2, 2, ctypes.byref(b), ctypes.byref(c)) < 0
     assert L.rz_shard_range(10, 2, 0, None, None) < 0
     T = rz.capi.RzTuneEntry * 4
