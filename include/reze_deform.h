@@ -235,7 +235,7 @@ int rz_deform_n(rz_ctx *ctx, uint32_t frames);
  * copy, no extra HBM) and owns everything per-frame (streams, pose slots, palettes, outputs, tuning state copied from `ctx`
  * at fork time). Alternate frames between the two (rz_set_pose* + rz_deform on one while the other's frame is in flight, or
  * rz_deform_pair for a replay) and the tail of frame f overlaps the ramp of frame f + 1: measured 16.3 -> 15.2 us per frame
- * on the 1/8 shard, 6.3 -> 4.4 us on the character (tools/shard_two_streams.py). While forks exist, static uploads fail on
+ * on the 1/8 shard, 6.3 -> 4.4 us on the character (tools/archive/shard_two_streams.py). While forks exist, static uploads fail on
  * both sides with RZ_ERR_INVALID; destroy the forks before the context they were forked from (rz_destroy refuses otherwise).
  * A fork cannot be forked and takes no part in gathers. */
 int rz_fork(rz_ctx *ctx, rz_ctx **fork_out);

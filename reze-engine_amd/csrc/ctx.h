@@ -81,13 +81,6 @@ int rccl_bind();
 }  // namespace rzi
 using rzi::kStageSlots;
 
-// Slots of the zero-copy pose ring. One hipEventRecord per RZ_ZC_SLOTS / 2 uploads guards slot reuse, and a record costs ~1.4 us of
-// stream time: measured on a 1/8 shard of C5 (tools/live_shard.py, per-frame-pose loop over the resident replay): 8 slots +0.86 us
-// per frame, 16 slots +0.50 us, 32 slots +0.37 us. 32 x <= 256 KB of pinned memory per context.
-#ifndef RZ_ZC_SLOTS
-#define RZ_ZC_SLOTS 32
-#endif
-
 struct rz_ctx {
     int device = 0;
     int n_cu = 256;
@@ -166,7 +159,7 @@ struct rz_ctx {
     // it was filled; that its readers are done is proven like a zero-copy slot's: ONE event per kBigBlocks / 2 uploads, recorded on
     // the compute stream at upload time and polled by the host before the block's next tenant is enqueued — no per-frame "slot is
     // free" hand-off between the streams (round 4 had one: a record on the compute stream + a wait on the upload stream per frame,
-    // measured at 5 - 8 us per frame: tools/overlapbench, profiles/r5_overlapbench.txt). 8 x 3.3 MB for C4.
+    // measured at 5 - 8 us per frame: tools/archive/overlapbench, profiles/r5_overlapbench.txt). 8 x 3.3 MB for C4.
     static constexpr int kBigBlocks = 8;
     float *big_blk[kBigBlocks] = {};
     size_t big_floats = 0;
@@ -224,11 +217,14 @@ struct rz_ctx {
     // device-mapped ring — no copy is enqueued at all. The first frame's kernels read it over the host link (rz_fk_kernel
     // the local pose; the one-launch deform kernel the world matrices, whose workgroup 0 also leaves them in the device
     // pose block for the frames that replay the pose); anything that needs a device-resident pose first (rz_prep_kernel)
-    // gets it through make_resident(). Measured on MI355X (tools/uploadbench): a 16.6 KB hipMemcpyAsync in front of a
+    // gets it through make_resident(). Measured on MI355X (tools/archive/uploadbench): a 16.6 KB hipMemcpyAsync in front of a
     // frame costs 18 us, two of <= 16 KB 9.5 us, reading the pinned slot from the kernel 7 us with the loads fully exposed.
     // A slot is reused kZcSlots (32) uploads later; one event per kZcSlots / 2 uploads (recorded on the compute stream at upload time) proves
     // its readers are done, so there is no per-frame marker either.
-    static constexpr int kZcSlots = RZ_ZC_SLOTS;    // a slot is reused kZcSlots uploads later; one event per kZcSlots / 2 uploads guards the reuse
+    // Slots of the ring: one hipEventRecord per kZcSlots / 2 uploads guards slot reuse, and a record costs ~1.4 us of stream time: measured
+    // on a 1/8 shard of C5 (tools/archive/live_shard.py, per-frame-pose loop over the resident replay): 8 slots +0.86 us per frame, 16 slots
+    // +0.50 us, 32 slots +0.37 us. 32 x <= 256 KB of pinned memory per context.
+    static constexpr int kZcSlots = 32;
     void *zc_host[kZcSlots] = {};
     void *zc_dev[kZcSlots] = {};
     size_t zc_bytes = 0;

@@ -32,12 +32,6 @@ namespace {
 
 constexpr int kBlock = 256;
 
-// Build-time switch (A/B builds: make flavor): bit log2(S) set = the kernel-argument morph list of the dense one-launch kernel with
-// morph split S is read through SGPRs (readfirstlane) instead of the per-lane indexed load the compiler folds the selects into.
-#ifndef RZ_PIN_ML
-#define RZ_PIN_ML 0
-#endif
-
 // Ablation switches for profiling experiments exist only in the tools-only build (make ablate ->
 // tools/ablate/libreze_deform_ablate.so, -DRZ_ABLATE). In the shipped library RZ_DBG is the constant 0, the branches
 // fold away, and rz_set_tuning("dbg", ...) is rejected: no key can make rz_deform emit anything but the deformed mesh.

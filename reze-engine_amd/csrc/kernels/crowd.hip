@@ -1,10 +1,6 @@
 // kernels/crowd.hip — instanced skin (BASELINE config C4: many poses of one static mesh) and its plan-time bone-subset pass.
 #include "fk.hip.h"
 
-#ifndef RZ_CROWD_PADDED
-#define RZ_CROWD_PADDED 1
-#endif
-
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -59,12 +55,9 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_kernel(const uint32_t
     constexpr int rstride = 3;                      // float4 per bone of a finished palette
     // SUB: this run's bone list. Its LENGTH is not read: every list is padded with bone 0 up to the plan's longest (k_bf >> 18), and a
     // workgroup stages and converts that many slots — a few matrices nobody gathers, in exchange for one dependent scalar load less at
-    // the head of the front (count -> list -> matrices was three round trips in front of the first store; RZ_CROWD_PADDED = 0: round 3's form)
-#if RZ_CROWD_PADDED
+    // the head of the front (count -> list -> matrices was three round trips in front of the first store in round 3's form, which read
+    // k_sub_count[wg_run]: -0.8 % in alternation, profiles/r5_timeline_c4.txt)
     const int ns = SUB ? (int)(k_bf >> 18) : 0;
-#else
-    const int ns = SUB ? (int)k_sub_count[wg_run] : 0;
-#endif
     const uint16_t *sub = SUB ? k_sub_list + (size_t)wg_run * kB : nullptr;      // (the lists' stride is the bone count)
     const int lrows = SUB ? ns * 3 : rows;          // float4 per pose of the finished LDS palettes
     float4 *stage = pal + (size_t)G * ns * 3;       // SUB, one-launch frame: staged world matrices sit behind the palette region
@@ -260,13 +253,9 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_fk_kernel(const uint3
     const uint32_t wg_group = k_order ? lin % n_groups : blockIdx.y, wg_run = k_order ? lin / n_groups : blockIdx.x;
     const int inst0 = (int)wg_group * G;
     const int ng = min(G, n_inst - inst0);
-    // (neither the run's closure length nor its list length is read: records and lists are padded to the plan's longest — RZ_CROWD_PADDED,
-    // as in rz_skin_instances_kernel — which takes two dependent scalar loads out of the front)
-#if RZ_CROWD_PADDED
+    // (neither the run's closure length nor its list length is read: records and lists are padded to the plan's longest, as in
+    // rz_skin_instances_kernel — which takes two dependent scalar loads out of the front)
     const int nc = rec_stride;
-#else
-    const int nc = (int)k_cnt[wg_run];
-#endif
     const uint4 *recs = k_rec + (size_t)wg_run * rec_stride * kSubFkWords;
     float4 *mA = reinterpret_cast<float4 *>(smem), *mB = mA + (size_t)G * nc * 3, *pal = mB + (size_t)G * nc * 3;
     // this thread's work items e = tid, tid + BLOCK: (pose g, closure slot c); past the end the LAST item is re-read (unpredicated loads)
@@ -300,11 +289,7 @@ __global__ void __launch_bounds__(BLOCK) rz_skin_instances_fk_kernel(const uint3
         nx = p.geom[3 * Vp + v]; ny = p.geom[4 * Vp + v]; nz = p.geom[5 * Vp + v];
         j01 = jp01[v]; j23 = jp23[v]; wq = p.weights[v];
     }
-#if RZ_CROWD_PADDED
     const int ns = (int)(k_g >> 18);                   // named bones = palette slots of a run (the longest list's)
-#else
-    const int ns = (int)p.sub_count[wg_run];          // named bones = palette slots of this run
-#endif
     const int lrows = ns * 3;
     // ---- the pose of every item: uploaded rotations (+ translations), or the motion sampled at the instance's frame ----
     float4 q[NIT], apq[NIT], ib0[NIT], ib1[NIT], ib2[NIT], ib3[NIT];

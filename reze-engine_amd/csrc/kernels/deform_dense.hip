@@ -39,11 +39,7 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
     // wave start: deform_parts.hip.h). For a frame that is one long stream that only pays at S = 8 (C3: 30 k vertices, 7.3 vs 7.6 us);
     // with fewer, longer-lived waves the kernel is FASTER reading everything out of `p` as in round 3 — measured in one process,
     // alternating builds (profiles/r5_ab_dense_entry.txt): 1/8 shard of C5 (S = 4) 17.52 -> 16.63 us, C5 (S = 2) 127.2 -> 126.0 us.
-    // (-DRZ_DENSE_LEAD_MASK=<bits by log2 S> overrides the choice for A/B builds.)
-#ifndef RZ_DENSE_LEAD_MASK
-#define RZ_DENSE_LEAD_MASK 8
-#endif
-    constexpr bool LEAD = (RZ_DENSE_LEAD_MASK >> (S == 1 ? 0 : S == 2 ? 1 : S == 4 ? 2 : 3)) & 1;
+    constexpr bool LEAD = S == 8;
     const float *a_geom = LEAD ? k_geom : p.geom;
     const float *a_world = LEAD ? k_world : (FAST ? (p.st_tag ? p.st_world : p.world) : (p.fk_on ? reinterpret_cast<const float *>(p.fk.bone_rec) : nullptr));
     const float *a_inv_bind = LEAD ? k_inv_bind : (FAST ? p.inv_bind : reinterpret_cast<const float *>((uintptr_t)(p.fk_on ? p.fk.sample.M : 0)));
@@ -226,27 +222,16 @@ __global__ void __launch_bounds__(kBlock, 2) rz_deform_dense_kernel(const float 
             // v_cndmask — no vector-memory load sits in front of the morph stream.
             auto entry = [&](int base, uint32_t &m, float &w) {
                 if (FAST) {
-                    // (PIN: the compiler folds the select chain below into ONE per-lane indexed load ml.idx[base + s] from the
-                    // kernel-argument segment, i.e. a vector-memory load in front of every group's morph loads; readfirstlane
-                    // keeps the entries in SGPRs — scalar loads — and the select a v_cndmask. NOTEBOOK.md R4.10 / R5.2.)
-                    constexpr bool PIN = (RZ_PIN_ML >> (S == 1 ? 0 : S == 2 ? 1 : S == 4 ? 2 : 3)) & 1;
-                    if constexpr (PIN) {
-                        auto sg = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-                        m = sg((uint32_t)ml.idx[base]); w = __uint_as_float(sg(__float_as_uint(ml.w[base])));
+                    // (The compiler folds the select chain below into ONE per-lane indexed load ml.idx[base + s] from the kernel-argument
+                    // segment. Keeping the entries in SGPRs instead — readfirstlane + v_cndmask — was measured twice under fresh-context
+                    // alternation: -0.05 % / +3.5 % in round 5's two sessions, +0.6 % on C5 and +1.9 % on the N = 2 shard in 10 of 10
+                    // rounds in round 6 (profiles/r6_ab_pin.txt): not adopted, the switch is gone.)
+                    m = (uint32_t)ml.idx[base]; w = ml.w[base];
 #pragma unroll
-                        for (int k = 1; k < S; ++k) {
-                            const uint32_t mk = sg((uint32_t)ml.idx[base + k]);
-                            const float wk = __uint_as_float(sg(__float_as_uint(ml.w[base + k])));
-                            m = (s == k) ? mk : m; w = (s == k) ? wk : w;
-                        }
-                    } else {
-                        m = (uint32_t)ml.idx[base]; w = ml.w[base];
-#pragma unroll
-                        for (int k = 1; k < S; ++k) {
-                            const uint32_t mk = (uint32_t)ml.idx[base + k];
-                            const float wk = ml.w[base + k];
-                            m = (s == k) ? mk : m; w = (s == k) ? wk : w;
-                        }
+                    for (int k = 1; k < S; ++k) {
+                        const uint32_t mk = (uint32_t)ml.idx[base + k];
+                        const float wk = ml.w[base + k];
+                        m = (s == k) ? mk : m; w = (s == k) ? wk : w;
                     }
                 } else {
                     m = s_idx[base + s]; w = s_w[base + s];

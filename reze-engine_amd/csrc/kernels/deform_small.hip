@@ -28,7 +28,7 @@
 // 20 — plain slots put a whole wave on the same few banks. The DMA cannot scatter, so the swizzle is applied on the way IN: lane L of a
 // burst fetches the entry whose slot L is (an involution inside aligned 16-entry groups: the burst still reads the same 256-byte
 // segments). Four bursts share one LDS base (M0); the instruction offset — added to the global AND the LDS address — steps through
-// them (rewriting M0 for every burst doubled the time a wave needs to issue a 20 KB piece: tools/dmabench, 2 155 vs 995 cycles).
+// them (rewriting M0 for every burst doubled the time a wave needs to issue a 20 KB piece: tools/archive/dmabench, 2 155 vs 995 cycles).
 #include "deform_parts.hip.h"
 
 namespace {

@@ -29,7 +29,7 @@ void inst_runs(const rz_ctx *c, int G, int blk, bool for_subsets, uint32_t *per,
 {
     // 256 threads = two workgroups per CU, 512 / 1024 = one whose 8 / 16 waves share one staged palette group — ONE round of
     // workgroups. With bone subsets (15-30 KB of LDS) two 512-thread workgroups fit a CU and more, shorter runs name fewer
-    // bones (36 -> 17 per run at 1024 workgroups), but whether that pays depends on the box: tools/c4_subsets.py measured
+    // bones (36 -> 17 per run at 1024 workgroups), but whether that pays depends on the box: tools/archive/c4_subsets.py measured
     // 256 / 512 / 768 / 1024 workgroups at 33.4 / 34.3 / 32.9 / 32.6 us on one MI355X and 33.1-33.4 / 42 / 42 / 42 us on two
     // others (profiles/archive/r3_c4_subsets.txt). One workgroup per CU is the shape that is good everywhere, so it is the default;
     // rz_autotune tries the others on the box it runs on.
@@ -126,7 +126,7 @@ bool inst_shape(const rz_ctx *c, InstShape *s)
     // workgroup size. Whole palettes: 512 threads for the one-launch frame (one workgroup of 8 waves per CU shares the 102 KB
     // group), 256 behind rz_prep_kernel / rz_fk_kernel (two workgroups of 80 KB each: measured best in round 2). Bone subsets
     // (30 KB): 512 threads in both forms — with finished rows staged the 512-thread kernel runs C4 in 32.1 us against 34.5 us
-    // for 256 threads (tools/c4_subsets.py, fast = 0 rows of profiles/archive/r3_c4_subsets.txt).
+    // for 256 threads (tools/archive/c4_subsets.py, fast = 0 rows of profiles/archive/r3_c4_subsets.txt).
     const bool forced = c->t_instblock == 256 || c->t_instblock == 512 || c->t_instblock == 1024;
     s->blk_full = forced ? c->t_instblock : (s->want_in_kernel ? 512 : 256);
     s->blk = forced ? c->t_instblock : (c->t_subsets != 0 ? 512 : s->blk_full);
@@ -160,7 +160,7 @@ Plan make_plan(const rz_ctx *c)
     // one-launch frame: single instance, and (dense) the active list fits the kernel arguments
     // Device-animated single character: the hierarchy solve (and the motion sampling) runs as the prologue of every
     // workgroup of the deform kernel — one launch per frame, no rz_fk_kernel / rz_prep_kernel in front of it. Measured
-    // (tools/fk_fuse_bench.py, 30 k vertices / 200 bones): sampled poses 11.5-17.3 -> 9.2-13.5 us per frame in every morph
+    // (tools/archive/fk_fuse_bench.py, 30 k vertices / 200 bones): sampled poses 11.5-17.3 -> 9.2-13.5 us per frame in every morph
     // mode (and 27.7 -> 24.5 us on a 1/8 shard of C5); local poses 12.7-14.4 -> 9.8-12.8 us without dense morphs, no gain
     // with them (there the three-kernel frame keeps its kernel-argument morph list and streams from its first instruction).
     // Automatic mode follows that; "fuse_fk" = 0 / 1 forces it.
@@ -202,7 +202,7 @@ Plan make_plan(const rz_ctx *c)
     if (v.mode == 1 && c->t_grid_cap <= 0 && per_wave >= 2 * qpw_step) per_wave = round_up(per_wave, qpw_step);
     pl.quads_per_wave = per_wave;
     pl.grid_x = std::max<uint32_t>(1, (pl.n_quads + per_wave * waves_per_wg - 1) / (per_wave * waves_per_wg));
-    // LDS write batching. Measured (tools/ablate_c5.py): parking a wave's WHOLE run and writing it once at the end
+    // LDS write batching. Measured (tools/archive/ablate_c5.py): parking a wave's WHOLE run and writing it once at the end
     // takes C5 from 127.6 to 124.5 us (the stores leave the read stream alone until the kernel's tail); flushing every
     // step gains nothing. So automatic mode turns it on exactly when the run fits the buffer (<= 640 vertices per wave).
     {
@@ -237,7 +237,7 @@ Plan make_plan(const rz_ctx *c)
                                 : std::max<uint32_t>(16u, (uint32_t)(avail / 16 * 16));
     }
     // instanced, morph-free frames: G poses per workgroup share one decode of each vertex, their palettes live in LDS.
-    // Where the palettes come from (measured on C4, tools/ablate_c4.py, frame = everything a frame launches):
+    // Where the palettes come from (measured on C4, tools/archive/ablate_c4.py, frame = everything a frame launches):
     //   prep kernel + 16-byte LDS-DMA of finished palettes (default, and always behind the on-device FK, which writes
     //       the palettes itself): 38.7-39.5 us (kernel 34 + 2.7 us prep + launch boundary);
     //   in-kernel (fast = 1): the skin kernel stages the group's world matrices (64-byte slots, same LDS-DMA) and

@@ -153,7 +153,7 @@ struct PoseParts {
 // is 0 0 0 1 and rz_pull_pose_kernel writes it back, so the device block holds what the host handed over — IF every bottom row is
 // exactly that (bit patterns: -0 is not 0), which the packing loop checks in passing (returns false: the caller sends the pose as it
 // is). Four bones per step: four 64-byte loads, three two-source permutes, three 64-byte NON-TEMPORAL stores — measured on the GPU
-// box's EPYC 9575F (tools/packbench, profiles/r5_packbench.txt) as fast as the memcpy it replaces while the ring is cache-resident
+// box's EPYC 9575F (tools/archive/packbench, profiles/r5_packbench.txt) as fast as the memcpy it replaces while the ring is cache-resident
 // (43 us for C4's 51 200 bones), and unlike cached stores it stays there when two contexts' rings (2 x 8 x 2.5 MB) no longer fit a
 // CCD's L3: masked 48-byte stores then read every line for ownership first and the per-frame loop of a context and its fork went from
 // 63 to 127-180 us per frame. (Needs AVX-512; without it the pose is not packed.)
@@ -305,7 +305,7 @@ static size_t stage_need(const rz_ctx *c, const PoseParts &pp)
 // by the front kernels — stream order is the only ordering needed, no event at all.
 static bool pose_piped(const rz_ctx *c, const PoseParts &pp) { return !c->overlap_on && pp.total > (256u << 10); }
 
-// How it crosses the host link (tools/overlapbench, tools/pullbench: profiles/r5_overlapbench.txt, r5_pullbench.txt):
+// How it crosses the host link (tools/archive/overlapbench, tools/pullbench: profiles/r5_overlapbench.txt, r5_pullbench.txt):
 //  * world matrices of a crowd are PULLED out of the slot by rz_pull_pose_kernel (kernels/front.hip), three rows per bone: the
 //    upload is what such a frame is bound by (3.28 MB: 84 us per hipMemcpyAsync back to back, 62 us pulled, 47 us pulled as rows),
 //    and that the pull's 16 workgroups slow a concurrent skin kernel down (27 -> 35 us) hides under it;

@@ -311,7 +311,7 @@ int rz_get_tuning(rz_ctx *c, const char *key, int *value)
         }
     }
     else if (!strncmp(key, "addr_", 5)) {
-        // diagnostics (tools/placement.py): where the allocator put a buffer — bits [12, 43) of its device address, i.e. the address in
+        // diagnostics (tools/archive/placement.py): where the allocator put a buffer — bits [12, 43) of its device address, i.e. the address in
         // 4 KB pages (where a buffer lands relative to the 2 MB large-page frame moves the C5 frame by 3 %: NOTEBOOK.md R5.3)
         const void *ptr = !strcmp(key, "addr_dense") ? (const void *)c->dense : !strcmp(key, "addr_out") ? (const void *)c->out_pos :
                           !strcmp(key, "addr_nrm") ? (const void *)c->out_nrm : !strcmp(key, "addr_geom") ? (const void *)c->geom : nullptr;

@@ -178,7 +178,7 @@ int rz_upload_morphs_dense(rz_ctx *c, uint32_t M, const float *deltas)
     const size_t Vp = c->Vp, V = c->V;
     size_t dense_off = 0;
 #ifdef RZ_ALL_VARIANTS
-    // tools-only build: place the morph planes `RZ_DENSE_OFFSET` bytes into a larger allocation (tools/placement.py: how much of the C5
+    // tools-only build: place the morph planes `RZ_DENSE_OFFSET` bytes into a larger allocation (tools/archive/placement.py: how much of the C5
     // frame's box-to-box spread is WHERE the 768 MB land). The offset is lost on free: hipFree gets the shifted pointer — leak, tools only.
     if (const char *e = getenv("RZ_DENSE_OFFSET")) dense_off = (size_t)strtoull(e, nullptr, 0) / 256 * 256;
 #endif

@@ -17,7 +17,7 @@ fresh = sys.argv[2].startswith("f")
 rounds = int(sys.argv[2].lstrip("f"))
 builds = [a.split("=", 1) for a in sys.argv[3:]]
 libs = [(n, rz.capi.load(p)) for n, p in builds]
-SHAPES = {"c5": (1000000, 256, 64, 1), "shard": (125184, 256, 64, 1), "c3": (30000, 200, 64, 1), "c2": (30000, 200, 0, 1), "c4": (30000, 200, 0, 256)}
+SHAPES = {"c5": (1000000, 256, 64, 1), "shard": (125184, 256, 64, 1), "shard2": (500224, 256, 64, 1), "shard4": (250112, 256, 64, 1), "c3": (30000, 200, 64, 1), "c2": (30000, 200, 0, 1), "c4": (30000, 200, 0, 256)}
 for wl in workloads:
     ctxs = []
     anim = None

@@ -2,7 +2,7 @@
   small single-character frames by events (C2, demo-shaped sparse, 2 %-spread sparse: kernel time of a resident replay),
   device-animated single characters (sampled / local poses: per-frame loops through the C ABI, and the resident replay)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

@@ -1,6 +1,6 @@
 """A/B of two library builds on the small single-character frames (C2, demo-shaped sparse, 2 %-spread sparse): kernel time by events."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

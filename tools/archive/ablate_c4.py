@@ -2,7 +2,7 @@
 dbg 0 = full kernel, 1 = gathers + math without the output stream, 2 = output stream without gathers / math,
 6 = full kernel without the palette staging at its start (garbage palettes), 7 = 2 + 6 (nothing but the mesh loads and the stores)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 # the ablation switches only exist in the tools-only build (make -C reze-engine_amd/csrc ablate)

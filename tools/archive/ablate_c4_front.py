@@ -1,7 +1,7 @@
 """What does the FRONT of a crowd workgroup cost (staging the matrices + forming the palette rows, during which its CU stores
 nothing)? C4 frame with and without it (dbg 8: tools-only ablation build, output is garbage), whole-palette and bone-subset forms."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

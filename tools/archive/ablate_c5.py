@@ -1,7 +1,7 @@
 """Ablation of the fused morph+skin kernel (C5 and its 1/8 shard) on one MI355X. dbg 0 = full; 3 = no palette;
 4 = morph phase only (no skin phase, no stores); 5 = skin phase without its output stream."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 # the ablation switches only exist in the tools-only build (make -C reze-engine_amd/csrc ablate)

@@ -1,6 +1,6 @@
 // Does hipExtLaunchKernel(..., hipExtAnyOrderLaunch) clear the AQL barrier bit on gfx950, i.e. can a small kernel launched
 // right behind a long one IN THE SAME STREAM start while the long one is still running? (hip_ext.h carries an old note
-// saying the flag is not supported on GFX9xx.)   hipcc --offload-arch=gfx950 -O3 tools/anyorder.hip -o tools/anyorder
+// saying the flag is not supported on GFX9xx.)   hipcc --offload-arch=gfx950 -O3 tools/archive/anyorder.hip -o tools/archive/anyorder
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <cstdio>

@@ -1,7 +1,7 @@
 """Is this one of the boxes where more than one round of crowd workgroups is slow (NOTEBOOK.md R3.1)? If so, compare the workgroup
 orders there. Prints BOX=good|bad first."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

@@ -1,7 +1,7 @@
 """Crowd size sweep: frame time of the one-launch crowd kernel vs instances (30 000 verts / 200 bones each). If time = fixed + bytes / rate,
 the fixed part is the launch ramp + palette staging + drain of ONE kernel and the rate is the write ceiling."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

@@ -1,7 +1,7 @@
 """C4 and device-animated C4 frames with and without the overlapped-front protocol (fronts of frame f+1 on the upload
 stream under the skin kernel of frame f), HIP-event timing of back-to-back frames + wall-clock per-frame loops."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

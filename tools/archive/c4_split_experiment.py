@@ -1,7 +1,7 @@
 """Would two independent half-crowds on two streams beat one crowd kernel? Two contexts (own streams) with 128 instances each,
 both queues filled, against one context with 256 instances: same total work per frame."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

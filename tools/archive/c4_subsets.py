@@ -1,7 +1,7 @@
 """C4 (256 x 30 000 / 200 bones / no morphs): bone-subset form of rz_skin_instances_kernel against the whole-palette form,
 over poses per workgroup x workgroup size x total workgroups. Frame = everything a frame launches (HIP events, rz_time_frames)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

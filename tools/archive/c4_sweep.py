@@ -1,7 +1,7 @@
 """C4 (256 x 30 000 / 200 bones / no morphs) launch-shape sweep of rz_skin_instances_kernel on one MI355X:
 workgroup size x poses per workgroup x total workgroups, kernel and whole-frame times from HIP events."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

@@ -1,7 +1,7 @@
 """Where does a host-animated crowd's per-frame time go? C4 (256 x 30 000 / 200 bones): rz_set_pose alone, rz_deform alone,
 both per frame (one stream), both alternating between the context and a fork (two in flight) — and the same at 128 / 64 poses."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

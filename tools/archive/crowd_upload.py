@@ -7,7 +7,7 @@ import os, sys, time
 if os.environ.get("RZ_TOOL_CPUS"):          # e.g. "0-63": run (and first-touch the pinned rings) on one NUMA node's cores
     lo, hi = os.environ["RZ_TOOL_CPUS"].split("-")
     os.sched_setaffinity(0, range(int(lo), int(hi) + 1))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

@@ -1,5 +1,5 @@
 // How fast can ONE wave bring a 20 KB piece of an L2-resident array into LDS?  (round 4: staging a step's sparse-morph rows)
-//   hipcc --offload-arch=gfx950 -O3 tools/dmabench.hip -o tools/dmabench
+//   hipcc --offload-arch=gfx950 -O3 tools/archive/dmabench.hip -o tools/archive/dmabench
 // forms: 0 = LDS-DMA, 16 B per lane, M0 rewritten for every 1 KiB burst          (what rz_deform_kernel MODE 2 did first)
 //        1 = LDS-DMA, M0 rewritten once per 4 bursts, instruction offsets in between
 //        2 = plain 16-byte loads into registers, 10 in flight, then ds_write_b128

@@ -1,7 +1,7 @@
 """Device-animated single character: three kernels per frame (rz_fk_kernel [+ rz_prep_kernel] + deform) vs ONE (fuse_fk: every
 workgroup of the deform kernel solves the hierarchy itself). Per-frame loops through the raw C ABI, GPU-bound."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

@@ -3,7 +3,7 @@
 // layout D[m][3][Vp]). A tile-major layout D[tile][m][3][TQ quads] makes the same 192 pieces one contiguous block. Both patterns
 // are emulated here with the kernel's own shape (persistent grid, 2 workgroups per CU, 4 waves, 24 nontemporal 16-byte loads in
 // flight per lane) next to the plain grid-stride stream of tools/membench; V = 1 M vertices, M = 64 -> 768 MB.
-// Build: hipcc --offload-arch=gfx950 -O3 tools/layoutbench.hip -o tools/layoutbench
+// Build: hipcc --offload-arch=gfx950 -O3 tools/archive/layoutbench.hip -o tools/archive/layoutbench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,5 +1,5 @@
 // LDS-gather and permuted-store micro-benchmarks behind the instanced (C4) kernel's design.
-//   hipcc --offload-arch=gfx950 -O3 tools/ldsbench.hip -o tools/ldsbench
+//   hipcc --offload-arch=gfx950 -O3 tools/archive/ldsbench.hip -o tools/archive/ldsbench
 // Q1  Does a ds_read_b128 with only part of the wave active cost fewer LDS cycles? (exec-masked palette gathers for
 //     vertices with fewer than four influences.) Same instruction count, different active-lane patterns.
 // Q2  What does a ds_bpermute_b32 cost next to it (un-permuting results inside a wave)?

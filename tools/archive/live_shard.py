@@ -1,6 +1,6 @@
 """Per-frame-pose loop of a 1/8 shard of C5 (rz_set_pose + rz_deform per frame) for one library build (REZE_LIB)."""
 import os, sys, time, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

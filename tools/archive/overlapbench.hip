@@ -1,5 +1,5 @@
 // overlapbench — does a kernel that pulls a crowd's pose over the host link overlap a store-bound frame kernel running on ANOTHER stream?
-//   hipcc --offload-arch=gfx950 -O3 tools/overlapbench.hip -o tools/overlapbench
+//   hipcc --offload-arch=gfx950 -O3 tools/archive/overlapbench.hip -o tools/archive/overlapbench
 // Frame stand-in: 256 workgroups x 512 threads filling 184 MB (C4's output stream), `fill_lds` bytes of dynamic LDS per workgroup.
 // Upload stand-in: the pull kernel of tools/pullbench (16 x 512, 4 loads in flight per lane) or hipMemcpyAsync from the same pinned memory.
 //  (a) each alone, back to back on its stream                      (b) both streams free-running, no dependency: N of each, wall time

@@ -1,5 +1,5 @@
 // packbench — how should the host lay a crowd's world matrices out in the pinned ring slot? memcpy of 64 B/bone against three ways of keeping the upper
-// three rows (48 B/bone), 51 200 bones (C4), eight destination slots cycled like the ring.   g++ -O3 -std=c++17 tools/packbench.cpp -o tools/packbench
+// three rows (48 B/bone), 51 200 bones (C4), eight destination slots cycled like the ring.   g++ -O3 -std=c++17 tools/archive/packbench.cpp -o tools/archive/packbench
 #include <immintrin.h>
 #include <chrono>
 #include <cstdio>

@@ -1,8 +1,8 @@
 """Where do a context's big buffers land, and does it matter? (NOTEBOOK.md R5.3) Fresh contexts of the C5 workload, one after the other in
 ONE process: device addresses (4 KB pages) of the morph planes / outputs / rest geometry and the event-timed kernel, then the same with
-the morph planes shifted inside a larger allocation (RZ_DENSE_OFFSET, tools-only build).   python tools/placement.py [c5|shard]"""
+the morph planes shifted inside a larger allocation (RZ_DENSE_OFFSET, tools-only build).   python tools/archive/placement.py [c5|shard]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

@@ -1,7 +1,7 @@
 """Do back-to-back frames of a small shard gain from overlapping their launch ramps / tails? Two contexts holding the SAME 1/8 shard of
 C5 (own streams, own output buffers) fed alternately, against one context running the same number of frames on one stream."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth

@@ -5,7 +5,7 @@
 //   D  fetch kernel (1 workgroup copies the 16.6 KB out of mapped pinned host memory) ; K
 //   E  K reads the 16.6 KB straight from mapped pinned host memory in EVERY workgroup
 //   F  D with the fetch done by the first workgroup of K itself, the others spin on a flag  (not built: needs co-residency)
-// hipcc --offload-arch=gfx950 -O3 tools/uploadbench.hip -o tools/uploadbench
+// hipcc --offload-arch=gfx950 -O3 tools/archive/uploadbench.hip -o tools/archive/uploadbench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Copies what tools/gpu_full.sh left under gpurun_out/full/ (scratch) into profiles/ (tracked) under the round's names, builds
-profiles/<tag>_autotune_stability.json from the consecutive runs (usage: collect_profiles.py [tag], default r5), and regenerates DESIGN.md's tables (tools/design_tables.py)."""
+profiles/<tag>_autotune_stability.json from the consecutive runs (usage: collect_profiles.py [tag], default r6), and regenerates DESIGN.md's tables (tools/design_tables.py)."""
 import glob
 import json
 import os
@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out", "full"), os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r5"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r6"
 n = 0
 for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))):
     try:
@@ -55,7 +55,7 @@ for name in ("c5", "c4"):
         stab[{"c5": "C5 (python bench.py)", "c4": "C4 (--config c4)"}[name]] = runs
 if stab:
     json.dump(stab, open(os.path.join(DST, "%s_autotune_stability.json" % TAG), "w"), indent=1)
-for t in ("shard_scaling", "live_loop", "node_frame_bench", "pytest_gpu", "smoke"):
+for t in ("shard_scaling", "live_loop", "node_frame_bench", "pytest_gpu", "smoke", "plan_sweep", "parity", "pullbench"):
     p = os.path.join(SRC, t + ".txt")
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(DST, "%s_%s.txt" % (TAG, t)))

@@ -5,10 +5,10 @@
     python tools/design_tables.py --check    exit 1 when DESIGN.md's block differs from what profiles/ says (tests/test_docs.py)
 
 Sources (all written on the GPU box by tools/gpu_full.sh / tools/gpu_profile.sh -> tools/parse_prof.py, then copied to profiles/):
-    profiles/r5_bench_*.json          bench.py lines (the driver contract), one per workload
-    profiles/r5_kernel_stats_*.txt    rocprofv3 --kernel-trace --stats of the same bench commands
+    profiles/r6_bench_*.json          bench.py lines (the driver contract), one per workload
+    profiles/r6_kernel_stats_*.txt    rocprofv3 --kernel-trace --stats of the same bench commands
     profiles/pmc_traffic.json         HBM bytes per launch from the PMC passes, keyed "<shape>|<kernel>"
-    profiles/r5_autotune_stability.json   what the launch-shape search picked in consecutive runs
+    profiles/r6_autotune_stability.json   what the launch-shape search picked in consecutive runs
 """
 import glob
 import json
@@ -18,15 +18,19 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
-TAG = "r5"
-PREV = "r4"
+TAG = "r6"
+PREV = "r5"
 BEGIN = "<!-- BEGIN GENERATED (tools/design_tables.py — do not edit by hand) -->"
 END = "<!-- END GENERATED -->"
 
 # file suffix -> what the line is (order = table order)
 LINES = [
     ("c5", "C5: 1 M verts / 256 bones / 64 dense morphs, 1 GPU — `python bench.py` (the driver's line)"),
+    ("c5_steps20", "the same with the driver's flags — `--steps 20 --warmup 5`"),
+    ("shard2", "one 1/2 shard of C5 (500 224 verts) — `--verts 500224`"),
+    ("shard4", "one 1/4 shard of C5 (250 112 verts) — `--verts 250112`"),
     ("shard8", "one 1/8 shard of C5 (125 184 verts), one stream — `--verts 125184 --frames-in-flight 1`"),
+    ("shard8_steps20", "the same shard with the driver's flags — `--verts 125184 --steps 20 --warmup 5`"),
     ("shard8_auto", "the same shard, default `--frames-in-flight auto`"),
     ("c4", "C4: 256 instances x 30 000 verts / 200 bones — `--config c4`"),
     ("c4_devicefk", "C4 with the hierarchy solved on the GPU — `--config c4 --device-fk`"),
@@ -37,6 +41,7 @@ LINES = [
     ("sparse2", "the same mesh, sparse morphs spread at 2 % density — `--config sparse2`"),
     ("c5_allgather1", "C5 through torch.distributed with one rank + the RCCL all-gather — `--allgather`"),
     ("rehearse8", "8 ranks sharing ONE GPU over gloo (plumbing rehearsal, not a scaling number) — `--gpus 8 --share-gpu --dist-backend gloo`"),
+    ("c4_rehearse8", "C4 over 8 ranks sharing ONE GPU, sharded along the instance axis (plumbing rehearsal) — `--config c4 --gpus 8 --share-gpu --dist-backend gloo`"),
 ]
 STATS = {"c5": "c5", "shard8": "shard", "c4": "c4", "c3": "c3", "demo": "demo"}
 
@@ -52,7 +57,7 @@ def load(suffix, tag=None):
 
 
 def rocprof_row(stats_name, kernel):
-    """(calls, avg_us, min_us, max_us[, workgroups]) of `kernel` in profiles/r5_kernel_stats_<name>.txt: its most-launched launch
+    """(calls, avg_us, min_us, max_us[, workgroups]) of `kernel` in profiles/r6_kernel_stats_<name>.txt: its most-launched launch
     shape when the file has the per-shape section (the plan the bench loops ran), else the all-shapes row of the stats"""
     p = os.path.join(PROF, "%s_kernel_stats_%s.txt" % (TAG, stats_name))
     if not os.path.exists(p):
@@ -83,8 +88,8 @@ def build():
     out.append("**Tracked bench lines** (`profiles/%s_bench_*.json`; times in µs; `frac` = algorithmic bytes ÷ event-timed kernel ÷ 8 TB/s, "
                "`frame` = the same over the whole frame; rocprof = average of that kernel in `profiles/%s_kernel_stats_*.txt`):" % (TAG, TAG))
     out.append("")
-    out.append("| line | N | step | verts/s | in flight | kernel the plan launches | kernel (events) | rocprof avg | frac | frame | traffic ÷ algorithmic | + pose upload | sampled on GPU |")
-    out.append("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    out.append("| line | N | step (event span) | step (host wall) | verts/s | in flight | kernel the plan launches | kernel (events) | rocprof avg | frac | frame | traffic ÷ algorithmic | + pose upload | sampled on GPU |")
+    out.append("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     have = []
     for suffix, what in LINES:
         d = load(suffix)
@@ -94,15 +99,46 @@ def build():
         c, r = d["config"], d["roofline"]
         rp = rocprof_row(STATS[suffix], r["kernel"]) if suffix in STATS else None
         tr = "—" if not r.get("traffic") else "%.4f" % (r["traffic"] / r["algorithmic_bytes_per_launch"])
-        out.append("| %s | %d | %s | %.4g | %s | `%s` | %s | %s | %.3f | %.3f | %s | %s | %s |" % (
-            what, d["n_gpus"], us(d["ms_per_step"]), d["value"], c.get("frames_in_flight", 1), r["kernel"], us(r["kernel_ms"]),
+        out.append("| %s | %d | %s | %s | %.4g | %s | `%s` | %s | %s | %.3f | %.3f | %s | %s | %s |" % (
+            what, d["n_gpus"], us(d["ms_per_step"]), us(c.get("ms_per_step_host_wall")), d["value"], c.get("frames_in_flight", 1), r["kernel"], us(r["kernel_ms"]),
             "—" if rp is None else "%.2f" % rp[1], r["frac"], r["frame_frac"], tr, us(c.get("frame_ms_with_pose_upload")), us(c.get("frame_ms_device_sampled_pose"))))
     out.append("")
+    # the scaling projection: rank 0's shard at N = 1, 2, 4, 8 on ONE GPU, by the event span and by the host's clock, at 500 and at the driver's 20 steps
+    proj = [(1, "c5"), (2, "shard2"), (4, "shard4"), (8, "shard8_auto")]
+    if all(load(sfx) is not None for _, sfx in proj):
+        out.append("**Projected strong scaling of C5 from rank 0's shard on ONE GPU** (`ms_per_step_one_stream` of the lines above: the hipEvent span of the K steps; "
+                   "the 8-GPU run itself is the driver's; `host wall` = the host's clock around the same K steps; the 20-step rows are the driver's flags):")
+        out.append("")
+        out.append("| N | shard | steps | step, event span (µs) | projected speed-up | step, host wall (µs) | speed-up by the host wall | fixed host cost per timed region (µs) | frac |")
+        out.append("|---|---|---|---|---|---|---|---|---|")
+        for steps_sfx in ("", "_steps20"):
+            base = load("c5" + steps_sfx)
+            if base is None:
+                continue
+            for n, sfx in proj:
+                d = load((sfx.replace("_auto", "") if steps_sfx else sfx) + steps_sfx)
+                if d is None:
+                    continue
+                c, cb = d["config"], base["config"]
+                out.append("| %d | %d | %d | %s | %.2f | %s | %.2f | %.1f | %.3f |" % (
+                    n, c["verts_per_gpu"], d["steps"], us(c["ms_per_step_one_stream"]), cb["ms_per_step_one_stream"] / c["ms_per_step_one_stream"],
+                    us(c.get("ms_per_step_one_stream_host_wall")), cb["ms_per_step_one_stream_host_wall"] / c["ms_per_step_one_stream_host_wall"],
+                    c.get("host_fixed_cost_us_per_timed_region", float("nan")), d["roofline"]["frac"]))
+        out.append("")
+    d4 = load("c4")
+    if d4 is not None and d4["config"].get("frame_ms_with_pose_mapped") is not None:
+        c = d4["config"]
+        out.append("**A host-animated crowd's per-frame loop (C4, world matrices; `profiles/%s_bench_c4.json`)** — resident replay %s µs; `rz_set_pose` + `rz_deform` per frame %s µs (two in flight %s); "
+                   "caller-written poses (`rz_map_pose` rows + one memmove standing in for the pose solve + `rz_commit_pose` + `rz_deform`) %s µs (two in flight %s); the same without the write "
+                   "(what the library and the host link cost) %s µs; local rotations and sampled motion: the `--device-fk` lines." % (
+                       TAG, us(c["ms_per_step_one_stream"]), us(c["frame_ms_with_pose_upload"]), us(c.get("frame_ms_with_pose_upload_two_in_flight")), us(c["frame_ms_with_pose_mapped"]),
+                       us(c.get("frame_ms_with_pose_mapped_two_in_flight")), us(c.get("frame_ms_with_pose_mapped_protocol_only"))))
+        out.append("")
     # what the round changed: the same lines of the previous round's tracked evidence
     rows = []
     for suffix, what in LINES:
         a, b = load(suffix, PREV), load(suffix)
-        if a is None or b is None or suffix in ("rehearse8", "c5_allgather1"):
+        if a is None or b is None or suffix in ("rehearse8", "c5_allgather1", "c4_rehearse8"):
             continue
         ca, cb = a["config"], b["config"]
 
@@ -112,7 +148,7 @@ def build():
                                                  pair(ca.get("frame_ms_with_pose_upload"), cb.get("frame_ms_with_pose_upload")), pair(ca.get("frame_ms_device_sampled_pose"), cb.get("frame_ms_device_sampled_pose"))))
     if rows:
         out.append("**Round %s → round %s, line by line** (`profiles/%s_bench_*.json` against `profiles/%s_bench_*.json`, µs; different boxes: differences under ≈ 3 %% are box noise "
-                   "(`profiles/r4_box_variance.txt`); the same-session A/B runs are in `profiles/%s_ab_*.txt`; round 5's lines run on the cores of the GPU's NUMA node (`config.numa_binding`)):" % (PREV[1:], TAG[1:], PREV, TAG, TAG))
+                   "(`profiles/r4_box_variance.txt`); the same-session A/B runs are in `profiles/%s_ab_*.txt`; both rounds' lines run on the cores of the GPU's NUMA node; round 6's steps are event spans, round 5's the host's clock):" % (PREV[1:], TAG[1:], PREV, TAG, TAG))
         out.append("")
         out.append("| line | frame, one stream | kernel (events) | frame + pose upload | frame, pose sampled on the GPU |")
         out.append("|---|---|---|---|---|")
@@ -187,6 +223,12 @@ def build():
         out.append("**RCCL evidence at N = 1** (`%s_bench_c5_allgather1.json`): communicator count %s, user rank %s, `%s` version %s (reused from the process: %s); all-gather %s µs per call, outside `value`." % (
             TAG, rc.get("comm_count"), rc.get("comm_user_rank"), rc.get("path"), rc.get("version"), rc.get("reused"), us(d["config"].get("allgather_ms"))))
         out.append("")
+    d = load("c4_rehearse8")
+    if d:
+        ranks = d["config"]["ranks"]
+        out.append("**C4 over 8 ranks on one GPU, instance-sharded** (`%s_bench_c4_rehearse8.json`): %s; per rank (first instance, instances): %s; no communicator (%s)." % (
+            TAG, d["config"]["workload"], ", ".join("(%d, %d)" % (r["instance_begin"], r["instances"]) for r in ranks), (ranks[0].get("rccl") or {}).get("skipped")))
+        out.append("")
     d = load("rehearse8")
     if d:
         ranks = d["config"]["ranks"]
@@ -237,7 +279,7 @@ def build_readme():
     """the short headline table of README.md"""
     out = [BEGIN, "", "| Config (BASELINE.json) | frame (µs) | verts/s | kernel: algorithmic GB/s | % of 8 TB/s (kernel / frame) |", "|---|---|---|---|---|"]
     for suffix, what in LINES:
-        if suffix in ("c5_allgather1", "rehearse8", "shard8_auto"):
+        if suffix in ("c5_allgather1", "rehearse8", "shard8_auto", "c4_rehearse8", "c5_steps20", "shard8_steps20"):
             continue
         d = load(suffix)
         if d is None:

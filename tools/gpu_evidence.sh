@@ -4,7 +4,7 @@
 # counters of the dominant kernels (tools/gpu_counters.sh) and the round's micro-benchmarks.
 #   usage: tools/gpu_evidence.sh <tag> [profile] [timelines] [counters] [micro]      default: all four parts      -> gpurun_out/ev/
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
-TAG=${1:-r5}; shift
+TAG=${1:-r6}; shift
 PARTS=${@:-profile timelines counters micro}
 O=gpurun_out/ev; rm -rf $O; mkdir -p $O/profiles
 for part in $PARTS; do
@@ -25,9 +25,9 @@ counters)
   bash tools/gpu_counters.sh c4 c4fk 2>&1 | grep -v "^$" | tail -20
   cd $R; mkdir -p $O/counters; cp gpurun_out/counters/summary_*.txt $O/counters/ 2>/dev/null ;;
 micro)
-  timeout 120 tools/overlapbench 2>&1 | tee $O/overlapbench.txt | tail -4
+  timeout 120 tools/archive/overlapbench 2>&1 | tee $O/overlapbench.txt | tail -4
   timeout 120 tools/pullbench 2>&1 | tee $O/pullbench.txt | tail -3
-  timeout 60 tools/packbench 2>&1 | tee $O/packbench.txt | tail -6
-  timeout 300 python tools/crowd_upload.py 256 2>&1 | grep -v Warning | tee $O/crowd_upload.txt ;;
+  timeout 60 tools/archive/packbench 2>&1 | tee $O/packbench.txt | tail -6
+  timeout 300 python tools/archive/crowd_upload.py 256 2>&1 | grep -v Warning | tee $O/crowd_upload.txt ;;
 esac
 done

@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r6"
 
 WORK = {   # name -> (title, V per GPU, B, M, I)
     "c5": ("python bench.py --steps 40 --warmup 5 (C5: 1M verts / 256 bones / 64 morphs, 1 GPU)", 1000000, 256, 64, 1),

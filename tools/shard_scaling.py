@@ -1,5 +1,6 @@
 """What each GPU runs at N = 1, 2, 4, 8 (strong scaling of C5): one shard of rz_shard_range(1 M, N, 0) on this GPU.
-Prints frame time, the projected N-GPU speed-up (t1 / tN) and the shard's algorithmic GB/s."""
+Prints frame time, the projected N-GPU speed-up (t1 / tN) and the shard's algorithmic GB/s — for the heuristic plan and after rz_autotune.
+Exit status 1 when the heuristic plan is more than 2 % slower than what the search adopts at any N (round 6)."""
 import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,6 +11,7 @@ mesh = synth.make_mesh(V, B)
 deltas, mw = synth.make_morphs_dense(V, M)
 t1 = None
 t1_wall = None
+worst = 0.0
 for N in (1, 2, 4, 8):
     b, n, _ = rz.shard.shard_of(V, N, 0)
     shard, d = rz.shard.cut_mesh(mesh, deltas, b, n)
@@ -25,6 +27,7 @@ for N in (1, 2, 4, 8):
                       "out_cap": ctx.get_tuning("effective_out_cap")}))
     ctx.autotune()
     t = min((ctx.time_frames(300) for _ in range(5)), key=lambda t: t["frame_ms"])
+    worst = max(worst, us / (t["frame_ms"] * 1e3) - 1.0)
     print(json.dumps({"N": N, "autotuned_frame_us": round(t["frame_ms"] * 1e3, 2), "split": ctx.get_tuning("effective_split"), "grid": ctx.get_tuning("effective_grid"), "projected_speedup_vs_untuned_t1": round(t1 / (t["frame_ms"] * 1e3), 2)}))
     # the same shard with two frames in flight (rz_fork: shared static data, own stream + outputs), wall clock per frame
     fk = ctx.fork()
@@ -39,3 +42,5 @@ for N in (1, 2, 4, 8):
                       "projected_speedup_best_mode_vs_N1_one_stream": round(t1_wall / min(one, two), 2)}))
     fk.close()
     ctx.close()
+print(json.dumps({"heuristic_behind_search_worst_pct": round(100 * worst, 2), "tolerance_pct": 2.0}))
+sys.exit(1 if worst > 0.02 else 0)
