@@ -1,4 +1,5 @@
 'use strict'
+// Source: host/src/index.ts (TypeScript). host/index.js is that file with its types erased (tools/ts_erase.py; no tsc in the image) - edit the .ts.
 // Same export list as the reference's engine/src/index.ts:1-2 (+ loaders and Model for host-side use).
 const { Engine } = require('./engine')
 const { Vec3, Quat, Mat4 } = require('./math')

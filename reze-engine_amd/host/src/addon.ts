@@ -6,17 +6,18 @@
  * the addon is missing the require throws with build instructions, and Engine.init() rethrows —
  * the same contract as the reference's "WebGPU is not supported" error (engine.ts:160-163).
  */
-const path = require('path')
+import * as path from 'path'
 
-let native = null
-let loadError = null
+import type { DeformAddon } from './types'
+let native: DeformAddon | null = null
+let loadError: Error | null = null
 try {
   native = require(path.join(__dirname, '..', 'reze_deform.node'))
 } catch (e) {
   loadError = e
 }
 
-function requireAddon() {
+function requireAddon(): DeformAddon {
   if (!native) {
     throw new Error('reze_deform.node is not available (' + (loadError && loadError.message) + '). Build it with ' +
       '`make -C reze-engine_amd/csrc` (hipcc --offload-arch=gfx950 + gcc); there is no CPU fallback.')
@@ -26,4 +27,4 @@ function requireAddon() {
 
 const isAvailable = () => native !== null
 
-module.exports = { requireAddon, isAvailable }
+export { requireAddon, isAvailable }

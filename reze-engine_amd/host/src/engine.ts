@@ -15,13 +15,15 @@
  * replacing performance.now()/window.setTimeout so a VMD can be stepped reproducibly — and
  * options { device, morphLayout: 'sparse'|'dense', realtime }.
  */
-const { Quat, Vec3 } = require('./math')
-const { PmxLoader } = require('./pmx-loader')
-const { VMDLoader } = require('./vmd-loader')
-const { VMDSampler } = require('./vmd-sampler')
-const { requireAddon } = require('./addon')
+import { Quat, Vec3 } from './math'
+import { PmxLoader } from './pmx-loader'
+import { VMDLoader } from './vmd-loader'
+import { VMDSampler } from './vmd-sampler'
+import { requireAddon } from './addon'
 
-let wallClock
+import type { Bounds, DeformAddon, DeformContext, DeformedMesh, EngineOptions, EngineStats, PhysicsLike, Shard, Timer, Timing, VMDKeyFrames } from './types'
+import type { Model } from './model'
+let wallClock: () => number
 try {
   const { performance } = require('perf_hooks')
   wallClock = () => performance.now()
@@ -30,7 +32,58 @@ try {
 }
 
 class Engine {
-  constructor(canvas, options) {
+  canvas: unknown
+  ambient: number
+  bloomIntensity: number
+  rimLightIntensity: number
+  cameraDistance: number
+  cameraTarget: Vec3
+  device: number
+  devices: number[]
+  deviceFK: boolean
+  outline: boolean
+  bounds: boolean
+  gather: boolean | 'direct'
+  morphLayout: 'sparse' | 'dense'
+  realtime: boolean
+  physics: PhysicsLike | null
+  lastPhysicsTime: number | null
+  native: DeformAddon | null
+  deviceSampling: boolean
+  instances: number
+  animationOnDevice: VMDKeyFrames | null
+  animationFor: Model | null
+  framesInFlight: 1 | 2
+  overrides: [Uint32Array, Float32Array, Uint32Array | null] | null
+  autotune: boolean
+  tuned: boolean
+  ctx: DeformContext | null
+  shards: Shard[]
+  currentModel: Model | null
+  animationFrames: VMDKeyFrames
+  hasAnimation: boolean
+  playingAnimation: boolean
+  timers: Timer[]
+  nextTimerId: number
+  animationTimers: number[]
+  breathingTimer: number | null
+  breathingBaseRotations: Map<string, Quat>
+  nowMs: number
+  loopHandle: unknown
+  renderLoopCallback: (() => void) | null
+  stats: EngineStats
+  frameTimeSamples: number[]
+  frameTimeSum: number
+  framesSinceLastUpdate: number
+  lastFpsUpdate: number
+  outPos: Float32Array | null
+  outNrm: Float32Array | null
+  outHull?: Float32Array
+  edgeScale?: Float32Array
+  modelDir?: string
+  sampler?: VMDSampler
+  samplerFor?: VMDKeyFrames
+  constructor(canvas: unknown, options?: EngineOptions) {
     this.canvas = canvas || null // accepted for signature compatibility; nothing is drawn
     const o = options || {}
     // render-only options are accepted and kept so existing call sites keep working (engine.ts:145-154)
@@ -91,11 +144,11 @@ class Engine {
     this.outNrm = null
   }
 
-  now() { return this.realtime ? wallClock() : this.nowMs }
+  now(): number { return this.realtime ? wallClock() : this.nowMs }
 
   // ---- lifecycle ----
   /** engine.ts:157-185: acquire the device. Throws when the addon or an MI355X is not available. */
-  async init() {
+  async init(): Promise<void> {
     if (this.framesInFlight === 2 && (this.devices.length > 1 || this.gather)) throw new Error('framesInFlight: 2 needs a single GPU and no gather')
     this.native = requireAddon()
     this.shards = this.devices.map((d) => ({ ctx: this.native.create(d), begin: 0, count: 0, fork: null, last: null, flip: 0 }))
@@ -103,7 +156,7 @@ class Engine {
     this.lastFpsUpdate = this.now()
   }
 
-  dispose() {
+  dispose(): void {
     this.stopRenderLoop()
     this.stopAnimation()
     this.stopBreathing()
@@ -115,7 +168,7 @@ class Engine {
 
   // ---- frames in flight ----
   /** Forks borrow the lender's static buffers: they go before anything static is replaced, and before the lender. */
-  dropForks() {
+  dropForks(): void {
     for (const s of this.shards) {
       if (s.fork) { this.native.destroy(s.fork); s.fork = null }
       s.last = null
@@ -124,7 +177,7 @@ class Engine {
   }
 
   /** The context the NEXT frame of shard `s` runs on. */
-  frameContext(s) {
+  frameContext(s: Shard): DeformContext {
     if (this.framesInFlight !== 2 || (this.autotune && !this.tuned)) { s.last = s.ctx; return s.ctx }
     if (!s.fork) { // made after the launch-shape search, so that it inherits the tuned plan
       s.fork = this.native.fork(s.ctx)
@@ -136,19 +189,19 @@ class Engine {
   }
 
   // ---- timers (window.setTimeout replacement that also works on a manual clock) ----
-  setTimer(fn, delayMs) {
+  setTimer(fn: () => void, delayMs: number): number {
     const t = { due: this.now() + delayMs, fn, id: this.nextTimerId++, handle: null }
     if (this.realtime) t.handle = setTimeout(() => { this.dropTimer(t.id); fn() }, delayMs)
     this.timers.push(t)
     return t.id
   }
 
-  dropTimer(id) {
+  dropTimer(id: number): void {
     const i = this.timers.findIndex((t) => t.id === id)
     if (i >= 0) { if (this.timers[i].handle) clearTimeout(this.timers[i].handle); this.timers.splice(i, 1) }
   }
 
-  fireDueTimers() {
+  fireDueTimers(): void {
     for (;;) { // earliest first; a callback may schedule more
       let best = -1
       for (let i = 0; i < this.timers.length; i++) {
@@ -162,7 +215,7 @@ class Engine {
 
   // ---- model ----
   /** engine.ts:1704-1721 */
-  async loadModel(path) {
+  async loadModel(path: string): Promise<void> {
     const parts = path.split('/')
     parts.pop()
     this.modelDir = parts.join('/') + '/'
@@ -171,7 +224,7 @@ class Engine {
   }
 
   /** engine.ts:1728-1832: one-off static upload (vertex / joints / weights / inverse bind [+ morph targets]). */
-  async setupModelBuffers(model) {
+  async setupModelBuffers(model: Model): Promise<void> {
     if (!this.ctx) throw new Error('Engine.init() has not been called')
     this.dropForks()
     this.overrides = null // they name bones of the previous model; the library drops its copy with the skeleton (rz_upload_skeleton)
@@ -260,24 +313,24 @@ class Engine {
       (morphs ? morphs.vertexIndex.length * 16 + V * 4 : 0)) / 1024 / 1024) * 100) / 100
   }
 
-  rotateBones(bones, rotations, durationMs) {
+  rotateBones(bones: string[], rotations: Quat[], durationMs?: number): void {
     if (this.currentModel) this.currentModel.rotateBones(bones, rotations, durationMs)
   }
 
   /** uv with the UV morphs (PMX type 3) applied, V x 2 — host-side: UVs never pass through the deformation kernel (engine.ts:273) */
-  getMorphedUVs() { return this.currentModel ? this.currentModel.getMorphedUVs() : new Float32Array(0) }
+  getMorphedUVs(): Float32Array { return this.currentModel ? this.currentModel.getMorphedUVs() : new Float32Array(0) }
 
-  setMorphWeights(namesOrIndices, weights) {
+  setMorphWeights(namesOrIndices: Array<string | number>, weights: ArrayLike<number>): void {
     if (this.currentModel) this.currentModel.setMorphWeights(namesOrIndices, weights)
   }
 
   // ---- animation ("VMD step", engine.ts:1419-1662) ----
-  async loadAnimation(path) {
+  async loadAnimation(path: string): Promise<void> {
     this.animationFrames = await VMDLoader.load(path)
     this.hasAnimation = true
   }
 
-  playAnimation(options) {
+  playAnimation(options?: { breathBones?: string[]; breathDuration?: number; breathRanges?: Record<string, number> }): void {
     if (this.animationFrames.length === 0) return
     this.stopAnimation()
     this.stopBreathing()
@@ -345,18 +398,18 @@ class Engine {
     }
   }
 
-  stopAnimation() {
+  stopAnimation(): void {
     for (const id of this.animationTimers) this.dropTimer(id)
     this.animationTimers = []
     this.playingAnimation = false
   }
 
-  stopBreathing() {
+  stopBreathing(): void {
     if (this.breathingTimer !== null) { this.dropTimer(this.breathingTimer); this.breathingTimer = null }
     this.breathingBaseRotations.clear()
   }
 
-  startBreathing(bones, baseRotations, rotationRanges, durationMs) {
+  startBreathing(bones: string[], baseRotations: Map<string, Quat>, rotationRanges?: Record<string, number>, durationMs?: number): void {
     if (!this.currentModel) return
     for (const b of bones) if (baseRotations.has(b)) this.breathingBaseRotations.set(b, baseRotations.get(b))
     const half = (durationMs === undefined ? 4000 : durationMs) / 2
@@ -378,7 +431,7 @@ class Engine {
 
   // ---- per frame ----
   /** engine.ts:2124-2136 + 2375-2402 minus the draw calls: pose on the CPU, deformation on the GPU. */
-  render() {
+  render(): void {
     if (!this.currentModel || !this.ctx) return
     const t0 = wallClock()
     const model = this.currentModel
@@ -416,7 +469,7 @@ class Engine {
    * keys) of the loaded animation: pose the model at `frame` (30 fps, fractional allowed) and deform one frame.
    * Independent of playAnimation()'s wall-clock tweens, which mirror the reference.
    */
-  seekFrame(frame) {
+  seekFrame(frame: number | ArrayLike<number>): void {
     if (!this.currentModel) return
     if (!this.sampler || this.samplerFor !== this.animationFrames) {
       this.sampler = new VMDSampler(this.animationFrames)
@@ -428,7 +481,7 @@ class Engine {
   }
 
   /** seekFrame with { deviceFK, deviceSampling }: upload the flattened motion once, then one float per frame. */
-  seekFrameOnDevice(frame) {
+  seekFrameOnDevice(frame: number | ArrayLike<number>): void {
     const model = this.currentModel
     if (this.animationOnDevice !== this.animationFrames || this.animationFor !== model) {
       const flat = this.sampler.flatten(model.runtimeSkeleton.nameIndex, model.getMorphCount() > 0 ? model.getMorphs() : null)
@@ -463,7 +516,7 @@ class Engine {
    * matrices solved from the un-overridden parent, as in the reference. `instances` (optional) names the crowd member
    * of each entry. On the host-FK path use the { physics } option instead — there the host owns the world matrices.
    */
-  setBoneWorldOverrides(boneIndices, worldMatrices, instances) {
+  setBoneWorldOverrides(boneIndices: ArrayLike<number>, worldMatrices: ArrayLike<number>, instances?: ArrayLike<number>): void {
     if (!this.ctx) throw new Error('Engine.init() has not been called')
     if (!this.deviceFK) throw new Error('setBoneWorldOverrides needs new Engine(canvas, { deviceFK: true }); with host FK pass { physics }')
     const b = boneIndices && boneIndices.length ? Uint32Array.from(boneIndices) : null
@@ -478,7 +531,7 @@ class Engine {
   }
 
   /** Deterministic stepping: move the clock to timeMs, fire the timers that came due, render one frame. */
-  step(timeMs) {
+  step(timeMs: number): void {
     if (this.realtime) throw new Error('step() needs new Engine(canvas, { realtime: false })')
     this.nowMs = timeMs
     this.fireDueTimers()
@@ -490,7 +543,7 @@ class Engine {
    * Needs { deviceFK, deviceSampling } — every instance is posed on the GPU at its own frame of the loaded motion,
    * seekFrame([f0, f1, ...]) — and a single GPU (instancing and vertex sharding are exclusive).
    */
-  setInstanceCount(n) {
+  setInstanceCount(n: number): void {
     if (!this.ctx || !this.currentModel) throw new Error('no model loaded')
     if (!this.deviceSampling) throw new Error('setInstanceCount needs new Engine(canvas, { deviceFK: true, deviceSampling: true })')
     if (this.shards.length > 1) throw new Error('instancing and vertex sharding are exclusive')
@@ -503,7 +556,7 @@ class Engine {
   }
 
   /** Blocking readback of the deformed mesh (the values the reference's vs() only ever feeds the rasteriser). */
-  getDeformed(instance) {
+  getDeformed(instance?: number): DeformedMesh {
     if (!this.ctx || !this.currentModel) throw new Error('no model loaded')
     if (instance !== undefined && instance !== 0) {
       if (!(instance > 0 && instance < this.instances)) throw new Error('instance ' + instance + ' out of range')
@@ -524,14 +577,14 @@ class Engine {
   }
 
   /** Inverted-hull positions the outline pipeline draws: worldPos + worldNormal * edgeSize * 0.01 (needs { outline: true }). */
-  getOutlineHull() {
+  getOutlineHull(): Float32Array {
     if (!this.outline) throw new Error('new Engine(canvas, { outline: true }) enables the outline hull')
     for (const s of this.shards) if (s.count > 0) this.native.readHull(s.last || s.ctx, 0, 0, s.count, this.outHull.subarray(s.begin * 3, (s.begin + s.count) * 3))
     return this.outHull
   }
 
   /** Axis-aligned bounds { min: [x,y,z], max: [x,y,z] } of the last deformed frame (needs { bounds: true }). */
-  getBounds() {
+  getBounds(): Bounds {
     if (!this.bounds) throw new Error('new Engine(canvas, { bounds: true }) enables the bounding-box reduction')
     const b = new Float32Array(6)
     const min = [Infinity, Infinity, Infinity], max = [-Infinity, -Infinity, -Infinity]
@@ -543,7 +596,7 @@ class Engine {
     return { min, max }
   }
 
-  runRenderLoop(callback) {
+  runRenderLoop(callback?: () => void): void {
     this.renderLoopCallback = callback || null
     const tick = () => {
       this.render()
@@ -553,13 +606,13 @@ class Engine {
     this.loopHandle = setTimeout(tick, 0)
   }
 
-  stopRenderLoop() {
+  stopRenderLoop(): void {
     if (this.loopHandle !== null) { clearTimeout(this.loopHandle); this.loopHandle = null }
     this.renderLoopCallback = null
   }
 
   /** engine.ts:2423-2445 (60-sample moving average, 1 Hz fps) + deformation figures. */
-  updateStats(frameTime) {
+  updateStats(frameTime: number): void {
     this.frameTimeSamples.push(frameTime)
     this.frameTimeSum += frameTime
     if (this.frameTimeSamples.length > 60) this.frameTimeSum -= this.frameTimeSamples.shift()
@@ -575,7 +628,7 @@ class Engine {
   }
 
   /** Time `frames` back-to-back frames of the current pose on the GPU (HIP events) and fold them into getStats(). */
-  measure(frames) {
+  measure(frames?: number): Timing {
     const t = this.native.timeFrames(this.ctx, frames || 100)
     this.stats.deformMs = t.frameMs
     this.stats.vertsPerSec = t.vertsPerFrame / (t.frameMs * 1e-3)
@@ -583,7 +636,7 @@ class Engine {
     return t
   }
 
-  getStats() { return Object.assign({}, this.stats) }
+  getStats(): EngineStats { return Object.assign({}, this.stats) }
 }
 
-module.exports = { Engine }
+export { Engine }

@@ -12,35 +12,39 @@
  * kinematics call without allocating, wrapped by thin classes for API compatibility.
  */
 
-function easeInOut(t) {
+import type { NumArray, Quad } from './types'
+function easeInOut(t: number): number {
   if (t < 0.5) return 2 * t * t
   const u = -2 * t + 2
   return 1 - (u * u) / 2
 }
 
 class Vec3 {
-  constructor(x, y, z) { this.x = x; this.y = y; this.z = z }
-  add(o) { return new Vec3(this.x + o.x, this.y + o.y, this.z + o.z) }
-  subtract(o) { return new Vec3(this.x - o.x, this.y - o.y, this.z - o.z) }
-  scale(k) { return new Vec3(this.x * k, this.y * k, this.z * k) }
-  dot(o) { return this.x * o.x + this.y * o.y + this.z * o.z }
-  cross(o) {
+  x: number
+  y: number
+  z: number
+  constructor(x: number, y: number, z: number) { this.x = x; this.y = y; this.z = z }
+  add(o: Vec3): Vec3 { return new Vec3(this.x + o.x, this.y + o.y, this.z + o.z) }
+  subtract(o: Vec3): Vec3 { return new Vec3(this.x - o.x, this.y - o.y, this.z - o.z) }
+  scale(k: number): Vec3 { return new Vec3(this.x * k, this.y * k, this.z * k) }
+  dot(o: Vec3): number { return this.x * o.x + this.y * o.y + this.z * o.z }
+  cross(o: Vec3): Vec3 {
     const ax = this.x, ay = this.y, az = this.z
     return new Vec3(ay * o.z - az * o.y, az * o.x - ax * o.z, ax * o.y - ay * o.x)
   }
-  length() { return Math.sqrt(this.x * this.x + this.y * this.y + this.z * this.z) }
-  normalize() {
+  length(): number { return Math.sqrt(this.x * this.x + this.y * this.y + this.z * this.z) }
+  normalize(): Vec3 {
     const n = this.length()
     return n === 0 ? new Vec3(0, 0, 0) : new Vec3(this.x / n, this.y / n, this.z / n)
   }
-  clone() { return new Vec3(this.x, this.y, this.z) }
+  clone(): Vec3 { return new Vec3(this.x, this.y, this.z) }
 }
 
 /* ---- quaternion kernels on plain numbers (x, y, z, w order everywhere) ---- */
 
 // Spherical interpolation with the reference's branch structure (math.ts:156-189): shortest arc,
 // normalised lerp above cos 0.9995, classic slerp otherwise. Writes into out[0..3].
-function slerpInto(out, ax, ay, az, aw, bx, by, bz, bw, t) {
+function slerpInto(out: NumArray, ax: number, ay: number, az: number, aw: number, bx: number, by: number, bz: number, bw: number, t: number): NumArray {
   let c = ax * bx + ay * by + az * bz + aw * bw
   if (c < 0) { c = -c; bx = -bx; by = -by; bz = -bz; bw = -bw }
   if (c > 0.9995) {
@@ -59,18 +63,22 @@ function slerpInto(out, ax, ay, az, aw, bx, by, bz, bw, t) {
 }
 
 class Quat {
-  constructor(x, y, z, w) { this.x = x; this.y = y; this.z = z; this.w = w }
-  add(o) { return new Quat(this.x + o.x, this.y + o.y, this.z + o.z, this.w + o.w) }
-  clone() { return new Quat(this.x, this.y, this.z, this.w) }
-  conjugate() { return new Quat(-this.x, -this.y, -this.z, this.w) }
-  length() { return Math.sqrt(this.x * this.x + this.y * this.y + this.z * this.z + this.w * this.w) }
-  normalize() {
+  x: number
+  y: number
+  z: number
+  w: number
+  constructor(x: number, y: number, z: number, w: number) { this.x = x; this.y = y; this.z = z; this.w = w }
+  add(o: Quat): Quat { return new Quat(this.x + o.x, this.y + o.y, this.z + o.z, this.w + o.w) }
+  clone(): Quat { return new Quat(this.x, this.y, this.z, this.w) }
+  conjugate(): Quat { return new Quat(-this.x, -this.y, -this.z, this.w) }
+  length(): number { return Math.sqrt(this.x * this.x + this.y * this.y + this.z * this.z + this.w * this.w) }
+  normalize(): Quat {
     const n = this.length()
     return n === 0 ? new Quat(0, 0, 0, 1) : new Quat(this.x / n, this.y / n, this.z / n, this.w / n)
   }
-  toArray() { return [this.x, this.y, this.z, this.w] }
+  toArray(): Quad { return [this.x, this.y, this.z, this.w] }
   // Hamilton product this * o
-  multiply(o) {
+  multiply(o: Quat): Quat {
     const x = this.x, y = this.y, z = this.z, w = this.w
     return new Quat(
       w * o.x + x * o.w + y * o.z - z * o.y,
@@ -79,18 +87,18 @@ class Quat {
       w * o.w - x * o.x - y * o.y - z * o.z)
   }
   // q v q^-1 via t = 2 q.xyz x v
-  rotateVec(v) {
+  rotateVec(v: Vec3): Vec3 {
     const x = this.x, y = this.y, z = this.z, w = this.w
     const tx = 2 * (y * v.z - z * v.y), ty = 2 * (z * v.x - x * v.z), tz = 2 * (x * v.y - y * v.x)
     return new Vec3(v.x + w * tx + (y * tz - z * ty), v.y + w * ty + (z * tx - x * tz), v.z + w * tz + (x * ty - y * tx))
   }
-  rotate(v) {
+  rotate(v: Vec3): Vec3 {
     const q = new Vec3(this.x, this.y, this.z)
     const uv = q.cross(v)
     return v.add(uv.scale(2 * this.w)).add(q.cross(uv).scale(2))
   }
   // ZXY order, left-handed (PMX); inverse of fromEuler
-  toEuler() {
+  toEuler(): Vec3 {
     const x = this.x, y = this.y, z = this.z, w = this.w
     const rx = Math.atan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y))
     const sp = 2 * (w * y - z * x)
@@ -98,11 +106,11 @@ class Quat {
     const rz = Math.atan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))
     return new Vec3(rx, ry, rz)
   }
-  static slerp(a, b, t) {
+  static slerp(a: Quat, b: Quat, t: number): Quat {
     const o = slerpInto([0, 0, 0, 1], a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, t)
     return new Quat(o[0], o[1], o[2], o[3])
   }
-  static fromEuler(rotX, rotY, rotZ) {
+  static fromEuler(rotX: number, rotY: number, rotZ: number): Quat {
     const cx = Math.cos(rotX * 0.5), sx = Math.sin(rotX * 0.5)
     const cy = Math.cos(rotY * 0.5), sy = Math.sin(rotY * 0.5)
     const cz = Math.cos(rotZ * 0.5), sz = Math.sin(rotZ * 0.5)
@@ -112,7 +120,7 @@ class Quat {
       cy * cx * sz - sy * sx * cz,
       cy * cx * cz + sy * sx * sz).normalize()
   }
-  static fromTo(from, to) {
+  static fromTo(from: Vec3, to: Vec3): Quat {
     const d = from.dot(to)
     if (d > 0.999999) return new Quat(0, 0, 0, 1)
     if (d < -0.999999) {
@@ -130,7 +138,7 @@ class Quat {
 /* ---- 4x4 kernels on Float32Array segments (column-major; doubles in flight, f32 on store) ---- */
 
 // out[oo..] = a[ao..] * b[bo..]; out must not alias a or b.
-function mulInto(out, oo, a, ao, b, bo) {
+function mulInto(out: NumArray, oo: number, a: NumArray, ao: number, b: NumArray, bo: number): void {
   for (let c = 0; c < 16; c += 4) {
     const b0 = b[bo + c], b1 = b[bo + c + 1], b2 = b[bo + c + 2], b3 = b[bo + c + 3]
     out[oo + c] = a[ao] * b0 + a[ao + 4] * b1 + a[ao + 8] * b2 + a[ao + 12] * b3
@@ -141,7 +149,7 @@ function mulInto(out, oo, a, ao, b, bo) {
 }
 
 // rotation matrix of a unit quaternion into out[oo..] (math.ts:352-384 term order)
-function quatToMatInto(out, oo, x, y, z, w) {
+function quatToMatInto(out: NumArray, oo: number, x: number, y: number, z: number, w: number): void {
   const x2 = x + x, y2 = y + y, z2 = z + z
   const xx = x * x2, xy = x * y2, xz = x * z2, yy = y * y2, yz = y * z2, zz = z * z2
   const wx = w * x2, wy = w * y2, wz = w * z2
@@ -151,29 +159,30 @@ function quatToMatInto(out, oo, x, y, z, w) {
   out[oo + 12] = 0; out[oo + 13] = 0; out[oo + 14] = 0; out[oo + 15] = 1
 }
 
-function identityInto(out, oo) {
+function identityInto(out: NumArray, oo: number): void {
   out.fill(0, oo, oo + 16)
   out[oo] = 1; out[oo + 5] = 1; out[oo + 10] = 1; out[oo + 15] = 1
 }
 
 class Mat4 {
-  constructor(values) { this.values = values }
-  static identity() { const v = new Float32Array(16); identityInto(v, 0); return new Mat4(v) }
-  static fromQuat(x, y, z, w) { const v = new Float32Array(16); quatToMatInto(v, 0, x, y, z, w); return new Mat4(v) }
-  static fromPositionRotation(position, rotation) {
+  values: Float32Array
+  constructor(values: Float32Array) { this.values = values }
+  static identity(): Mat4 { const v = new Float32Array(16); identityInto(v, 0); return new Mat4(v) }
+  static fromQuat(x: number, y: number, z: number, w: number): Mat4 { const v = new Float32Array(16); quatToMatInto(v, 0, x, y, z, w); return new Mat4(v) }
+  static fromPositionRotation(position: Vec3, rotation: Quat): Mat4 {
     const m = Mat4.fromQuat(rotation.x, rotation.y, rotation.z, rotation.w)
     m.values[12] = position.x; m.values[13] = position.y; m.values[14] = position.z
     return m
   }
-  static multiplyArrays(a, aOffset, b, bOffset, out, outOffset) { mulInto(out, outOffset, a, aOffset, b, bOffset) }
+  static multiplyArrays(a: Float32Array, aOffset: number, b: Float32Array, bOffset: number, out: Float32Array, outOffset: number): void { mulInto(out, outOffset, a, aOffset, b, bOffset) }
   // left-handed (Z+ forward) projection, depth 0..1
-  static perspective(fov, aspect, near, far) {
+  static perspective(fov: number, aspect: number, near: number, far: number): Mat4 {
     const f = 1.0 / Math.tan(fov / 2), ri = 1.0 / (far - near)
     const v = new Float32Array(16)
     v[0] = f / aspect; v[5] = f; v[10] = (far + near) * ri; v[11] = 1; v[14] = -near * far * ri * 2
     return new Mat4(v)
   }
-  static lookAt(eye, target, up) {
+  static lookAt(eye: Vec3, target: Vec3, up: Vec3): Mat4 {
     const fwd = target.subtract(eye).normalize()
     const right = up.cross(fwd).normalize()
     const u = fwd.cross(right).normalize()
@@ -181,7 +190,7 @@ class Mat4 {
       right.x, u.x, fwd.x, 0, right.y, u.y, fwd.y, 0, right.z, u.z, fwd.z, 0,
       -right.dot(eye), -u.dot(eye), -fwd.dot(eye), 1]))
   }
-  static toQuatFromArray(m, offset) {
+  static toQuatFromArray(m: Float32Array, offset: number): Quat {
     const m00 = m[offset], m01 = m[offset + 4], m02 = m[offset + 8]
     const m10 = m[offset + 1], m11 = m[offset + 5], m12 = m[offset + 9]
     const m20 = m[offset + 2], m21 = m[offset + 6], m22 = m[offset + 10]
@@ -203,14 +212,14 @@ class Mat4 {
     const k = 1 / Math.hypot(x, y, z, w)
     return new Quat(x * k, y * k, z * k, w * k)
   }
-  multiply(other) { const v = new Float32Array(16); mulInto(v, 0, this.values, 0, other.values, 0); return new Mat4(v) }
-  clone() { return new Mat4(this.values.slice()) }
-  getPosition() { return new Vec3(this.values[12], this.values[13], this.values[14]) }
-  toQuat() { return Mat4.toQuatFromArray(this.values, 0) }
-  setIdentity() { identityInto(this.values, 0); return this }
-  translateInPlace(tx, ty, tz) { this.values[12] += tx; this.values[13] += ty; this.values[14] += tz; return this }
+  multiply(other: Mat4): Mat4 { const v = new Float32Array(16); mulInto(v, 0, this.values, 0, other.values, 0); return new Mat4(v) }
+  clone(): Mat4 { return new Mat4(this.values.slice()) }
+  getPosition(): Vec3 { return new Vec3(this.values[12], this.values[13], this.values[14]) }
+  toQuat(): Quat { return Mat4.toQuatFromArray(this.values, 0) }
+  setIdentity(): this { identityInto(this.values, 0); return this }
+  translateInPlace(tx: number, ty: number, tz: number): this { this.values[12] += tx; this.values[13] += ty; this.values[14] += tz; return this }
   // general inverse by cofactors of 2x2 sub-determinants; singular (|det| < 1e-10) -> identity + warning
-  inverse() {
+  inverse(): Mat4 {
     const m = this.values
     const a00 = m[0], a01 = m[1], a02 = m[2], a03 = m[3], a10 = m[4], a11 = m[5], a12 = m[6], a13 = m[7]
     const a20 = m[8], a21 = m[9], a22 = m[10], a23 = m[11], a30 = m[12], a31 = m[13], a32 = m[14], a33 = m[15]
@@ -247,4 +256,4 @@ class Mat4 {
 
 const kernels = { slerpInto, mulInto, quatToMatInto, identityInto }
 
-module.exports = { easeInOut, Vec3, Quat, Mat4, kernels }
+export { easeInOut, Vec3, Quat, Mat4, kernels }

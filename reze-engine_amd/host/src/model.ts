@@ -15,12 +15,14 @@
  * performance.now(), model.ts:160,249 — not reproducible frame for frame) and vertex-morph state
  * (names, sparse targets, weights, group-morph flattening) feeding the fused GPU kernel.
  */
-const { Quat, easeInOut, kernels } = require('./math')
+import { Quat, easeInOut, kernels } from './math'
+import type { Bone, Material, MorphSet, NumArray, PosedLocals, RotTweenState, Skeleton, SkeletonRuntime, Skinning, Texture } from './types'
+import type { VMDSampler } from './vmd-sampler'
 const { slerpInto, mulInto, quatToMatInto, identityInto } = kernels
 
 const VERTEX_STRIDE = 8 // floats per vertex: x y z nx ny nz u v  (model.ts:4, :196-200)
 
-let defaultClock
+let defaultClock: () => number
 try {
   const { performance } = require('perf_hooks')
   defaultClock = () => performance.now()
@@ -29,6 +31,35 @@ try {
 }
 
 class Model {
+  vertexData: Float32Array
+  vertexCount: number
+  indexData: Uint32Array
+  textures: Texture[]
+  materials: Material[]
+  skeleton: Skeleton
+  skinning: Skinning
+  rigidbodies: unknown[]
+  joints: unknown[]
+  clock: () => number
+  runtimeSkeleton: SkeletonRuntime
+  rotTweenState: RotTweenState
+  solveOrder: number[]
+  _rot: Float32Array
+  _app: Float32Array
+  _tmpA: Float32Array
+  _tmpB: Float32Array
+  _tr: Float32Array
+  _q: number[]
+  applyLocalTranslations: boolean
+  morphs: MorphSet | null
+  morphWeights: Float32Array
+  effectiveMorphWeights: Float32Array
+  morphNameIndex: Record<string, number>
+  hasBoneMorphs: boolean
+  poseRotations: Float32Array
+  poseTranslations: Float32Array
+  _uv?: Float32Array
+  _uvWeights?: Float32Array
   /**
    * @param {Float32Array} vertexData interleaved 8 floats / vertex
    * @param {Uint32Array} indexData
@@ -41,7 +72,7 @@ class Model {
    * @param {object|null} [morphs] { names, types, offsets:Uint32Array(M+1), vertexIndex:Uint32Array,
    *                                 deltas:Float32Array(E*3), groups: Array<Array<[child, ratio]>|null> }
    */
-  constructor(vertexData, indexData, textures, materials, skeleton, skinning, rigidbodies, joints, morphs) {
+  constructor(vertexData: Float32Array, indexData: Uint32Array, textures: Texture[], materials: Material[], skeleton: Skeleton, skinning: Skinning, rigidbodies?: unknown[], joints?: unknown[], morphs?: MorphSet | null) {
     if (!skeleton || !skeleton.bones || skeleton.bones.length === 0) throw new Error('Model has no bones')
     this.vertexData = vertexData
     this.vertexCount = vertexData.length / VERTEX_STRIDE
@@ -99,7 +130,7 @@ class Model {
     this.poseTranslations = new Float32Array(this.hasBoneMorphs ? n * 3 : 0)
   }
 
-  static parentFirstOrder(bones) {
+  static parentFirstOrder(bones: Bone[]): number[] {
     const n = bones.length
     const state = new Uint8Array(n)
     const order = []
@@ -114,24 +145,24 @@ class Model {
   }
 
   /** Replace performance.now() (deterministic tests / offline stepping). */
-  setClock(fn) { this.clock = fn || defaultClock }
+  setClock(fn: (() => number) | null): void { this.clock = fn || defaultClock }
 
   // ---- static data getters (model.ts:196-238) ----
-  getVertices() { return this.vertexData }
-  getTextures() { return this.textures }
-  getMaterials() { return this.materials }
-  getVertexCount() { return this.vertexCount }
-  getIndices() { return this.indexData }
-  getSkeleton() { return this.skeleton }
-  getSkinning() { return this.skinning }
-  getRigidbodies() { return this.rigidbodies }
-  getJoints() { return this.joints }
-  getBoneNames() { return this.skeleton.bones.map((b) => b.name) }
-  getBoneWorldMatrices() { return this.runtimeSkeleton.worldMatrices }
-  getBoneInverseBindMatrices() { return this.skeleton.inverseBindMatrices }
+  getVertices(): Float32Array { return this.vertexData }
+  getTextures(): Texture[] { return this.textures }
+  getMaterials(): Material[] { return this.materials }
+  getVertexCount(): number { return this.vertexCount }
+  getIndices(): Uint32Array { return this.indexData }
+  getSkeleton(): Skeleton { return this.skeleton }
+  getSkinning(): Skinning { return this.skinning }
+  getRigidbodies(): unknown[] { return this.rigidbodies }
+  getJoints(): unknown[] { return this.joints }
+  getBoneNames(): string[] { return this.skeleton.bones.map((b) => b.name) }
+  getBoneWorldMatrices(): Float32Array { return this.runtimeSkeleton.worldMatrices }
+  getBoneInverseBindMatrices(): Float32Array { return this.skeleton.inverseBindMatrices }
 
   // ---- pose API ----
-  _tweenValue(idx, now, out) {
+  _tweenValue(idx: number, now: number, out: NumArray): number {
     const st = this.rotTweenState
     const qi = idx * 4
     const dur = Math.max(1, st.durationMs[idx])
@@ -142,7 +173,7 @@ class Model {
   }
 
   /** model.ts:246-315 — immediate set (durationMs 0/undefined) or arm a quadratic-ease slerp tween. */
-  rotateBones(names, quats, durationMs) {
+  rotateBones(names: string[], quats: Quat[], durationMs?: number): void {
     const st = this.rotTweenState
     const rot = this.runtimeSkeleton.localRotations
     const nameIndex = this.runtimeSkeleton.nameIndex
@@ -175,7 +206,7 @@ class Model {
   }
 
   /** model.ts:158-194 */
-  updateRotationTweens() {
+  updateRotationTweens(): void {
     const st = this.rotTweenState
     const rot = this.runtimeSkeleton.localRotations
     const now = this.clock()
@@ -190,7 +221,7 @@ class Model {
   }
 
   /** model.ts:325-328 */
-  evaluatePose() {
+  evaluatePose(): void {
     this.updateRotationTweens()
     this.computeWorldMatrices()
   }
@@ -203,7 +234,7 @@ class Model {
    * Quat.slerp(identity, rotation, w) (math.ts:156-189, :77-85); entries fold in ascending morph order; the runtime arrays
    * (tween / animation state) are left untouched. GPU twin: fk_solve's bone-morph pass (csrc/deform_kernels.hip).
    */
-  posedLocals() {
+  posedLocals(): PosedLocals {
     const rs = this.runtimeSkeleton
     const raw = { rot: rs.localRotations, tra: rs.localTranslations, moved: false }
     if (!this.hasBoneMorphs) return raw
@@ -236,7 +267,7 @@ class Model {
    * |ratio|)) * R when appendRotate && valid parent && |clamp(ratio,-1,1)| > 1e-6; append-move only
    * inside that branch; L = T(bind) * R * T(add); W = W_parent * L.
    */
-  computeWorldMatrices() {
+  computeWorldMatrices(): void {
     const bones = this.skeleton.bones
     const n = bones.length
     const { rot, tra, moved } = this.posedLocals()
@@ -291,7 +322,7 @@ class Model {
   }
 
   /** Pose every bone the sampler keys at `frame` (rotation + translation), and every morph it keys. Un-keyed bones keep their state. */
-  applySampledFrame(sampler, frame) {
+  applySampledFrame(sampler: VMDSampler, frame: number): void {
     const rot = this.runtimeSkeleton.localRotations, tra = this.runtimeSkeleton.localTranslations
     this.applyLocalTranslations = true
     for (const name of sampler.boneNames()) {
@@ -309,12 +340,12 @@ class Model {
   }
 
   // ---- morphs (no reference counterpart; PMX layout per pmx-loader.ts:471-488) ----
-  getMorphNames() { return this.morphs ? this.morphs.names.slice() : [] }
-  getMorphCount() { return this.morphs ? this.morphs.names.length : 0 }
-  getMorphs() { return this.morphs }
+  getMorphNames(): string[] { return this.morphs ? this.morphs.names.slice() : [] }
+  getMorphCount(): number { return this.morphs ? this.morphs.names.length : 0 }
+  getMorphs(): MorphSet | null { return this.morphs }
 
   /** names or indices + weights; unknown names are ignored like unknown bones in rotateBones. */
-  setMorphWeights(namesOrIndices, weights) {
+  setMorphWeights(namesOrIndices: Array<string | number>, weights: ArrayLike<number>): void {
     if (!this.morphs) return
     for (let i = 0; i < namesOrIndices.length; i++) {
       const key = namesOrIndices[i]
@@ -324,17 +355,17 @@ class Model {
     }
   }
 
-  getMorphWeights() { return this.morphWeights }
+  getMorphWeights(): Float32Array { return this.morphWeights }
 
   /**
    * Weights the deformation consumes: vertex morphs (type 1) and bone morphs (type 2) keep their own weight plus, for
    * every group morph (type 0) that lists them, w_group * ratio (pmx-loader.ts:479-482). Other morph types
    * (UV / material / flip / impulse) touch neither positions nor bones and contribute nothing.
    */
-  getEffectiveMorphWeights() { return this._flattenGroups(this.effectiveMorphWeights, 1, 2) }
+  getEffectiveMorphWeights(): Float32Array { return this._flattenGroups(this.effectiveMorphWeights, 1, 2) }
 
   // own weight of the morphs whose type lies in [lo, hi], plus what group morphs feed them
-  _flattenGroups(out, lo, hi) {
+  _flattenGroups(out: Float32Array, lo: number, hi: number): Float32Array {
     if (!this.morphs) return out
     const { types, groups } = this.morphs
     const w = this.morphWeights
@@ -354,7 +385,7 @@ class Model {
    * renderer binds them from the static vertex buffer — so this is a sparse host-side update of a V x 2 array, not GPU
    * work. The reference has no counterpart (its loader skips the section, pmx-loader.ts:498-507).
    */
-  getMorphedUVs() {
+  getMorphedUVs(): Float32Array {
     const V = this.vertexCount
     if (!this._uv) this._uv = new Float32Array(V * 2)
     const uv = this._uv, vd = this.vertexData
@@ -373,4 +404,4 @@ class Model {
   }
 }
 
-module.exports = { Model, VERTEX_STRIDE }
+export { Model, VERTEX_STRIDE }

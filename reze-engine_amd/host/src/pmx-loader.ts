@@ -17,39 +17,50 @@
  * `loadFromBuffer` entry for tests. Rigid bodies / joints are parsed for API completeness but the
  * physics that consumes them is out of scope here.
  */
-const fs = require('fs')
-const { TextDecoder } = require('util')
-const { Model } = require('./model')
-const { Mat4, Vec3 } = require('./math')
+import * as fs from 'fs'
+import { TextDecoder } from 'util'
+import { Model } from './model'
+import { Mat4, Vec3 } from './math'
 
+import type { Bone, Material, MorphSet, Texture, Triple } from './types'
+interface PmxHeader { version: number; encoding: number; extraVec4: number; vertexIndexSize: number; textureIndexSize: number; materialIndexSize: number; boneIndexSize: number; morphIndexSize: number; rigidBodyIndexSize: number }
+interface Geometry { count: number; vertexData: Float32Array; joints: Uint16Array; weights: Uint8Array }
 class Cursor {
-  constructor(arrayBuffer, byteOffset, byteLength) {
+  view: DataView
+  bytes: Uint8Array
+  pos: number
+  end: number
+  constructor(arrayBuffer: ArrayBuffer, byteOffset: number, byteLength: number) {
     this.view = new DataView(arrayBuffer, byteOffset || 0, byteLength)
     this.bytes = new Uint8Array(arrayBuffer, byteOffset || 0, byteLength)
     this.pos = 0
     this.end = this.view.byteLength
   }
-  need(n) {
+  need(n: number): void {
     if (this.pos + n > this.end) throw new RangeError('Offset ' + this.pos + ' + ' + n + ' exceeds buffer bounds ' + this.end)
   }
-  u8() { this.need(1); return this.view.getUint8(this.pos++) }
-  i8() { this.need(1); return this.view.getInt8(this.pos++) }
-  u16() { this.need(2); const v = this.view.getUint16(this.pos, true); this.pos += 2; return v }
-  i16() { this.need(2); const v = this.view.getInt16(this.pos, true); this.pos += 2; return v }
-  i32() { this.need(4); const v = this.view.getInt32(this.pos, true); this.pos += 4; return v }
-  f32() { this.need(4); const v = this.view.getFloat32(this.pos, true); this.pos += 4; return v }
-  skip(n) { this.need(n); this.pos += n }
+  u8(): number { this.need(1); return this.view.getUint8(this.pos++) }
+  i8(): number { this.need(1); return this.view.getInt8(this.pos++) }
+  u16(): number { this.need(2); const v = this.view.getUint16(this.pos, true); this.pos += 2; return v }
+  i16(): number { this.need(2); const v = this.view.getInt16(this.pos, true); this.pos += 2; return v }
+  i32(): number { this.need(4); const v = this.view.getInt32(this.pos, true); this.pos += 4; return v }
+  f32(): number { this.need(4); const v = this.view.getFloat32(this.pos, true); this.pos += 4; return v }
+  skip(n: number): void { this.need(n); this.pos += n }
   // vertex index: 1 -> uint8, 2 -> uint16, 4 -> int32   (pmx-loader.ts:981-990)
-  vertexIndex(size) { return size === 1 ? this.u8() : size === 2 ? this.u16() : this.i32() }
+  vertexIndex(size: number): number { return size === 1 ? this.u8() : size === 2 ? this.u16() : this.i32() }
   // every other index is signed: 1 -> int8, 2 -> int16, 4 -> int32   (:992-1005)
-  index(size) { return size === 1 ? this.i8() : size === 2 ? this.i16() : this.i32() }
-  vec3() { return [this.f32(), this.f32(), this.f32()] }
+  index(size: number): number { return size === 1 ? this.i8() : size === 2 ? this.i16() : this.i32() }
+  vec3(): Triple { return [this.f32(), this.f32(), this.f32()] }
 }
 
-function clamp(v, lo, hi) { return Math.max(lo, Math.min(hi, v)) }
+function clamp(v: number, lo: number, hi: number): number { return Math.max(lo, Math.min(hi, v)) }
 
 class PmxLoader {
-  constructor(buffer) {
+  cur: Cursor
+  h: PmxHeader | null
+  decoder: TextDecoder
+  modelName: string
+  constructor(buffer: ArrayBuffer | Uint8Array) {
     // accept ArrayBuffer or Node Buffer / typed array views
     if (buffer instanceof ArrayBuffer) this.cur = new Cursor(buffer, 0, buffer.byteLength)
     else this.cur = new Cursor(buffer.buffer, buffer.byteOffset, buffer.byteLength)
@@ -57,10 +68,10 @@ class PmxLoader {
   }
 
   /** Reference signature: PmxLoader.load(url) -> Promise<Model> (pmx-loader.ts:30-33). */
-  static async load(path) { return PmxLoader.loadFromBuffer(fs.readFileSync(path)) }
-  static loadFromBuffer(buffer) { return new PmxLoader(buffer).parse() }
+  static async load(path: string): Promise<Model> { return PmxLoader.loadFromBuffer(fs.readFileSync(path)) }
+  static loadFromBuffer(buffer: ArrayBuffer | Uint8Array): Model { return new PmxLoader(buffer).parse() }
 
-  text() {
+  text(): string {
     const c = this.cur
     const len = c.i32()
     if (len <= 0) return ''
@@ -71,7 +82,7 @@ class PmxLoader {
     return s
   }
 
-  parse() {
+  parse(): Model {
     this.header()
     const geo = this.vertices()
     const indices = this.indices()
@@ -87,11 +98,11 @@ class PmxLoader {
     return this.toModel(geo, indices, textures, materials, bones, morphs, rigidbodies, joints)
   }
 
-  guard(what, fn, fallback) {
+  guard<T>(what: string, fn: () => T, fallback: T): T {
     try { return fn() } catch (e) { console.warn('Error parsing ' + what + ':', e.message); return fallback }
   }
 
-  header() {
+  header(): void {
     const c = this.cur
     const sig = String.fromCharCode(c.u8(), c.u8(), c.u8())
     if (sig !== 'PMX') throw new Error('Not a PMX file')
@@ -111,7 +122,7 @@ class PmxLoader {
     this.text(); this.text(); this.text()
   }
 
-  vertices() {
+  vertices(): Geometry {
     const c = this.cur, h = this.h
     const count = c.i32()
     const pos = new Float32Array(count * 3), nrm = new Float32Array(count * 3), uv = new Float32Array(count * 2)
@@ -151,7 +162,7 @@ class PmxLoader {
     return { count, pos, nrm, uv, joints, weights }
   }
 
-  indices() {
+  indices(): Uint32Array {
     const c = this.cur
     const n = c.i32()
     const out = new Uint32Array(n)
@@ -159,14 +170,14 @@ class PmxLoader {
     return out
   }
 
-  textures() {
+  textures(): Texture[] {
     const n = this.cur.i32()
     const out = []
     for (let i = 0; i < n; i++) { const p = this.text(); out.push({ path: p, name: p.split('/').pop() || p }) }
     return out
   }
 
-  materials() {
+  materials(): Material[] {
     const c = this.cur, h = this.h
     const n = c.i32()
     const out = []
@@ -201,7 +212,7 @@ class PmxLoader {
     return out
   }
 
-  bones() {
+  bones(): Bone[] {
     const c = this.cur, bs = this.h.boneIndexSize
     const n = c.i32()
     const raw = new Array(n)
@@ -239,7 +250,7 @@ class PmxLoader {
   }
 
   // Morph section. Layout as documented by the reference's skipMorphs() (pmx-loader.ts:462-541).
-  morphs(vertexCount, boneCount) {
+  morphs(vertexCount: number, boneCount: number): MorphSet {
     const c = this.cur, h = this.h
     const n = c.i32()
     if (n < 0 || n > 100000) throw new RangeError('Suspicious morph count: ' + n)
@@ -302,7 +313,7 @@ class PmxLoader {
     return { names, types, panels, groups, offsets, vertexIndex: Uint32Array.from(vidx), deltas: Float32Array.from(dxyz), boneEntries, uvEntries }
   }
 
-  displayFrames() {
+  displayFrames(): boolean {
     const c = this.cur, h = this.h
     const n = c.i32()
     if (n < 0 || n > 100000) throw new RangeError('Suspicious display frame count: ' + n)
@@ -314,7 +325,7 @@ class PmxLoader {
     return true
   }
 
-  rigidbodies() {
+  rigidbodies(): unknown[] {
     const c = this.cur
     const n = c.i32()
     if (n < 0 || n > 10000) throw new RangeError('Suspicious rigidbody count: ' + n)
@@ -335,7 +346,7 @@ class PmxLoader {
     return out
   }
 
-  joints() {
+  joints(): unknown[] {
     const c = this.cur, rs = this.h.rigidBodyIndexSize
     const n = c.i32()
     if (n < 0 || n > 10000) throw new RangeError('Suspicious joint count: ' + n)
@@ -354,7 +365,7 @@ class PmxLoader {
   }
 
   // translation-only inverse bind: IB = T(-sum of parent-relative offsets)   (pmx-loader.ts:791-824)
-  static inverseBind(bones) {
+  static inverseBind(bones: Bone[]): Float32Array {
     const n = bones.length
     const world = new Float32Array(n * 3)
     const done = new Uint8Array(n)
@@ -384,7 +395,7 @@ class PmxLoader {
   }
 
   // Joints outside the skeleton lose their weight; the rest is rescaled to exactly 255 (pmx-loader.ts:855-951).
-  static sanitizeSkinning(joints, weights, boneCount) {
+  static sanitizeSkinning(joints: Uint16Array, weights: Uint8Array, boneCount: number): void {
     const ok = (j) => j >= 0 && j < boneCount
     for (let o = 0; o < joints.length; o += 4) {
       let sum = 0, valid = 0
@@ -410,7 +421,7 @@ class PmxLoader {
     }
   }
 
-  toModel(geo, indices, textures, materials, bones, morphs, rigidbodies, joints) {
+  toModel(geo: Geometry, indices: Uint32Array, textures: Texture[], materials: Material[], bones: Bone[], morphs: MorphSet | null, rigidbodies: unknown[], joints: unknown[]): Model {
     const n = geo.count
     const vertexData = new Float32Array(n * 8)
     for (let v = 0; v < n; v++) {
@@ -426,4 +437,4 @@ class PmxLoader {
   }
 }
 
-module.exports = { PmxLoader }
+export { PmxLoader }

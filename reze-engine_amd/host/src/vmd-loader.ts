@@ -14,18 +14,23 @@
  * name + u32 frame + f32 weight) is returned as `result.morphFrames` — the source of the morph
  * weights the fused kernel consumes (SURVEY §8f rank 2).
  */
-const fs = require('fs')
-const { TextDecoder } = require('util')
-const { Quat, Vec3 } = require('./math')
+import * as fs from 'fs'
+import { TextDecoder } from 'util'
+import { Quat, Vec3 } from './math'
 
+import type { VMDKeyFrames } from './types'
 const FRAME_RATE = 30.0
 
-function makeDecoder() {
+function makeDecoder(): TextDecoder {
   try { return new TextDecoder('shift-jis') } catch (e) { return new TextDecoder('utf-8') }
 }
 
 class VMDLoader {
-  constructor(buffer) {
+  view: DataView
+  bytes: Uint8Array
+  pos: number
+  decoder: TextDecoder
+  constructor(buffer: ArrayBuffer | Uint8Array) {
     if (buffer instanceof ArrayBuffer) { this.view = new DataView(buffer); this.bytes = new Uint8Array(buffer) }
     else {
       this.view = new DataView(buffer.buffer, buffer.byteOffset, buffer.byteLength)
@@ -35,17 +40,17 @@ class VMDLoader {
     this.decoder = makeDecoder()
   }
 
-  static async load(path) { return VMDLoader.loadFromBuffer(fs.readFileSync(path)) }
-  static loadFromBuffer(buffer) { return new VMDLoader(buffer).parse() }
+  static async load(path: string): Promise<VMDKeyFrames> { return VMDLoader.loadFromBuffer(fs.readFileSync(path)) }
+  static loadFromBuffer(buffer: ArrayBuffer | Uint8Array): VMDKeyFrames { return new VMDLoader(buffer).parse() }
 
-  need(n) {
+  need(n: number): void {
     if (this.pos + n > this.view.byteLength) throw new RangeError('Offset ' + this.pos + ' + ' + n + ' exceeds buffer bounds ' + this.view.byteLength)
   }
-  u32() { this.need(4); const v = this.view.getUint32(this.pos, true); this.pos += 4; return v }
-  f32() { this.need(4); const v = this.view.getFloat32(this.pos, true); this.pos += 4; return v }
+  u32(): number { this.need(4); const v = this.view.getUint32(this.pos, true); this.pos += 4; return v }
+  f32(): number { this.need(4); const v = this.view.getFloat32(this.pos, true); this.pos += 4; return v }
 
   // fixed 15-byte, NUL-terminated Shift-JIS name
-  name15() {
+  name15(): string {
     this.need(15)
     let n = 0
     while (n < 15 && this.bytes[this.pos + n] !== 0) n++
@@ -54,7 +59,7 @@ class VMDLoader {
     try { return this.decoder.decode(raw) } catch (e) { return String.fromCharCode.apply(null, raw) }
   }
 
-  parse() {
+  parse(): VMDKeyFrames {
     this.need(30)
     const magic = String.fromCharCode.apply(null, this.bytes.subarray(0, 30))
     if (magic.indexOf('Vocaloid Motion Data') !== 0) throw new Error('Invalid VMD file header')
@@ -104,4 +109,4 @@ class VMDLoader {
   }
 }
 
-module.exports = { VMDLoader, FRAME_RATE }
+export { VMDLoader, FRAME_RATE }

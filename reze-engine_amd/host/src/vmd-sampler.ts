@@ -12,10 +12,11 @@
  *   [X_x1, Y_x1, Z_x1, R_x1,  X_y1, Y_y1, Z_y1, R_y1,  X_x2, Y_x2, Z_x2, R_x2,  X_y2, Y_y2, Z_y2, R_y2]
  * i.e. curve c in {X,Y,Z,R} = cubic Bezier through (0,0), (x1,y1), (x2,y2), (1,1), stored on the LATER key.
  */
-const { kernels } = require('./math')
+import { kernels } from './math'
 
 // y(x) of the cubic Bezier (0,0) (x1,y1) (x2,y2) (1,1): solve x(t) = x by bisection-refined Newton, return y(t)
-function bezier(x, x1, y1, x2, y2) {
+import type { BoneFrame, BoneSample, FlatMotion, MorphFrame, MorphSet, Triple, VMDKeyFrames } from './types'
+function bezier(x: number, x1: number, y1: number, x2: number, y2: number): number {
   if (x <= 0) return 0
   if (x >= 1) return 1
   if (x1 === y1 && x2 === y2) return x // the default 20,20,107,107 curve is the identity
@@ -34,8 +35,12 @@ function bezier(x, x1, y1, x2, y2) {
 }
 
 class VMDSampler {
+  bones: Map<string, BoneFrame[]>
+  morphs: Map<string, MorphFrame[]>
+  lastFrame: number
+  _q: number[]
   /** @param keyFrames result of VMDLoader.load / loadFromBuffer (array + .morphFrames) */
-  constructor(keyFrames) {
+  constructor(keyFrames: VMDKeyFrames) {
     this.bones = new Map() // name -> keys sorted by frame
     for (const kf of keyFrames) {
       for (const b of kf.boneFrames) {
@@ -56,7 +61,7 @@ class VMDSampler {
     this._q = [0, 0, 0, 1]
   }
 
-  static span(keys, frame) { // index i with keys[i].frame <= frame < keys[i+1].frame (clamped)
+  static span(keys: Array<{ frame: number }>, frame: number): Triple { // index i with keys[i].frame <= frame < keys[i+1].frame (clamped)
     let lo = 0, hi = keys.length - 1
     if (frame <= keys[0].frame) return [0, 0, 0]
     if (frame >= keys[hi].frame) return [hi, hi, 0]
@@ -65,7 +70,7 @@ class VMDSampler {
   }
 
   /** -> { rotation: [x,y,z,w], position: [x,y,z] } of one bone at `frame`, or null when the motion does not key it */
-  sampleBone(name, frame) {
+  sampleBone(name: string, frame: number): BoneSample | null {
     const keys = this.bones.get(name)
     if (!keys) return null
     const [i0, i1, x] = VMDSampler.span(keys, frame)
@@ -83,7 +88,7 @@ class VMDSampler {
     }
   }
 
-  sampleMorph(name, frame) {
+  sampleMorph(name: string, frame: number): number | null {
     const keys = this.morphs.get(name)
     if (!keys) return null
     const [i0, i1, x] = VMDSampler.span(keys, frame)
@@ -96,7 +101,7 @@ class VMDSampler {
    * Model.getEffectiveMorphWeights adds them — its own track (vertex morphs only), then the group morphs that list it,
    * ascending. `morphs` is Model.getMorphs() ({ names, types, groups }) or null.
    */
-  flatten(boneNameIndex, morphs) {
+  flatten(boneNameIndex: Record<string, number>, morphs: Pick<MorphSet, 'names' | 'types' | 'groups'> | null): FlatMotion {
     const tracks = []
     for (const [name, keys] of this.bones) {
       const b = boneNameIndex[name]
@@ -154,8 +159,8 @@ class VMDSampler {
     return out
   }
 
-  boneNames() { return Array.from(this.bones.keys()) }
-  morphNames() { return Array.from(this.morphs.keys()) }
+  boneNames(): string[] { return Array.from(this.bones.keys()) }
+  morphNames(): string[] { return Array.from(this.morphs.keys()) }
 }
 
-module.exports = { VMDSampler, bezier }
+export { VMDSampler, bezier }
