@@ -446,10 +446,14 @@ def main():
     # What is timed, and by which clock (round 6). The K steps sit between barrier + synchronize on both sides, as the contract says. Inside
     # that bracket they are timed TWICE: by a hipEvent pair on the stream the frames run on (rz_time_span; SURVEY 8d prescribes event pairs
     # around the back-to-back frames) and by the host's clock around the same call + synchronize. The host clock carries a fixed cost per
-    # timed region — the first launch, the wake-up from the final wait: ~20 us (profiles/r6_bench_shard8_steps20.json) — which is nothing
-    # in 500 steps of C5 and 6 % of the driver's 20 steps of a 16.6 us shard frame. `ms_per_step` / `value` are the event span; the host
-    # wall of the same K steps is reported beside it (config.ms_per_step_host_wall, config.host_fixed_cost_us_per_timed_region). Both are
-    # MAX over ranks.
+    # timed region — the first launch, the wake-up from the final wait: ~30 us (profiles/r6_bench_shard8_steps20.json) — which is nothing
+    # in 500 steps of C5 and 9 % of the driver's 20 steps of a 16.6 us shard frame. `ms_per_step` / `value` are the event span; the host
+    # wall is reported beside it (config.ms_per_step_host_wall, config.host_fixed_cost_us_per_timed_region). Both are MAX over ranks.
+    # LEAD untimed frames sit in front of the opening event in the same call (rz_time_span): the K timed steps are enqueued while the GPU
+    # is busy with them and run back to back from the first one, as in a render loop — without them the first timed step waits ~5 us
+    # behind the event for its own launch. The host wall covers LEAD + K frames and is divided by LEAD + K.
+    LEAD = 2
+
     def timed(span_call, sync_all):
         barrier()
         t0 = time.perf_counter()
@@ -479,19 +483,19 @@ def main():
             in_flight = 2
         elif args.frames_in_flight == "auto":
             nc = 200                    # (not a function of --steps: the driver's 20 steps must not decide the mode from 20 frames)
-            t1 = min(timed(lambda: ctx.time_span(nc), ctx.sync)[0] for _ in range(3)) / nc * 1e3
-            t2 = min(timed(lambda: ctx.time_span(nc, fork), sync_pair)[0] for _ in range(3)) / nc * 1e3
+            t1 = min(timed(lambda: ctx.time_span(nc, lead=LEAD), ctx.sync)[0] for _ in range(3)) / nc * 1e3
+            t2 = min(timed(lambda: ctx.time_span(nc, fork, lead=LEAD), sync_pair)[0] for _ in range(3)) / nc * 1e3
             in_flight = 2 if t2 < 0.97 * t1 else 1
             calib = {"frames": nc, "one_stream_ms": t1, "two_in_flight_ms": t2, "rule": "two in flight when >= 3 % faster (max over ranks, best of 3)"}
 
     def one_stream():
         ctx.deform_n(args.warmup)
-        return timed(lambda: ctx.time_span(args.steps), ctx.sync)
+        return timed(lambda: ctx.time_span(args.steps, lead=LEAD), ctx.sync)
 
     def paired():
         ctx.deform_pair(fork, args.warmup)
         sync_pair()
-        return timed(lambda: ctx.time_span(args.steps, fork), sync_pair)
+        return timed(lambda: ctx.time_span(args.steps, fork, lead=LEAD), sync_pair)
 
     def kernel_timing():
         """roofline of the dominant kernel: HIP events on the context's own stream, one kernel at a time (200 frames whatever --steps is)"""
@@ -778,8 +782,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
-            "timed_by": "hipEvent pair on the frames' stream around exactly K steps (rz_time_span), inside barrier + synchronize on both sides, MAX over ranks; "
-                        "the host clock around the same K steps: config.ms_per_step_host_wall",
+            "timed_by": "hipEvent pair on the frames' stream around exactly K steps (rz_time_span), %d untimed lead-in frames in front of the opening event, all inside "
+                        "barrier + synchronize on both sides, MAX over ranks; the host clock around the same region (lead-in + K frames, divided by their count): "
+                        "config.ms_per_step_host_wall" % LEAD,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -814,10 +819,11 @@ def main():
                 "frames_in_flight_calibrated": in_flight,
                 "frames_in_flight_rule": "value / ms_per_step are the one-stream loop unless two frames in flight were calibrated faster (>= 3 %), their K timed steps were faster than the one-stream loop's too, AND their step is not shorter than the event-timed kernel (a step never undercuts its own kernel: such an overlap is reported in ms_per_step_two_frames_in_flight only)",
                 "frames_in_flight_choice": ("--frames-in-flight " + args.frames_in_flight) if calib is None else calib,
-                "ms_per_step_host_wall": elapsed_wall * 1e3 / args.steps,
-                "value_host_wall": verts / elapsed_wall,
-                "host_fixed_cost_us_per_timed_region": (elapsed_wall - elapsed) * 1e6,
-                "ms_per_step_one_stream_host_wall": one_wall * 1e3 / args.steps,
+                "lead_in_frames": LEAD,
+                "ms_per_step_host_wall": elapsed_wall * 1e3 / (args.steps + LEAD),
+                "value_host_wall": verts / elapsed_wall * (args.steps + LEAD) / args.steps,
+                "host_fixed_cost_us_per_timed_region": (elapsed_wall - elapsed * (args.steps + LEAD) / args.steps) * 1e6,
+                "ms_per_step_one_stream_host_wall": one_wall * 1e3 / (args.steps + LEAD),
                 "frame_ms_with_pose_mapped": mapped_ms,
                 "frame_ms_with_pose_mapped_protocol_only": mapped_bare_ms,
                 "frame_ms_with_pose_mapped_two_in_flight": mapped_pair_ms,

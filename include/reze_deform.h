@@ -269,11 +269,14 @@ int rz_read_aabb(rz_ctx *ctx, uint32_t instance, float min_max6[6]);
  * prep kernel alone the same way. Blocking. */
 int rz_time_frames(rz_ctx *ctx, uint32_t frames, rz_timing *out);
 
-/* Benchmark helper ("hipEvent pairs around the back-to-back frames"): `frames` frames of the resident pose exactly as
- * rz_deform_n enqueues them — or, with a fork in `b`, as rz_deform_pair alternates them — between two events on the context's stream;
- * blocks until they have drained and returns the span between the events in ms. The host's own clock around the same calls adds a
- * fixed ~20 us per timed region (first launch + waking up from the wait), 6 % of 20 steps of a 16.6 us frame. b = NULL: one stream. */
-int rz_time_span(rz_ctx *a, rz_ctx *b, uint32_t frames, double *span_ms);
+/* Benchmark helper ("hipEvent pairs around >= 200 back-to-back frames after 20 warm-up frames"): `lead` untimed frames, then
+ * `frames` timed frames of the resident pose exactly as rz_deform_n enqueues them — or, with a fork in `b`, as rz_deform_pair alternates
+ * them — the timed ones between two events on the context's stream; blocks until they have drained and returns the span between the
+ * events in ms. The lead frames sit in front of the opening event in the SAME call, so the timed frames are enqueued behind a busy GPU and
+ * run back to back from the first one (lead = 0: the first timed frame starts on an idle GPU and waits ~5 us for its own launch). The
+ * host's clock around the same calls adds a fixed ~30 us per timed region (first launch + waking up from the wait): 9 % of 20 steps of a
+ * 16.6 us frame. b = NULL: one stream. */
+int rz_time_span(rz_ctx *a, rz_ctx *b, uint32_t lead, uint32_t frames, double *span_ms);
 
 /* Tuning knobs (bench sweeps / tests); 0 / -1 = automatic. Keys: "morph_split" (0,1,2,4,8 lanes
  * per vertex quad; without dense targets it only sets the wave step: 1 -> 256 vertices, >= 4 -> 64), "unroll" (0,4,8 morphs in flight per lane), "grid_cap" (total workgroups),

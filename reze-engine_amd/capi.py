@@ -141,7 +141,7 @@ def load(path=None):
         L.rz_instance_range.argtypes = [u32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(u32), ctypes.POINTER(u32)]
         L.rz_map_pose.argtypes = [vp, ctypes.c_int, ctypes.POINTER(fp), ctypes.POINTER(fp)]
         L.rz_commit_pose.argtypes = [vp]
-        L.rz_time_span.argtypes = [vp, vp, u32, ctypes.POINTER(ctypes.c_double)]
+        L.rz_time_span.argtypes = [vp, vp, u32, u32, ctypes.POINTER(ctypes.c_double)]
     for name in SYMBOLS:
         # (libraries older than the current ABI — tools/ab_inproc.py loads them side by side — lack the newer symbols: OPTIONAL_SYMBOLS)
         if name != "rz_last_error" and (name not in OPTIONAL_SYMBOLS or hasattr(L, name)):
@@ -575,10 +575,11 @@ class DeformContext:
                 raise RzError(-1, "a mapped frame call failed: " + L.rz_last_error().decode("utf-8", "replace"))
         return call, check
 
-    def time_span(self, frames, other=None):
-        """rz_time_span: ms between two events on the stream around `frames` back-to-back frames (with `other`, a fork: alternating)."""
+    def time_span(self, frames, other=None, lead=0):
+        """rz_time_span: ms between two events on the stream around `frames` back-to-back frames (with `other`, a fork: alternating),
+        `lead` untimed frames in front of the opening event."""
         ms = ctypes.c_double(0.0)
-        self._chk(self._L.rz_time_span(self._h, other._h if other is not None else None, int(frames), ctypes.byref(ms)))
+        self._chk(self._L.rz_time_span(self._h, other._h if other is not None else None, int(lead), int(frames), ctypes.byref(ms)))
         return ms.value
 
     def deform(self):

@@ -238,20 +238,31 @@ int rz_deform_pair(rz_ctx *a, rz_ctx *b, uint32_t frames)
 
 // The K-step span of a benchmark's timed region, by a hipEvent pair ON the stream instead of the host's clock around
 // enqueue + synchronize: at 20 steps of a 16.6 us shard frame the host's fixed cost per timed region (first launch, wake-up from the
-// final wait: ~20 us, profiles/r6_bench_shard8_steps20.json) is 6 % of the region.
-int rz_time_span(rz_ctx *a, rz_ctx *b, uint32_t frames, double *span_ms)
+// final wait: ~30 us, profiles/r6_bench_shard8_steps20.json) is 9 % of the region. `lead` untimed frames go in FRONT of the opening
+// event, in the same call: the host enqueues the event and the first timed frames while the GPU is busy with them, so the K timed frames
+// run back to back from the first one — a render loop never starts a frame on an idle GPU; without them the first timed frame waits for
+// its own launch (~5 us behind the event, another 3 % of 20 shard frames).
+int rz_time_span(rz_ctx *a, rz_ctx *b, uint32_t lead, uint32_t frames, double *span_ms)
 {
     if (!span_ms || frames == 0) return fail(RZ_ERR_INVALID, "rz_time_span: bad arguments");
     *span_ms = 0.0;
     if (int r = use(a)) return r;
     float ms = 0.f;
     if (!b) {
+        if (lead)
+            if (int r = rz_deform_n(a, lead)) return r;
         HIP_TRY(hipEventRecord(a->ev0, a->stream));
         if (int r = rz_deform_n(a, frames)) return r;
         HIP_TRY(hipEventRecord(a->ev1, a->stream));
     } else {
         if (a == b || a->device != b->device) return fail(RZ_ERR_INVALID, "rz_time_span needs two different contexts on one device");
-        // the span opens on a's stream and b's first frame waits for it; it closes on a's stream behind b's last frame
+        // the span opens on a's stream — behind a's share of the lead frames AND b's (a waits for them) — and b's first timed frame waits
+        // for it; it closes on a's stream behind b's last frame
+        if (lead) {
+            if (int r = rz_deform_pair(a, b, lead + (lead & 1u))) return r;         // (an even count: the timed frames start on a again)
+            HIP_TRY(hipEventRecord(b->ev0, b->stream));
+            HIP_TRY(hipStreamWaitEvent(a->stream, b->ev0, 0));
+        }
         HIP_TRY(hipEventRecord(a->ev0, a->stream));
         HIP_TRY(hipStreamWaitEvent(b->stream, a->ev0, 0));
         if (int r = rz_deform_pair(a, b, frames)) return r;
@@ -402,7 +413,7 @@ __attribute__((visibility("default"))) int rz_debug_gate(rz_ctx *c, int close)
 #endif
 
 #ifdef RZ_ABLATE
-// tools-only build (make ablate): per-wave timeline of the frames that follow (tools/timeline.py). Not part of the C ABI.
+// tools-only build (make ablate): per-wave timeline of the frames that follow (tools/archive/timeline.py). Not part of the C ABI.
 __attribute__((visibility("default"))) int rz_debug_timeline_arm(rz_ctx *c, uint32_t *waves)
 {
     if (int r = use(c)) return r;

@@ -37,7 +37,7 @@ constexpr int kBlock = 256;
 // fold away, and rz_set_tuning("dbg", ...) is rejected: no key can make rz_deform emit anything but the deformed mesh.
 #ifdef RZ_ABLATE
 #define RZ_DBG(p) ((p).dbg)
-// Per-wave TIMELINE (tools-only build, rz_set_tuning dbg = 100; tools/timeline.py): a wave keeps up to seven readings of the
+// Per-wave TIMELINE (tools-only build, rz_set_tuning dbg = 100; tools/archive/timeline.py): a wave keeps up to seven readings of the
 // chip-wide 100 MHz counter (s_memrealtime: 10 ns steps, the same clock on every XCD) in scalar registers and writes them out
 // when it ends, with the XCC / CU / SIMD it ran on (16 x u64 per wave: 0..6 stamps, 7 where, 8..12 stamps inside the fused
 // hierarchy solve). Slot 6 is taken after every store of the wave has been acknowledged.

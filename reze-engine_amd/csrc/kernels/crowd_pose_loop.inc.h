@@ -1,6 +1,6 @@
 // kernels/crowd_pose_loop.inc.h — the pose loop of the crowd kernels, included TEXTUALLY into the body of rz_skin_instances_kernel and
 // rz_skin_instances_fk_kernel (crowd.hip) right behind the barrier that publishes the workgroup's palettes. A device function with the
-// same body compiled to a different instruction stream (22 instructions more, other schedule: tools/isa_diff.py), and the C4 frame sits
+// same body compiled to a different instruction stream (22 instructions more, other schedule: tools/archive/isa_diff.py), and the C4 frame sits
 // on the store stream's edge — so the two kernels share the text, not a call.
 // In scope at the point of inclusion: BLOCK, NTS, SUB (compile time); p, pal, ng, lrows, inst0, Vp, v_begin, v_end, bmax, jp01, jp23,
 // tid, vert_of(); the run's FIRST vertex already loaded into v, x, y, z, nx, ny, nz, j01, j23, wq; rstride (float4 per palette bone).

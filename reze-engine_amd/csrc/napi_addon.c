@@ -407,18 +407,20 @@ static napi_value fn_commit_pose(napi_env env, napi_callback_info info)
     return rc ? throw_rz(env, rc) : undef(env);
 }
 
-/* timeSpan(ctx, forkCtx | null, frames) -> ms between two events on the stream around `frames` back-to-back frames (rz_time_span). */
+/* timeSpan(ctx, forkCtx | null, frames, lead = 0) -> ms between two events on the stream around `frames` back-to-back frames, `lead` untimed
+ * frames in front of the opening event (rz_time_span). */
 static napi_value fn_time_span(napi_env env, napi_callback_info info)
 {
     ARGS(3);
     CTX(0);
     rz_ctx *other = NULL;
     napi_valuetype t;
-    uint32_t n;
-    if (napi_typeof(env, argv[1], &t) != napi_ok || !get_u32(env, argv[2], &n)) return throw_msg(env, "timeSpan(ctx, forkCtx | null, frames)");
+    uint32_t n, lead = 0;
+    if (napi_typeof(env, argv[1], &t) != napi_ok || !get_u32(env, argv[2], &n)) return throw_msg(env, "timeSpan(ctx, forkCtx | null, frames, lead = 0)");
+    if (argc > 3 && !get_u32(env, argv[3], &lead)) return throw_msg(env, "timeSpan: lead is a frame count");
     if (t != napi_null && t != napi_undefined && !get_ctx(env, argv[1], &other)) return throw_msg(env, "timeSpan: the second argument is a fork or null");
     double ms = 0.0;
-    int rc = rz_time_span(ctx, other, n, &ms);
+    int rc = rz_time_span(ctx, other, lead, n, &ms);
     if (rc) return throw_rz(env, rc);
     napi_value v;
     napi_create_double(env, ms, &v);

@@ -195,11 +195,15 @@ Plan make_plan(const rz_ctx *c)
     gx = std::max<uint32_t>(1, std::min(gx, max_useful));
     uint32_t per_wave = (pl.n_quads + gx * waves_per_wg - 1) / (gx * waves_per_wg);
     per_wave = std::max<uint32_t>(8, round_up(per_wave, 8));
-    // dense frames: whole steps. A run of 2.5 or 3.5 steps ends every wave on a step with half its lanes idle — the stream runs at half
-    // rate for the last third of the frame; rounding the run up to whole steps (fewer workgroups) was 4.5 % faster at 875 k vertices and
-    // never slower where a run has at least two steps. Shorter runs keep the 8-quad grain: there, more workgroups beat whole steps
-    // (188 k vertices, S = 4: 1.5 steps on 489 workgroups 25.5 us, 2 steps on 367 27.8 us).
-    if (v.mode == 1 && c->t_grid_cap <= 0 && per_wave >= 2 * qpw_step) per_wave = round_up(per_wave, qpw_step);
+    // dense frames: whole steps — where they are cheap. A run of 3.5 steps ends every wave on a step with half its lanes idle; rounding the
+    // run up to 4 (875 k vertices: 489 -> 428 workgroups) was 4.5 % faster. But the grid must stay close to two workgroups on EVERY CU:
+    // at 282 k vertices 2.5 -> 3 steps (440 -> 367 workgroups: 111 CUs with two workgroups, 145 with one) was 9 % SLOWER, in six fresh
+    // processes out of six (profiles/r6_fresh_plans.txt). So the run is rounded up only when that costs at most one eighth of the
+    // workgroups (k >= 0.875 ceil(k)); shorter runs keep the 8-quad grain.
+    if (v.mode == 1 && c->t_grid_cap <= 0 && per_wave > qpw_step) {
+        const uint32_t whole = round_up(per_wave, qpw_step);
+        if ((uint64_t)per_wave * 8 >= (uint64_t)whole * 7) per_wave = whole;
+    }
     pl.quads_per_wave = per_wave;
     pl.grid_x = std::max<uint32_t>(1, (pl.n_quads + per_wave * waves_per_wg - 1) / (per_wave * waves_per_wg));
     // LDS write batching. Measured (tools/archive/ablate_c5.py): parking a wave's WHOLE run and writing it once at the end

@@ -113,7 +113,7 @@ export interface DeformAddon {
   readPalette(ctx: DeformContext, instance: number, rows: Float32Array): void
   readGathered(ctx: DeformContext, v0: number, n: number, positions: Float32Array | null, normals: Float32Array | null): void
   timeFrames(ctx: DeformContext, frames: number): Timing
-  timeSpan(ctx: DeformContext, fork: DeformContext | null, frames: number): number
+  timeSpan(ctx: DeformContext, fork: DeformContext | null, frames: number, lead?: number): number
   autotune(ctx: DeformContext, frames?: number): void
   setTuning(ctx: DeformContext, key: string, value: number): void
   getTuning(ctx: DeformContext, key: string): number

@@ -65,8 +65,9 @@ STUB = textwrap.dedent('''
         def sync(self):
             d = self.busy_until - time.perf_counter()
             if d > 0: time.sleep(d)
-        def time_span(self, frames, other=None):
-            # the stand-in's "events": virtual GPU time from the first frame's start to the last frame's end
+        def time_span(self, frames, other=None, lead=0):
+            # the stand-in's "events": virtual GPU time from the first TIMED frame's start to the last frame's end
+            if lead: self.deform_n(lead)
             t0 = max(self.busy_until, time.perf_counter())
             if other is None: self.deform_n(frames)
             else: self.deform_pair(other, frames)
@@ -133,7 +134,7 @@ def _scaling_intact(d):
     c = d["config"]
     assert "hipEvent" in d["timed_by"]
     assert c["ms_per_step_host_wall"] >= d["ms_per_step"] > 0 and c["host_fixed_cost_us_per_timed_region"] >= 0
-    assert abs(c["value_host_wall"] - 65536 / (c["ms_per_step_host_wall"] * 1e-3)) <= 1e-6 * c["value_host_wall"]
+    assert abs(c["value_host_wall"] - 65536 / (c["ms_per_step_host_wall"] * 1e-3)) <= 1e-6 * c["value_host_wall"] and c["lead_in_frames"] == 2
 
 
 @pytest.mark.parametrize("mode", ["fail", "fail_allgather"])

@@ -27,7 +27,7 @@ def expect_fail(name, rc):
 fp = ctypes.POINTER(ctypes.c_float)
 # null context everywhere
 for name in rz.capi.SYMBOLS:
-    if name in ("rz_last_error", "rz_abi_version", "rz_device_count", "rz_device_numa_node", "rz_create", "rz_shard_range", "rz_gather_chunk", "rz_comm_unique_id",
+    if name in ("rz_last_error", "rz_abi_version", "rz_device_count", "rz_device_numa_node", "rz_create", "rz_shard_range", "rz_instance_range", "rz_gather_chunk", "rz_comm_unique_id",
                 "rz_comm_init_all", "rz_allgather_all", "rz_gather_direct", "rz_destroy", "rz_rccl_info", "rz_autotune_pick"):      # rz_destroy(NULL) is a no-op, like free; rz_autotune_pick takes a table and returns an index
         continue
     f = getattr(L, name)
@@ -48,6 +48,11 @@ expect_fail("read before anything", L.rz_read(h, 0, 0, 1, N, N))
 expect_fail("create(NULL out)", L.rz_create(0, N))
 expect_fail("create(device 99)", L.rz_create(99, ctypes.byref(ctypes.c_void_p())))
 expect_fail("shard_range(NULL)", L.rz_shard_range(100, 2, 0, N, N))
+expect_fail("instance_range(NULL)", L.rz_instance_range(100, 2, 0, N, N))
+expect_fail("instance_range(rank >= n)", L.rz_instance_range(100, 2, 2, ctypes.byref(ctypes.c_uint32()), ctypes.byref(ctypes.c_uint32())))
+expect_fail("commit_pose without a mapping", L.rz_commit_pose(h))
+expect_fail("map_pose before a skeleton", L.rz_map_pose(h, 0, ctypes.byref(fp()), N))
+expect_fail("time_span before anything", L.rz_time_span(h, N, 0, 3, ctypes.byref(ctypes.c_double())))
 expect_fail("shard_range(rank >= n)", L.rz_shard_range(100, 2, 5, ctypes.byref(ctypes.c_uint32()), ctypes.byref(ctypes.c_uint32())))
 expect_fail("gather_direct(NULL list)", L.rz_gather_direct(N, 2, 100, 0))
 expect_fail("comm_init_all(NULL list)", L.rz_comm_init_all(N, 2, 100))
@@ -56,6 +61,12 @@ expect_fail("comm_unique_id(NULL)", L.rz_comm_unique_id(N))
 m = synth.make_mesh(300, 6, seed=1)
 c.upload_mesh(m["pos"], m["nrm"], m["joints"], m["weights"]); c.upload_skeleton(m["inv_bind"])
 expect_fail("set_pose(NULL world)", L.rz_set_pose(h, N, N))
+expect_fail("map_pose(NULL out)", L.rz_map_pose(h, 0, N, N))
+expect_fail("map_pose(layout 5)", L.rz_map_pose(h, 5, ctypes.byref(fp()), N))
+expect_fail("map_pose(rows for one character)", L.rz_map_pose(h, 1, ctypes.byref(fp()), N))
+expect_fail("time_span(0 frames)", L.rz_time_span(h, N, 2, 0, ctypes.byref(ctypes.c_double())))
+expect_fail("time_span(NULL out)", L.rz_time_span(h, N, 0, 3, N))
+expect_fail("time_span(ctx, ctx)", L.rz_time_span(h, h, 0, 3, ctypes.byref(ctypes.c_double())))
 expect_fail("dense morphs NULL deltas", L.rz_upload_morphs_dense(h, 3, N))
 expect_fail("sparse morphs NULL offsets", L.rz_upload_morphs_sparse(h, 3, N, N, N))
 off = (ctypes.c_uint32 * 3)(0, 5, 2)

@@ -1,9 +1,9 @@
 #!/bin/bash
 # SQ / LDS / TCC / TCP counters of the dominant kernel of every tracked workload on the CURRENT tree (round 5: replaces gpu_c4_counters.sh,
 # gpu_c5_counters.sh, gpu_pmc_sq.sh, gpu_sparse_counters.sh). One PMC group per rocprofv3 run (kernel-trace only, as gpurun demands);
-# FETCH_SIZE / WRITE_SIZE traffic comes from gpu_profile.sh. The write-path groups are also collected for tools/storebench — the same
+# FETCH_SIZE / WRITE_SIZE traffic comes from gpu_profile.sh. The write-path groups are also collected for tools/archive/storebench — the same
 # 184 MB written with no loads and no math — so the C4 kernel's store stalls can be read against the fill's own.
-#   usage: [PMC_GROUPS="1 2 3"] tools/gpu_counters.sh [workload ...]      default: c5 shard c4 c4fk demo store, all five groups      -> gpurun_out/counters/summary_<workload>.txt
+#   usage: [PMC_GROUPS="1 2 3"] tools/archive/gpu_counters.sh [workload ...]      default: c5 shard c4 c4fk demo store, all five groups      -> gpurun_out/counters/summary_<workload>.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/counters; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -14,7 +14,7 @@ CMD[shard]="python $R/bench.py --verts 125184 --steps 60 --warmup 5 $COMMON"
 CMD[c4]="python $R/bench.py --config c4 --steps 40 --warmup 4 $COMMON"
 CMD[c4fk]="python $R/bench.py --config c4 --device-fk --steps 40 --warmup 4 $COMMON"
 CMD[demo]="python $R/bench.py --config demo --steps 100 --warmup 10 $COMMON"
-CMD[store]="$R/tools/storebench"
+CMD[store]="$R/tools/archive/storebench"
 declare -A KEY
 KEY[c5]="rz_deform_dense"; KEY[shard]="rz_deform_dense"; KEY[c4]="rz_skin_instances_kernel"; KEY[c4fk]="rz_skin_instances_fk"; KEY[demo]="rz_deform_small"; KEY[store]="void k<0>"
 G1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"

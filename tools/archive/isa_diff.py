@@ -1,4 +1,4 @@
-"""Compare two directories of normalised per-kernel disassembly (tools/isa_dump.sh): for every kernel of the NEW directory, the kernel it
+"""Compare two directories of normalised per-kernel disassembly (tools/archive/isa_dump.sh): for every kernel of the NEW directory, the kernel it
 replaces in the OLD one (rz_deform_kernel<S,U,MODE,NT,NTS,GEO,FAST> was split into rz_deform_dense_kernel<S,U,NT,NTS,GEO,FAST> and
 rz_deform_small_kernel<S,MODE,NTS,GEO,FAST>), identical or not, instruction counts, and the mnemonic histogram differences."""
 import collections, difflib, os, re, sys

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Disassemble every kernel of the given .hip files (product flags + extra flags) into one normalised text file per kernel:
-#   tools/isa_dump.sh <outdir> [-DFLAG ...] -- file.hip [file2.hip ...]
+#   tools/archive/isa_dump.sh <outdir> [-DFLAG ...] -- file.hip [file2.hip ...]
 # (addresses and encodings stripped, so two builds of the same code compare equal with diff; used to check that a refactor leaves
-# the instruction streams alone: tools/isa_diff.py)
+# the instruction streams alone: tools/archive/isa_diff.py)
 OUT=$1; shift
 FL=()
 while [ "$1" != "--" ]; do FL+=("$1"); shift; done; shift

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Register / scratch use of every kernel of a .hip file, read from the code object's metadata (no GPU needed):
-#   tools/kernel_regs.sh [file.hip] [extra flags...]   -> "<vgpr> <sgpr> <sgpr spills> <scratch B> <kernel>" per kernel, sorted by VGPRs
+#   tools/archive/kernel_regs.sh [file.hip] [extra flags...]   -> "<vgpr> <sgpr> <sgpr spills> <scratch B> <kernel>" per kernel, sorted by VGPRs
 D=$(cd "$(dirname "$0")/../reze-engine_amd/csrc" && pwd)
 F=${1:-$D/deform_kernels.hip}; shift
 T=$(mktemp -d)

@@ -2,14 +2,14 @@
 Every wave stamps the chip-wide 100 MHz counter (10 ns steps) at: 0 entry, 1 prologue done, 2 first step's morph phase done,
 3 palette published, 4 first step's skin phase issued, 5 last step done, 6 all stores acknowledged (crowd kernel: 0 entry,
 1 staged matrices landed, 2 palettes published, 3 first vertex step done, 5 last step issued, 6 stores acknowledged).
-usage: python tools/timeline.py <config> [key=value ...]     config: c2 c3 demo sparse2 shard c5 c4 | sampled-c2 sampled-demo local-c2 local-c4 sampled-c4"""
+usage: python tools/archive/timeline.py <config> [key=value ...]     config: c2 c3 demo sparse2 shard c5 c4 | sampled-c2 sampled-demo local-c2 local-c4 sampled-c4"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import reze_engine_amd as rz
 from reze_engine_amd import synth
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = rz.capi.load(os.path.join(ROOT, "tools", "ablate", "libreze_deform_ablate.so"))
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 tune = dict(kv.split("=") for kv in sys.argv[2:])

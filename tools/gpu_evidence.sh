@@ -1,7 +1,7 @@
 #!/bin/bash
 # Second evidence session of a round (the first is tools/gpu_full.sh): rocprofv3 kernel stats + PMC traffic (tools/gpu_profile.sh) condensed
 # ON the box (the CSVs are hundreds of MB; gpurun_out/ travels back under 64 MiB), per-wave timelines of every tracked workload, the
-# counters of the dominant kernels (tools/gpu_counters.sh) and the round's micro-benchmarks.
+# counters of the dominant kernels (tools/archive/gpu_counters.sh) and the round's micro-benchmarks.
 #   usage: tools/gpu_evidence.sh <tag> [profile] [timelines] [counters] [micro]      default: all four parts      -> gpurun_out/ev/
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 TAG=${1:-r6}; shift
@@ -17,12 +17,12 @@ profile)
   rm -rf gpurun_out/prof ;;
 timelines)
   for c in c2 c3 sparse2 demo sampled-c2 local-c2 sampled-demo shard c4 local-c4 sampled-c4 c5; do
-    timeout 200 python tools/timeline.py $c 2>&1 | grep -v "amdgpu.ids" > $O/timeline_$c.txt; head -1 $O/timeline_$c.txt | cut -c1-200
+    timeout 200 python tools/archive/timeline.py $c 2>&1 | grep -v "amdgpu.ids" > $O/timeline_$c.txt; head -1 $O/timeline_$c.txt | cut -c1-200
   done ;;
 counters)
   rm -rf gpurun_out/counters
-  PMC_GROUPS="1 2 3" bash tools/gpu_counters.sh c5 shard demo 2>&1 | grep -v "^$" | tail -20      # (the write-path groups matter for the store-bound crowd kernels)
-  bash tools/gpu_counters.sh c4 c4fk 2>&1 | grep -v "^$" | tail -20
+  PMC_GROUPS="1 2 3" bash tools/archive/gpu_counters.sh c5 shard demo 2>&1 | grep -v "^$" | tail -20      # (the write-path groups matter for the store-bound crowd kernels)
+  bash tools/archive/gpu_counters.sh c4 c4fk 2>&1 | grep -v "^$" | tail -20
   cd $R; mkdir -p $O/counters; cp gpurun_out/counters/summary_*.txt $O/counters/ 2>/dev/null ;;
 micro)
   timeout 120 tools/archive/overlapbench 2>&1 | tee $O/overlapbench.txt | tail -4
