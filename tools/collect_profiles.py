@@ -30,7 +30,7 @@ for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))):
         tj = os.path.join(DST, "pmc_traffic.json")
         if rf.get("traffic") is None and os.path.exists(tj):
             sparse = {"demo": "_demo", "sparse2": "_sparse2"}.get(os.path.basename(f)[len("bench_"):-len(".json")], "")
-            key = "V%d_B%d_M%d_I%d%s|%s" % (c["verts_per_gpu"], c["bones"], c["morphs"], c["instances"], sparse, rf["kernel"])
+            key = "V%d_B%d_M%d_I%d%s|%s" % (c["verts_per_gpu"], c["bones"], c["morphs"], c.get("instances_per_gpu", c["instances"]), sparse, rf["kernel"])
             rec = json.load(open(tj))
             if key in rec:
                 rf["traffic"] = rec[key]["hbm_bytes_per_launch"]
