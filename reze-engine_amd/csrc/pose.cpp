@@ -518,19 +518,22 @@ int rz_commit_pose(rz_ctx *c)
     const size_t bones = (size_t)c->I * c->B;
     char *st = c->map_ptr;
     const float *mw = c->M > 0 ? reinterpret_cast<const float *>(st + bones * (rows ? 48 : 64)) : nullptr;
-    if (int r = pose_kind_changes(c, false)) return r;
     const PoseParts pp = pose_parts(c, nullptr, bones * 64, nullptr, 0, false, nullptr);
-    // the same decisions as at map time, on the state as it is NOW
+    // the same decisions as at map time, on the state as it is NOW (a context under the overlapped-front protocol was refused at map time
+    // and a world-matrix pose never switches it on by itself) — all of them BEFORE anything is changed: a refused commit leaves the
+    // resident pose as it was
+    if (c->t_overlap == 1 || c->overlap_on) return fail(RZ_ERR_UNSUPPORTED, "rz_commit_pose: the overlapped-front protocol was switched on since rz_map_pose; hand the pose over with rz_set_pose");
     const bool zc_now = pose_zero_copy(c, pp);
     bool same = c->map_zc ? (zc_now && c->zc_host[c->map_slot] == static_cast<void *>(st) && c->zc_uploads == c->map_upload)
                           : (!zc_now && c->stage[c->map_slot] == static_cast<void *>(st));
-    const bool pull = !c->map_zc && same && pose_pullable(c, pp, c->map_slot) && (rows || c->t_pull == 1 || c->t_pull < 0);
+    const bool pull = !c->map_zc && same && pose_pullable(c, pp, c->map_slot) && c->t_pull != 0;       // ("pose_pull" = 0 since the map: rows are refused below)
     if (rows && !pull) same = false;
     if (!same) {
         if (rows) return fail(RZ_ERR_UNSUPPORTED, "rz_commit_pose: the context changed since rz_map_pose and this pose can no longer be pulled as rows: map it again");
         // a plain rz_set_pose out of the mapped memory (the slot it takes is the NEXT one of its ring, never the source)
         return upload_pose(c, st, bones * 64, nullptr, 0, false, mw);
     }
+    if (int r = pose_kind_changes(c, false)) return r;
     if (c->map_zc) zc_publish(c, pp, c->map_slot, c->map_upload);
     else if (int r = copy_send(c, pp, c->map_slot, pull, rows)) return r;
     c->pose_I = c->I;

@@ -117,6 +117,19 @@ def test_mapped_crowd_pose_equals_the_pose_handed_over(rz, V, B, I, M):
             assert np.array_equal(got[i][0], ref[i][0]) and np.array_equal(got[i][1], ref[i][1]), "layout %d instance %d" % (layout, i)
         for i in (0, I - 1):
             assert np.array_equal(c.read_world(i).reshape(B, 16), worlds[i].reshape(B, 16))
+    # a commit that has to be refused (rows mapped, then the pull switched off: nothing on the host could expand them) changes nothing:
+    # the resident pose is still the one frames deform
+    mats, _ = c.map_pose(rz.capi.POSE_ROWS12)
+    mats[:] = _rows(worlds[::-1])
+    c.set_tuning(pose_pull=0)
+    with pytest.raises(rz.RzError) as e:
+        c.commit_pose()
+    assert e.value.code == -6
+    c.set_tuning(pose_pull=-1)
+    c.deform()
+    assert np.array_equal(c.read(I - 1)[0], ref[I - 1][0]) and np.array_equal(c.read(0)[1], ref[0][1])
+    with pytest.raises(rz.RzError):
+        c.set_tuning(overlap=1) or c.map_pose()                 # the opt-in overlapped-front protocol hands its poses over with rz_set_pose
     c.close()
 
 
