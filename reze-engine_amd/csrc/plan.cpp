@@ -13,16 +13,46 @@ int auto_split(const rz_ctx *c)
     // S lanes share a quad, so waves = quads * S / 64, and a wave step is 256 / S vertices whose skin phase (and output stores) follow
     // its morph loads. Measured on MI355X, round 6 (tools/plan_sweep.py: 15 mesh sizes x {S} x {whole steps per wave}, round-robin
     // medians, profiles/r6_plan_sweep.txt): the 1 M-vertex mesh streams 3 % faster with two lanes per quad than with one and S = 2 stays
-    // best down to ~300 k vertices; below that a wave at S = 2 is left with ONE long step — every wave loads first and skins last, nothing
+    // best down to ~365 k vertices (see below); under ~300 k a wave at S = 2 is left with ONE long step — every wave loads first and skins last, nothing
     // overlaps (250 k vertices: 37.4 us, against 34.7 us as two steps at S = 4) — so S = 4 down to ~95 k vertices, where the same
     // happens to it, and S = 8 below (C3). A dense frame never runs at S = 1, which also keeps rz_autotune's pick on the heuristic plan
     // instead of flipping between two near-equal candidates from run to run.
+    // The S = 2 / S = 4 boundary sits where S = 4 stops filling three whole 64-vertex steps per wave of the persistent grid (~367 k
+    // vertices): between 300 k and 365 k vertices S = 2 left every wave with 1.25-1.5 steps and ran 6-12 % behind S = 4 in every one of
+    // 24 fresh processes (tools/fresh_plans.py, profiles/r6_fresh_plans_mid.txt: 313 856 vertices 47.2-47.8 us against 41.1-41.9).
     const uint64_t quads = (uint64_t)c->Vp / 4 * c->I;
     int S = 2;
-    if (quads * 2 / 64 < 2400) S = 4;
+    if (quads * 2 / 64 < 2870) S = 4;
     if (quads * 4 / 64 < 1500) S = 8;
     while (S > 1 && (uint32_t)S > c->M) S >>= 1;
     return S;
+}
+
+// Quads per wave of a frame's persistent grid: `cap` workgroups of four waves, every wave one contiguous run (a multiple of 8 quads =
+// 128 B per plane). `rules` = the heuristics of a dense single-mesh frame whose launch shape the caller left to the library.
+uint32_t run_per_wave(uint32_t n_quads, uint32_t cap, int S, bool rules, bool one_mesh)
+{
+    const uint32_t waves_per_wg = 4, qpw_step = 64 / (uint32_t)S;
+    const uint32_t max_useful = (n_quads + waves_per_wg * qpw_step - 1) / (waves_per_wg * qpw_step);
+    const uint32_t gx = std::max<uint32_t>(1, std::min(std::max<uint32_t>(1, cap), max_useful));
+    uint32_t per_wave = (n_quads + gx * waves_per_wg - 1) / (gx * waves_per_wg);
+    per_wave = std::max<uint32_t>(8, round_up(per_wave, 8));
+    if (!rules) return per_wave;
+    // whole steps — where they are cheap. A run of 3.5 steps ends every wave on a step with half its lanes idle; rounding the
+    // run up to 4 (875 k vertices: 489 -> 428 workgroups) was 4.5 % faster. But the grid must stay close to two workgroups on EVERY CU:
+    // at 282 k vertices 2.5 -> 3 steps (440 -> 367 workgroups: 111 CUs with two workgroups, 145 with one) was 9 % SLOWER, in six fresh
+    // processes out of six (profiles/r6_fresh_plans.txt). So the run is rounded up only when that costs at most one eighth of the
+    // workgroups (k >= 0.875 ceil(k)); shorter runs keep the 8-quad grain.
+    if (per_wave > qpw_step) {
+        const uint32_t whole = round_up(per_wave, qpw_step);
+        if ((uint64_t)per_wave * 8 >= (uint64_t)whole * 7) per_wave = whole;
+    }
+    // ... and a run of between one and two steps becomes ONE step per wave on as many workgroups as that takes — the hardware deals the
+    // second round out as slots free up. S = 2 (what is left of 367-395 k vertices once S = 4 took its share, auto_split): 5 % faster than
+    // 1.5 steps per wave in 8 fresh processes of 8 (375 k: 51.2 -> 48.4 us, 390 k: 53.8 -> 51.0; profiles/r6_fresh_plans_mid.txt). S = 4
+    // (132-190 k vertices): 1-4 % faster in 16 sizes of 16 and in 8 fresh processes of 8 (profiles/r6_onestep_sweep.txt, r6_fresh_plans_mid.txt).
+    if (one_mesh && (S == 2 || S == 4) && per_wave > qpw_step && per_wave < 2 * qpw_step) per_wave = qpw_step;
+    return per_wave;
 }
 
 void inst_runs(const rz_ctx *c, int G, int blk, bool for_subsets, uint32_t *per, uint32_t *runs)
@@ -178,7 +208,7 @@ Plan make_plan(const rz_ctx *c)
     pl.grid_x = 1;
     pl.prep = !v.fast && !pl.fuse_fk;
     // persistent, balanced grid: `cap` workgroups in total, every wave owns an equal contiguous run of quads
-    const uint32_t waves_per_wg = 4, qpw_step = 64 / (uint32_t)v.S;
+    const uint32_t waves_per_wg = 4;
     // measured (profiles/archive/r1_*sweep*): 2 workgroups per CU for one big mesh, 8 per instance when instanced
     uint32_t cap = c->t_grid_cap > 0 ? (uint32_t)c->t_grid_cap : std::max(2u * (uint32_t)c->n_cu, 8u * c->I);
     // dense frames at S = 8 (under ~95 k vertices): ONE 32-vertex step per wave even where that takes a second round of workgroups —
@@ -190,19 +220,16 @@ Plan make_plan(const rz_ctx *c)
             ((v.fast && !c->zc_local && !c->world_resident) ||
              (pl.fuse_fk && c->zc_local && !c->pose_sampled && (!c->local_resident || !c->mw_resident)));
     if (pl.pf && cap > 1) cap -= 1;
-    uint32_t gx = std::max<uint32_t>(1, cap / std::max<uint32_t>(1, c->I));
-    const uint32_t max_useful = (pl.n_quads + waves_per_wg * qpw_step - 1) / (waves_per_wg * qpw_step);
-    gx = std::max<uint32_t>(1, std::min(gx, max_useful));
-    uint32_t per_wave = (pl.n_quads + gx * waves_per_wg - 1) / (gx * waves_per_wg);
-    per_wave = std::max<uint32_t>(8, round_up(per_wave, 8));
-    // dense frames: whole steps — where they are cheap. A run of 3.5 steps ends every wave on a step with half its lanes idle; rounding the
-    // run up to 4 (875 k vertices: 489 -> 428 workgroups) was 4.5 % faster. But the grid must stay close to two workgroups on EVERY CU:
-    // at 282 k vertices 2.5 -> 3 steps (440 -> 367 workgroups: 111 CUs with two workgroups, 145 with one) was 9 % SLOWER, in six fresh
-    // processes out of six (profiles/r6_fresh_plans.txt). So the run is rounded up only when that costs at most one eighth of the
-    // workgroups (k >= 0.875 ceil(k)); shorter runs keep the 8-quad grain.
-    if (v.mode == 1 && c->t_grid_cap <= 0 && per_wave > qpw_step) {
-        const uint32_t whole = round_up(per_wave, qpw_step);
-        if ((uint64_t)per_wave * 8 >= (uint64_t)whole * 7) per_wave = whole;
+    const bool dense_rules = v.mode == 1 && c->t_grid_cap <= 0, one_mesh = c->I == 1;
+    const uint32_t cap_i = std::max<uint32_t>(1, cap / std::max<uint32_t>(1, c->I));
+    uint32_t per_wave = run_per_wave(pl.n_quads, cap_i, v.S, dense_rules, one_mesh);
+    // S = 2 pays where it leaves a wave WHOLE steps (1 M: 4, 750 k: 3, 500 k: 2 — there it is 1-3 % ahead of S = 4). Where it does not
+    // (2.25 / 2.5 / 3.25 steps of 128 vertices) the same grid at S = 4 — 64-vertex steps, the ragged last one half the size — was faster in
+    // every one of 36 fresh processes: 530-580 k vertices 7-8 %, 596-613 k 3 %, 797-845 k 4 % (profiles/r6_fresh_plans_hi.txt). Its own
+    // runs keep the 8-quad grain: rounded up to whole 64-vertex steps on fewer workgroups they were 0.4-4 % slower in 28 processes of 28.
+    if (dense_rules && one_mesh && c->t_split <= 0 && v.S == 2 && c->M >= 4 && per_wave > 32 && per_wave % 32 != 0) {
+        v.S = 4;
+        per_wave = run_per_wave(pl.n_quads, cap_i, v.S, false, true);
     }
     pl.quads_per_wave = per_wave;
     pl.grid_x = std::max<uint32_t>(1, (pl.n_quads + per_wave * waves_per_wg - 1) / (per_wave * waves_per_wg));

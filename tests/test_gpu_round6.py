@@ -379,13 +379,16 @@ def test_the_launcher_picks_the_variant_a_frame_needs(rz, oracle):
         c.close()
 
 
-@pytest.mark.parametrize("verts,split,grid", [(1000000, 2, 489), (875008, 2, 428), (500224, 2, 489), (281600, 4, 440), (250112, 4, 489), (125184, 4, 489), (93952, 8, 734), (30000, 8, 235)])
+@pytest.mark.parametrize("verts,split,grid", [(1000000, 2, 489), (875008, 2, 428), (797440, 4, 480), (625152, 4, 489), (530432, 4, 461), (500224, 2, 489), (400128, 2, 391), (375040, 2, 733), (333568, 4, 435), (313856, 4, 491), (281600, 4, 440), (250112, 4, 489), (156416, 4, 611), (125184, 4, 489), (93952, 8, 734), (30000, 8, 235)])
 def test_heuristic_plan_at_the_shard_sizes_of_c5(rz, verts, split, grid):
     """Review item 2: what make_plan picks at the shard sizes of N = 1, 2, 4, 8 (and between them, and C3) — the morph split the round-6
     sweeps found best there (profiles/r6_plan_sweep.txt: at 250 112 vertices S = 2 left every wave with one long step, 37.4 us against
     34.7 at S = 4), whole wave steps where that costs at most one eighth of the workgroups (875 k: 428 workgroups of 4 steps) and not
     where it would leave half the CUs with one workgroup (282 k: 440, not 367 — profiles/r6_fresh_plans.txt), one step per wave at
-    S = 8. The plan is a pure function of the sizes: the morph data may be anything."""
+    S = 8; S = 4 up to ~365 k vertices (the N = 3 shard: three whole steps per wave instead of S = 2's 1.5); one step per wave on as many
+    workgroups as that takes where 1.5 would be left (375 k at S = 2, 156 k at S = 4) — profiles/r6_fresh_plans_mid.txt; and S = 4 on the same
+    grid wherever S = 2 would leave a ragged run (2.25 / 2.5 / 3.25 steps: 530 k, 625 k, 797 k — profiles/r6_fresh_plans_hi.txt). The plan is a
+    pure function of the sizes: the morph data may be anything."""
     B, M = 256, 64
     mesh = synth.make_mesh_range(verts, B, 0, min(verts, 4096))
     c = rz.DeformContext(0)

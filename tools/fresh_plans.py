@@ -2,7 +2,7 @@
 """Round 6: is a launch shape robust, or only good where the allocator happened to put the buffers? Every (size, generator) runs in a
 FRESH process — new context, new allocations — and times a handful of plans round-robin; repeated, the spread of one plan across the
 processes is its placement sensitivity (250 112 vertices, S = 4 / 489 workgroups: 32.4 - 36.6 us; S = 4 / 245: 34.4 - 34.9 us).
-  python tools/fresh_plans.py [sizes] [repetitions]   -> profiles/r6_fresh_plans.txt"""
+  python tools/fresh_plans.py [sizes] [repetitions] [plans: S:G,... with G = x1 for one step per wave]   -> profiles/r6_fresh_plans.txt"""
 import json
 import os
 import subprocess
@@ -26,6 +26,9 @@ ctx.set_pose(mesh["world"], mw)
 for _ in range(20): ctx.deform_n(200)
 ctx.sync()
 plans = [(0, 0), (4, 256), (4, 512), (2, 256), (4, 1024)]
+if len(sys.argv) > 3:       # "S:G,..." — G = workgroups, or x1 = as many as one step per wave takes
+    nq = (n + 3) // 4
+    plans = [(0, 0)] + [(int(s), -(-nq // (4 * (64 // int(s)))) if g == "x1" else int(g)) for s, g in (x.split(":") for x in sys.argv[3].split(","))]
 t = {p: [] for p in plans}
 for r in range(4):
     for p in plans:
@@ -40,9 +43,10 @@ print(json.dumps({"verts": n, "gen": gen, "us": out}))
 ''' % ROOT
 sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [250112, 218880, 187648, 281600]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+extra = [sys.argv[3]] if len(sys.argv) > 3 else []
 for n in sizes:
     for rep in range(reps):
         for gen in ("range", "whole"):
-            p = subprocess.run([sys.executable, "-c", CHILD, str(n), gen], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            p = subprocess.run([sys.executable, "-c", CHILD, str(n), gen] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
             print(lines[-1] if lines else "FAILED " + p.stderr.decode()[-300:], flush=True)
