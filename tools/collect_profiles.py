@@ -55,7 +55,7 @@ for name in ("c5", "c4"):
         stab[{"c5": "C5 (python bench.py)", "c4": "C4 (--config c4)"}[name]] = runs
 if stab:
     json.dump(stab, open(os.path.join(DST, "%s_autotune_stability.json" % TAG), "w"), indent=1)
-for t in ("shard_scaling", "live_loop", "node_frame_bench", "pytest_gpu", "smoke", "plan_sweep", "parity", "pullbench", "fresh_plans"):
+for t in ("shard_scaling", "live_loop", "node_frame_bench", "pytest_gpu", "smoke", "plan_sweep", "parity", "pullbench", "fresh_plans", "fresh_plans_final", "onestep_sweep"):
     p = os.path.join(SRC, t + ".txt")
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(DST, "%s_%s.txt" % (TAG, t)))

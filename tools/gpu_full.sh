@@ -48,6 +48,9 @@ echo "== the heuristic plan among the launch shapes, at the shard sizes and betw
 timeout 900 python tools/plan_sweep.py --sizes 1000000,875008,750080,625152,500224,437760,375040,312576,250112,218880,187648,156416,125184,93952,62720 --steps-per-wave 1,2,3,4,6,8 --rounds 3 --frames 150 --out $O/plan_sweep.json > $O/plan_sweep.txt 2>&1; echo "plan_sweep rc=$?" >> $O/plan_sweep.txt; grep heuristic_behind $O/plan_sweep.txt
 echo "== launch shapes in fresh processes (placement sensitivity)"
 timeout 600 python tools/fresh_plans.py 250112,281600,218880 3 > $O/fresh_plans.txt 2>&1; tail -4 $O/fresh_plans.txt
+timeout 600 python tools/fresh_plans.py 313856,333568,375040,530432,625152,797440 2 2:512,4:512,4:x1,2:x1 > $O/fresh_plans_final.txt 2>&1; tail -2 $O/fresh_plans_final.txt
+echo "== the persistent grid against one step per wave, 46 sizes (final heuristics)"
+timeout 600 python tools/onestep_sweep.py > $O/onestep_sweep.txt 2>>$O/bench.err; wc -l $O/onestep_sweep.txt
 echo "== parity of every BASELINE config (max / p99.9)"
 timeout 900 python tools/parity_report.py > $O/parity.txt 2>$O/parity.err; tail -14 $O/parity.txt
 echo "== pullbench"
