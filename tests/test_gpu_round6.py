@@ -403,3 +403,30 @@ def test_heuristic_plan_at_the_shard_sizes_of_c5(rz, verts, split, grid):
     c.deform()
     assert np.isfinite(c.read(0, 0, 64)[0]).all()
     c.close()
+
+
+@pytest.mark.parametrize("verts,split,grid", [(156416, 4, 611), (313856, 4, 491), (375040, 2, 733), (530432, 4, 461)])
+def test_launch_shapes_of_the_second_pass_against_the_oracle(rz, oracle, verts, split, grid):
+    """The launch shapes round 6's second pass introduced (NOTEBOOK R6.9) — one step per wave on more workgroups than fit at once (S = 4:
+    611, S = 2: 733), S = 4 runs of 2.5 and 4.5 steps on the persistent grid — against the oracle over the WHOLE mesh, dense morphs
+    streaming (12 targets keep the upload small; the plan depends on the vertex count alone), and bit for bit against the same mesh
+    under S = 1 on a plain persistent grid: every vertex is written exactly once whatever the partition."""
+    from helpers import assert_parity
+    B, M = 64, 12
+    mesh = synth.make_mesh_range(verts, B, 0, verts)
+    deltas, mw = synth.make_morphs_dense_range(verts, M, 0, verts)
+    c = rz.DeformContext(0)
+    c.upload_mesh(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"]); c.upload_skeleton(mesh["inv_bind"]); c.upload_morphs_dense(deltas)
+    c.set_pose(mesh["world"], mw)
+    assert (c.get_tuning("effective_split"), c.get_tuning("effective_grid")) == (split, grid)
+    c.deform()
+    pg, ng = c.read()
+    pr, nr = oracle.deform(mesh["pos"], mesh["nrm"], mesh["joints"], mesh["weights"], mesh["world"], mesh["inv_bind"], deltas, mw)
+    assert_parity(pg, ng, pr, nr, "%d vertices at S = %d / %d workgroups" % (verts, split, grid))
+    c.set_tuning(morph_split=1, grid_cap=512)
+    c.deform()
+    p1, n1 = c.read()
+    # (the S lanes of a quad add their partial sums in another order than one lane does: positions agree to rounding, normals follow)
+    assert_parity(p1, n1, pr, nr, "%d vertices at S = 1" % verts)
+    assert np.abs(p1 - pg).max() <= 2e-6 * max(1.0, np.abs(pr).max()) + 1e-5
+    c.close()
