@@ -31,7 +31,7 @@ class Walk:
     # ---- state changes -------------------------------------------------------------------------------------------
     def new_mesh(self):
         V = int(self.rng.choice([1, 3, 257, 1023, 2048, 4099, 9001]))
-        B = int(self.rng.choice([1, 2, 7, 64, 300]))
+        B = int(self.rng.choice([1, 2, 7, 64, 300, 300, 700]))          # (300 x 17 instances, 700 x 6: poses of more than 256 KB — pulled rows, the device block ring)
         self.mesh = synth.make_mesh(V, B, seed=int(self.rng.integers(1 << 30)))
         self.c.upload_mesh(self.mesh["pos"], self.mesh["nrm"], self.mesh["joints"], self.mesh["weights"])
         self.c.upload_skeleton(self.mesh["inv_bind"])
@@ -81,7 +81,7 @@ class Walk:
         self.anim = None            # its (empty) morph feeds were sized for the old morph set
 
     def new_instances(self):
-        self.I = int(self.rng.choice([1, 1, 2, 5, 13]))
+        self.I = int(self.rng.choice([1, 1, 2, 5, 13, 17]))              # (17 x 300 bones: a pose of more than 256 KB — the crowd upload path)
         if self.I > 1 and (self.edge is not None or self.aabb):
             pass                                            # allowed: the generic kernel carries the consumers
         self.c.set_instances(self.I)
@@ -108,6 +108,43 @@ class Walk:
         else:
             self.aabb = not self.aabb
             self.c.enable_aabb(self.aabb)
+
+    def put_world(self, worlds, mw):
+        """World matrices: handed over (rz_set_pose) or WRITTEN IN PLACE (ABI 7: rz_map_pose / rz_commit_pose) — as whole matrices or as
+        the 48-byte rows a crowd's pull kernel reads — with something else happening between the map and the commit: a tuning key, frames
+        of the resident pose. A map or a commit the context has to refuse (rows for a pose its frame reads in place, the overlapped-front
+        protocol, the pull switched off since the map) must leave everything as it was: the pose is then handed over whole."""
+        I, rng, capi = self.I, self.rng, self.rz.capi
+        whole = worlds if I > 1 else worlds[0]
+        if rng.random() < 0.5:
+            self.c.set_pose(whole, mw)
+            return
+        rows = rng.random() < 0.5
+        try:
+            mats, wts = self.c.map_pose(capi.POSE_ROWS12 if rows else capi.POSE_WORLD16)
+        except capi.RzError:
+            self.log.append('map refused')
+            self.c.set_pose(whole, mw)
+            return
+        w4 = np.asarray(worlds, np.float32).reshape(I, -1, 4, 4)
+        mats[:] = w4[..., :3].reshape(I, -1, 12) if rows else w4.reshape(I, -1, 16)
+        if wts is not None and mw is not None:
+            wts[:] = mw
+        r = rng.random()
+        if r < 0.35:
+            self.new_tuning()
+        elif r < 0.6:
+            try:
+                self.c.deform_n(int(rng.choice([1, 3])))        # frames of the RESIDENT pose while the next one is being written
+                self.log.append('frames under a mapping')
+            except capi.RzError:
+                pass                                            # (no resident pose of this skeleton / morph set yet: refused, nothing changed)
+        try:
+            self.c.commit_pose()
+            self.log.append('mapped rows' if rows else 'mapped')
+        except capi.RzError:
+            self.log.append('commit refused')
+            self.c.set_pose(whole, mw)
 
     # ---- pose + check ----------------------------------------------------------------------------------------------
     def pose_and_check(self):
@@ -160,7 +197,7 @@ class Walk:
             self.c.set_pose_local(q, mw, t)
         else:
             worlds = np.stack([synth.make_pose(m["parents"], m["bind"], B, seed=int(rng.integers(1 << 30))) for _ in range(I)])
-            self.c.set_pose(worlds if I > 1 else worlds[0], mw)
+            self.put_world(worlds, mw)
         if rng.random() < 0.15:
             self.c.autotune(3)
             self.log.append('autotune')
@@ -229,6 +266,8 @@ def test_random_walk_over_the_abi_state_machine(rz, rzv, oracle, seed):
             w.pose_and_check()
     w.pose_and_check()
     assert w.checked >= 20
+    print("walk %d: %d poses checked; %s" % (seed, w.checked, ", ".join("%s x %d" % (k, w.log.count(k)) for k in (
+        "mapped", "mapped rows", "map refused", "commit refused", "frames under a mapping", "autotune"))))
     w.c.close()
 
 
