@@ -338,6 +338,25 @@ Plan make_plan(const rz_ctx *c)
     return pl;
 }
 
+#ifdef RZ_ALL_VARIANTS
+}  // namespace rzi
+// tools-only build (make variants), test hook — not part of the C ABI: the launch shape make_plan picks for the one-launch dense frame of
+// one mesh of these sizes on a device of n_cu compute units (no GPU involved: the plan is a pure function of the sizes), so that the CPU
+// suite can hold the heuristics of DESIGN.md 4.4 to their table.
+extern "C" __attribute__((visibility("default"))) int rz_debug_plan_dense(uint32_t V, uint32_t B, uint32_t M, int n_cu, int *split, int *grid, int *quads_per_wave, int *out_cap)
+{
+    if (V == 0 || M == 0 || n_cu <= 0 || !split || !grid || !quads_per_wave) return RZ_ERR_INVALID;
+    rz_ctx c;
+    c.n_cu = n_cu; c.V = V; c.Vp = rzi::round_up(V, rzi::kVertPad); c.B = B; c.M = M; c.I = 1; c.morph_mode = 1;
+    c.ml.count = M <= (uint32_t)kKargMorphs ? (int)M : -1;
+    const rzi::Plan pl = rzi::make_plan(&c);
+    *split = pl.v.S; *grid = (int)pl.grid_x; *quads_per_wave = (int)pl.quads_per_wave;
+    if (out_cap) *out_cap = (int)pl.out_cap;
+    return RZ_OK;
+}
+namespace rzi {
+#endif
+
 // Bring the run lists of the bone-subset crowd frame in line with the launch shape the next frame asks for. One small kernel
 // and one readback of `runs` counters, only when the shape, the mesh or the skeleton changed — never per frame.
 int ensure_run_subsets(rz_ctx *c)

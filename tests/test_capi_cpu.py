@@ -144,3 +144,42 @@ def test_crowd_pose_packing_loop_on_the_host():
                 v = w.copy()
                 v[bad_bone, col, 3] = val
                 assert L.rz_debug_pack_rows(v.ctypes.data_as(fp), bones, out.ctypes.data_as(fp)) == 0, (bones, bad_bone, col, val)
+
+
+def test_launch_shape_heuristics_of_dense_frames():
+    """make_plan for the one-launch dense frame is a pure function of the sizes; the tools-only build exports it (rz_debug_plan_dense, no GPU
+    involved). The table is tests/test_gpu_round6.py::test_heuristic_plan_at_the_shard_sizes_of_c5's — what the round-6 sweeps found best
+    on MI355X (profiles/r6_plan_sweep.txt, r6_fresh_plans*.txt, NOTEBOOK R6.2 / R6.9) — and over a sweep of 400 sizes every plan covers the
+    mesh, fits the kernel's limits and follows the rules the table came from: a wave's run is a whole number of S = 2 steps or the frame
+    runs at S = 4 / 8; a run between one and two steps does not exist at S = 2 / 4; the shard sizes of N = 1, 2, 4, 8 keep their plans."""
+    import ctypes
+    import reze_engine_amd as rz
+    if not os.path.exists(rz.capi.VARIANTS_LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "reze-engine_amd", "csrc"), "variants"])
+    L = ctypes.CDLL(rz.capi.VARIANTS_LIB_PATH)
+    ci = ctypes.c_int
+
+    def plan(V, B=256, M=64, ncu=256):
+        s, g, q, o = ci(), ci(), ci(), ci()
+        assert L.rz_debug_plan_dense(V, B, M, ncu, ctypes.byref(s), ctypes.byref(g), ctypes.byref(q), ctypes.byref(o)) == 0
+        return s.value, g.value, q.value, o.value
+
+    table = [(1000000, 2, 489), (875008, 2, 428), (797440, 4, 480), (625152, 4, 489), (530432, 4, 461), (500224, 2, 489), (400128, 2, 391), (375040, 2, 733),
+             (333568, 4, 435), (313856, 4, 491), (281600, 4, 440), (250112, 4, 489), (156416, 4, 611), (125184, 4, 489), (93952, 8, 734)]
+    for V, S, grid in table:
+        assert plan(V)[:2] == (S, grid), (V, plan(V))
+    assert plan(30000, B=200)[:2] == (8, 235)                                  # C3
+    assert plan(1000000, M=1)[0] == 1 and plan(1000000, M=2)[0] == 2         # the split never exceeds the morph count
+    assert L.rz_debug_plan_dense(0, 256, 64, 256, ctypes.byref(ci()), ctypes.byref(ci()), ctypes.byref(ci()), None) < 0
+    for V in range(20000, 1220000, 3000):
+        S, grid, qpw, cap = plan(V)
+        nq, step = (V + 3) // 4, 64 // S
+        assert S in (2, 4, 8) and qpw % 8 == 0 and qpw >= 8 and grid >= 1
+        assert grid * 4 * qpw >= nq > (grid - 1) * 4 * qpw, (V, S, grid, qpw)           # the grid covers the mesh and no workgroup is idle
+        if S == 2:
+            assert qpw % step == 0, (V, qpw)                                           # whole 128-vertex steps, or the frame is not at S = 2
+        if S in (2, 4):
+            assert not (step < qpw < 2 * step), (V, S, qpw)                              # never between one and two steps
+        if S == 8:
+            assert qpw == 8                                                            # one 32-vertex step per wave
+        assert cap == 0 or (cap % 64 == 0 and cap <= 640 and cap >= qpw * 4)           # a parked run fits its buffer
