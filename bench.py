@@ -525,7 +525,8 @@ def main():
     # pair loop that then ran SLOWER than the timed one-stream loop (seen on C4 --device-fk: 34.5 us one stream, 37.0 two in flight)
     # leaves the one-stream loop as the headline.
     headline_in_flight = in_flight
-    if in_flight == 2 and pair_ms is not None and (pair_ms < timing["deform_kernel_ms"] or pair_ms >= one_ms):
+    # (round 6: "faster" = by at least 1 % — a C4 line came out "2 in flight" at 33.58 us against 33.62 one stream, which says nothing)
+    if in_flight == 2 and pair_ms is not None and (pair_ms < timing["deform_kernel_ms"] or pair_ms > 0.99 * one_ms):
         headline_in_flight = 1
     elapsed = pair_el if headline_in_flight == 2 else one_el
     elapsed_wall = pair_wall if headline_in_flight == 2 else one_wall
@@ -817,7 +818,7 @@ def main():
                 "frame_ms_with_pose_upload_two_in_flight": with_upload_pair_ms,
                 "frames_in_flight": headline_in_flight,
                 "frames_in_flight_calibrated": in_flight,
-                "frames_in_flight_rule": "value / ms_per_step are the one-stream loop unless two frames in flight were calibrated faster (>= 3 %), their K timed steps were faster than the one-stream loop's too, AND their step is not shorter than the event-timed kernel (a step never undercuts its own kernel: such an overlap is reported in ms_per_step_two_frames_in_flight only)",
+                "frames_in_flight_rule": "value / ms_per_step are the one-stream loop unless two frames in flight were calibrated faster (>= 3 %), their K timed steps were faster than the one-stream loop's too (by >= 1 %), AND their step is not shorter than the event-timed kernel (a step never undercuts its own kernel: such an overlap is reported in ms_per_step_two_frames_in_flight only)",
                 "frames_in_flight_choice": ("--frames-in-flight " + args.frames_in_flight) if calib is None else calib,
                 "lead_in_frames": LEAD,
                 "ms_per_step_host_wall": elapsed_wall * 1e3 / (args.steps + LEAD),
