@@ -7,7 +7,7 @@ size (the work changes by < 3 % over the sweep; `frac` normalises by the bytes).
 allocations), the sizes in shuffled order, the whole pass twice: a pattern that repeats in both passes belongs to the stride, one that
 does not belongs to the placement (NOTEBOOK R5.3).
 
-  python tools/stride_sweep.py [--bases 625152,312576,156416] [--steps 24] [--step 1024] [--passes 2]
+  python tools/archive/stride_sweep.py [--bases 625152,312576,156416] [--steps 24] [--step 1024] [--passes 2]
 """
 import argparse
 import json
@@ -16,7 +16,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import reze_engine_amd as rz  # noqa: E402
 from reze_engine_amd import synth  # noqa: E402

@@ -3,11 +3,7 @@
 FRESH process — new context, new allocations — and times a handful of plans round-robin; repeated, the spread of one plan across the
 processes is its placement sensitivity (250 112 vertices, S = 4 / 489 workgroups: 32.4 - 36.6 us; S = 4 / 245: 34.4 - 34.9 us).
   python tools/fresh_plans.py [sizes] [repetitions] [plans: S:G,... with G = x1 for one step per wave]   -> profiles/r6_fresh_plans.txt"""
-import json
-import os
-import subprocess
-import sys
-
+import json, os, subprocess, sys       # noqa: E401
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
 import sys, json

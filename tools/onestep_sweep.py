@@ -3,18 +3,12 @@
 takes (the hardware deals them out as slots free up), at mesh sizes between and at the shard sizes of N = 1 ... 8. Every size in a fresh
 context; heuristic plan, S = 4 / 2 / 8 with one step per wave, timed round-robin (3 rounds of `frames` frames, median).
   python tools/onestep_sweep.py [--sizes ...]"""
-import argparse
-import json
-import os
-import sys
-
+import argparse, json, os, sys      # noqa: E401
 import numpy as np
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import reze_engine_amd as rz  # noqa: E402
 from reze_engine_amd import synth  # noqa: E402
-
 
 def main():
     ap = argparse.ArgumentParser()
@@ -62,7 +56,6 @@ def main():
             row["S%d_one_step" % p[0]] = {"grid": shape[p][1], "us": round(med[p], 3), "vs_heuristic_pct": round((med[p] / med[h] - 1) * 100, 2)}
         print(json.dumps(row), flush=True)
         ctx.close()
-
 
 if __name__ == "__main__":
     main()
