@@ -710,6 +710,11 @@ def main():
 
         def rccl_phase():
             rec, ms = None, None
+            # The current device is PER THREAD (a new thread starts on device 0) and torch's object collectives put their tensors on
+            # "cuda" = the calling thread's current device: without this every rank but 0 would hand NCCL tensors of a GPU that is not
+            # its communicator's — a failure only a real multi-GPU node can show (gloo and the one-rank RCCL line never see it).
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local_rank)
             try:
                 uid = [rz.capi.comm_unique_id() if rank == 0 else None]
                 if dist is not None:
@@ -729,10 +734,15 @@ def main():
             except Exception as e:          # noqa: BLE001
                 sys.stderr.write("[bench] RCCL communicator / all-gather failed on rank %d: %r\n" % (rank, e))
                 rec = {"error": repr(e)}
-            got = gather((rec, ms))
-            box["ranks"] = [g[0] for g in got]
-            times = [g[1] for g in got]
-            box["ag_ms"] = None if any(t is None for t in times) else max(times)
+            try:
+                got = gather((rec, ms))
+                box["ranks"] = [g[0] for g in got]
+                times = [g[1] for g in got]
+                box["ag_ms"] = None if any(t is None for t in times) else max(times)
+            except Exception as e:          # noqa: BLE001  (the exchange of the records itself failed: this rank reports what it has)
+                sys.stderr.write("[bench] rank %d could not exchange the RCCL records: %r\n" % (rank, e))
+                box["ranks"] = [rec if r == rank else {"error": "records not exchanged: %r" % (e,)} for r in range(world_size)]
+                box["ag_ms"] = None
             box["done"] = True
         th = threading.Thread(target=rccl_phase, daemon=True)
         th.start()
