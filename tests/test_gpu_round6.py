@@ -405,11 +405,12 @@ def test_heuristic_plan_at_the_shard_sizes_of_c5(rz, verts, split, grid):
     c.close()
 
 
-@pytest.mark.parametrize("verts,split,grid", [(156416, 4, 611), (313856, 4, 491), (375040, 2, 733), (530432, 4, 461)])
+@pytest.mark.parametrize("verts,split,grid", [(156416, 4, 611), (156419, 4, 612), (313856, 4, 491), (313859, 4, 491), (375040, 2, 733), (375043, 2, 733), (530432, 4, 461)])
 def test_launch_shapes_of_the_second_pass_against_the_oracle(rz, oracle, verts, split, grid):
     """The launch shapes round 6's second pass introduced (NOTEBOOK R6.9) — one step per wave on more workgroups than fit at once (S = 4:
     611, S = 2: 733), S = 4 runs of 2.5 and 4.5 steps on the persistent grid — against the oracle over the WHOLE mesh, dense morphs
-    streaming (12 targets keep the upload small; the plan depends on the vertex count alone), and bit for bit against the same mesh
+    streaming (12 targets keep the upload small; the plan depends on the vertex count alone; vertex counts that are no multiple of 4 leave
+    the last quad, the last step and the last workgroup ragged), and against the same mesh
     under S = 1 on a plain persistent grid: every vertex is written exactly once whatever the partition."""
     from helpers import assert_parity
     B, M = 64, 12
