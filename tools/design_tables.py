@@ -43,7 +43,7 @@ LINES = [
     ("rehearse8", "8 ranks sharing ONE GPU over gloo (plumbing rehearsal, not a scaling number) — `--gpus 8 --share-gpu --dist-backend gloo`"),
     ("c4_rehearse8", "C4 over 8 ranks sharing ONE GPU, sharded along the instance axis (plumbing rehearsal) — `--config c4 --gpus 8 --share-gpu --dist-backend gloo`"),
 ]
-STATS = {"c5": "c5", "shard8": "shard", "c4": "c4", "c3": "c3", "demo": "demo"}
+STATS = {"c5": "c5", "shard2": "shard2", "shard4": "shard4", "shard8": "shard", "c4": "c4", "c3": "c3", "demo": "demo"}
 
 
 def load(suffix, tag=None):
@@ -175,7 +175,7 @@ def build():
         out.append("")
     # the profiled runs themselves: events vs rocprof in the SAME run
     rows = []
-    for name in ("c5", "shard", "c4", "c3", "demo"):
+    for name in ("c5", "shard2", "shard4", "shard", "c4", "c3", "demo"):
         pj = os.path.join(PROF, "%s_bench_under_rocprof_%s.json" % (TAG, name))
         if not os.path.exists(pj):
             continue

@@ -20,6 +20,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r6"
 
 WORK = {   # name -> (title, V per GPU, B, M, I)
     "c5": ("python bench.py --steps 40 --warmup 5 (C5: 1M verts / 256 bones / 64 morphs, 1 GPU)", 1000000, 256, 64, 1),
+    "shard2": ("python bench.py --verts 500224 (one 1/2 shard of C5)", 500224, 256, 64, 1),
+    "shard4": ("python bench.py --verts 250112 (one 1/4 shard of C5)", 250112, 256, 64, 1),
     "shard": ("python bench.py --verts 125184 (one 1/8 shard of C5)", 125184, 256, 64, 1),
     "c4": ("python bench.py --config c4 (256 x 30000 verts / 200 bones, instanced)", 30000, 200, 0, 256),
     "c3": ("python bench.py --config c3 (30000 verts / 200 bones / 64 morphs)", 30000, 200, 64, 1),
