@@ -1,8 +1,8 @@
 #!/bin/bash
 # Register / scratch use of every kernel of a .hip file, read from the code object's metadata (no GPU needed):
 #   tools/archive/kernel_regs.sh [file.hip] [extra flags...]   -> "<vgpr> <sgpr> <sgpr spills> <scratch B> <kernel>" per kernel, sorted by VGPRs
-D=$(cd "$(dirname "$0")/../reze-engine_amd/csrc" && pwd)
-F=${1:-$D/deform_kernels.hip}; shift
+D=$(cd "$(dirname "$0")/../../reze-engine_amd/csrc" && pwd)
+F=${1:-$D/kernels/deform_dense.hip}; shift
 T=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-kernarg-preload-count=16 -I$D "$@" --offload-device-only -c "$F" -o $T/k.co || exit 1
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=$T/k.co --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$T/k.elf || exit 1
