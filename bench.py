@@ -497,9 +497,14 @@ def main():
         sync_pair()
         return timed(lambda: ctx.time_span(args.steps, fork, lead=LEAD), sync_pair)
 
+    kernel_reps = []
+
     def kernel_timing():
-        """roofline of the dominant kernel: HIP events on the context's own stream, one kernel at a time (200 frames whatever --steps is)"""
-        return ctx.time_frames(200)
+        """roofline of the dominant kernel: HIP events on the context's own stream, one kernel at a time — SURVEY 8d's protocol: event pairs
+        around 200 back-to-back frames (whatever --steps is), the MEDIAN of 5 repetitions"""
+        reps = sorted((ctx.time_frames(200) for _ in range(5)), key=lambda t: t["deform_kernel_ms"])
+        kernel_reps[:] = [t["deform_kernel_ms"] for t in reps]
+        return reps[2]
 
     # Order: the K steps on ONE stream (the timed steps themselves, or — when two frames in flight were chosen — the
     # secondary number), then the kernel's own timing straight after them, in the same state of the GPU, then anything that
@@ -865,6 +870,7 @@ def main():
                 "frac_of_measured_ceiling": (achieved / ceiling) if ceiling else None,
                 "algorithmic_bytes_per_launch": timing["algorithmic_bytes_per_frame"],
                 "kernel_ms": timing["deform_kernel_ms"],
+                "kernel_ms_repetitions": list(kernel_reps),       # 5 x 200 event-timed frames, ascending; kernel_ms is their median
                 "kernel_ms_check": kcheck,
                 "frame_frac": timing["algorithmic_bytes_per_frame"] / (timing["frame_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             },
